@@ -1,0 +1,327 @@
+/*
+ * roadsurf.h — C-ABI of the MI355X-native RoadSurf hot path.
+ *
+ * Everything here is plain C: pointers, sizes, PODs.  No torch types, no C++.
+ * Citations are file:line into the reference tree (fmidev/RoadSurf v1.6.1).
+ *
+ * Three layers, bottom up:
+ *   1. rs_hip_*   device-resident SoA API (HIP kernels, streams).  This is what
+ *                 the Fortran host orchestration binds through ISO_C_BINDING
+ *                 and what bench.py drives through ctypes.
+ *   2. rs_host_*  host-array convenience entry (pack -> H2D -> kernels -> D2H),
+ *                 used by the Fortran `runsimulation_batch`.
+ *   3. runsimulation / runsimulation_batch   the reference's own BIND(C) entry
+ *                 (examples/example1/src/Simulation.f90:4-6, declared on the
+ *                 C++ side at examples/example1/src/roadrunner.cpp:22-29) and
+ *                 its batched extension.  Implemented in Fortran
+ *                 (roadsurf_amd/fortran/RoadSurfHip.f90) on top of layers 1-2.
+ */
+#ifndef ROADSURF_H
+#define ROADSURF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------
+ * The five Bind(C) structs of the reference boundary, byte-identical.
+ * ---------------------------------------------------------------------- */
+
+/* src/InputPointers.f90.inc:4-27 == examples/example1/src/InputPointers.h:7-30
+ * sizeof == 160.  The reference declares the arrays `const` but mutates VZ[0]
+ * (src/Initialization.f90:121-123) and SW_dir[i] (src/InputOutput.f90:75-77);
+ * so do we, hence no const here. */
+typedef struct InputPointers {
+  int32_t inputLen;
+  double *c_tair;
+  double *c_tdew;
+  double *c_VZ;
+  double *c_Rhz;
+  double *c_prec;
+  double *c_SW;
+  double *c_LW;
+  double *c_SW_dir;
+  double *c_LW_net;
+  double *c_TSurfObs;
+  int32_t *c_PrecPhase;
+  double *c_local_horizons; /* [360] */
+  double *c_Depth;
+  int32_t *c_year;
+  int32_t *c_month;
+  int32_t *c_day;
+  int32_t *c_hour;
+  int32_t *c_minute;
+  int32_t *c_second;
+} InputPointers;
+
+/* src/OutputPointers.f90.inc:4-17 == examples/example1/src/OutputPointers.h:5-16
+ * sizeof == 56 */
+typedef struct OutputPointers {
+  int32_t outputLen;
+  double *c_TsurfOut;
+  double *c_SnowOut;
+  double *c_WaterOut;
+  double *c_IceOut;
+  double *c_DepositOut;
+  double *c_Ice2Out;
+} OutputPointers;
+
+/* Fortran view: src/InputSettings.f90.inc:4-18.  The C++ struct
+ * (examples/example1/src/InputSettings.h:13-26) has no force_tsurf member; the
+ * Fortran side reads the padding at offset 12.  We expose the Fortran view
+ * (the one that is actually read) and keep the C++ tail out of it. */
+typedef struct InputSettings {
+  int32_t SimLen;
+  int32_t use_coupling;
+  int32_t use_relaxation;
+  int32_t force_tsurf;
+  double DTSecs;
+  double tsurfOutputDepth;
+  int32_t NLayers;
+  int32_t coupling_minutes;
+  double couplingEffectReduction;
+  int32_t outputStep;
+} InputSettings;
+
+/* src/InputParameters.f90.inc:4-91 == examples/example1/src/InputParameters.h:18-110
+ * 69 consecutive doubles (552 B). */
+typedef struct InputParameters {
+  double NightOn, NightOff, CalmLimDay, CalmLimNgt, TrfFricNgt, TrFfricDay;
+  double Grav, SB_Const, VK_Const, LVap, LFus, WatDens, SnowDens, IceDens,
+      DepDens, WatMHeat, PorEvaF;
+  double ZRefW, ZRefT, ZeroDisp, ZMom, ZHeat, Emiss, Albedo,
+      Albedo_surroundings, MaxPormms, TClimG, DampDpth, Omega, AZ, DampWearF,
+      AlbDry, AlbSnow, vsh1, vsh2, Poro1, Poro2, RhoB1, RhoB2, Silt1, Silt2;
+  double freezing_limit_normal, snow_melting_limit_normal,
+      ice_melting_limit_normal, frost_melting_limit_normal,
+      frost_formation_limit_normal, T4Melt_normal;
+  double TLimColdH, TLimColdL, WetSnowFormR, WetSnowMeltR;
+  double PLimSnow, PLimRain, MaxSnowmms, MaxDepmms, MaxIcemms, MaxExtmms;
+  double MissValI, MissValR;
+  double Snow2IceFac;
+  double MinPrecmm, MinWatmms, MinSnowmms;
+  double MaxWatmms;
+  double WDampLim, WWetLim;
+  double WWearLim;
+  double MinDepmms, MinIcemms;
+} InputParameters;
+
+/* src/LocalParameters.f90.inc:4-15 == examples/example1/src/LocalParameters.h:17-25
+ * sizeof == 72 */
+typedef struct LocalParameters {
+  double tair_relax;
+  double VZ_relax;
+  double RH_relax;
+  int32_t couplingIndexI;
+  double couplingTsurf;
+  double lat;
+  double lon;
+  double sky_view;
+  int32_t InitLenI;
+} LocalParameters;
+
+/* Fill *p with the reference defaults (examples/example1/src/InputParameters.h:18-94)
+ * and the DTSecs-derived limits (examples/example1/src/InputParameters.cpp:13-21). */
+void rs_default_parameters(InputParameters *p, double DTSecs);
+/* examples/example1/src/InputSettings.h:13-23 defaults, force_tsurf = 0. */
+void rs_default_settings(InputSettings *s, int32_t SimLen);
+/* examples/example1/src/LocalParameters.h:17-25 defaults. */
+void rs_default_local(LocalParameters *l);
+
+/* ------------------------------------------------------------------------
+ * Layer 3: the reference entry point and its batched extension (Fortran).
+ * ---------------------------------------------------------------------- */
+
+/* Drop-in for examples/example1/src/Simulation.f90:4-117.  One point, whole
+ * time series, synchronous, no return value; failure leaves -9999.0 in the
+ * unwritten outputs (src/Initialization.f90:404-411).  Runs on the GPU. */
+void runsimulation(OutputPointers *outPointers, const InputPointers *inPointers,
+                   const InputSettings *inSettings,
+                   const InputParameters *inputParam,
+                   const LocalParameters *localParam);
+
+/* Extension: n independent points with shared settings/parameters, one
+ * OutputPointers/InputPointers/LocalParameters per point (exactly what the
+ * reference driver builds per point, examples/example1/src/roadrunner.cpp:404-406).
+ * status: 0 ok, <0 error (rs_last_error() has the text). */
+void runsimulation_batch(int32_t n, OutputPointers *outPointers,
+                         const InputPointers *inPointers,
+                         const InputSettings *inSettings,
+                         const InputParameters *inputParam,
+                         const LocalParameters *localParam, int32_t *status);
+
+/* ------------------------------------------------------------------------
+ * Model constants: everything that is uniform over points once settings and
+ * parameters are shared.  Built on the HOST by Fortran (same compiler, same
+ * REAL(4)-literal semantics as the reference's init code) and uploaded once.
+ * Restates src/Initialization.f90:181-235,310-358,479-557,
+ * src/BalanceModel.f90:132-186,254-279 and the REAL(4) folds of
+ * src/Cond.f90:78-102.
+ * ---------------------------------------------------------------------- */
+#define RS_MAX_LAYERS 32
+
+typedef struct RsConstants {
+  int32_t NLayers;
+  int32_t SimLen;
+  int32_t use_relaxation;
+  int32_t force_tsurf;
+  double DTSecs;
+  double Tph;              /* DTSecs/3600.0  src/Initialization.f90:92 */
+  double tsurfOutputDepth; /* <0: use depth(i) */
+  /* layer tables, 1-based like the reference; index 0 unused except ZDpth */
+  double ZDpth[RS_MAX_LAYERS + 2];  /* 1..NLayers+1 */
+  double DyC[RS_MAX_LAYERS + 2];    /* 1..NLayers */
+  double condDZ[RS_MAX_LAYERS + 2]; /* 1..NLayers  -(CC/DyK), constant in time */
+  double WCont[RS_MAX_LAYERS + 2];  /* 1..NLayers */
+  double dryCap[RS_MAX_LAYERS + 2]; /* 1..NLayers  (1-Poro)*vsh of the layer */
+  double HSfac1;                    /* (ZDpth(2)-ZDpth(1)) used by HS(1) */
+  double initSlopeDen;              /* ZDpth(N+1)-ZDpth(4), initTemp :274 */
+  /* boundary layer  src/Initialization.f90:330-337 */
+  double logMom, logHeat, logCond, logUstar;
+  double VK_Const, ZRefT, Grav, LVap, LFus;
+  /* radiation */
+  double Emiss, SB_Const, Albedo0;
+  /* day/night  src/Initialization.f90:461-467 */
+  double NightOn, NightOff, CalmLimDay, CalmLimNgt, TrfFricNgt, TrFfricDay;
+  /* storage parameters (RoadCondParameters subset actually read) */
+  double MaxPormms, MissValI, MinPrecmm, MinWatmms, MinSnowmms, MinDepmms,
+      MinIcemms, MaxSnowmms, MaxDepmms, MaxIcemms, MaxWatmms, AlbDry, AlbSnow,
+      WatDens, WatMHeat, PorEvaF, DampWearF, TLimFreeze, TLimMeltSnow,
+      TLimMeltIce, TLimMeltDep, TLimDew, TLimColdH, TLimColdL, WetSnowFormR,
+      WetSnowMeltR, PLimSnow, PLimRain, WWetLim, WWearLim, T4Melt0;
+  /* REAL(4)-folded wear constants  src/Cond.f90:78-102 */
+  double wSnowTran, wSnow2Ice, wIce, wIce2, wDep, wWat;
+  /* REAL(4) literals used on the path, widened */
+  double c27315;
+} RsConstants;
+
+/* Fortran (roadsurf_amd/fortran/RoadSurfHip.f90).  status 0 ok. */
+void rs_build_constants(const InputSettings *inSettings,
+                        const InputParameters *inputParam, RsConstants *out,
+                        int32_t *status);
+/* Bottom boundary temperature Tmp(NLayers+1) for a start date
+ * (src/Initialization.f90:266-268, src/BalanceModel.f90:325-351). Fortran. */
+double rs_bottom_temperature(const InputParameters *inputParam,
+                             const RsConstants *consts, int32_t year,
+                             int32_t month, int32_t day);
+
+/* ------------------------------------------------------------------------
+ * Layer 1: device-resident SoA API.
+ *
+ * Layout in HBM.  Points are the fastest axis everywhere:
+ *   forcing / outputs:  field[t * t_stride + p],  t_stride >= npoints
+ *   carried state:      state[v * npoints_padded + p]
+ * so a wavefront (64 consecutive points) reads/writes 512 contiguous bytes
+ * per field per time step.
+ * ---------------------------------------------------------------------- */
+
+typedef struct RsPlan RsPlan; /* opaque */
+
+/* One step-resolution forcing window resident on the device (device pointers).
+ * Index t_local = 0 corresponds to absolute (1-based, reference) time index
+ * `t0`.  Optional streams may be NULL:
+ *   tsurfobs NULL -> all missing (-9999.9);  depth NULL -> all missing;
+ *   tdew NULL -> not range-checked (treated as in range).
+ * hour: int32, either shared [t] (hour_pstride = 0) or per point
+ * [t*t_stride + p] (hour_pstride = 1). */
+typedef struct RsForcing {
+  const double *tair, *tdew, *vz, *rhz, *prec, *sw, *lw;
+  const double *tsurfobs, *depth;
+  const int32_t *precphase;
+  const int32_t *hour;
+  int64_t t_stride;     /* elements between consecutive time indices */
+  int32_t hour_pstride; /* 0 shared axis, 1 per point */
+} RsForcing;
+
+typedef struct RsOutputs {
+  double *tsurf, *snow, *water, *ice, *deposit, *ice2;
+  int64_t t_stride;
+  int32_t decimate; /* 1: every step (reference SaveOutput); k>1: only indices
+                       i with (i-1) % k == 0 are written, at row (i-1)/k */
+} RsOutputs;
+
+/* Per-point parameters (device pointers, [npoints]). */
+typedef struct RsPointParams {
+  const double *tbottom;  /* Tmp(NLayers+1), src/Initialization.f90:267 */
+  const int32_t *initlen; /* LocalParameters.InitLenI */
+  const double *tair_relax, *vz_relax, *rh_relax; /* may be NULL if !use_relaxation */
+} RsPointParams;
+
+const char *rs_last_error(void);
+int rs_hip_device_count(void);
+
+/* Create a plan for `npoints` points on HIP device `device`; uploads constants,
+ * allocates the carried-state block.  `stream` is a hipStream_t (0 = default),
+ * all rs_hip_* work of this plan is enqueued on it. */
+RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints,
+                           const RsConstants *consts, void *stream);
+void rs_hip_plan_destroy(RsPlan *plan);
+int64_t rs_hip_plan_npoints(const RsPlan *plan);
+size_t rs_hip_plan_state_bytes(const RsPlan *plan);
+
+/* Initialization (src/Initialization.f90:65-147, device part): builds the
+ * initial profile and storages from forcing index 1 (t_local 0 of `f`, which
+ * must have t0 == 1).  Also applies the VZ(1) >= 0.4 clamp logically (the
+ * kernel clamps at i == 1; device forcing is not modified). */
+int rs_hip_init_state(RsPlan *plan, const RsForcing *f, const RsPointParams *pp);
+
+/* Advance all points over absolute time indices [t0, t0+nsteps) using the
+ * window `f` (whose t_local 0 is absolute index t0) and write outputs for
+ * those indices into `o` (row 0 = index t0, or decimated as described).
+ * Handles the reference's final-step semantics when the range includes
+ * SimLen (lastValues, src/InputOutput.f90:169-198).
+ * Asynchronous on the plan's stream.  Returns 0 or <0. */
+int rs_hip_step(RsPlan *plan, const RsForcing *f, const RsOutputs *o,
+                const RsPointParams *pp, int32_t t0, int32_t nsteps);
+
+/* Copy the carried state block device->host / host->device (checkpointing,
+ * tests).  Layout: [RS_NSTATE][npoints_padded] doubles. */
+int rs_hip_state_download(RsPlan *plan, double *host, size_t bytes);
+int rs_hip_state_upload(RsPlan *plan, const double *host, size_t bytes);
+/* Number of points with the sticky failure flag set (src/InputOutput.f90:66). */
+int64_t rs_hip_failed_count(RsPlan *plan);
+int rs_hip_sync(RsPlan *plan);
+
+/* Synthetic forcing: hourly knots from a counter-based hash,
+ * expanded to step resolution by the same linear rule the reference driver
+ * uses (examples/example1/src/JsonSource.cpp:115-170).  Device kernels;
+ * host twins with identical arithmetic are in roadsurf_amd/csrc/rs_synth.h. */
+typedef struct RsSynthSpec {
+  uint64_t seed;
+  int64_t point_offset;   /* global id of local point 0 (multi-GPU shards) */
+  int32_t steps_per_knot; /* 3600/DTSecs = 120 */
+  int32_t start_hour;     /* hour of day at absolute index 1 */
+} RsSynthSpec;
+
+/* Fill step-resolution forcing for absolute indices [t0, t0+nsteps) into the
+ * caller's device buffers (RsForcing pointers are written here, hence the
+ * cast-away of const inside).  hour is written as a shared [nsteps] axis. */
+int rs_hip_synth_fill(RsPlan *plan, const RsSynthSpec *spec, const RsForcing *f,
+                      int32_t t0, int32_t nsteps);
+
+/* Time the last rs_hip_step launch with HIP events on the plan's stream:
+ * returns milliseconds of the most recent step-kernel launch, or <0. */
+float rs_hip_last_step_ms(RsPlan *plan);
+
+/* ------------------------------------------------------------------------
+ * Layer 2: host-array batch (used by the Fortran runsimulation_batch).
+ * Inputs are the per-point arrays of the reference boundary; packing to SoA,
+ * H2D, kernels and D2H happen inside, tiled over points.  tbottom[n] is
+ * computed by the Fortran caller.  Returns 0 or <0.
+ * ---------------------------------------------------------------------- */
+int rs_host_run_batch(int32_t n, OutputPointers *outPointers,
+                      const InputPointers *inPointers,
+                      const RsConstants *consts,
+                      const LocalParameters *localParam, const double *tbottom,
+                      int32_t device);
+
+#define RS_ABI_VERSION 1
+int rs_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROADSURF_H */

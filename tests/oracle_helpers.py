@@ -1,0 +1,146 @@
+"""Test-side loader for the CPU oracles (TEST INFRASTRUCTURE).
+
+Two libraries share one harness ABI (``oracle/harness.c``):
+
+* ``oracle/_ref/libroadsurf_ref.so`` — the reference's own Fortran, built by
+  ``oracle/build_ref.sh`` (only where ``/root/reference`` exists, or prebuilt);
+* ``oracle/liboracle.so`` — our C restatement (``oracle/roadsurf_oracle.c``).
+
+Nothing under ``roadsurf_amd/`` imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from roadsurf_amd import abi  # noqa: E402
+
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+PORT_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libroadsurf_ref.so")
+
+F64_IN = ("tair", "tdew", "vz", "rhz", "prec", "sw", "lw", "sw_dir", "lw_net", "tsurfobs", "depth")
+I32_AXIS = ("year", "month", "day", "hour", "minute", "second")
+F64_OUT = ("tsurf", "snow", "water", "ice", "deposit", "ice2")
+
+
+class HarnessArrays(C.Structure):
+    _fields_ = (
+        [(n, abi.c_double_p) for n in F64_IN]
+        + [("precphase", abi.c_int32_p)]
+        + [(n, abi.c_int32_p) for n in I32_AXIS]
+        + [("local_horizons", abi.c_double_p)]
+        + [(n, abi.c_double_p) for n in F64_OUT]
+    )
+
+
+def build_port() -> None:
+    subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+
+
+def build_ref() -> None:
+    subprocess.check_call(["bash", os.path.join(ORACLE_DIR, "build_ref.sh")], stdout=subprocess.DEVNULL)
+
+
+_libs: dict[str, C.CDLL] = {}
+
+
+def load(kind: str) -> C.CDLL:
+    """kind: 'port' (C restatement) or 'ref' (reference Fortran)."""
+    if kind in _libs:
+        return _libs[kind]
+    path = PORT_SO if kind == "port" else REF_SO
+    if kind == "port" and not os.path.exists(path):
+        build_port()
+    if kind == "ref" and not os.path.exists(path):
+        if os.path.isdir("/root/reference/src"):
+            build_ref()
+        else:
+            raise FileNotFoundError(path)
+    lib = C.CDLL(path)
+    lib.harness_run_points.restype = C.c_int
+    lib.harness_run_points.argtypes = [
+        C.c_int32, C.POINTER(HarnessArrays), C.POINTER(abi.InputSettings),
+        C.POINTER(abi.InputParameters), C.POINTER(abi.LocalParameters), C.c_int32,
+    ]
+    lib.harness_max_threads.restype = C.c_int
+    _libs[kind] = lib
+    return lib
+
+
+def have_ref() -> bool:
+    return os.path.exists(REF_SO) or os.path.isdir("/root/reference/src")
+
+
+def time_axis(simlen: int, dtsecs: float = 30.0, start=(2024, 1, 10, 0, 0, 0)):
+    """Shared time axis, all points (start 2024-01-10 00:00)."""
+    import datetime as dt
+
+    t0 = dt.datetime(*start)
+    ax = {k: np.empty(simlen, np.int32) for k in I32_AXIS}
+    for i in range(simlen):
+        t = t0 + dt.timedelta(seconds=i * dtsecs)
+        ax["year"][i], ax["month"][i], ax["day"][i] = t.year, t.month, t.day
+        ax["hour"][i], ax["minute"][i], ax["second"][i] = t.hour, t.minute, t.second
+    return ax
+
+
+def synth_forcing(n: int, simlen: int, seed: int = 1234, point_offset: int = 0,
+                  steps_per_knot: int = 120, start_hour: int = 0) -> dict[str, np.ndarray]:
+    """Host twin of the device generator: per-point [n][simlen] arrays."""
+    lib = load("port")
+    f = {k: np.empty((n, simlen), np.float64) for k in F64_IN}
+    f["precphase"] = np.empty((n, simlen), np.int32)
+    hour = np.empty(simlen, np.int32)
+    lib.synth_fill_points.restype = None
+    lib.synth_fill_points.argtypes = (
+        [C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+        + [abi.c_double_p] * 11 + [abi.c_int32_p, abi.c_int32_p]
+    )
+    lib.synth_fill_points(
+        seed, point_offset, n, simlen, steps_per_knot, start_hour,
+        *[f[k].ctypes.data_as(abi.c_double_p) for k in F64_IN],
+        f["precphase"].ctypes.data_as(abi.c_int32_p), hour.ctypes.data_as(abi.c_int32_p),
+    )
+    ax = time_axis(simlen, 3600.0 / steps_per_knot, (2024, 1, 10, start_hour, 0, 0))
+    assert np.array_equal(ax["hour"], hour)
+    f.update(ax)
+    f["hour"] = hour
+    return f
+
+
+def run_oracle(kind: str, forcing: dict[str, np.ndarray], settings: abi.InputSettings,
+               params: abi.InputParameters, local, nthreads: int = 0,
+               copy_inputs: bool = True):
+    """Run n points through an oracle.  Returns (outputs dict [n][simlen], mutated inputs, threads)."""
+    lib = load(kind)
+    n, simlen = forcing["tair"].shape
+    assert simlen == settings.SimLen
+    f = {k: (np.array(v, copy=True) if copy_inputs else v) for k, v in forcing.items()}
+    for k in F64_IN:
+        assert f[k].dtype == np.float64 and f[k].flags.c_contiguous and f[k].shape == (n, simlen), k
+    assert f["precphase"].dtype == np.int32 and f["precphase"].shape == (n, simlen)
+    out = {k: np.full((n, simlen), np.nan) for k in F64_OUT}
+    a = HarnessArrays()
+    for k in F64_IN:
+        setattr(a, k, f[k].ctypes.data_as(abi.c_double_p))
+    a.precphase = f["precphase"].ctypes.data_as(abi.c_int32_p)
+    for k in I32_AXIS:
+        assert f[k].dtype == np.int32 and f[k].shape == (simlen,)
+        setattr(a, k, f[k].ctypes.data_as(abi.c_int32_p))
+    hz = forcing.get("local_horizons")
+    a.local_horizons = hz.ctypes.data_as(abi.c_double_p) if hz is not None else None
+    for k in F64_OUT:
+        setattr(a, k, out[k].ctypes.data_as(abi.c_double_p))
+    if isinstance(local, abi.LocalParameters):
+        local = [local] * n
+    larr = (abi.LocalParameters * n)(*local)
+    used = lib.harness_run_points(n, C.byref(a), C.byref(settings), C.byref(params), larr, nthreads)
+    return out, f, used
