@@ -171,14 +171,16 @@ typedef struct RsConstants {
   double DTSecs;
   double Tph;              /* DTSecs/3600.0  src/Initialization.f90:92 */
   double tsurfOutputDepth; /* <0: use depth(i) */
-  /* layer tables, 1-based like the reference; index 0 unused except ZDpth */
-  double ZDpth[RS_MAX_LAYERS + 2];  /* 1..NLayers+1 */
-  double DyC[RS_MAX_LAYERS + 2];    /* 1..NLayers */
-  double condDZ[RS_MAX_LAYERS + 2]; /* 1..NLayers  -(CC/DyK), constant in time */
-  double WCont[RS_MAX_LAYERS + 2];  /* 1..NLayers */
-  double dryCap[RS_MAX_LAYERS + 2]; /* 1..NLayers  (1-Poro)*vsh of the layer */
-  double HSfac1;                    /* (ZDpth(2)-ZDpth(1)) used by HS(1) */
-  double initSlopeDen;              /* ZDpth(N+1)-ZDpth(4), initTemp :274 */
+  double twoDT;            /* 2.0*DTSecs, divisor of HS  src/BalanceModel.f90:241 */
+  /* layer tables, 1-based like the reference (index 0 unused) */
+  double ZDpth[RS_MAX_LAYERS + 2];  /* 1..NLayers+1  src/Initialization.f90:217-235 */
+  double DyC[RS_MAX_LAYERS + 2];    /* 1..NLayers    src/Initialization.f90:193-196 */
+  double condDZ[RS_MAX_LAYERS + 2]; /* 1..NLayers  -(CC/DyK): constant in time because
+                                       CC and DyK never change (src/BalanceModel.f90:145,150) */
+  double WCont[RS_MAX_LAYERS + 2];  /* 1..NLayers    src/Initialization.f90:207-213 */
+  double dryCap[RS_MAX_LAYERS + 2]; /* 1..NLayers  (1.0-Poro)*vsh of the layer
+                                       (src/BalanceModel.f90:233,235) */
+  double HSfac1;                    /* ZDpth(2)-ZDpth(1), HS(1)  src/BalanceModel.f90:240 */
   /* boundary layer  src/Initialization.f90:330-337 */
   double logMom, logHeat, logCond, logUstar;
   double VK_Const, ZRefT, Grav, LVap, LFus;
@@ -186,16 +188,17 @@ typedef struct RsConstants {
   double Emiss, SB_Const, Albedo0;
   /* day/night  src/Initialization.f90:461-467 */
   double NightOn, NightOff, CalmLimDay, CalmLimNgt, TrfFricNgt, TrFfricDay;
-  /* storage parameters (RoadCondParameters subset actually read) */
+  /* storage parameters: the RoadCondParameters members the path reads
+   * (src/Initialization.f90:479-557) */
   double MaxPormms, MissValI, MinPrecmm, MinWatmms, MinSnowmms, MinDepmms,
       MinIcemms, MaxSnowmms, MaxDepmms, MaxIcemms, MaxWatmms, AlbDry, AlbSnow,
       WatDens, WatMHeat, PorEvaF, DampWearF, TLimFreeze, TLimMeltSnow,
       TLimMeltIce, TLimMeltDep, TLimDew, TLimColdH, TLimColdL, WetSnowFormR,
       WetSnowMeltR, PLimSnow, PLimRain, WWetLim, WWearLim, T4Melt0;
-  /* REAL(4)-folded wear constants  src/Cond.f90:78-102 */
+  /* REAL(4)-folded wear constants  src/Cond.f90:78-102:
+   * (0.2+0.25), 0.25/(0.2+0.25), 1.1*2.0*0.145, 1.1*2.0*(4.0*0.290),
+   * 0.5*2.0*(4.0*0.290), 0.145 */
   double wSnowTran, wSnow2Ice, wIce, wIce2, wDep, wWat;
-  /* REAL(4) literals used on the path, widened */
-  double c27315;
 } RsConstants;
 
 /* Fortran (roadsurf_amd/fortran/RoadSurfHip.f90).  status 0 ok. */
@@ -239,8 +242,11 @@ typedef struct RsForcing {
 typedef struct RsOutputs {
   double *tsurf, *snow, *water, *ice, *deposit, *ice2;
   int64_t t_stride;
-  int32_t decimate; /* 1: every step (reference SaveOutput); k>1: only indices
-                       i with (i-1) % k == 0 are written, at row (i-1)/k */
+  int32_t decimate; /* 1: every step (reference SaveOutput, src/InputOutput.f90:151-165);
+                       k>1: only indices i with (i-1) % k == 0 are written (what the
+                       reference driver keeps, examples/example1/src/roadrunner.cpp:290,303) */
+  int64_t row0;     /* absolute output row r = (i-1)/decimate is stored at buffer
+                       row r - row0 */
 } RsOutputs;
 
 /* Per-point parameters (device pointers, [npoints]). */
@@ -296,15 +302,31 @@ typedef struct RsSynthSpec {
   int32_t start_hour;     /* hour of day at absolute index 1 */
 } RsSynthSpec;
 
-/* Fill step-resolution forcing for absolute indices [t0, t0+nsteps) into the
- * caller's device buffers (RsForcing pointers are written here, hence the
- * cast-away of const inside).  hour is written as a shared [nsteps] axis. */
-int rs_hip_synth_fill(RsPlan *plan, const RsSynthSpec *spec, const RsForcing *f,
-                      int32_t t0, int32_t nsteps);
+/* Number of doubles per point and knot in a knot buffer. */
+#define RS_KNOT_FIELDS 9
+/* Generate hourly knots k0..k0+nknots-1 into `knots` (device,
+ * [nknots][RS_KNOT_FIELDS][npoints_padded] doubles; npoints_padded from
+ * rs_hip_plan_npoints_padded). */
+int rs_hip_synth_knots(RsPlan *plan, const RsSynthSpec *spec, double *knots,
+                       int32_t k0, int32_t nknots);
+/* Expand knots to step-resolution forcing for absolute indices
+ * [t0, t0+nsteps) into the caller's device buffers `f` (written here).  The
+ * knot buffer must hold knots (t0-1)/spk .. (t0+nsteps-2)/spk + 1, the first
+ * of them being knot k0.  hour is written as a shared [nsteps] axis. */
+int rs_hip_expand_forcing(RsPlan *plan, const RsSynthSpec *spec,
+                          const double *knots, int32_t k0, int32_t nknots,
+                          const RsForcing *f, int32_t t0, int32_t nsteps);
 
-/* Time the last rs_hip_step launch with HIP events on the plan's stream:
- * returns milliseconds of the most recent step-kernel launch, or <0. */
-float rs_hip_last_step_ms(RsPlan *plan);
+/* Kernel flavour: 0 auto (register profile when NLayers == 15, else LDS
+ * profile), 1 register profile, 2 LDS profile. */
+int rs_hip_set_variant(RsPlan *plan, int32_t variant);
+
+/* Device timing of the step kernel with HIP events recorded on the plan's
+ * stream around every rs_hip_step launch since the last reset.  Returns the
+ * summed milliseconds (synchronises on the last event) and the launch count. */
+int rs_hip_timing_reset(RsPlan *plan);
+double rs_hip_timing_step_ms(RsPlan *plan, int32_t *nlaunches);
+int64_t rs_hip_plan_npoints_padded(const RsPlan *plan);
 
 /* ------------------------------------------------------------------------
  * Layer 2: host-array batch (used by the Fortran runsimulation_batch).

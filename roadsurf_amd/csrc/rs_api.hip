@@ -1,0 +1,392 @@
+/*
+ * rs_api.hip — the C-ABI of include/roadsurf.h, layer 1 (device-resident SoA).
+ *
+ * A plan owns: the HIP device, a stream (the caller's, e.g. torch's current
+ * stream, or the default), the uploaded constants, the carried-state block
+ * [RS_NSTATE][npoints_padded] in HBM and a pool of HIP events used to time
+ * the step kernel on that stream.
+ */
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/roadsurf.h"
+#include "rs_kernels.h"
+#include "rs_state.h"
+
+static thread_local char g_err[512] = "";
+
+static int set_err(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return -1;
+}
+
+#define HIP_OK(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+static bool g_slot_used[64][RS_CONST_SLOTS];
+
+struct RsPlan {
+  int device = 0;
+  int64_t npoints = 0, np_pad = 0;
+  RsConstants c{};
+  hipStream_t stream = nullptr;
+  double *state = nullptr;
+  unsigned long long *counter = nullptr;
+  int variant = RS_VARIANT_AUTO;
+  int cslot = -1;
+  std::vector<hipEvent_t> ev; /* start/stop pairs */
+  size_t ev_used = 0;
+  bool timing = false;
+};
+
+extern "C" {
+
+const char *rs_last_error(void) { return g_err; }
+void rs_host_set_error(const char *msg) { set_err("%s", msg ? msg : ""); }
+int rs_abi_version(void) { return RS_ABI_VERSION; }
+
+int rs_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void rs_default_parameters(InputParameters *p, double DTSecs) {
+  /* examples/example1/src/InputParameters.h:18-94 */
+  std::memset(p, 0, sizeof(*p));
+  p->NightOn = 19.0; p->NightOff = 4.0; p->CalmLimDay = 1.5; p->CalmLimNgt = 0.4;
+  p->TrfFricNgt = 5.0; p->TrFfricDay = 10.0;
+  p->Grav = 9.81; p->SB_Const = 5.67e-8; p->VK_Const = 0.4; p->LVap = 2.452E6;
+  p->LFus = 0.334E6; p->WatDens = 999.87; p->SnowDens = 100.0; p->IceDens = 920.0;
+  p->DepDens = 920.0; p->WatMHeat = 333000.0; p->PorEvaF = 1.0;
+  p->ZRefW = 10.0; p->ZRefT = 2.0; p->ZeroDisp = 0.0; p->ZMom = 0.4000; p->ZHeat = 0.0010;
+  p->Emiss = 0.95; p->Albedo = 0.10; p->Albedo_surroundings = 0.15; p->MaxPormms = 1.0;
+  p->TClimG = 6.4; p->DampDpth = 2.7; p->Omega = 2.0 * M_PI / 365.0; p->AZ = 0.6;
+  p->DampWearF = 0.5; p->AlbDry = 0.1; p->AlbSnow = 0.6; p->vsh1 = 1.94e+06;
+  p->vsh2 = 1.28e+06; p->Poro1 = 0.1; p->Poro2 = 0.4; p->RhoB1 = 2.11; p->RhoB2 = 1.6;
+  p->Silt1 = 0.1; p->Silt2 = 0.8;
+  p->freezing_limit_normal = -0.25; p->snow_melting_limit_normal = 0.25;
+  p->ice_melting_limit_normal = 0.25; p->frost_melting_limit_normal = 1.25;
+  p->frost_formation_limit_normal = 0.25; p->T4Melt_normal = 0.25;
+  p->TLimColdH = -19.0; p->TLimColdL = -21.0; p->WetSnowFormR = 0.1; p->WetSnowMeltR = 0.6;
+  p->PLimSnow = 0.3; p->PLimRain = 0.7; p->MaxSnowmms = 100.0; p->MaxDepmms = 2.0;
+  p->MaxIcemms = 50.0; p->MaxExtmms = 1.0;
+  p->MissValI = -9999; p->MissValR = -99.99;
+  p->Snow2IceFac = 0.5;
+  /* examples/example1/src/InputParameters.cpp:13-21 */
+  p->MinPrecmm = 0.05 * DTSecs / 3600.0;
+  p->MinWatmms = 0.01 * DTSecs / 3600.0;
+  p->MinSnowmms = 0.1 * DTSecs / 3600.0;
+  p->MaxWatmms = p->MaxPormms + p->MaxExtmms;
+  p->WDampLim = 0.1 * p->MaxPormms;
+  p->WWetLim = 0.9 * p->MaxPormms;
+  p->WWearLim = 0.1 * p->MaxPormms;
+  p->MinDepmms = 0.01 * DTSecs / 3600.0;
+  p->MinIcemms = 0.05 * DTSecs / 3600.0;
+}
+
+void rs_default_settings(InputSettings *s, int32_t SimLen) {
+  /* examples/example1/src/InputSettings.h:13-23 */
+  std::memset(s, 0, sizeof(*s));
+  s->SimLen = SimLen;
+  s->DTSecs = 30.0;
+  s->tsurfOutputDepth = -9999.9;
+  s->NLayers = 15;
+  s->coupling_minutes = 180;
+  s->couplingEffectReduction = 4.0 * 3600;
+  s->outputStep = 60;
+}
+
+void rs_default_local(LocalParameters *l) {
+  /* examples/example1/src/LocalParameters.h:17-25 */
+  std::memset(l, 0, sizeof(*l));
+  l->tair_relax = l->VZ_relax = l->RH_relax = -9999.0;
+  l->couplingIndexI = -9999;
+  l->couplingTsurf = -9999.0;
+  l->lat = l->lon = -9999.0;
+  l->sky_view = 1.0;
+  l->InitLenI = 0;
+}
+
+RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints, const RsConstants *consts,
+                           void *stream) {
+  if (!consts || npoints <= 0) {
+    set_err("rs_hip_plan_create: bad arguments");
+    return nullptr;
+  }
+  if (consts->NLayers < 5 || consts->NLayers > RS_MAX_LAYERS) {
+    set_err("rs_hip_plan_create: NLayers=%d outside [5,%d]", consts->NLayers, RS_MAX_LAYERS);
+    return nullptr;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_err("rs_hip_plan_create: no HIP device visible - this library has no CPU path");
+    return nullptr;
+  }
+  if (device < 0 || device >= ndev || device >= 64) {
+    set_err("rs_hip_plan_create: device %d out of range (%d visible)", device, ndev);
+    return nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    set_err("rs_hip_plan_create: hipSetDevice(%d) failed", device);
+    return nullptr;
+  }
+  RsPlan *pl = new RsPlan();
+  pl->device = device;
+  pl->npoints = npoints;
+  pl->np_pad = (npoints + RS_BLOCK - 1) / RS_BLOCK * RS_BLOCK;
+  pl->c = *consts;
+  pl->stream = (hipStream_t)stream;
+  const size_t bytes = (size_t)RS_NSTATE * pl->np_pad * sizeof(double);
+  if (hipMalloc(&pl->state, bytes) != hipSuccess ||
+      hipMalloc(&pl->counter, sizeof(unsigned long long)) != hipSuccess) {
+    set_err("rs_hip_plan_create: hipMalloc of %zu state bytes failed", bytes);
+    if (pl->state) (void)hipFree(pl->state);
+    delete pl;
+    return nullptr;
+  }
+  (void)hipMemsetAsync(pl->state, 0, bytes, pl->stream);
+  /* claim a slot of the per-device __constant__ table */
+  for (int sidx = 0; sidx < RS_CONST_SLOTS; ++sidx)
+    if (!g_slot_used[device][sidx]) {
+      g_slot_used[device][sidx] = true;
+      pl->cslot = sidx;
+      break;
+    }
+  if (pl->cslot < 0 || rs_upload_constants(pl->cslot, &pl->c, pl->stream) != hipSuccess) {
+    set_err("rs_hip_plan_create: no free constant slot (max %d plans per device) or upload failed",
+            RS_CONST_SLOTS);
+    if (pl->cslot >= 0) g_slot_used[device][pl->cslot] = false;
+    (void)hipFree(pl->state);
+    (void)hipFree(pl->counter);
+    delete pl;
+    return nullptr;
+  }
+  return pl;
+}
+
+void rs_hip_plan_destroy(RsPlan *pl) {
+  if (!pl) return;
+  (void)hipSetDevice(pl->device);
+  (void)hipStreamSynchronize(pl->stream);
+  for (hipEvent_t e : pl->ev) (void)hipEventDestroy(e);
+  if (pl->cslot >= 0) g_slot_used[pl->device][pl->cslot] = false;
+  (void)hipFree(pl->state);
+  (void)hipFree(pl->counter);
+  delete pl;
+}
+
+int64_t rs_hip_plan_npoints(const RsPlan *pl) { return pl ? pl->npoints : 0; }
+int64_t rs_hip_plan_npoints_padded(const RsPlan *pl) { return pl ? pl->np_pad : 0; }
+size_t rs_hip_plan_state_bytes(const RsPlan *pl) {
+  return pl ? (size_t)RS_NSTATE * pl->np_pad * sizeof(double) : 0;
+}
+
+int rs_hip_set_variant(RsPlan *pl, int32_t variant) {
+  if (!pl || variant < 0 || variant > 2) return set_err("rs_hip_set_variant: bad arguments");
+  if (variant == RS_VARIANT_REG && pl->c.NLayers != 15)
+    return set_err("register-profile kernel is built for NLayers == 15 only (got %d)",
+                   pl->c.NLayers);
+  pl->variant = variant;
+  return 0;
+}
+
+static int check_forcing(const RsPlan *pl, const RsForcing *f, const char *who) {
+  if (!f || !f->tair || !f->vz || !f->rhz || !f->prec || !f->sw || !f->lw || !f->precphase ||
+      !f->hour)
+    return set_err("%s: forcing streams tair,vz,rhz,prec,sw,lw,precphase,hour are required", who);
+  if (f->t_stride < pl->npoints)
+    return set_err("%s: forcing t_stride %lld < npoints %lld", who, (long long)f->t_stride,
+                   (long long)pl->npoints);
+  return 0;
+}
+
+int rs_hip_init_state(RsPlan *pl, const RsForcing *f, const RsPointParams *pp) {
+  if (!pl) return set_err("rs_hip_init_state: null plan");
+  if (check_forcing(pl, f, "rs_hip_init_state")) return -1;
+  if (!pp || !pp->tbottom) return set_err("rs_hip_init_state: tbottom is required");
+  HIP_OK(hipSetDevice(pl->device));
+  rs::InitArgs a;
+  a.cslot = pl->cslot;
+  a.f = *f;
+  a.pp = *pp;
+  a.state = pl->state;
+  a.npoints = pl->npoints;
+  a.np_pad = pl->np_pad;
+  HIP_OK(rs_launch_init(a, pl->stream));
+  return 0;
+}
+
+int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPointParams *pp,
+                int32_t t0, int32_t nsteps) {
+  if (!pl) return set_err("rs_hip_step: null plan");
+  if (check_forcing(pl, f, "rs_hip_step")) return -1;
+  if (!pp || !pp->tbottom) return set_err("rs_hip_step: tbottom is required");
+  if (!o || !o->tsurf || !o->snow || !o->water || !o->ice || !o->deposit || !o->ice2)
+    return set_err("rs_hip_step: all six output streams are required");
+  if (o->t_stride < pl->npoints) return set_err("rs_hip_step: output t_stride < npoints");
+  if (o->decimate < 1) return set_err("rs_hip_step: decimate must be >= 1");
+  if (t0 < 1 || nsteps < 1 || (int64_t)t0 + nsteps - 1 > pl->c.SimLen)
+    return set_err("rs_hip_step: window [%d,%d) outside [1,SimLen=%d]", t0, t0 + nsteps,
+                   pl->c.SimLen);
+  {
+    const int64_t first = ((int64_t)t0 - 1 + o->decimate - 1) / o->decimate;
+    if (first < o->row0) return set_err("rs_hip_step: output row0 %lld beyond first row %lld",
+                                        (long long)o->row0, (long long)first);
+  }
+  HIP_OK(hipSetDevice(pl->device));
+  /* LEAN kernel is exact when nothing optional can act: no observation forcing
+   * after index 1 (at index 1 it is a no-op: the profile was initialised from
+   * the same observation, src/Initialization.f90:256-259), no output depth, no
+   * relaxation, no Tdew check. */
+  const bool full = (pp->initlen != nullptr) || pl->c.force_tsurf || (f->depth != nullptr) ||
+                    (pl->c.tsurfOutputDepth >= 0.0) ||
+                    (pl->c.use_relaxation && pp->tair_relax != nullptr) || (f->tdew != nullptr);
+  if (pl->c.use_relaxation && pp->tair_relax && (!pp->vz_relax || !pp->rh_relax || !pp->initlen))
+    return set_err("rs_hip_step: relaxation needs tair_relax, vz_relax, rh_relax and initlen");
+  rs::StepArgs a;
+  a.cslot = pl->cslot;
+  a.f = *f;
+  a.o = *o;
+  a.pp = *pp;
+  a.state = pl->state;
+  a.npoints = pl->npoints;
+  a.np_pad = pl->np_pad;
+  a.t0 = t0;
+  a.nsteps = nsteps;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (pl->timing) {
+    if (pl->ev_used + 2 > pl->ev.size()) {
+      hipEvent_t x, y;
+      HIP_OK(hipEventCreate(&x));
+      HIP_OK(hipEventCreate(&y));
+      pl->ev.push_back(x);
+      pl->ev.push_back(y);
+    }
+    e0 = pl->ev[pl->ev_used];
+    e1 = pl->ev[pl->ev_used + 1];
+    pl->ev_used += 2;
+    HIP_OK(hipEventRecord(e0, pl->stream));
+  }
+  HIP_OK(rs_launch_step(a, pl->c.NLayers, full, pl->variant, pl->stream));
+  if (pl->timing) HIP_OK(hipEventRecord(e1, pl->stream));
+  return 0;
+}
+
+int rs_hip_timing_reset(RsPlan *pl) {
+  if (!pl) return set_err("rs_hip_timing_reset: null plan");
+  pl->timing = true;
+  pl->ev_used = 0;
+  return 0;
+}
+
+double rs_hip_timing_step_ms(RsPlan *pl, int32_t *nlaunches) {
+  if (!pl) return -1.0;
+  double total = 0.0;
+  if (nlaunches) *nlaunches = (int32_t)(pl->ev_used / 2);
+  if (pl->ev_used == 0) return 0.0;
+  if (hipEventSynchronize(pl->ev[pl->ev_used - 1]) != hipSuccess) return -1.0;
+  for (size_t i = 0; i + 1 < pl->ev_used; i += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pl->ev[i], pl->ev[i + 1]) != hipSuccess) return -1.0;
+    total += ms;
+  }
+  return total;
+}
+
+int rs_hip_state_download(RsPlan *pl, double *host, size_t bytes) {
+  if (!pl || !host || bytes != rs_hip_plan_state_bytes(pl))
+    return set_err("rs_hip_state_download: bad arguments");
+  HIP_OK(hipSetDevice(pl->device));
+  HIP_OK(hipMemcpyAsync(host, pl->state, bytes, hipMemcpyDeviceToHost, pl->stream));
+  HIP_OK(hipStreamSynchronize(pl->stream));
+  return 0;
+}
+
+int rs_hip_state_upload(RsPlan *pl, const double *host, size_t bytes) {
+  if (!pl || !host || bytes != rs_hip_plan_state_bytes(pl))
+    return set_err("rs_hip_state_upload: bad arguments");
+  HIP_OK(hipSetDevice(pl->device));
+  HIP_OK(hipMemcpyAsync(pl->state, host, bytes, hipMemcpyHostToDevice, pl->stream));
+  HIP_OK(hipStreamSynchronize(pl->stream));
+  return 0;
+}
+
+int64_t rs_hip_failed_count(RsPlan *pl) {
+  if (!pl) return -1;
+  if (hipSetDevice(pl->device) != hipSuccess) return -1;
+  unsigned long long h = 0;
+  if (hipMemsetAsync(pl->counter, 0, sizeof(h), pl->stream) != hipSuccess) return -1;
+  if (rs_launch_count_failed(pl->state, pl->np_pad, pl->npoints, pl->counter, pl->stream) !=
+      hipSuccess)
+    return -1;
+  if (hipMemcpyAsync(&h, pl->counter, sizeof(h), hipMemcpyDeviceToHost, pl->stream) != hipSuccess)
+    return -1;
+  if (hipStreamSynchronize(pl->stream) != hipSuccess) return -1;
+  return (int64_t)h;
+}
+
+int rs_hip_sync(RsPlan *pl) {
+  if (!pl) return set_err("rs_hip_sync: null plan");
+  HIP_OK(hipSetDevice(pl->device));
+  HIP_OK(hipStreamSynchronize(pl->stream));
+  return 0;
+}
+
+int rs_hip_synth_knots(RsPlan *pl, const RsSynthSpec *spec, double *knots, int32_t k0,
+                       int32_t nknots) {
+  if (!pl || !spec || !knots || nknots < 1 || k0 < 0)
+    return set_err("rs_hip_synth_knots: bad arguments");
+  if (nknots > 65535) return set_err("rs_hip_synth_knots: at most 65535 knots per call");
+  HIP_OK(hipSetDevice(pl->device));
+  rs::KnotArgs a;
+  a.spec = *spec;
+  a.knots = knots;
+  a.npoints = pl->npoints;
+  a.np_pad = pl->np_pad;
+  a.k0 = k0;
+  HIP_OK(rs_launch_knots(a, nknots, pl->stream));
+  return 0;
+}
+
+int rs_hip_expand_forcing(RsPlan *pl, const RsSynthSpec *spec, const double *knots, int32_t k0,
+                          int32_t nknots, const RsForcing *f, int32_t t0, int32_t nsteps) {
+  if (!pl || !spec || !knots || !f) return set_err("rs_hip_expand_forcing: bad arguments");
+  if (check_forcing(pl, f, "rs_hip_expand_forcing")) return -1;
+  if (nsteps < 1 || nsteps > 65535 || t0 < 1)
+    return set_err("rs_hip_expand_forcing: 1 <= nsteps <= 65535, t0 >= 1");
+  const int32_t spk = spec->steps_per_knot;
+  if (spk < 1) return set_err("rs_hip_expand_forcing: steps_per_knot < 1");
+  const int32_t kfirst = (t0 - 1) / spk;
+  const int32_t tlast = t0 + nsteps - 2; /* 0-based */
+  const int32_t klast = tlast / spk + ((tlast % spk) ? 1 : 0);
+  if (kfirst < k0 || klast >= k0 + nknots)
+    return set_err("rs_hip_expand_forcing: need knots %d..%d, buffer has %d..%d", kfirst, klast,
+                   k0, k0 + nknots - 1);
+  if (f->hour_pstride) return set_err("rs_hip_expand_forcing: hour must be a shared axis");
+  HIP_OK(hipSetDevice(pl->device));
+  rs::ExpandArgs a;
+  a.f = *f;
+  a.knots = knots;
+  a.npoints = pl->npoints;
+  a.np_pad = pl->np_pad;
+  a.k0 = k0;
+  a.t0 = t0;
+  a.spk = spk;
+  a.start_hour = spec->start_hour;
+  HIP_OK(rs_launch_expand(a, nsteps, pl->stream));
+  return 0;
+}
+
+} /* extern "C" */

@@ -1,0 +1,251 @@
+/*
+ * rs_host.hip — layer 2 of include/roadsurf.h: host-array batch entry used by
+ * the Fortran `runsimulation_batch` (roadsurf_amd/fortran/RoadSurfHip.f90).
+ *
+ * The reference boundary hands over one contiguous [SimLen] array per point
+ * and field (examples/example1/src/InputData.cpp:5-26, OutputData.cpp:5-13).
+ * The kernels want points on the fastest axis.  So, per tile of points and per
+ * chunk of time:
+ *     host rows --memcpy--> pinned [field][point][t]  --H2D-->  device
+ *     device: LDS-tiled transpose to [field][t][point]  -> step kernel ->
+ *     transpose outputs back to [field][point][t]  --D2H-->  pinned -> rows
+ * The carried state stays on the device between chunks.  Everything runs on
+ * one stream per call; the rate of this path is PCIe/host-memcpy bound and is
+ * quoted separately from the device-resident rate.
+ */
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/roadsurf.h"
+#include "rs_kernels.h"
+
+extern "C" void rs_host_set_error(const char *msg);
+
+namespace {
+
+constexpr int TS = 32; /* transpose tile */
+
+/* src[r][c] (rows x cols, leading dim ld_src) -> dst[c][r] (leading dim ld_dst) */
+template <typename T>
+__global__ void __launch_bounds__(TS *8) transpose_kernel(const T *__restrict__ src,
+                                                           T *__restrict__ dst, int rows, int cols,
+                                                           int64_t ld_src, int64_t ld_dst) {
+  __shared__ T tile[TS][TS + 1];
+  const int c0 = blockIdx.x * TS, r0 = blockIdx.y * TS;
+  for (int j = threadIdx.y; j < TS; j += 8) {
+    const int r = r0 + j, c = c0 + threadIdx.x;
+    if (r < rows && c < cols) tile[j][threadIdx.x] = src[(int64_t)r * ld_src + c];
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < TS; j += 8) {
+    const int c = c0 + j, r = r0 + threadIdx.x;
+    if (r < rows && c < cols) dst[(int64_t)c * ld_dst + r] = tile[threadIdx.x][j];
+  }
+}
+
+template <typename T>
+hipError_t transpose(const T *src, T *dst, int rows, int cols, int64_t ld_src, int64_t ld_dst,
+                     hipStream_t s) {
+  dim3 g((cols + TS - 1) / TS, (rows + TS - 1) / TS), b(TS, 8);
+  hipLaunchKernelGGL(transpose_kernel<T>, g, b, 0, s, src, dst, rows, cols, ld_src, ld_dst);
+  return hipGetLastError();
+}
+
+struct Dev {
+  void *p = nullptr;
+  ~Dev() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t n) { return hipMalloc(&p, n); }
+};
+struct Pinned {
+  void *p = nullptr;
+  ~Pinned() {
+    if (p) (void)hipHostFree(p);
+  }
+  hipError_t alloc(size_t n) { return hipHostMalloc(&p, n, hipHostMallocDefault); }
+};
+
+int fail(const char *what, hipError_t e) {
+  char buf[256];
+  snprintf(buf, sizeof(buf), "rs_host_run_batch: %s: %s", what, hipGetErrorString(e));
+  rs_host_set_error(buf);
+  return -10;
+}
+
+#define HOK(expr)                                   \
+  do {                                              \
+    hipError_t e_ = (expr);                         \
+    if (e_ != hipSuccess) return fail(#expr, e_);   \
+  } while (0)
+
+enum { F_TAIR, F_TDEW, F_VZ, F_RHZ, F_PREC, F_SW, F_LW, F_OBS, F_DEPTH, NF64 };
+
+inline const double *in_f64(const InputPointers &ip, int f) {
+  switch (f) {
+    case F_TAIR: return ip.c_tair;
+    case F_TDEW: return ip.c_tdew;
+    case F_VZ: return ip.c_VZ;
+    case F_RHZ: return ip.c_Rhz;
+    case F_PREC: return ip.c_prec;
+    case F_SW: return ip.c_SW;
+    case F_LW: return ip.c_LW;
+    case F_OBS: return ip.c_TSurfObs;
+    default: return ip.c_Depth;
+  }
+}
+inline double *out_f64(const OutputPointers &op, int f) {
+  switch (f) {
+    case 0: return op.c_TsurfOut;
+    case 1: return op.c_SnowOut;
+    case 2: return op.c_WaterOut;
+    case 3: return op.c_IceOut;
+    case 4: return op.c_DepositOut;
+    default: return op.c_Ice2Out;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rs_host_default_device(void) {
+  const char *e = getenv("ROADSURF_HIP_DEVICE");
+  return e ? atoi(e) : 0;
+}
+
+int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointers *inPointers,
+                      const RsConstants *consts, const LocalParameters *localParam,
+                      const double *tbottom, int32_t device) {
+  if (n < 1 || !outPointers || !inPointers || !consts || !localParam || !tbottom) {
+    rs_host_set_error("rs_host_run_batch: bad arguments");
+    return -1;
+  }
+  const int L = consts->SimLen;
+  /* tile sizes: bounded pinned staging (~0.5 GB) whatever n and SimLen are */
+  const char *ep = getenv("ROADSURF_HIP_TILE_POINTS"), *et = getenv("ROADSURF_HIP_CHUNK_STEPS");
+  const int P = std::min<int64_t>(n, ep ? std::max(1, atoi(ep)) : 16384);
+  const int TC = std::min(L, et ? std::max(1, atoi(et)) : 256);
+  const int Ppad = (P + RS_BLOCK - 1) / RS_BLOCK * RS_BLOCK;
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    rs_host_set_error("rs_host_run_batch: no HIP device visible - this library has no CPU path");
+    return -9;
+  }
+  HOK(hipSetDevice(device));
+  hipStream_t stream;
+  HOK(hipStreamCreate(&stream));
+
+  const size_t in_elems = (size_t)P * TC, tp_elems = (size_t)Ppad * TC;
+  Pinned h_in, h_out, h_i32;
+  Dev d_pt, d_tp, d_i32pt, d_i32tp, d_out_tp, d_out_pt, d_pp64, d_pp32;
+  HOK(h_in.alloc(in_elems * NF64 * sizeof(double)));
+  HOK(h_out.alloc(in_elems * 6 * sizeof(double)));
+  HOK(h_i32.alloc(in_elems * 2 * sizeof(int32_t)));
+  HOK(d_pt.alloc(in_elems * NF64 * sizeof(double)));
+  HOK(d_tp.alloc(tp_elems * NF64 * sizeof(double)));
+  HOK(d_i32pt.alloc(in_elems * 2 * sizeof(int32_t)));
+  HOK(d_i32tp.alloc(tp_elems * 2 * sizeof(int32_t)));
+  HOK(d_out_tp.alloc(tp_elems * 6 * sizeof(double)));
+  HOK(d_out_pt.alloc(in_elems * 6 * sizeof(double)));
+  HOK(d_pp64.alloc((size_t)Ppad * 4 * sizeof(double)));
+  HOK(d_pp32.alloc((size_t)Ppad * sizeof(int32_t)));
+  std::vector<double> pp64((size_t)Ppad * 4);
+  std::vector<int32_t> pp32(Ppad);
+
+  int rc = 0;
+  for (int64_t p0 = 0; p0 < n && rc == 0; p0 += P) {
+    const int m = (int)std::min<int64_t>(P, n - p0);
+    RsPlan *plan = rs_hip_plan_create(device, m, consts, stream);
+    if (!plan) {
+      rc = -11; /* rs_last_error() is set */
+      break;
+    }
+    const int64_t mp = rs_hip_plan_npoints_padded(plan);
+    /* per-point parameters */
+    for (int p = 0; p < m; ++p) {
+      pp64[p] = tbottom[p0 + p];
+      pp64[(size_t)Ppad + p] = localParam[p0 + p].tair_relax;
+      pp64[(size_t)2 * Ppad + p] = localParam[p0 + p].VZ_relax;
+      pp64[(size_t)3 * Ppad + p] = localParam[p0 + p].RH_relax;
+      pp32[p] = localParam[p0 + p].InitLenI;
+    }
+    HOK(hipMemcpyAsync(d_pp64.p, pp64.data(), pp64.size() * sizeof(double),
+                       hipMemcpyHostToDevice, stream));
+    HOK(hipMemcpyAsync(d_pp32.p, pp32.data(), pp32.size() * sizeof(int32_t),
+                       hipMemcpyHostToDevice, stream));
+    RsPointParams pp;
+    pp.tbottom = (double *)d_pp64.p;
+    pp.tair_relax = (double *)d_pp64.p + Ppad;
+    pp.vz_relax = (double *)d_pp64.p + 2 * (size_t)Ppad;
+    pp.rh_relax = (double *)d_pp64.p + 3 * (size_t)Ppad;
+    pp.initlen = (int32_t *)d_pp32.p;
+
+    for (int t0 = 1; t0 <= L; t0 += TC) {
+      const int len = std::min(TC, L - t0 + 1);
+      /* gather rows into pinned staging [field][p][len] */
+      double *hin = (double *)h_in.p;
+      int32_t *hi = (int32_t *)h_i32.p;
+#pragma omp parallel for schedule(static)
+      for (int p = 0; p < m; ++p) {
+        const InputPointers &ip = inPointers[p0 + p];
+        for (int f = 0; f < NF64; ++f)
+          std::memcpy(hin + ((size_t)f * m + p) * len, in_f64(ip, f) + (t0 - 1),
+                      (size_t)len * sizeof(double));
+        std::memcpy(hi + (size_t)p * len, ip.c_PrecPhase + (t0 - 1), (size_t)len * sizeof(int32_t));
+        std::memcpy(hi + ((size_t)m + p) * len, ip.c_hour + (t0 - 1), (size_t)len * sizeof(int32_t));
+      }
+      HOK(hipMemcpyAsync(d_pt.p, hin, (size_t)NF64 * m * len * sizeof(double),
+                         hipMemcpyHostToDevice, stream));
+      HOK(hipMemcpyAsync(d_i32pt.p, hi, (size_t)2 * m * len * sizeof(int32_t),
+                         hipMemcpyHostToDevice, stream));
+      for (int f = 0; f < NF64; ++f)
+        HOK(transpose((const double *)d_pt.p + (size_t)f * m * len,
+                      (double *)d_tp.p + (size_t)f * mp * TC, m, len, len, mp, stream));
+      for (int f = 0; f < 2; ++f)
+        HOK(transpose((const int32_t *)d_i32pt.p + (size_t)f * m * len,
+                      (int32_t *)d_i32tp.p + (size_t)f * mp * TC, m, len, len, mp, stream));
+      RsForcing fo;
+      double *b = (double *)d_tp.p;
+      const size_t fs = (size_t)mp * TC;
+      fo.tair = b + F_TAIR * fs; fo.tdew = b + F_TDEW * fs; fo.vz = b + F_VZ * fs;
+      fo.rhz = b + F_RHZ * fs; fo.prec = b + F_PREC * fs; fo.sw = b + F_SW * fs;
+      fo.lw = b + F_LW * fs; fo.tsurfobs = b + F_OBS * fs; fo.depth = b + F_DEPTH * fs;
+      fo.precphase = (int32_t *)d_i32tp.p;
+      fo.hour = (int32_t *)d_i32tp.p + fs;
+      fo.t_stride = mp;
+      fo.hour_pstride = 1;
+      RsOutputs oo;
+      double *ob = (double *)d_out_tp.p;
+      oo.tsurf = ob; oo.snow = ob + fs; oo.water = ob + 2 * fs; oo.ice = ob + 3 * fs;
+      oo.deposit = ob + 4 * fs; oo.ice2 = ob + 5 * fs;
+      oo.t_stride = mp;
+      oo.decimate = 1;
+      oo.row0 = t0 - 1;
+      if (t0 == 1 && rs_hip_init_state(plan, &fo, &pp) != 0) { rc = -12; break; }
+      if (rs_hip_step(plan, &fo, &oo, &pp, t0, len) != 0) { rc = -13; break; }
+      for (int f = 0; f < 6; ++f)
+        HOK(transpose((const double *)d_out_tp.p + (size_t)f * fs,
+                      (double *)d_out_pt.p + (size_t)f * m * len, len, m, mp, len, stream));
+      HOK(hipMemcpyAsync(h_out.p, d_out_pt.p, (size_t)6 * m * len * sizeof(double),
+                         hipMemcpyDeviceToHost, stream));
+      HOK(hipStreamSynchronize(stream));
+      const double *hout = (const double *)h_out.p;
+#pragma omp parallel for schedule(static)
+      for (int p = 0; p < m; ++p)
+        for (int f = 0; f < 6; ++f)
+          std::memcpy(out_f64(outPointers[p0 + p], f) + (t0 - 1), hout + ((size_t)f * m + p) * len,
+                      (size_t)len * sizeof(double));
+    }
+    rs_hip_plan_destroy(plan);
+  }
+  (void)hipStreamDestroy(stream);
+  return rc;
+}
+
+} /* extern "C" */

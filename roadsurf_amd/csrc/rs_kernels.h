@@ -1,0 +1,55 @@
+/* rs_kernels.h — kernel argument blocks and host launchers (internal). */
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/roadsurf.h"
+#include "rs_synth.h"
+
+#define RS_BLOCK 256
+#define RS_CONST_SLOTS 16 /* concurrent plans per device */
+
+enum { RS_VARIANT_AUTO = 0, RS_VARIANT_REG = 1, RS_VARIANT_LDS = 2 };
+
+namespace rs {
+
+struct StepArgs {
+  int32_t cslot; /* index into the __constant__ table */
+  RsForcing f;
+  RsOutputs o;
+  RsPointParams pp;
+  double *state;
+  int64_t npoints, np_pad;
+  int32_t t0, nsteps;
+};
+
+struct InitArgs {
+  int32_t cslot;
+  RsForcing f;
+  RsPointParams pp;
+  double *state;
+  int64_t npoints, np_pad;
+};
+
+struct KnotArgs {
+  RsSynthSpec spec;
+  double *knots;
+  int64_t npoints, np_pad;
+  int32_t k0;
+};
+
+struct ExpandArgs {
+  RsForcing f;
+  const double *knots;
+  int64_t npoints, np_pad;
+  int32_t k0, t0, spk, start_hour;
+};
+
+}  // namespace rs
+
+hipError_t rs_upload_constants(int slot, const RsConstants *c, hipStream_t stream);
+hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
+                          hipStream_t stream);
+hipError_t rs_launch_init(const rs::InitArgs &a, hipStream_t stream);
+hipError_t rs_launch_knots(const rs::KnotArgs &a, int32_t nknots, hipStream_t stream);
+hipError_t rs_launch_expand(const rs::ExpandArgs &a, int32_t nsteps, hipStream_t stream);
+hipError_t rs_launch_count_failed(const double *st, int64_t np_pad, int64_t npoints,
+                                  unsigned long long *out, hipStream_t stream);

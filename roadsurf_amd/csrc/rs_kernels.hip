@@ -1,0 +1,421 @@
+/*
+ * rs_kernels.hip — HIP kernels (gfx950) of the RoadSurf hot path.
+ *
+ * Mapping: ONE POINT PER LANE, persistent over a window of time steps.  A
+ * 256-thread workgroup owns 256 consecutive points; lane l of a wavefront reads
+ * forcing[t][p0 + l], so each field-step is one coalesced 512-B wave access,
+ * and writes the six outputs the same way.  The carried state (SURVEY.md
+ * Appendix B, ~30 doubles) is loaded from the SoA state block once per launch,
+ * lives in VGPRs for the whole window and is stored back once.
+ *
+ * Two flavours of the same physics (rs_physics.hpp):
+ *   step_kernel_reg<NL>  NLayers known at compile time: the ground temperature
+ *                        profile is a fully unrolled register array.
+ *   step_kernel_lds      any NLayers <= RS_MAX_LAYERS: the profile is staged in
+ *                        LDS as [layer][lane] columns (conflict-free: lane l
+ *                        touches 8-byte word l of a 2-KiB row).
+ * Each comes in a LEAN variant (no observation forcing beyond index 1, no output
+ * depth, no relaxation, no Tdew check: the BASELINE workload) and a FULL variant.
+ *
+ * No MFMA: there is no contraction anywhere in this path.  The time loop is
+ * sequential per point (explicit Euler in time), points are independent.
+ */
+#include <hip/hip_runtime.h>
+#include "rs_physics.hpp"
+#include "rs_state.h"
+#include "rs_synth.h"
+#include "rs_kernels.h"
+
+namespace rs {
+
+constexpr int kBlock = RS_BLOCK;
+
+/* Model constants live in constant memory (address space 4): every access is a
+ * scalar load through the scalar cache.  The time loop re-derives the slot
+ * index through an empty asm every iteration so that the compiler cannot hoist
+ * ~220 uniform doubles (= 440 SGPRs, against 102 available) out of the loop and
+ * then spill them into VGPR lanes; loaded at the point of use they cost one
+ * s_load each and no live range. */
+__constant__ RsConstants g_consts[RS_CONST_SLOTS];
+
+template <int NL>
+struct RegProfile {
+  double v[NL];
+  __device__ __forceinline__ constexpr int nlayers() const { return NL; }
+  __device__ __forceinline__ double get(int j) const { return v[j - 1]; }
+  __device__ __forceinline__ void set(int j, double x) { v[j - 1] = x; }
+};
+
+struct LdsProfile {
+  double *col; /* &lds[threadIdx.x]; layer stride = kBlock doubles */
+  int n;
+  __device__ __forceinline__ int nlayers() const { return n; }
+  __device__ __forceinline__ double get(int j) const { return col[(j - 1) * kBlock]; }
+  __device__ __forceinline__ void set(int j, double x) { col[(j - 1) * kBlock] = x; }
+};
+
+template <class Prof>
+__device__ __forceinline__ void load_state(const double *__restrict__ st, int64_t np, int64_t p,
+                                           Prof &T, Scalars &s) {
+  const int N = T.nlayers();
+#pragma unroll
+  for (int j = 1; j <= N; ++j) T.set(j, st[(int64_t)(RS_ST_TMP0 + j - 1) * np + p]);
+  s.tnw1 = st[(int64_t)RS_ST_TNW1 * np + p];
+  s.tnw2 = st[(int64_t)RS_ST_TNW2 * np + p];
+  s.tsurf = st[(int64_t)RS_ST_TSURF * np + p];
+  s.wat = st[(int64_t)RS_ST_WAT * np + p];
+  s.snow = st[(int64_t)RS_ST_SNOW * np + p];
+  s.ice = st[(int64_t)RS_ST_ICE * np + p];
+  s.ice2 = st[(int64_t)RS_ST_ICE2 * np + p];
+  s.dep = st[(int64_t)RS_ST_DEP * np + p];
+  s.q2melt = st[(int64_t)RS_ST_Q2MELT * np + p];
+  s.t4melt = st[(int64_t)RS_ST_T4MELT * np + p];
+  s.albedo = st[(int64_t)RS_ST_ALBEDO * np + p];
+  s.verycold = st[(int64_t)RS_ST_VERYCOLD * np + p] != 0.0;
+  s.failed = st[(int64_t)RS_ST_FAILED * np + p] != 0.0;
+  s.tair_end = st[(int64_t)RS_ST_TAIR_END * np + p];
+  s.vz_end = st[(int64_t)RS_ST_VZ_END * np + p];
+  s.rh_end = st[(int64_t)RS_ST_RH_END * np + p];
+}
+
+template <class Prof>
+__device__ __forceinline__ void store_state(double *__restrict__ st, int64_t np, int64_t p,
+                                            const Prof &T, const Scalars &s) {
+  const int N = T.nlayers();
+#pragma unroll
+  for (int j = 1; j <= N; ++j) st[(int64_t)(RS_ST_TMP0 + j - 1) * np + p] = T.get(j);
+  st[(int64_t)RS_ST_TNW1 * np + p] = s.tnw1;
+  st[(int64_t)RS_ST_TNW2 * np + p] = s.tnw2;
+  st[(int64_t)RS_ST_TSURF * np + p] = s.tsurf;
+  st[(int64_t)RS_ST_WAT * np + p] = s.wat;
+  st[(int64_t)RS_ST_SNOW * np + p] = s.snow;
+  st[(int64_t)RS_ST_ICE * np + p] = s.ice;
+  st[(int64_t)RS_ST_ICE2 * np + p] = s.ice2;
+  st[(int64_t)RS_ST_DEP * np + p] = s.dep;
+  st[(int64_t)RS_ST_Q2MELT * np + p] = s.q2melt;
+  st[(int64_t)RS_ST_T4MELT * np + p] = s.t4melt;
+  st[(int64_t)RS_ST_ALBEDO * np + p] = s.albedo;
+  st[(int64_t)RS_ST_VERYCOLD * np + p] = s.verycold ? 1.0 : 0.0;
+  st[(int64_t)RS_ST_FAILED * np + p] = s.failed ? 1.0 : 0.0;
+  st[(int64_t)RS_ST_TAIR_END * np + p] = s.tair_end;
+  st[(int64_t)RS_ST_VZ_END * np + p] = s.vz_end;
+  st[(int64_t)RS_ST_RH_END * np + p] = s.rh_end;
+}
+
+template <bool FULL>
+__device__ __forceinline__ Forcing load_forcing(const RsForcing &f, int64_t row, int64_t p,
+                                                int32_t k) {
+  Forcing o;
+  const int64_t off = row + p;
+  o.tair = f.tair[off];
+  o.vz = f.vz[off];
+  o.rhz = f.rhz[off];
+  o.prec = f.prec[off];
+  o.sw = f.sw[off];
+  o.lw = f.lw[off];
+  o.phase = f.precphase[off];
+  o.hour = f.hour_pstride ? f.hour[off] : f.hour[k];
+  if (FULL) {
+    o.tdew = f.tdew ? f.tdew[off] : 0.0;
+    o.tsurfobs = f.tsurfobs ? f.tsurfobs[off] : R4(-9999.9);
+    o.depth = f.depth ? f.depth[off] : R4(-9999.9);
+  } else {
+    o.tdew = 0.0;
+    o.tsurfobs = R4(-9999.9);
+    o.depth = R4(-9999.9);
+  }
+  return o;
+}
+
+__device__ __forceinline__ void store_outputs(const RsOutputs &o, int32_t i, int64_t p,
+                                              const Scalars &s, bool valid) {
+  int64_t r = (int64_t)(i - 1);
+  if (o.decimate > 1) {
+    if (r % o.decimate != 0) return;
+    r /= o.decimate;
+  }
+  const int64_t off = (r - o.row0) * o.t_stride + p;
+  const double miss = R4(-9999.0); /* src/Initialization.f90:404-411 */
+  o.tsurf[off] = valid ? s.tsurf : miss;
+  o.snow[off] = valid ? s.snow : miss;
+  o.water[off] = valid ? s.wat : miss;
+  o.ice[off] = valid ? s.ice : miss;
+  o.deposit[off] = valid ? s.dep : miss;
+  o.ice2[off] = valid ? s.ice2 : miss;
+}
+
+/* The time loop of runsimulation (examples/example1/src/Simulation.f90:57-115)
+ * for one point over absolute indices [t0, t0+nsteps). */
+template <bool FULL, class Prof>
+__device__ __forceinline__ void time_loop(const StepArgs &a, int64_t p, Prof &T, Scalars &s) {
+  int32_t slot = a.cslot;
+  const RsConstants &c0 = g_consts[slot];
+  const double tbot = a.pp.tbottom[p];
+  int32_t initlen = 0;
+  bool relax = false;
+  double tairR = 0, vzR = 0, rhR = 0;
+  if (FULL) {
+    initlen = a.pp.initlen ? a.pp.initlen[p] : 0;
+    if (c0.use_relaxation && a.pp.tair_relax) {
+      /* setInputParam, src/InputOutput.f90:19-26: targets pass through REAL(4) */
+      tairR = (double)(float)a.pp.tair_relax[p];
+      vzR = (double)(float)a.pp.vz_relax[p];
+      rhR = (double)(float)a.pp.rh_relax[p];
+      relax = !(tairR < R4(-100.0) || tairR > R4(100.0) || vzR < R4(0.0) || vzR > R4(100.0) ||
+                rhR < R4(0.0) || rhR > 110);
+    }
+  }
+
+  Forcing nxt = load_forcing<FULL>(a.f, 0, p, 0);
+  for (int32_t k = 0; k < a.nsteps; ++k) {
+    asm volatile("" : "+s"(slot));
+    const RsConstants &c = g_consts[slot];
+    const int32_t i = a.t0 + k;
+    Forcing f = nxt;
+    if (k + 1 < a.nsteps) nxt = load_forcing<FULL>(a.f, (int64_t)(k + 1) * a.f.t_stride, p, k + 1);
+
+    if (s.failed) { /* loop has exited in the reference: outputs stay -9999.0 */
+      store_outputs(a.o, i, p, s, false);
+      continue;
+    }
+    double tair = f.tair, vz = f.vz, rhz = f.rhz;
+    /* src/Initialization.f90:121-123: VZ(1) is raised to 0.4 in the input array */
+    if (i == 1 && vz < R4(0.4)) vz = R4(0.4);
+    const double prec_ts = f.prec / 3600 * c.DTSecs; /* src/InputOutput.f90:111,186 */
+
+    if (i < c.SimLen) {
+      Forcing chk = f;
+      chk.vz = vz;
+      if (check_values(chk, s.tsurf, FULL && a.f.tdew != nullptr)) s.failed = true;
+      if (FULL) {
+        /* SetCurrentValues obs forcing, src/InputOutput.f90:116-148 */
+        if ((i <= initlen || c.force_tsurf) && f.tsurfobs > R4(-100.0)) {
+          T.set(1, f.tsurfobs);
+          T.set(2, f.tsurfobs);
+          const double depth = (c.tsurfOutputDepth >= R4(0.0)) ? c.tsurfOutputDepth : f.depth;
+          s.tsurf = surface_temperature(c, T, tbot, depth);
+        }
+        /* RelaxationOperations, src/Relaxation.f90:10-47 */
+        if (relax) {
+          if (i == initlen) {
+            s.tair_end = tair;
+            s.vz_end = vz;
+            s.rh_end = rhz;
+          }
+          if (i > initlen) {
+            const double den = (double)(4.f * 3600.f);
+            const double e = rs_exp(-((c.DTSecs * i) - (c.DTSecs * initlen)) / den);
+            tair = tair - (tairR - s.tair_end) * e;
+            vz = vz - (vzR - s.vz_end) * e;
+            rhz = rhz - (rhR - s.rh_end) * e;
+            if (rhz > R4(100.)) rhz = R4(100.0);
+          }
+        }
+      }
+    } else {
+      /* lastValues, src/InputOutput.f90:169-198: no checks, no obs forcing, no
+       * relaxation; the pre-step surface temperature uses depth(SimLen) only */
+      if (FULL) s.tsurf = surface_temperature(c, T, tbot, f.depth);
+    }
+    model_step(c, s, T, tbot, tair, vz, rhz, prec_ts, f.sw, f.lw, f.phase, f.hour, f.depth);
+    store_outputs(a.o, i, p, s, true);
+  }
+}
+
+template <int NL, bool FULL>
+__global__ void __launch_bounds__(kBlock) step_kernel_reg(const StepArgs a) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= a.npoints) return;
+  RegProfile<NL> T;
+  Scalars s;
+  load_state(a.state, a.np_pad, p, T, s);
+  time_loop<FULL>(a, p, T, s);
+  store_state(a.state, a.np_pad, p, T, s);
+}
+
+template <bool FULL>
+__global__ void __launch_bounds__(kBlock) step_kernel_lds(const StepArgs a) {
+  extern __shared__ double lds[]; /* [NLayers][kBlock] */
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= a.npoints) return; /* no barriers below: each lane owns its column */
+  LdsProfile T{lds + threadIdx.x, g_consts[a.cslot].NLayers};
+  Scalars s;
+  load_state(a.state, a.np_pad, p, T, s);
+  time_loop<FULL>(a, p, T, s);
+  store_state(a.state, a.np_pad, p, T, s);
+}
+
+/* Device part of Initialization (src/Initialization.f90:65-147): initial
+ * profile (initTemp :238-287), surface state (initSurf :290-308), T4Melt
+ * (condInit :518), albedo (InitParam :339).  The first CalcBLCondAndLE call
+ * (:138-139) and the first CalcHCapHCond (:109) only produce values that are
+ * overwritten before they are read, so they are not executed. */
+__global__ void __launch_bounds__(kBlock) init_kernel(const InitArgs a) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= a.npoints) return;
+  const RsConstants &c = g_consts[a.cslot];
+  const int N = c.NLayers;
+  const double tair = a.f.tair[p];
+  const double tobs = a.f.tsurfobs ? a.f.tsurfobs[p] : R4(-9999.9);
+  const double depth = a.f.depth ? a.f.depth[p] : R4(-9999.9);
+  const double tbot = a.pp.tbottom[p];
+  const double t4 = (tobs > -100) ? tobs : tair;
+  const int64_t np = a.np_pad;
+  double *st = a.state;
+  for (int i = 1; i <= 4; ++i) st[(int64_t)(RS_ST_TMP0 + i - 1) * np + p] = t4;
+  for (int i = 5; i <= N; ++i)
+    st[(int64_t)(RS_ST_TMP0 + i - 1) * np + p] =
+        t4 + (tbot - t4) / (c.ZDpth[N + 1] - c.ZDpth[4]) * (c.ZDpth[i] - c.ZDpth[4]);
+  for (int i = N + 1; i <= RS_MAX_LAYERS; ++i) st[(int64_t)(RS_ST_TMP0 + i - 1) * np + p] = 0.0;
+  double tsurf;
+  if (depth >= 0) {
+    /* getTempAtDepth on the fresh profile, src/Initialization.f90:129-136 */
+    if (fabs(depth - R4(0.0)) < R4(0.00001)) {
+      tsurf = t4;
+    } else if (depth > c.ZDpth[N + 1]) {
+      tsurf = tbot;
+    } else {
+      tsurf = 0.0;
+      for (int k = 1; k <= N; ++k) {
+        if (depth > c.ZDpth[k] && depth <= c.ZDpth[k + 1]) {
+          const double tk = st[(int64_t)(RS_ST_TMP0 + k - 1) * np + p];
+          const double tk1 = (k == N) ? tbot : st[(int64_t)(RS_ST_TMP0 + k) * np + p];
+          tsurf = tk + (depth - c.ZDpth[k]) * (tk1 - tk) / (c.ZDpth[k + 1] - c.ZDpth[k]);
+          break;
+        }
+      }
+    }
+  } else {
+    tsurf = (t4 + t4) / R4(2.0);
+  }
+  st[(int64_t)RS_ST_TNW1 * np + p] = t4;
+  st[(int64_t)RS_ST_TNW2 * np + p] = t4;
+  st[(int64_t)RS_ST_TSURF * np + p] = tsurf;
+  st[(int64_t)RS_ST_WAT * np + p] = R4(0.0);
+  st[(int64_t)RS_ST_SNOW * np + p] = R4(0.0);
+  st[(int64_t)RS_ST_ICE * np + p] = R4(0.0);
+  st[(int64_t)RS_ST_ICE2 * np + p] = R4(0.0);
+  st[(int64_t)RS_ST_DEP * np + p] = R4(0.0);
+  st[(int64_t)RS_ST_Q2MELT * np + p] = R4(0.0);
+  st[(int64_t)RS_ST_T4MELT * np + p] = c.T4Melt0;
+  st[(int64_t)RS_ST_ALBEDO * np + p] = c.Albedo0;
+  st[(int64_t)RS_ST_VERYCOLD * np + p] = 0.0;
+  st[(int64_t)RS_ST_FAILED * np + p] = 0.0;
+  st[(int64_t)RS_ST_TAIR_END * np + p] = R4(-99.9); /* src/Initialization.f90:377-379 */
+  st[(int64_t)RS_ST_VZ_END * np + p] = R4(-99.9);
+  st[(int64_t)RS_ST_RH_END * np + p] = R4(-99.9);
+}
+
+/* Hourly knots of the synthetic workload, [knot][RS_KNOT_FIELDS][np_pad]. */
+__global__ void __launch_bounds__(kBlock) synth_knots_kernel(const KnotArgs a) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= a.npoints) return;
+  const int32_t k = a.k0 + blockIdx.y;
+  const RsSynthKnot q = rs_sy_knot(a.spec.seed, a.spec.point_offset + p, k, a.spec.start_hour);
+  double *base = a.knots + ((int64_t)blockIdx.y * RS_KNOT_FIELDS) * a.np_pad + p;
+  base[0 * a.np_pad] = q.tair;
+  base[1 * a.np_pad] = q.tdew;
+  base[2 * a.np_pad] = q.vz;
+  base[3 * a.np_pad] = q.rhz;
+  base[4 * a.np_pad] = q.prec;
+  base[5 * a.np_pad] = q.sw;
+  base[6 * a.np_pad] = q.lw;
+  base[7 * a.np_pad] = q.tsurf0;
+  base[8 * a.np_pad] = (double)q.phase;
+}
+
+/* Knots -> step resolution, the device twin of the reference driver's
+ * interpolation (examples/example1/src/JsonSource.cpp:115-172): linear between
+ * knots, PrecPhase from the later knot.  Pure streaming: reads two knot rows
+ * per field, writes nsteps rows. blockIdx.y = local time index. */
+__global__ void __launch_bounds__(kBlock) expand_kernel(const ExpandArgs a) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= a.npoints) return;
+  const int32_t tl = blockIdx.y;
+  const int32_t i = a.t0 + tl;
+  const int32_t t = i - 1;
+  const int32_t k = t / a.spk, r = t - k * a.spk;
+  const double *ka = a.knots + ((int64_t)(k - a.k0) * RS_KNOT_FIELDS) * a.np_pad + p;
+  const double *kb = ka + (int64_t)RS_KNOT_FIELDS * a.np_pad;
+  const int64_t off = (int64_t)tl * a.f.t_stride + p;
+  double *out[7] = {(double *)a.f.tair, (double *)a.f.tdew, (double *)a.f.vz, (double *)a.f.rhz,
+                    (double *)a.f.prec, (double *)a.f.sw, (double *)a.f.lw};
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    if (!out[q]) continue;
+    const double v0 = ka[(int64_t)q * a.np_pad];
+    out[q][off] = (r == 0) ? v0 : rs_sy_lerp(v0, kb[(int64_t)q * a.np_pad], r, a.spk);
+  }
+  if (a.f.tsurfobs) ((double *)a.f.tsurfobs)[off] = (i == 1) ? ka[7 * a.np_pad] : -9999.9;
+  if (a.f.depth) ((double *)a.f.depth)[off] = -9999.9;
+  ((int32_t *)a.f.precphase)[off] =
+      (int32_t)((r == 0) ? ka[8 * a.np_pad] : kb[8 * a.np_pad]);
+  if (p == 0 && !a.f.hour_pstride) ((int32_t *)a.f.hour)[tl] = rs_sy_hour(i, a.spk, a.start_hour);
+}
+
+__global__ void __launch_bounds__(kBlock) count_failed_kernel(const double *st, int64_t np_pad,
+                                                              int64_t npoints,
+                                                              unsigned long long *out) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool bad = p < npoints && st[(int64_t)RS_ST_FAILED * np_pad + p] != 0.0;
+  const unsigned long long m = __ballot(bad);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+}
+
+}  // namespace rs
+
+/* ---- launchers (host) --------------------------------------------------- */
+
+static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + RS_BLOCK - 1) / RS_BLOCK)); }
+
+hipError_t rs_upload_constants(int slot, const RsConstants *c, hipStream_t stream) {
+  if (slot < 0 || slot >= RS_CONST_SLOTS) return hipErrorInvalidValue;
+  return hipMemcpyToSymbolAsync(HIP_SYMBOL(rs::g_consts), c, sizeof(RsConstants),
+                                (size_t)slot * sizeof(RsConstants), hipMemcpyHostToDevice, stream);
+}
+
+hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
+                          hipStream_t stream) {
+  const dim3 g = grid_for(a.npoints), b(RS_BLOCK);
+  if (variant == RS_VARIANT_AUTO) variant = (NL == 15) ? RS_VARIANT_REG : RS_VARIANT_LDS;
+  if (variant == RS_VARIANT_REG) {
+    if (NL != 15) return hipErrorInvalidValue;
+    if (full)
+      hipLaunchKernelGGL((rs::step_kernel_reg<15, true>), g, b, 0, stream, a);
+    else
+      hipLaunchKernelGGL((rs::step_kernel_reg<15, false>), g, b, 0, stream, a);
+  } else {
+    const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
+    if (full)
+      hipLaunchKernelGGL((rs::step_kernel_lds<true>), g, b, lds, stream, a);
+    else
+      hipLaunchKernelGGL((rs::step_kernel_lds<false>), g, b, lds, stream, a);
+  }
+  return hipGetLastError();
+}
+
+hipError_t rs_launch_init(const rs::InitArgs &a, hipStream_t stream) {
+  hipLaunchKernelGGL(rs::init_kernel, grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t rs_launch_knots(const rs::KnotArgs &a, int32_t nknots, hipStream_t stream) {
+  dim3 g = grid_for(a.npoints);
+  g.y = (unsigned)nknots;
+  hipLaunchKernelGGL(rs::synth_knots_kernel, g, dim3(RS_BLOCK), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t rs_launch_expand(const rs::ExpandArgs &a, int32_t nsteps, hipStream_t stream) {
+  dim3 g = grid_for(a.npoints);
+  g.y = (unsigned)nsteps;
+  hipLaunchKernelGGL(rs::expand_kernel, g, dim3(RS_BLOCK), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t rs_launch_count_failed(const double *st, int64_t np_pad, int64_t npoints,
+                                  unsigned long long *out, hipStream_t stream) {
+  hipLaunchKernelGGL(rs::count_failed_kernel, grid_for(npoints), dim3(RS_BLOCK), 0, stream, st,
+                     np_pad, npoints, out);
+  return hipGetLastError();
+}

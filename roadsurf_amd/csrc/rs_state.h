@@ -1,0 +1,37 @@
+/*
+ * rs_state.h — layout of the per-point carried state in HBM.
+ *
+ * state[slot * npoints_padded + p], doubles.  Slots 0..RS_MAX_LAYERS-1 hold the
+ * ground temperature profile Tmp(1..NLayers) (reference: ground%Tmp,
+ * src/GroundVariables.f90.inc); the named slots hold what SURVEY.md Appendix B
+ * lists as the state that must persist across time steps.  Everything else the
+ * reference keeps in its derived types is either constant (RsConstants) or
+ * recomputed every step.
+ */
+#ifndef RS_STATE_H
+#define RS_STATE_H
+
+#include "../../include/roadsurf.h"
+
+enum RsStateSlot {
+  RS_ST_TMP0 = 0,                /* Tmp(1) ... Tmp(NLayers) at slots 0..NLayers-1 */
+  RS_ST_TNW1 = RS_MAX_LAYERS,    /* TmpNw(1): differs from Tmp(1) only after obs forcing */
+  RS_ST_TNW2,                    /* TmpNw(2)   (src/InputOutput.f90:122-124 vs BalanceModel.f90:215) */
+  RS_ST_TSURF,                   /* surf%TsurfAve */
+  RS_ST_WAT,                     /* surf%SrfWatmms */
+  RS_ST_SNOW,                    /* surf%SrfSnowmms */
+  RS_ST_ICE,                     /* surf%SrfIcemms */
+  RS_ST_ICE2,                    /* surf%SrfIce2mms */
+  RS_ST_DEP,                     /* surf%SrfDepmms */
+  RS_ST_Q2MELT,                  /* surf%Q2Melt */
+  RS_ST_T4MELT,                  /* surf%T4Melt */
+  RS_ST_ALBEDO,                  /* ground%Albedo */
+  RS_ST_VERYCOLD,                /* surf%VeryCold as 0.0/1.0 */
+  RS_ST_FAILED,                  /* settings%simulation_failed as 0.0/1.0 */
+  RS_ST_TAIR_END,                /* atm%TairInitEnd (relaxation) */
+  RS_ST_VZ_END,                  /* atm%VZInitEnd */
+  RS_ST_RH_END,                  /* atm%RhzInitEnd */
+  RS_NSTATE
+};
+
+#endif

@@ -1,0 +1,260 @@
+"""Device-resident driver of the HIP path (layer 1 of ``include/roadsurf.h``).
+
+PyTorch is plumbing here: it owns the HBM buffers (``torch.empty`` on the
+``cuda`` device), the stream and, in ``bench.py``, ``torch.distributed``.  All
+arithmetic happens in ``libroadsurf_hip.so``; tensors cross the boundary as raw
+device pointers.
+
+Layouts (points are the fastest axis, see ``include/roadsurf.h``)::
+
+    forcing / outputs   tensor[t, p]   shape [nsteps, npoints_padded]
+    per-point params    tensor[p]
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import torch
+
+from . import abi, lib
+
+F64_FORCING = ("tair", "tdew", "vz", "rhz", "prec", "sw", "lw", "tsurfobs", "depth")
+OUT_FIELDS = ("tsurf", "snow", "water", "ice", "deposit", "ice2")
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def require_gpu() -> None:
+    if not torch.cuda.is_available():
+        raise RuntimeError("roadsurf_amd needs a HIP device (torch.cuda.is_available() is False); "
+                           "there is no CPU path")
+
+
+@dataclass
+class ForcingWindow:
+    """Step-resolution forcing for ``nsteps`` consecutive time indices on the device."""
+    nsteps: int
+    t_stride: int
+    tensors: dict = field(default_factory=dict)  # name -> torch tensor or None
+    hour_per_point: bool = False
+
+    @classmethod
+    def empty(cls, nsteps: int, np_pad: int, device, optional=("tdew", "tsurfobs", "depth")):
+        t = {}
+        for n in F64_FORCING:
+            if n in ("tdew", "tsurfobs", "depth") and n not in optional:
+                t[n] = None
+            else:
+                t[n] = torch.empty((nsteps, np_pad), dtype=torch.float64, device=device)
+        t["precphase"] = torch.empty((nsteps, np_pad), dtype=torch.int32, device=device)
+        t["hour"] = torch.empty((nsteps,), dtype=torch.int32, device=device)
+        return cls(nsteps, np_pad, t)
+
+    def struct(self, row: int = 0) -> lib.RsForcing:
+        f = lib.RsForcing()
+        for n in F64_FORCING + ("precphase",):
+            t = self.tensors.get(n)
+            setattr(f, n, None if t is None else C.c_void_p(t[row].data_ptr()))
+        h = self.tensors["hour"]
+        f.hour = C.c_void_p(h[row].data_ptr())
+        f.t_stride = self.t_stride
+        f.hour_pstride = 1 if self.hour_per_point else 0
+        return f
+
+
+@dataclass
+class OutputWindow:
+    nrows: int
+    t_stride: int
+    tensors: dict
+    decimate: int = 1
+
+    @classmethod
+    def empty(cls, nrows: int, np_pad: int, device, decimate: int = 1):
+        t = {n: torch.empty((nrows, np_pad), dtype=torch.float64, device=device) for n in OUT_FIELDS}
+        return cls(nrows, np_pad, t, decimate)
+
+    def struct(self, row0: int) -> lib.RsOutputs:
+        o = lib.RsOutputs()
+        for n in OUT_FIELDS:
+            setattr(o, n, C.c_void_p(self.tensors[n].data_ptr()))
+        o.t_stride = self.t_stride
+        o.decimate = self.decimate
+        o.row0 = row0
+        return o
+
+
+class Plan:
+    """RAII wrapper of ``RsPlan``: one shard of points on one GPU, one stream."""
+
+    def __init__(self, npoints: int, settings: abi.InputSettings, params: abi.InputParameters,
+                 device: int | None = None, stream: torch.cuda.Stream | None = None):
+        require_gpu()
+        self.L = lib.load()
+        self.device_index = torch.cuda.current_device() if device is None else device
+        self.device = torch.device("cuda", self.device_index)
+        self.stream = stream or torch.cuda.current_stream(self.device)
+        self.settings, self.params = settings, params
+        self.consts = lib.build_constants(settings, params)
+        self.npoints = npoints
+        self._h = self.L.rs_hip_plan_create(self.device_index, npoints, C.byref(self.consts),
+                                            C.c_void_p(self.stream.cuda_stream))
+        if not self._h:
+            raise RuntimeError("rs_hip_plan_create failed: " + lib.last_error())
+        self.np_pad = int(self.L.rs_hip_plan_npoints_padded(self._h))
+        self._pp_keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.rs_hip_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    # -- per-point parameters -------------------------------------------------
+    def point_params(self, tbottom, initlen=None, tair_relax=None, vz_relax=None, rh_relax=None):
+        """tbottom: float (uniform) or tensor[np_pad]; others tensors or None."""
+        if not torch.is_tensor(tbottom):
+            tbottom = torch.full((self.np_pad,), float(tbottom), dtype=torch.float64,
+                                 device=self.device)
+        keep = (tbottom, initlen, tair_relax, vz_relax, rh_relax)
+        pp = lib.RsPointParams()
+        pp.tbottom = _ptr(tbottom)
+        pp.initlen = _ptr(initlen)
+        pp.tair_relax = _ptr(tair_relax)
+        pp.vz_relax = _ptr(vz_relax)
+        pp.rh_relax = _ptr(rh_relax)
+        self._pp_keep = keep
+        return pp
+
+    def uniform_tbottom(self, year=2024, month=1, day=10) -> float:
+        return lib.bottom_temperature(self.params, self.consts, year, month, day)
+
+    # -- kernels ----------------------------------------------------------------
+    def init_state(self, window: ForcingWindow, pp) -> None:
+        f = window.struct(0)
+        lib.check(self.L.rs_hip_init_state(self._h, C.byref(f), C.byref(pp)), "rs_hip_init_state")
+
+    def step(self, window: ForcingWindow, out: OutputWindow, pp, t0: int, nsteps: int,
+             window_row: int = 0, out_row0: int | None = None) -> None:
+        f = window.struct(window_row)
+        o = out.struct((t0 - 1 + out.decimate - 1) // out.decimate if out_row0 is None else out_row0)
+        lib.check(self.L.rs_hip_step(self._h, C.byref(f), C.byref(o), C.byref(pp), t0, nsteps),
+                  "rs_hip_step")
+
+    def set_variant(self, v: int) -> None:
+        lib.check(self.L.rs_hip_set_variant(self._h, v), "rs_hip_set_variant")
+
+    def sync(self) -> None:
+        lib.check(self.L.rs_hip_sync(self._h), "rs_hip_sync")
+
+    def failed_count(self) -> int:
+        return int(self.L.rs_hip_failed_count(self._h))
+
+    def timing_reset(self) -> None:
+        self.L.rs_hip_timing_reset(self._h)
+
+    def timing_step_ms(self):
+        n = C.c_int32(0)
+        ms = self.L.rs_hip_timing_step_ms(self._h, C.byref(n))
+        return float(ms), int(n.value)
+
+    def state(self) -> torch.Tensor:
+        """Carried state block as a host tensor [RS_NSTATE, np_pad]."""
+        nb = self.L.rs_hip_plan_state_bytes(self._h)
+        t = torch.empty((nb // 8 // self.np_pad, self.np_pad), dtype=torch.float64)
+        lib.check(self.L.rs_hip_state_download(self._h, C.c_void_p(t.data_ptr()), nb),
+                  "rs_hip_state_download")
+        return t
+
+    def load_state(self, t: torch.Tensor) -> None:
+        t = t.contiguous()
+        lib.check(self.L.rs_hip_state_upload(self._h, C.c_void_p(t.data_ptr()), t.numel() * 8),
+                  "rs_hip_state_upload")
+
+    # -- synthetic workload -----------------------------------------------------
+    def synth_knots(self, seed: int, nknots: int, point_offset: int = 0, steps_per_knot: int = 120,
+                    start_hour: int = 0):
+        spec = lib.RsSynthSpec(seed, point_offset, steps_per_knot, start_hour)
+        knots = torch.empty((nknots, lib.RS_KNOT_FIELDS, self.np_pad), dtype=torch.float64,
+                            device=self.device)
+        lib.check(self.L.rs_hip_synth_knots(self._h, C.byref(spec), C.c_void_p(knots.data_ptr()),
+                                            0, nknots), "rs_hip_synth_knots")
+        return spec, knots
+
+    def expand(self, spec, knots, window: ForcingWindow, t0: int, nsteps: int) -> None:
+        f = window.struct(0)
+        lib.check(self.L.rs_hip_expand_forcing(self._h, C.byref(spec), C.c_void_p(knots.data_ptr()),
+                                               0, knots.shape[0], C.byref(f), t0, nsteps),
+                  "rs_hip_expand_forcing")
+
+
+def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputParameters,
+               local, chunk: int = 0, variant: int = 0, device: int = 0,
+               lean_if_possible: bool = True, year_month_day=None):
+    """Run host arrays ``forcing[name][n, SimLen]`` (numpy, reference layout) through the
+    device-resident API and return outputs ``[n, SimLen]`` as numpy.  Test/bench helper:
+    transposes with torch on the device, windows of ``chunk`` steps (0 = whole series)."""
+    import numpy as np
+
+    require_gpu()
+    n, L = forcing["tair"].shape
+    assert L == settings.SimLen
+    dev = torch.device("cuda", device)
+    plan = Plan(n, settings, params, device)
+    if variant:
+        plan.set_variant(variant)
+    npad = plan.np_pad
+    if isinstance(local, abi.LocalParameters):
+        local = [local] * n
+    initlen = np.array([l.InitLenI for l in local], np.int32)
+    relax_on = settings.use_relaxation == 1
+    need_full = (not lean_if_possible) or initlen.max() > 1 or settings.force_tsurf == 1 or \
+        relax_on or settings.tsurfOutputDepth >= 0 or (forcing["depth"] >= 0).any()
+
+    def pad_t(a, dtype):  # [n, L] -> device [L, npad]
+        t = torch.zeros((L, npad), dtype=dtype, device=dev)
+        t[:, :n] = torch.from_numpy(np.ascontiguousarray(a)).to(dev).T
+        return t
+
+    tens = {k: pad_t(forcing[k], torch.float64) for k in ("tair", "vz", "rhz", "prec", "sw", "lw")}
+    tens["tsurfobs"] = pad_t(forcing["tsurfobs"], torch.float64)
+    for k in ("tdew", "depth"):
+        tens[k] = pad_t(forcing[k], torch.float64) if need_full else None
+    tens["precphase"] = pad_t(forcing["precphase"], torch.int32)
+    tens["hour"] = torch.from_numpy(np.ascontiguousarray(forcing["hour"])).to(dev)
+    win = ForcingWindow(L, npad, tens)
+    if year_month_day is None:
+        year_month_day = (int(forcing["year"][0]), int(forcing["month"][0]), int(forcing["day"][0]))
+    tb = plan.uniform_tbottom(*year_month_day)
+
+    def pp_vec(vals, dtype):
+        t = torch.zeros((npad,), dtype=dtype, device=dev)
+        t[:n] = torch.tensor(vals, dtype=dtype)
+        return t
+
+    if need_full:
+        pp = plan.point_params(
+            tb, pp_vec(initlen.tolist(), torch.int32),
+            pp_vec([l.tair_relax for l in local], torch.float64) if relax_on else None,
+            pp_vec([l.VZ_relax for l in local], torch.float64) if relax_on else None,
+            pp_vec([l.RH_relax for l in local], torch.float64) if relax_on else None)
+    else:
+        pp = plan.point_params(tb)
+    out = OutputWindow.empty(L, npad, dev)
+    plan.init_state(win, pp)
+    chunk = chunk or L
+    t0 = 1
+    while t0 <= L:
+        ns = min(chunk, L - t0 + 1)
+        plan.step(win, out, pp, t0, ns, window_row=t0 - 1, out_row0=0)
+        t0 += ns
+    plan.sync()
+    res = {k: out.tensors[k][:, :n].T.contiguous().cpu().numpy() for k in OUT_FIELDS}
+    nfail = plan.failed_count()
+    plan.close()
+    return res, nfail

@@ -1,0 +1,413 @@
+!> RoadSurfHip — Fortran host orchestration of the MI355X RoadSurf hot path.
+!!
+!! This module is the host side of the device boundary: it keeps the
+!! reference's own C-interop surface and calls the HIP kernels through an
+!! ISO_C_BINDING shim (roadsurf_amd/csrc/rs_api.hip, rs_host.hip):
+!!
+!!  * the five Bind(C) types of the boundary, field for field
+!!    (reference: src/InputPointers.f90.inc:4-27, src/OutputPointers.f90.inc:4-17,
+!!     src/InputSettings.f90.inc:4-18, src/InputParameters.f90.inc:4-91,
+!!     src/LocalParameters.f90.inc:4-15);
+!!  * `runsimulation`, the reference's only BIND(C) procedure
+!!    (examples/example1/src/Simulation.f90:4-6), same dummy arguments, now a
+!!    one-point call into the batched GPU path;
+!!  * `runsimulation_batch`, the many-point extension;
+!!  * `rs_build_constants` / `rs_bottom_temperature`: everything the reference
+!!    computes once per point in Initialization (src/Initialization.f90) that
+!!    is in fact uniform over points — layer grid, conductivities, the four
+!!    logarithms, REAL(4)-folded wear constants.  It is computed HERE, on the
+!!    host, by the same compiler family that builds the reference, so default
+!!    REAL literals, REAL(4) sub-expressions and `**` lower exactly as they do
+!!    there (SURVEY.md Appendix C); the kernels only ever see the doubles.
+!!
+!! The time loop itself, and every per-step subroutine of the reference's
+!! module RoadSurf, run on the device (roadsurf_amd/csrc/rs_physics.hpp).
+module RoadSurfHip
+   use, intrinsic :: iso_c_binding
+   implicit none
+   private
+
+   integer, parameter, public :: RS_MAX_LAYERS = 32
+
+   type, bind(C), public :: InputPointers
+      integer(c_int) :: inputLen
+      type(c_ptr) :: c_tair, c_tdew, c_VZ, c_Rhz, c_prec, c_SW, c_LW, c_SW_dir, c_LW_net
+      type(c_ptr) :: c_TSurfObs, c_PrecPhase, c_local_horizons, c_Depth
+      type(c_ptr) :: c_year, c_month, c_day, c_hour, c_minute, c_second
+   end type InputPointers
+
+   type, bind(C), public :: OutputPointers
+      integer(c_int) :: outputLen
+      type(c_ptr) :: c_TsurfOut, c_SnowOut, c_WaterOut, c_IceOut, c_DepositOut, c_Ice2Out
+   end type OutputPointers
+
+   type, bind(C), public :: InputSettings
+      integer(c_int) :: SimLen, use_coupling, use_relaxation, force_tsurf
+      real(c_double) :: DTSecs, tsurfOutputDepth
+      integer(c_int) :: NLayers, coupling_minutes
+      real(c_double) :: couplingEffectReduction
+      integer(c_int) :: outputStep
+   end type InputSettings
+
+   type, bind(C), public :: InputParameters
+      real(c_double) :: NightOn, NightOff, CalmLimDay, CalmLimNgt, TrfFricNgt, TrFfricDay
+      real(c_double) :: Grav, SB_Const, VK_Const, LVap, LFus, WatDens, SnowDens, IceDens
+      real(c_double) :: DepDens, WatMHeat, PorEvaF
+      real(c_double) :: ZRefW, ZRefT, ZeroDisp, ZMom, ZHeat, Emiss, Albedo
+      real(c_double) :: Albedo_surroundings, MaxPormms, TClimG, DampDpth, Omega, AZ, DampWearF
+      real(c_double) :: AlbDry, AlbSnow, vsh1, vsh2, Poro1, Poro2, RhoB1, RhoB2, Silt1, Silt2
+      real(c_double) :: freezing_limit_normal, snow_melting_limit_normal
+      real(c_double) :: ice_melting_limit_normal, frost_melting_limit_normal
+      real(c_double) :: frost_formation_limit_normal, T4Melt_normal
+      real(c_double) :: TLimColdH, TLimColdL, WetSnowFormR, WetSnowMeltR
+      real(c_double) :: PLimSnow, PLimRain, MaxSnowmms, MaxDepmms, MaxIcemms, MaxExtmms
+      real(c_double) :: MissValI, MissValR
+      real(c_double) :: Snow2IceFac
+      real(c_double) :: MinPrecmm, MinWatmms, MinSnowmms
+      real(c_double) :: MaxWatmms
+      real(c_double) :: WDampLim, WWetLim
+      real(c_double) :: WWearLim
+      real(c_double) :: MinDepmms, MinIcemms
+   end type InputParameters
+
+   type, bind(C), public :: LocalParameters
+      real(c_double) :: tair_relax, VZ_relax, RH_relax
+      integer(c_int) :: couplingIndexI
+      real(c_double) :: couplingTsurf, lat, lon, sky_view
+      integer(c_int) :: InitLenI
+   end type LocalParameters
+
+   !> Mirror of `RsConstants` in include/roadsurf.h (same order, same types).
+   type, bind(C), public :: RsConstants
+      integer(c_int) :: NLayers, SimLen, use_relaxation, force_tsurf
+      real(c_double) :: DTSecs, Tph, tsurfOutputDepth, twoDT
+      real(c_double) :: ZDpth(0:RS_MAX_LAYERS + 1)
+      real(c_double) :: DyC(0:RS_MAX_LAYERS + 1)
+      real(c_double) :: condDZ(0:RS_MAX_LAYERS + 1)
+      real(c_double) :: WCont(0:RS_MAX_LAYERS + 1)
+      real(c_double) :: dryCap(0:RS_MAX_LAYERS + 1)
+      real(c_double) :: HSfac1
+      real(c_double) :: logMom, logHeat, logCond, logUstar
+      real(c_double) :: VK_Const, ZRefT, Grav, LVap, LFus
+      real(c_double) :: Emiss, SB_Const, Albedo0
+      real(c_double) :: NightOn, NightOff, CalmLimDay, CalmLimNgt, TrfFricNgt, TrFfricDay
+      real(c_double) :: MaxPormms, MissValI, MinPrecmm, MinWatmms, MinSnowmms, MinDepmms
+      real(c_double) :: MinIcemms, MaxSnowmms, MaxDepmms, MaxIcemms, MaxWatmms, AlbDry, AlbSnow
+      real(c_double) :: WatDens, WatMHeat, PorEvaF, DampWearF, TLimFreeze, TLimMeltSnow
+      real(c_double) :: TLimMeltIce, TLimMeltDep, TLimDew, TLimColdH, TLimColdL, WetSnowFormR
+      real(c_double) :: WetSnowMeltR, PLimSnow, PLimRain, WWetLim, WWearLim, T4Melt0
+      real(c_double) :: wSnowTran, wSnow2Ice, wIce, wIce2, wDep, wWat
+   end type RsConstants
+
+   interface
+      !> C shim, roadsurf_amd/csrc/rs_host.hip
+      function rs_host_run_batch(n, outPointers, inPointers, consts, localParam, tbottom, device) &
+         bind(C, name='rs_host_run_batch') result(rc)
+         import :: c_int, c_double, OutputPointers, InputPointers, RsConstants, LocalParameters
+         integer(c_int), value :: n
+         type(OutputPointers), intent(inout) :: outPointers(*)
+         type(InputPointers), intent(in) :: inPointers(*)
+         type(RsConstants), intent(in) :: consts
+         type(LocalParameters), intent(in) :: localParam(*)
+         real(c_double), intent(in) :: tbottom(*)
+         integer(c_int), value :: device
+         integer(c_int) :: rc
+      end function rs_host_run_batch
+
+      subroutine rs_host_set_error(msg) bind(C, name='rs_host_set_error')
+         import :: c_char
+         character(kind=c_char), intent(in) :: msg(*)
+      end subroutine rs_host_set_error
+
+      function rs_host_default_device() bind(C, name='rs_host_default_device') result(dev)
+         import :: c_int
+         integer(c_int) :: dev
+      end function rs_host_default_device
+   end interface
+
+   public :: rs_build_constants, rs_bottom_temperature, runsimulation, runsimulation_batch
+
+contains
+
+   !> Day of year, 1 January = 1 (restates src/BalanceModel.f90:325-351).
+   pure integer function day_of_year(year, month, day) result(doy)
+      integer, intent(in) :: year, month, day
+      integer, parameter :: before(12) = [0, 31, 59, 90, 120, 151, 181, 212, 243, 273, 304, 334]
+      integer :: leap
+      leap = 1 - min(mod(year, 4), 1) + min(mod(year, 100), 1) - min(mod(year, 400), 1)
+      doy = before(month) + day
+      if (month > 2) doy = doy + leap
+   end function day_of_year
+
+   !> Uniform model constants (see include/roadsurf.h, RsConstants).
+   subroutine rs_build_constants(inSettings, inputParam, c, status) bind(C, name='rs_build_constants')
+      type(InputSettings), intent(in) :: inSettings
+      type(InputParameters), intent(in) :: inputParam
+      type(RsConstants), intent(out) :: c
+      integer(c_int), intent(out) :: status
+
+      integer :: n, k
+      real(8) :: zadd, thick, cond
+      real(8) :: a1, b1, c1, d1, a2, b2, c2, d2, efc
+
+      status = 0
+      n = inSettings%NLayers
+      if (n < 5 .or. n > RS_MAX_LAYERS) then
+         status = -1
+         return
+      end if
+      if (inSettings%SimLen < 1 .or. .not. (inSettings%DTSecs > 0.0d0)) then
+         status = -1
+         return
+      end if
+
+      c%NLayers = n
+      c%SimLen = inSettings%SimLen
+      c%use_relaxation = merge(1, 0, inSettings%use_relaxation == 1)
+      c%force_tsurf = merge(1, 0, inSettings%force_tsurf == 1)
+      c%DTSecs = inSettings%DTSecs
+      c%Tph = inSettings%DTSecs/3600.0          ! src/Initialization.f90:92
+      c%tsurfOutputDepth = inSettings%tsurfOutputDepth
+      c%twoDT = 2.0*inSettings%DTSecs           ! src/BalanceModel.f90:241
+
+      c%ZDpth = 0.0d0; c%DyC = 0.0d0; c%condDZ = 0.0d0; c%WCont = 0.0d0; c%dryCap = 0.0d0
+
+      ! layer interfaces: thickness grows geometrically (src/Initialization.f90:217-235).
+      ! The growth term is a default-REAL expression and must stay one.
+      zadd = 0.02
+      c%ZDpth(1) = 0.0
+      do k = 1, n
+         c%ZDpth(k + 1) = c%ZDpth(k) + 0.0103*1.4**(k - 1) + zadd
+      end do
+
+      ! node spacings (src/Initialization.f90:193-205)
+      c%DyC(1) = (c%ZDpth(2) - c%ZDpth(1))/2.0
+      do k = 2, n
+         c%DyC(k) = (c%ZDpth(k + 1) - c%ZDpth(k - 1))/2.0
+      end do
+      c%HSfac1 = c%ZDpth(2) - c%ZDpth(1)
+
+      ! water content and dry heat capacity per layer: two materials, the top
+      ! two layers are asphalt (src/Initialization.f90:207-213, src/BalanceModel.f90:232-236)
+      do k = 1, n
+         if (k <= 2) then
+            c%WCont(k) = 0.01
+            c%dryCap(k) = (1.0 - inputParam%Poro1)*inputParam%vsh1
+         else
+            c%WCont(k) = 0.3
+            c%dryCap(k) = (1.0 - inputParam%Poro2)*inputParam%vsh2
+         end if
+      end do
+
+      ! conductivity (Campbell 1985) -> condDZ, constant in time
+      ! (src/BalanceModel.f90:158-186, 254-279, 145-151)
+      a1 = 0.65 - 0.78*inputParam%RhoB1 + 0.60*inputParam%RhoB1*inputParam%RhoB1
+      b1 = 1.06*inputParam%RhoB1
+      if (inputParam%Silt1 > 0.00001) then
+         c1 = 1 + 2.6/sqrt(inputParam%Silt1)
+      else
+         c1 = 0.
+      end if
+      d1 = 0.03 + 0.1*inputParam%RhoB1*inputParam%RhoB1
+      a2 = 0.65 - 0.78*inputParam%RhoB2 + 0.60*inputParam%RhoB2*inputParam%RhoB2
+      b2 = 1.06*inputParam%RhoB2
+      if (inputParam%Silt2 > 0.00001) then
+         c2 = 1 + 2.6/sqrt(inputParam%Silt2)
+      else
+         c2 = 0.
+      end if
+      d2 = 0.03 + 0.1*inputParam%RhoB2*inputParam%RhoB2
+      efc = 4
+      do k = 1, n
+         thick = c%ZDpth(k + 1) - c%ZDpth(k)
+         if (k <= 2) then
+            cond = a1 + b1*c%WCont(k) - (a1 - d1)*exp(-(c1*c%WCont(k))**efc)
+         else
+            cond = a2 + b2*c%WCont(k) - (a2 - d2)*exp(-(c2*c%WCont(k))**efc)
+         end if
+         c%condDZ(k) = -(cond/thick)
+      end do
+
+      ! boundary layer logarithms (src/Initialization.f90:330-337)
+      c%logMom = log((inputParam%ZRefW + inputParam%ZMom)/inputParam%ZMom)
+      c%logHeat = log((inputParam%ZRefW + inputParam%ZHeat)/inputParam%ZHeat)
+      c%logCond = log((inputParam%ZRefW - inputParam%ZeroDisp + inputParam%ZHeat)/inputParam%ZHeat)
+      c%logUstar = log((inputParam%ZRefW - inputParam%ZeroDisp + inputParam%ZMom)/inputParam%ZMom)
+      c%VK_Const = inputParam%VK_Const
+      c%ZRefT = inputParam%ZRefT
+      c%Grav = inputParam%Grav
+      c%LVap = inputParam%LVap
+      c%LFus = inputParam%LFus
+      c%Emiss = inputParam%Emiss
+      c%SB_Const = inputParam%SB_Const
+      c%Albedo0 = inputParam%Albedo
+
+      c%NightOn = inputParam%NightOn
+      c%NightOff = inputParam%NightOff
+      c%CalmLimDay = inputParam%CalmLimDay
+      c%CalmLimNgt = inputParam%CalmLimNgt
+      c%TrfFricNgt = inputParam%TrfFricNgt
+      c%TrFfricDay = inputParam%TrFfricDay
+
+      ! storage thresholds (src/Initialization.f90:479-557)
+      c%MaxPormms = inputParam%MaxPormms
+      c%MissValI = inputParam%MissValI
+      c%MinPrecmm = inputParam%MinPrecmm
+      c%MinWatmms = inputParam%MinWatmms
+      c%MinSnowmms = inputParam%MinSnowmms
+      c%MinDepmms = inputParam%MinDepmms
+      c%MinIcemms = inputParam%MinIcemms
+      c%MaxSnowmms = inputParam%MaxSnowmms
+      c%MaxDepmms = inputParam%MaxDepmms
+      c%MaxIcemms = inputParam%MaxIcemms
+      c%MaxWatmms = inputParam%MaxWatmms
+      c%AlbDry = inputParam%AlbDry
+      c%AlbSnow = inputParam%AlbSnow
+      c%WatDens = inputParam%WatDens
+      c%WatMHeat = inputParam%WatMHeat
+      c%PorEvaF = inputParam%PorEvaF
+      c%DampWearF = inputParam%DampWearF
+      c%TLimFreeze = inputParam%freezing_limit_normal
+      c%TLimMeltSnow = inputParam%snow_melting_limit_normal
+      c%TLimMeltIce = inputParam%ice_melting_limit_normal
+      c%TLimMeltDep = inputParam%frost_melting_limit_normal
+      c%TLimDew = inputParam%frost_formation_limit_normal
+      c%TLimColdH = inputParam%TLimColdH
+      c%TLimColdL = inputParam%TLimColdL
+      c%WetSnowFormR = inputParam%WetSnowFormR
+      c%WetSnowMeltR = inputParam%WetSnowMeltR
+      c%PLimSnow = inputParam%PLimSnow
+      c%PLimRain = inputParam%PLimRain
+      c%WWetLim = inputParam%WWetLim
+      c%WWearLim = inputParam%WWearLim
+      c%T4Melt0 = inputParam%T4Melt_normal
+
+      ! traffic wear coefficients: default-REAL constant expressions
+      ! (src/Cond.f90:78,86,89,92,96,100)
+      c%wSnowTran = (0.2 + 0.25)
+      c%wSnow2Ice = 0.25/(0.2 + 0.25)
+      c%wIce = 1.1*2.0*0.145
+      c%wIce2 = 1.1*2.0*(4.0*0.290)
+      c%wDep = 0.5*2.0*(4.0*0.290)
+      c%wWat = 0.145
+   end subroutine rs_build_constants
+
+   !> Climatological bottom-boundary temperature Tmp(NLayers+1) for a start date
+   !! (src/Initialization.f90:266-268).
+   function rs_bottom_temperature(inputParam, c, year, month, day) &
+      bind(C, name='rs_bottom_temperature') result(tb)
+      type(InputParameters), intent(in) :: inputParam
+      type(RsConstants), intent(in) :: c
+      integer(c_int), value :: year, month, day
+      real(c_double) :: tb
+      integer :: juld
+      juld = day_of_year(int(year), int(month), int(day))
+      tb = inputParam%TClimG + inputParam%AZ*sin(inputParam%Omega*juld + &
+                                                  inputParam%Omega*(-170) - (c%ZDpth(c%NLayers + 1)/inputParam%DampDpth))
+   end function rs_bottom_temperature
+
+   subroutine fail(msg, status, code)
+      character(len=*), intent(in) :: msg
+      integer(c_int), intent(out) :: status
+      integer, intent(in) :: code
+      call rs_host_set_error(trim(msg)//c_null_char)
+      status = code
+   end subroutine fail
+
+   !> n independent points, shared settings/parameters.  status = 0 on success.
+   subroutine runsimulation_batch(n, outPointers, inPointers, inSettings, inputParam, localParam, status) &
+      bind(C, name='runsimulation_batch')
+      integer(c_int), value :: n
+      type(OutputPointers), intent(inout) :: outPointers(n)
+      type(InputPointers), intent(in) :: inPointers(n)
+      type(InputSettings), intent(in) :: inSettings
+      type(InputParameters), intent(in) :: inputParam
+      type(LocalParameters), intent(in) :: localParam(n)
+      integer(c_int), intent(out) :: status
+
+      type(RsConstants) :: consts
+      real(c_double), allocatable :: tbottom(:)
+      integer(c_int), pointer :: yy(:), mm(:), dd(:)
+      real(c_double), pointer :: vz(:)
+      integer :: p
+      integer(c_int) :: rc
+
+      status = 0
+      if (n < 1) return
+      call rs_build_constants(inSettings, inputParam, consts, rc)
+      if (rc /= 0) then
+         call fail('runsimulation_batch: bad settings (NLayers in 5..32, SimLen >= 1, DTSecs > 0)', status, -1)
+         return
+      end if
+
+      do p = 1, n
+         ! coupling switches itself off without a usable observation
+         ! (src/InputOutput.f90:34-36); a usable one needs the coupling replay,
+         ! which is not on the device yet (SURVEY.md 8f rank 2)
+         if (inSettings%use_coupling == 1 .and. .not. (localParam(p)%couplingTsurf < -100 .or. &
+                                                         localParam(p)%couplingIndexI < 1)) then
+            call fail('runsimulation_batch: coupling (use_coupling=1 with a valid observation) is not supported yet', &
+                      status, -2)
+            return
+         end if
+         if (localParam(p)%sky_view < 1.0 .and. localParam(p)%sky_view > -0.01) then
+            call fail('runsimulation_batch: sky-view radiation (0 <= sky_view < 1) is not supported yet', status, -3)
+            return
+         end if
+         if (inPointers(p)%inputLen < inSettings%SimLen .or. outPointers(p)%outputLen < inSettings%SimLen) then
+            call fail('runsimulation_batch: inputLen/outputLen shorter than SimLen', status, -4)
+            return
+         end if
+      end do
+
+      allocate (tbottom(n))
+      do p = 1, n
+         call c_f_pointer(inPointers(p)%c_year, yy, [1])
+         call c_f_pointer(inPointers(p)%c_month, mm, [1])
+         call c_f_pointer(inPointers(p)%c_day, dd, [1])
+         tbottom(p) = rs_bottom_temperature(inputParam, consts, yy(1), mm(1), dd(1))
+         ! the reference raises VZ(1) to 0.4 in the caller's array
+         ! (src/Initialization.f90:121-123); keep that visible side effect
+         call c_f_pointer(inPointers(p)%c_VZ, vz, [1])
+         if (vz(1) < 0.4) vz(1) = 0.4
+      end do
+
+      rc = rs_host_run_batch(n, outPointers, inPointers, consts, localParam, tbottom, rs_host_default_device())
+      if (rc /= 0) status = rc
+      deallocate (tbottom)
+   end subroutine runsimulation_batch
+
+   !> Drop-in for the reference's runsimulation (examples/example1/src/Simulation.f90:4-117).
+   !! No status argument, as in the reference: on a device/runtime error the
+   !! outputs are left at -9999.0 and the message goes to standard error.
+   subroutine runsimulation(outPointers, inPointers, inSettings, inputParam, localParam) &
+      bind(C, name='runsimulation')
+      type(OutputPointers), intent(inout) :: outPointers
+      type(InputPointers), intent(in) :: inPointers
+      type(InputSettings), intent(in) :: inSettings
+      type(InputParameters), intent(in) :: inputParam
+      type(LocalParameters), intent(in) :: localParam
+      type(OutputPointers) :: o(1)
+      type(InputPointers) :: i(1)
+      type(LocalParameters) :: l(1)
+      integer(c_int) :: status
+      real(c_double), pointer :: arr(:)
+      integer :: k
+      o(1) = outPointers
+      i(1) = inPointers
+      l(1) = localParam
+      call runsimulation_batch(1_c_int, o, i, inSettings, inputParam, l, status)
+      if (status /= 0) then
+         write (0, *) 'runsimulation (HIP): failed with status ', status
+         ! src/Initialization.f90:397-412: unwritten outputs read -9999.0
+         call c_f_pointer(outPointers%c_TsurfOut, arr, [outPointers%outputLen]); arr = -9999.0
+         call c_f_pointer(outPointers%c_SnowOut, arr, [outPointers%outputLen]); arr = -9999.0
+         call c_f_pointer(outPointers%c_WaterOut, arr, [outPointers%outputLen]); arr = -9999.0
+         call c_f_pointer(outPointers%c_IceOut, arr, [outPointers%outputLen]); arr = -9999.0
+         call c_f_pointer(outPointers%c_DepositOut, arr, [outPointers%outputLen]); arr = -9999.0
+         call c_f_pointer(outPointers%c_Ice2Out, arr, [outPointers%outputLen]); arr = -9999.0
+      end if
+      k = 0
+   end subroutine runsimulation
+
+end module RoadSurfHip
