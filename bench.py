@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the RoadSurf hot path on MI355X.
+
+Metric (BASELINE.json): point-timesteps/s at 1 M points x 48 h, fp64.
+
+One bench "step" = one full pass of the hot path over the workload:
+    init kernel  ->  for every time chunk:  expand kernel (hourly knots -> DTSecs
+    grid, the device twin of the reference driver's interpolation)  ->  step
+    kernel (the model: 5 761 time indices per point in all).
+Inputs resident in HBM before the timed region: the hourly forcing knots of every
+point (what an NWP source delivers).  Step-resolution forcing for 1 M points x
+5 761 indices is 300 GB (> 288 GB HBM), so it is produced per chunk
+on the device and consumed from HBM by the step kernel; the six outputs are
+written every time index (reference SaveOutput semantics) into a chunk buffer.
+
+Multi-GPU: one process per GPU (torch.distributed.run), points sharded with no
+data-path collective; the only collectives are the timing barrier and the MAX
+over ranks.  Weak scaling: every GPU gets --points points.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+ALGO_BYTES_PER_UNIT = 100.0    # 52 B read + 48 B written per point-timestep
+
+
+def cpu_baseline(sample_points: int, simlen: int, seed: int):
+    """Reference Fortran (oracle/_ref, kind 'reference') or, if absent, the C port,
+    OpenMP over points on this box's host cores, on a bounded sample of the workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_helpers as oh
+    from roadsurf_amd import abi
+
+    kind = "ref" if os.path.exists(oh.REF_SO) else "port"
+    s = abi.default_settings(simlen)
+    p = abi.default_parameters()
+    l = abi.default_local()
+    l.InitLenI = 1
+    f = oh.synth_forcing(sample_points, simlen, seed=seed)
+    oh.run_oracle(kind, {k: (v[:64] if v.ndim == 2 else v) for k, v in f.items()}, s, p, l)  # warm
+    t = time.perf_counter()
+    _, _, threads = oh.run_oracle(kind, f, s, p, l, copy_inputs=False)
+    dt = time.perf_counter() - t
+    return {
+        "value": sample_points * simlen / dt,
+        "unit": "point-timesteps/s",
+        "cores": int(threads),
+        "kind": "reference" if kind == "ref" else "port",
+        "sample": f"{sample_points} points x {simlen} time indices of the same synthetic workload "
+                  f"(seed {seed}), OpenMP over points, {dt:.2f} s wall",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--points", type=int, default=1_000_000, help="points per GPU")
+    ap.add_argument("--hours", type=int, default=48)
+    ap.add_argument("--chunk", type=int, default=240, help="time indices per step-kernel launch")
+    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 register profile, 2 LDS profile")
+    ap.add_argument("--seed", type=int, default=20240110)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4096)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from roadsurf_amd import abi, device
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    device.require_gpu()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    spk = 120                      # 3600 s / DTSecs 30 s
+    simlen = args.hours * spk + 1  # examples/example1/src/InputSettings.cpp:98
+    settings = abi.default_settings(simlen)
+    params = abi.default_parameters()
+    n = args.points
+    plan = device.Plan(n, settings, params, local_rank)
+    if args.variant:
+        plan.set_variant(args.variant)
+    npad = plan.np_pad
+    nknots = args.hours + 2
+    spec, knots = plan.synth_knots(args.seed, nknots, point_offset=rank * n, steps_per_knot=spk)
+    chunk = min(args.chunk, simlen)
+    win = device.ForcingWindow.empty(chunk, npad, dev, optional=())
+    out = device.OutputWindow.empty(chunk, npad, dev)
+    # index-1 window for the init kernel: needs TsurfObs(1)
+    win0 = device.ForcingWindow.empty(1, npad, dev, optional=("tsurfobs",))
+    pp = plan.point_params(plan.uniform_tbottom(2024, 1, 10))
+
+    def one_pass():
+        plan.expand(spec, knots, win0, 1, 1)
+        plan.init_state(win0, pp)
+        t0 = 1
+        while t0 <= simlen:
+            ns = min(chunk, simlen - t0 + 1)
+            plan.expand(spec, knots, win, t0, ns)
+            plan.step(win, out, pp, t0, ns, out_row0=t0 - 1)
+            t0 += ns
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        one_pass()
+    fence()
+    plan.timing_reset()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass()
+    fence()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    step_ms, nlaunch = plan.timing_step_ms()
+    nfail = plan.failed_count()
+
+    units_per_pass = n * simlen
+    value = world * units_per_pass * args.steps / elapsed
+    # dominant kernel: step kernel, HIP events on its own stream around every launch
+    avg_launch_s = step_ms / 1e3 / max(nlaunch, 1)
+    units_per_launch = units_per_pass * args.steps / max(nlaunch, 1)
+    achieved = ALGO_BYTES_PER_UNIT * units_per_launch / avg_launch_s / 1e9
+
+    if rank == 0:
+        line = {
+            "metric": "point_timesteps_per_s",
+            "value": value,
+            "unit": "point-timesteps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{n} synthetic points per GPU x {args.hours} h (SimLen {simlen}, "
+                            f"DTSecs 30, NLayers 15), fp64, outputs every time index",
+                "points_per_gpu": n,
+                "simlen": simlen,
+                "chunk_steps": chunk,
+                "kernel_variant": {0: "auto(reg15)", 1: "reg15", 2: "lds"}[args.variant],
+                "parallelism": f"points sharded over {world} GPU(s), no collectives",
+                "failed_points": int(nfail),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "rs::step_kernel_*",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "avg_launch_ms": avg_launch_s * 1e3,
+                "launches": nlaunch,
+                "units_per_launch": units_per_launch,
+                "step_kernel_only_value": units_per_pass * args.steps / (step_ms / 1e3),
+                "note": "fp64-VALU-bound kernel (SURVEY.md 8d): the HBM fraction is reported "
+                        "as the contract asks, the binding roofline is vector fp64 issue",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, simlen, args.seed)
+        print(json.dumps(line), flush=True)
+    plan.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
