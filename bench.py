@@ -168,7 +168,7 @@ def main() -> None:
                 "points_per_gpu": n,
                 "simlen": simlen,
                 "chunk_steps": chunk,
-                "kernel_variant": {0: "auto(reg15)", 1: "reg15", 2: "lds"}[args.variant],
+                "kernel_variant": args.variant,
                 "parallelism": f"points sharded over {world} GPU(s), no collectives",
                 "failed_points": int(nfail),
             },

@@ -194,8 +194,9 @@ size_t rs_hip_plan_state_bytes(const RsPlan *pl) {
 }
 
 int rs_hip_set_variant(RsPlan *pl, int32_t variant) {
-  if (!pl || variant < 0 || variant > 2) return set_err("rs_hip_set_variant: bad arguments");
-  if (variant == RS_VARIANT_REG && pl->c.NLayers != 15)
+  if (!pl || variant < 0 || variant % 10 > 2 || variant / 10 > 4)
+    return set_err("rs_hip_set_variant: bad arguments");
+  if (variant % 10 == RS_VARIANT_REG && pl->c.NLayers != 15)
     return set_err("register-profile kernel is built for NLayers == 15 only (got %d)",
                    pl->c.NLayers);
   pl->variant = variant;
@@ -385,7 +386,9 @@ int rs_hip_expand_forcing(RsPlan *pl, const RsSynthSpec *spec, const double *kno
   a.t0 = t0;
   a.spk = spk;
   a.start_hour = spec->start_hour;
-  HIP_OK(rs_launch_expand(a, nsteps, pl->stream));
+  a.kfirst = kfirst;
+  a.nsteps = nsteps;
+  HIP_OK(rs_launch_expand(a, (t0 + nsteps - 2) / spk - kfirst + 1, pl->stream));
   return 0;
 }
 

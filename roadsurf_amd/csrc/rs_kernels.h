@@ -41,6 +41,7 @@ struct ExpandArgs {
   const double *knots;
   int64_t npoints, np_pad;
   int32_t k0, t0, spk, start_hour;
+  int32_t kfirst, nsteps;
 };
 
 }  // namespace rs
@@ -50,6 +51,6 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
                           hipStream_t stream);
 hipError_t rs_launch_init(const rs::InitArgs &a, hipStream_t stream);
 hipError_t rs_launch_knots(const rs::KnotArgs &a, int32_t nknots, hipStream_t stream);
-hipError_t rs_launch_expand(const rs::ExpandArgs &a, int32_t nsteps, hipStream_t stream);
+hipError_t rs_launch_expand(const rs::ExpandArgs &a, int32_t nintervals, hipStream_t stream);
 hipError_t rs_launch_count_failed(const double *st, int64_t np_pad, int64_t npoints,
                                   unsigned long long *out, hipStream_t stream);

@@ -222,8 +222,8 @@ __device__ __forceinline__ void time_loop(const StepArgs &a, int64_t p, Prof &T,
   }
 }
 
-template <int NL, bool FULL>
-__global__ void __launch_bounds__(kBlock) step_kernel_reg(const StepArgs a) {
+template <int NL, bool FULL, int WPE>
+__global__ void __launch_bounds__(kBlock, WPE) step_kernel_reg(const StepArgs a) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= a.npoints) return;
   RegProfile<NL> T;
@@ -233,8 +233,8 @@ __global__ void __launch_bounds__(kBlock) step_kernel_reg(const StepArgs a) {
   store_state(a.state, a.np_pad, p, T, s);
 }
 
-template <bool FULL>
-__global__ void __launch_bounds__(kBlock) step_kernel_lds(const StepArgs a) {
+template <bool FULL, int WPE>
+__global__ void __launch_bounds__(kBlock, WPE) step_kernel_lds(const StepArgs a) {
   extern __shared__ double lds[]; /* [NLayers][kBlock] */
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= a.npoints) return; /* no barriers below: each lane owns its column */
@@ -326,31 +326,44 @@ __global__ void __launch_bounds__(kBlock) synth_knots_kernel(const KnotArgs a) {
 
 /* Knots -> step resolution, the device twin of the reference driver's
  * interpolation (examples/example1/src/JsonSource.cpp:115-172): linear between
- * knots, PrecPhase from the later knot.  Pure streaming: reads two knot rows
- * per field, writes nsteps rows. blockIdx.y = local time index. */
+ * knots, PrecPhase from the later knot.  One thread = one point over one knot
+ * interval (blockIdx.y): the two knot rows are read once, then up to
+ * steps_per_knot rows are streamed out, each a coalesced 2-KiB store per block
+ * and field. */
 __global__ void __launch_bounds__(kBlock) expand_kernel(const ExpandArgs a) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= a.npoints) return;
-  const int32_t tl = blockIdx.y;
-  const int32_t i = a.t0 + tl;
-  const int32_t t = i - 1;
-  const int32_t k = t / a.spk, r = t - k * a.spk;
+  const int32_t k = a.kfirst + (int32_t)blockIdx.y;        /* knot interval [k, k+1) */
+  int32_t tlo = k * a.spk, thi = tlo + a.spk;              /* 0-based time range */
+  if (tlo < a.t0 - 1) tlo = a.t0 - 1;
+  if (thi > a.t0 - 1 + a.nsteps) thi = a.t0 - 1 + a.nsteps;
+  if (tlo >= thi) return;
   const double *ka = a.knots + ((int64_t)(k - a.k0) * RS_KNOT_FIELDS) * a.np_pad + p;
   const double *kb = ka + (int64_t)RS_KNOT_FIELDS * a.np_pad;
-  const int64_t off = (int64_t)tl * a.f.t_stride + p;
-  double *out[7] = {(double *)a.f.tair, (double *)a.f.tdew, (double *)a.f.vz, (double *)a.f.rhz,
-                    (double *)a.f.prec, (double *)a.f.sw, (double *)a.f.lw};
+  const bool need_b = (thi - 1) > k * a.spk; /* some r > 0 in range */
+  double v0[7], v1[7];
 #pragma unroll
   for (int q = 0; q < 7; ++q) {
-    if (!out[q]) continue;
-    const double v0 = ka[(int64_t)q * a.np_pad];
-    out[q][off] = (r == 0) ? v0 : rs_sy_lerp(v0, kb[(int64_t)q * a.np_pad], r, a.spk);
+    v0[q] = ka[(int64_t)q * a.np_pad];
+    v1[q] = need_b ? kb[(int64_t)q * a.np_pad] : v0[q];
   }
-  if (a.f.tsurfobs) ((double *)a.f.tsurfobs)[off] = (i == 1) ? ka[7 * a.np_pad] : -9999.9;
-  if (a.f.depth) ((double *)a.f.depth)[off] = -9999.9;
-  ((int32_t *)a.f.precphase)[off] =
-      (int32_t)((r == 0) ? ka[8 * a.np_pad] : kb[8 * a.np_pad]);
-  if (p == 0 && !a.f.hour_pstride) ((int32_t *)a.f.hour)[tl] = rs_sy_hour(i, a.spk, a.start_hour);
+  const double ts0 = ka[7 * a.np_pad];
+  const int32_t ph0 = (int32_t)ka[8 * a.np_pad];
+  const int32_t ph1 = need_b ? (int32_t)kb[8 * a.np_pad] : ph0;
+  double *out[7] = {(double *)a.f.tair, (double *)a.f.tdew, (double *)a.f.vz, (double *)a.f.rhz,
+                    (double *)a.f.prec, (double *)a.f.sw, (double *)a.f.lw};
+  for (int32_t t = tlo; t < thi; ++t) {
+    const int32_t r = t - k * a.spk;
+    const int64_t off = (int64_t)(t - (a.t0 - 1)) * a.f.t_stride + p;
+#pragma unroll
+    for (int q = 0; q < 7; ++q)
+      if (out[q]) out[q][off] = (r == 0) ? v0[q] : rs_sy_lerp(v0[q], v1[q], r, a.spk);
+    if (a.f.tsurfobs) ((double *)a.f.tsurfobs)[off] = (t == 0) ? ts0 : -9999.9;
+    if (a.f.depth) ((double *)a.f.depth)[off] = -9999.9;
+    ((int32_t *)a.f.precphase)[off] = (r == 0) ? ph0 : ph1;
+    if (p == 0 && !a.f.hour_pstride)
+      ((int32_t *)a.f.hour)[t - (a.t0 - 1)] = rs_sy_hour(t + 1, a.spk, a.start_hour);
+  }
 }
 
 __global__ void __launch_bounds__(kBlock) count_failed_kernel(const double *st, int64_t np_pad,
@@ -377,19 +390,32 @@ hipError_t rs_upload_constants(int slot, const RsConstants *c, hipStream_t strea
 hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
                           hipStream_t stream) {
   const dim3 g = grid_for(a.npoints), b(RS_BLOCK);
+  /* variant = flavour + 10 * waves-per-SIMD bound (0 = default for the flavour) */
+  int wpe = variant / 10;
+  variant %= 10;
   if (variant == RS_VARIANT_AUTO) variant = (NL == 15) ? RS_VARIANT_REG : RS_VARIANT_LDS;
   if (variant == RS_VARIANT_REG) {
     if (NL != 15) return hipErrorInvalidValue;
-    if (full)
-      hipLaunchKernelGGL((rs::step_kernel_reg<15, true>), g, b, 0, stream, a);
-    else
-      hipLaunchKernelGGL((rs::step_kernel_reg<15, false>), g, b, 0, stream, a);
+    if (wpe == 0) wpe = 2;
+#define RS_REG(W)                                                                        \
+  if (wpe == W) {                                                                        \
+    if (full)                                                                            \
+      hipLaunchKernelGGL((rs::step_kernel_reg<15, true, W>), g, b, 0, stream, a);        \
+    else                                                                                 \
+      hipLaunchKernelGGL((rs::step_kernel_reg<15, false, W>), g, b, 0, stream, a);       \
+  }
+    RS_REG(1) RS_REG(2) RS_REG(3) RS_REG(4)
   } else {
     const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
-    if (full)
-      hipLaunchKernelGGL((rs::step_kernel_lds<true>), g, b, lds, stream, a);
-    else
-      hipLaunchKernelGGL((rs::step_kernel_lds<false>), g, b, lds, stream, a);
+    if (wpe == 0) wpe = 3;
+#define RS_LDS(W)                                                                        \
+  if (wpe == W) {                                                                        \
+    if (full)                                                                            \
+      hipLaunchKernelGGL((rs::step_kernel_lds<true, W>), g, b, lds, stream, a);          \
+    else                                                                                 \
+      hipLaunchKernelGGL((rs::step_kernel_lds<false, W>), g, b, lds, stream, a);         \
+  }
+    RS_LDS(2) RS_LDS(3) RS_LDS(4)
   }
   return hipGetLastError();
 }
@@ -406,9 +432,9 @@ hipError_t rs_launch_knots(const rs::KnotArgs &a, int32_t nknots, hipStream_t st
   return hipGetLastError();
 }
 
-hipError_t rs_launch_expand(const rs::ExpandArgs &a, int32_t nsteps, hipStream_t stream) {
+hipError_t rs_launch_expand(const rs::ExpandArgs &a, int32_t nintervals, hipStream_t stream) {
   dim3 g = grid_for(a.npoints);
-  g.y = (unsigned)nsteps;
+  g.y = (unsigned)nintervals;
   hipLaunchKernelGGL(rs::expand_kernel, g, dim3(RS_BLOCK), 0, stream, a);
   return hipGetLastError();
 }

@@ -89,6 +89,15 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so; two HIP runtimes in one
+    # process do not share the device.  Import torch FIRST so that our library's
+    # DT_NEEDED libamdhip64.so.7 resolves to the copy torch has already mapped.
+    # (A pure C/C++/Fortran host, e.g. the reference's roadrunner, simply gets
+    # /opt/rocm/lib/libamdhip64.so.7 via the rpath.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing - build it with `make -C roadsurf_amd` "

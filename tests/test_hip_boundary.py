@@ -1,0 +1,135 @@
+"""GPU tests of the drop-in boundary (runsimulation / runsimulation_batch, the
+reference's BIND(C) entry, examples/example1/src/Simulation.f90:4-6) and of the
+synthetic-workload kernels."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_helpers as oh
+from roadsurf_amd import abi, lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _pointers(f, out, p):
+    ip = abi.InputPointers()
+    ip.inputLen = f["tair"].shape[1]
+    for name, key in (("c_tair", "tair"), ("c_tdew", "tdew"), ("c_VZ", "vz"), ("c_Rhz", "rhz"),
+                      ("c_prec", "prec"), ("c_SW", "sw"), ("c_LW", "lw"), ("c_SW_dir", "sw_dir"),
+                      ("c_LW_net", "lw_net"), ("c_TSurfObs", "tsurfobs"), ("c_Depth", "depth")):
+        setattr(ip, name, f[key][p].ctypes.data_as(abi.c_double_p))
+    ip.c_PrecPhase = f["precphase"][p].ctypes.data_as(abi.c_int32_p)
+    hz = np.zeros(360)
+    ip.c_local_horizons = hz.ctypes.data_as(abi.c_double_p)
+    for name, key in (("c_year", "year"), ("c_month", "month"), ("c_day", "day"), ("c_hour", "hour"),
+                      ("c_minute", "minute"), ("c_second", "second")):
+        setattr(ip, name, f[key].ctypes.data_as(abi.c_int32_p))
+    op = abi.OutputPointers()
+    op.outputLen = ip.inputLen
+    for name, key in (("c_TsurfOut", "tsurf"), ("c_SnowOut", "snow"), ("c_WaterOut", "water"),
+                      ("c_IceOut", "ice"), ("c_DepositOut", "deposit"), ("c_Ice2Out", "ice2")):
+        setattr(op, name, out[key][p].ctypes.data_as(abi.c_double_p))
+    return ip, op, hz
+
+
+def _kind():
+    return "ref" if oh.have_ref() else "port"
+
+
+def test_runsimulation_single_point_dropin():
+    L = lib.load()
+    n, SL = 3, 2881
+    f = oh.synth_forcing(n, SL, seed=11)
+    f["vz"][1, 0] = 0.1  # exercises the VZ(1) >= 0.4 side effect on the caller's array
+    s = abi.default_settings(SL); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
+    ora, fmut, _ = oh.run_oracle(_kind(), f, s, p, l)
+    g = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in f.items()}
+    out = {k: np.full((n, SL), np.nan) for k in oh.F64_OUT}
+    for pt in range(n):
+        ip, op, keep = _pointers(g, out, pt)
+        L.runsimulation(C.byref(op), C.byref(ip), C.byref(s), C.byref(p), C.byref(l))
+    for k in oh.F64_OUT:
+        assert np.abs(out[k] - ora[k]).max() < 1e-6, k
+    assert g["vz"][1, 0] == fmut["vz"][1, 0] == np.float64(np.float32(0.4))
+
+
+def test_runsimulation_batch_matches_oracle(monkeypatch):
+    L = lib.load()
+    n, SL = 700, 1441
+    # small tiles/chunks so the tiling logic is exercised (3 point tiles, 6 time chunks)
+    monkeypatch.setenv("ROADSURF_HIP_TILE_POINTS", "300")
+    monkeypatch.setenv("ROADSURF_HIP_CHUNK_STEPS", "250")
+    f = oh.synth_forcing(n, SL, seed=3)
+    f["tsurfobs"][:, :400] = f["tair"][:, :400] + 0.3
+    f["tair"][5, 700] = -200.0  # one failing point
+    s = abi.default_settings(SL); s.use_relaxation = 1
+    p = abi.default_parameters()
+    ls = []
+    for i in range(n):
+        li = abi.default_local(); li.InitLenI = 400
+        li.tair_relax = float(f["tair"][i, 400]) - 1.0; li.VZ_relax = 2.0; li.RH_relax = 90.0
+        ls.append(li)
+    ora, _, _ = oh.run_oracle(_kind(), f, s, p, ls)
+    g = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in f.items()}
+    out = {k: np.full((n, SL), np.nan) for k in oh.F64_OUT}
+    ips = (abi.InputPointers * n)(); ops = (abi.OutputPointers * n)(); keep = []
+    for pt in range(n):
+        ip, op, hz = _pointers(g, out, pt)
+        ips[pt], ops[pt] = ip, op
+        keep.append(hz)
+    larr = (abi.LocalParameters * n)(*ls)
+    st = C.c_int32(99)
+    L.runsimulation_batch(n, ops, ips, C.byref(s), C.byref(p), larr, C.byref(st))
+    assert st.value == 0, lib.last_error()
+    for k in oh.F64_OUT:
+        miss = ora[k] == -9999.0
+        assert np.array_equal(miss, out[k] == -9999.0), k
+        assert np.abs(np.where(miss, 0, out[k] - ora[k])).max() < 1e-6, k
+    assert (out["tsurf"][5] == -9999.0).sum() == SL - 701
+
+
+def test_batch_rejects_unsupported_rows_loudly():
+    L = lib.load()
+    n, SL = 1, 241
+    f = oh.synth_forcing(n, SL, seed=3)
+    out = {k: np.full((n, SL), np.nan) for k in oh.F64_OUT}
+    ip, op, hz = _pointers(f, out, 0)
+    s = abi.default_settings(SL); p = abi.default_parameters()
+    l = abi.default_local(); l.sky_view = 0.7
+    st = C.c_int32(0)
+    L.runsimulation_batch(1, C.byref(op), C.byref(ip), C.byref(s), C.byref(p), C.byref(l), C.byref(st))
+    assert st.value == -3 and "sky-view" in lib.last_error()
+    l = abi.default_local(); l.couplingIndexI = 100; l.couplingTsurf = -2.0
+    s.use_coupling = 1
+    L.runsimulation_batch(1, C.byref(op), C.byref(ip), C.byref(s), C.byref(p), C.byref(l), C.byref(st))
+    assert st.value == -2 and "coupling" in lib.last_error()
+
+
+def test_device_synth_equals_host_twin():
+    """knots + expand kernels produce bit-identical forcing to the host generator
+    that feeds the oracle."""
+    import torch
+    from roadsurf_amd import device
+    n, SL, spk = 1000, 1441, 120
+    host = oh.synth_forcing(n, SL, seed=99, point_offset=12345)
+    s = abi.default_settings(SL); p = abi.default_parameters()
+    plan = device.Plan(n, s, p, 0)
+    spec, knots = plan.synth_knots(99, SL // spk + 2, point_offset=12345, steps_per_knot=spk)
+    dev = plan.device
+    # odd window boundaries on purpose
+    bounds = [1, 2, 100, 121, 500, 1201, SL + 1]
+    got = {k: np.empty((SL, n)) for k in ("tair", "tdew", "vz", "rhz", "prec", "sw", "lw", "tsurfobs")}
+    got["precphase"] = np.empty((SL, n), np.int32)
+    hours = np.empty(SL, np.int32)
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        w = device.ForcingWindow.empty(b - a, plan.np_pad, dev, optional=("tdew", "tsurfobs"))
+        plan.expand(spec, knots, w, a, b - a)
+        plan.sync()
+        for k in got:
+            got[k][a - 1:b - 1] = w.tensors[k][:, :n].cpu().numpy()
+        hours[a - 1:b - 1] = w.tensors["hour"].cpu().numpy()
+    for k in got:
+        assert np.array_equal(got[k].T, host[k]), k
+    assert np.array_equal(hours, host["hour"])
+    plan.close()
