@@ -78,7 +78,7 @@ def main() -> None:
     import torch
     import torch.distributed as dist
 
-    from roadsurf_amd import abi, device
+    from roadsurf_amd import abi, device, sharding
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -101,7 +101,8 @@ def main() -> None:
         plan.set_variant(args.variant)
     npad = plan.np_pad
     nknots = args.hours + 2
-    spec, knots = plan.synth_knots(args.seed, nknots, point_offset=rank * n, steps_per_knot=spk)
+    offset, _ = sharding.weak_shard(n, rank)
+    spec, knots = plan.synth_knots(args.seed, nknots, point_offset=offset, steps_per_knot=spk)
     chunk = min(args.chunk, simlen)
     win = device.ForcingWindow.empty(chunk, npad, dev, optional=())
     out = device.OutputWindow.empty(chunk, npad, dev)
@@ -134,10 +135,7 @@ def main() -> None:
         one_pass()
     fence()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.max_over_ranks(elapsed, dist if world > 1 else None, dev)
     step_ms, nlaunch = plan.timing_step_ms()
     nfail = plan.failed_count()
 

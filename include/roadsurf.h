@@ -342,6 +342,11 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers,
 
 #define RS_ABI_VERSION 1
 int rs_abi_version(void);
+/* sizeof of the boundary structs as the C side / the Fortran side see them
+ * (0 InputPointers, 1 OutputPointers, 2 InputSettings, 3 InputParameters,
+ * 4 LocalParameters, 5 RsConstants); bindings assert that they agree. */
+int64_t rs_abi_sizeof(int which);
+int64_t rs_fortran_sizeof(int which);
 
 #ifdef __cplusplus
 }

@@ -823,6 +823,22 @@ void runsimulation(OutputPointers *out, const InputPointers *in, const InputSett
 
 /* ---- known-answer probes (tests only) ---------------------------------- */
 
+/* Products of Initialization; same signature as ref_probe_init (oracle/ref_probe.f90). */
+void oracle_probe_init(const InputPointers *in, OutputPointers *out, const InputSettings *s,
+                       const InputParameters *P, const LocalParameters *lp, double *zdpth,
+                       double *dyc, double *dyk, double *cc, double *conddz, double *tmp,
+                       double *logs, double *tsurfave) {
+  Model M;
+  Initialization(&M, out, in, s, P, lp);
+  for (int i = 1; i <= s->NLayers + 1; ++i) zdpth[i - 1] = M.ZDpth[i];
+  for (int i = 1; i <= s->NLayers; ++i) {
+    dyc[i - 1] = M.DyC[i]; dyk[i - 1] = M.DyK[i]; cc[i - 1] = M.CC[i]; conddz[i - 1] = M.condDZ[i];
+  }
+  for (int i = 0; i <= s->NLayers + 1; ++i) tmp[i] = M.Tmp[i];
+  logs[0] = M.logMom; logs[1] = M.logHeat; logs[2] = M.logCond; logs[3] = M.logUstar;
+  *tsurfave = M.TsurfAve;
+}
+
 /* One CalcBLCondAndLE call on default-initialised parameters. */
 void oracle_probe_blcond(const InputSettings *s, const InputParameters *P, double TsurfAve,
                          double Tair, double VZ, double Rhz, double SrfWatmms, double *BLCond,

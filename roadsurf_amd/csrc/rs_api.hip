@@ -55,6 +55,19 @@ extern "C" {
 const char *rs_last_error(void) { return g_err; }
 void rs_host_set_error(const char *msg) { set_err("%s", msg ? msg : ""); }
 int rs_abi_version(void) { return RS_ABI_VERSION; }
+/* layout cross-check for bindings: 0 InputPointers 1 OutputPointers 2 InputSettings
+ * 3 InputParameters 4 LocalParameters 5 RsConstants */
+int64_t rs_abi_sizeof(int which) {
+  switch (which) {
+    case 0: return sizeof(InputPointers);
+    case 1: return sizeof(OutputPointers);
+    case 2: return sizeof(InputSettings);
+    case 3: return sizeof(InputParameters);
+    case 4: return sizeof(LocalParameters);
+    case 5: return sizeof(RsConstants);
+    default: return -1;
+  }
+}
 
 int rs_hip_device_count(void) {
   int n = 0;

@@ -126,8 +126,31 @@ module RoadSurfHip
    end interface
 
    public :: rs_build_constants, rs_bottom_temperature, runsimulation, runsimulation_batch
+   public :: rs_fortran_sizeof
 
 contains
+
+   !> Size in bytes of the boundary types as this Fortran unit lays them out
+   !! (cross-checked against the C header by tests/test_abi_layout.py).
+   function rs_fortran_sizeof(which) bind(C, name='rs_fortran_sizeof') result(nbytes)
+      integer(c_int), value :: which
+      integer(c_int64_t) :: nbytes
+      type(InputPointers) :: a0
+      type(OutputPointers) :: a1
+      type(InputSettings) :: a2
+      type(InputParameters) :: a3
+      type(LocalParameters) :: a4
+      type(RsConstants) :: a5
+      select case (which)
+      case (0); nbytes = c_sizeof(a0)
+      case (1); nbytes = c_sizeof(a1)
+      case (2); nbytes = c_sizeof(a2)
+      case (3); nbytes = c_sizeof(a3)
+      case (4); nbytes = c_sizeof(a4)
+      case (5); nbytes = c_sizeof(a5)
+      case default; nbytes = -1
+      end select
+   end function rs_fortran_sizeof
 
    !> Day of year, 1 January = 1 (restates src/BalanceModel.f90:325-351).
    pure integer function day_of_year(year, month, day) result(doy)

@@ -78,7 +78,7 @@ EXPORTS = (
     "rs_hip_init_state", "rs_hip_step", "rs_hip_state_download", "rs_hip_state_upload",
     "rs_hip_failed_count", "rs_hip_sync", "rs_hip_synth_knots", "rs_hip_expand_forcing",
     "rs_hip_set_variant", "rs_hip_timing_reset", "rs_hip_timing_step_ms",
-    "rs_host_run_batch", "rs_abi_version",
+    "rs_host_run_batch", "rs_abi_version", "rs_abi_sizeof", "rs_fortran_sizeof",
 )
 
 _lib = None
@@ -150,6 +150,9 @@ def load() -> C.CDLL:
     L.rs_host_run_batch.argtypes = [C.c_int32, P(abi.OutputPointers), P(abi.InputPointers),
                                     P(RsConstants), P(abi.LocalParameters), P(C.c_double),
                                     C.c_int32]
+    for n in ("rs_abi_sizeof", "rs_fortran_sizeof"):
+        getattr(L, n).argtypes = [C.c_int]
+        getattr(L, n).restype = C.c_int64
     _lib = L
     return L
 

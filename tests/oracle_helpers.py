@@ -144,3 +144,30 @@ def run_oracle(kind: str, forcing: dict[str, np.ndarray], settings: abi.InputSet
     larr = (abi.LocalParameters * n)(*local)
     used = lib.harness_run_points(n, C.byref(a), C.byref(settings), C.byref(params), larr, nthreads)
     return out, f, used
+
+
+def point_pointers(f: dict, p: int, out: dict | None = None):
+    """InputPointers/OutputPointers for point p of reference-layout arrays (keeps arrays alive)."""
+    n, L = f["tair"].shape
+    ip = abi.InputPointers()
+    ip.inputLen = L
+    for name, key in (("c_tair", "tair"), ("c_tdew", "tdew"), ("c_VZ", "vz"), ("c_Rhz", "rhz"),
+                      ("c_prec", "prec"), ("c_SW", "sw"), ("c_LW", "lw"), ("c_SW_dir", "sw_dir"),
+                      ("c_LW_net", "lw_net"), ("c_TSurfObs", "tsurfobs"), ("c_Depth", "depth")):
+        setattr(ip, name, f[key][p].ctypes.data_as(abi.c_double_p))
+    ip.c_PrecPhase = f["precphase"][p].ctypes.data_as(abi.c_int32_p)
+    hz = np.zeros(360)
+    ip.c_local_horizons = hz.ctypes.data_as(abi.c_double_p)
+    for name in I32_AXIS:
+        setattr(ip, "c_" + name, f[name].ctypes.data_as(abi.c_int32_p))
+    if out is None:
+        out = {k: np.full((1, L), np.nan) for k in F64_OUT}
+        row = 0
+    else:
+        row = p
+    op = abi.OutputPointers()
+    op.outputLen = L
+    for name, key in (("c_TsurfOut", "tsurf"), ("c_SnowOut", "snow"), ("c_WaterOut", "water"),
+                      ("c_IceOut", "ice"), ("c_DepositOut", "deposit"), ("c_Ice2Out", "ice2")):
+        setattr(op, name, out[key][row].ctypes.data_as(abi.c_double_p))
+    return ip, op, (hz, out)

@@ -1,0 +1,139 @@
+"""GPU: the HIP path against the committed golden fixtures (captured from the
+reference), and size-independent properties at BASELINE.json's full size
+(1 000 000 points x 48 h) where no oracle run is affordable:
+  * shard independence: a point's series does not depend on which batch / GPU
+    shard it is computed in (bit-identical),
+  * determinism: two passes give identical bits (wrap-around checksum of checksums),
+  * range invariants: storages within their configured limits, |Tsurf| <= 100, no NaN,
+  * a sampled oracle check at the full-size run's global point ids.
+Tolerance vs the reference: 1e-6 K / 1e-6 mm (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+import golden_helpers as gh
+import oracle_helpers as oh
+from roadsurf_amd import abi
+
+pytestmark = pytest.mark.gpu
+SPK = 120
+TOL = 1e-6
+
+
+def test_golden_scenarios_on_gpu():
+    from roadsurf_amd import device
+    z = gh.load("e2e_scenarios.npz")
+    K = {k[5:]: z[k] for k in z.files if k.startswith("knot_")}
+    L = 48 * SPK + 1
+    f = gh.expand_knots(K, L, SPK)
+    s = abi.default_settings(L); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
+    idx = z["out_index"]
+    for variant in (1, 2):
+        res, nfail = device.run_points(f, s, p, l, variant=variant)
+        assert nfail == 1
+        for k in oh.F64_OUT:
+            want = z[f"out_{k}"]
+            got = res[k][:, idx]
+            assert np.array_equal(want == -9999.0, got == -9999.0), k
+            assert np.abs(np.where(want == -9999.0, 0, got - want)).max() < TOL, k
+
+
+def test_golden_feature_cases_on_gpu():
+    from roadsurf_amd import device
+    z = gh.load("e2e_features.npz")
+    K = {k[5:]: z[k] for k in z.files if k.startswith("knot_")}
+    L = 12 * SPK + 1
+    f2 = gh.expand_knots(K, L, SPK)
+    f2["tsurfobs"][:, :360] = f2["tair"][:, :360] - 0.7
+    f2["tsurfobs"][::2, 100:150] = -9999.9
+    p = abi.default_parameters()
+    ls = []
+    for i in range(6):
+        li = abi.default_local(); li.InitLenI = 360
+        li.tair_relax = float(z["tair_relax"][i]); li.VZ_relax = 3.0; li.RH_relax = 85.0
+        ls.append(li)
+    idx = z["out_index"]
+
+    def check(tag, f, s):
+        res, _ = device.run_points(f, s, p, ls)
+        for k in oh.F64_OUT:
+            assert np.abs(res[k][:, idx] - z[f"{tag}_{k}"]).max() < TOL, (tag, k)
+
+    s = abi.default_settings(L); s.use_relaxation = 1
+    check("relax", f2, s)
+    s = abi.default_settings(L); s.tsurfOutputDepth = 0.05
+    check("depthset", f2, s)
+    f3 = {k: v.copy() for k, v in f2.items()}
+    f3["depth"][:] = 0.0; f3["depth"][::2] = 0.12; f3["depth"][1::4] = 7.0
+    check("deptharr", f3, abi.default_settings(L))
+    s = abi.default_settings(L); s.force_tsurf = 1
+    check("force", f2, s)
+    s = abi.default_settings(L); s.NLayers = 9
+    check("nl9", f2, s)
+
+
+def _synthetic_pass(plan, spec, knots, simlen, chunk, sample_cols, pp):
+    """One full pass; returns (checksum, sampled outputs [6][simlen][ncols], mins, maxs)."""
+    import torch
+    from roadsurf_amd import device
+    dev = plan.device
+    win = device.ForcingWindow.empty(chunk, plan.np_pad, dev, optional=())
+    win0 = device.ForcingWindow.empty(1, plan.np_pad, dev, optional=("tsurfobs",))
+    out = device.OutputWindow.empty(chunk, plan.np_pad, dev)
+    plan.expand(spec, knots, win0, 1, 1)
+    plan.init_state(win0, pp)
+    n = plan.npoints
+    checksum = torch.zeros((), dtype=torch.int64, device=dev)
+    mins = {k: float("inf") for k in device.OUT_FIELDS}
+    maxs = {k: float("-inf") for k in device.OUT_FIELDS}
+    cols = torch.as_tensor(sample_cols, device=dev)
+    sampled = {k: [] for k in device.OUT_FIELDS}
+    t0 = 1
+    while t0 <= simlen:
+        ns = min(chunk, simlen - t0 + 1)
+        plan.expand(spec, knots, win, t0, ns)
+        plan.step(win, out, pp, t0, ns, out_row0=t0 - 1)
+        for k in device.OUT_FIELDS:
+            o = out.tensors[k][:ns, :n]
+            checksum += o.view(torch.int64).sum()
+            mins[k] = min(mins[k], float(o.min())); maxs[k] = max(maxs[k], float(o.max()))
+            assert not torch.isnan(o).any()
+            sampled[k].append(o[:, cols].clone())
+        t0 += ns
+    plan.sync()
+    return int(checksum.item()), {k: torch.cat(v).cpu().numpy() for k, v in sampled.items()}, mins, maxs
+
+
+def test_full_size_properties_1M_points_48h():
+    from roadsurf_amd import device
+    n, hours, seed, chunk = 1_000_000, 48, 20240110, 240
+    L = hours * SPK + 1
+    s = abi.default_settings(L); p = abi.default_parameters()
+    plan = device.Plan(n, s, p, 0)
+    spec, knots = plan.synth_knots(seed, hours + 2, steps_per_knot=SPK)
+    pp = plan.point_params(plan.uniform_tbottom(2024, 1, 10))
+    # sampled global ids: a contiguous block per region so that they can be re-run as shards
+    blocks = [0, 333_312, 999_744]
+    cols = np.concatenate([np.arange(b, b + 64) for b in blocks])
+    c1, samp1, mins, maxs = _synthetic_pass(plan, spec, knots, L, chunk, cols, pp)
+    c2, samp2, _, _ = _synthetic_pass(plan, spec, knots, L, chunk, cols, pp)
+    assert c1 == c2, "two passes over the same inputs differ"
+    for k in device.OUT_FIELDS:
+        assert np.array_equal(samp1[k], samp2[k])
+    assert plan.failed_count() == 0
+    # range invariants (storage limits: examples/example1/src/InputParameters.h:78-81, MaxWatmms)
+    assert -100.0 <= mins["tsurf"] and maxs["tsurf"] <= 100.0
+    for k, hi in (("snow", p.MaxSnowmms), ("water", p.MaxWatmms), ("ice", p.MaxIcemms),
+                  ("deposit", p.MaxDepmms), ("ice2", p.MaxIcemms)):
+        assert mins[k] >= 0.0 and maxs[k] <= hi, (k, mins[k], maxs[k])
+    assert maxs["snow"] > 1 and maxs["ice"] > 1 and maxs["deposit"] > 0.1  # workload is not trivial
+    plan.close()
+    # shard independence + oracle spot check: re-run each sampled block as its own tiny batch
+    l = abi.default_local(); l.InitLenI = 1
+    for bi, b in enumerate(blocks):
+        f = oh.synth_forcing(64, L, seed=seed, point_offset=b)
+        res, _ = device.run_points(f, s, p, l)
+        ora, _, _ = oh.run_oracle("ref" if oh.have_ref() else "port", f, s, p, l)
+        for k in device.OUT_FIELDS:
+            big = samp1[k][:, bi * 64:(bi + 1) * 64].T  # [64][L]
+            assert np.array_equal(big, res[k]), ("shard independence", k, b)
+            assert np.abs(big - ora[k]).max() < TOL, ("oracle", k, b)

@@ -1,0 +1,75 @@
+"""Host-side logic that needs no GPU: the Fortran constants builder against the
+reference's own Initialization products (golden), sharding, argument validation."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import golden_helpers as gh
+from roadsurf_amd import abi, lib, sharding
+
+
+@pytest.mark.parametrize("tag,nl,mod", [("nl15", 15, False), ("nl8", 8, False), ("nl32", 32, False),
+                                        ("nl15mod", 15, True)])
+def test_fortran_constants_equal_reference_initialization(tag, nl, mod):
+    z = gh.load("init_products.npz")
+    s = abi.default_settings(5761); s.NLayers = nl
+    p = abi.default_parameters()
+    if mod:
+        p.RhoB1 = 1.9; p.Silt2 = 0.0; p.ZMom = 0.2; p.ZeroDisp = 0.5; p.Poro1 = 0.15; p.TClimG = 4.0
+    c = lib.build_constants(s, p)
+    assert np.array_equal(np.array(c.ZDpth)[1:nl + 2], z[f"{tag}_zdpth"][:nl + 1])
+    assert np.array_equal(np.array(c.DyC)[1:nl + 1], z[f"{tag}_dyc"][:nl])
+    assert np.array_equal(np.array(c.condDZ)[1:nl + 1], z[f"{tag}_conddz"][:nl])
+    assert [c.logMom, c.logHeat, c.logCond, c.logUstar] == list(z[f"{tag}_logs"])
+    # bottom boundary temperature = the reference's Tmp(NLayers+1) for 2024-01-10
+    assert lib.bottom_temperature(p, c, 2024, 1, 10) == z[f"{tag}_tmp"][nl + 1]
+    assert c.HSfac1 == z[f"{tag}_zdpth"][1] - z[f"{tag}_zdpth"][0]
+    assert c.dryCap[1] == (np.float64(np.float32(1.0)) - p.Poro1) * p.vsh1
+    assert c.WCont[1] == np.float64(np.float32(0.01)) and c.WCont[3] == np.float64(np.float32(0.3))
+
+
+def test_wear_constants_fold_in_single_precision():
+    c = lib.build_constants(abi.default_settings(10), abi.default_parameters())
+    f = np.float32
+    assert c.wSnowTran == float(f(0.2) + f(0.25))
+    assert c.wSnow2Ice == float(f(0.25) / (f(0.2) + f(0.25)))
+    assert c.wIce == float(f(1.1) * f(2.0) * f(0.145))
+    assert c.wIce2 == float(f(1.1) * f(2.0) * (f(4.0) * f(0.290)))
+    assert c.wDep == float(f(0.5) * f(2.0) * (f(4.0) * f(0.290)))
+    assert c.wWat == float(f(0.145))
+    assert c.Tph == 30.0 / 3600.0 and c.twoDT == 60.0
+
+
+def test_leap_years_in_bottom_temperature():
+    p = abi.default_parameters()
+    c = lib.build_constants(abi.default_settings(10), p)
+    z = c.ZDpth[16]
+
+    def want(doy):
+        return p.TClimG + p.AZ * np.sin(p.Omega * doy + p.Omega * (-170) - (z / p.DampDpth))
+
+    assert lib.bottom_temperature(p, c, 2023, 3, 1) == want(60)
+    assert lib.bottom_temperature(p, c, 2024, 3, 1) == want(61)
+    assert lib.bottom_temperature(p, c, 1900, 3, 1) == want(60)
+    assert lib.bottom_temperature(p, c, 2000, 12, 31) == want(366)
+
+
+def test_constants_reject_bad_settings():
+    p = abi.default_parameters()
+    for nl in (4, 33):
+        s = abi.default_settings(10); s.NLayers = nl
+        with pytest.raises(ValueError):
+            lib.build_constants(s, p)
+    s = abi.default_settings(0)
+    with pytest.raises(ValueError):
+        lib.build_constants(s, p)
+
+
+def test_shards_partition_the_points():
+    for total, world in ((1_000_000, 8), (10, 3), (7, 8)):
+        spans = [sharding.strong_shard(total, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+        for (o1, c1), (o2, _) in zip(spans[:-1], spans[1:]):
+            assert o1 + c1 == o2
+    assert sharding.weak_shard(1000, 3) == (3000, 1000)

@@ -1,0 +1,123 @@
+"""The CPU restatement (oracle/roadsurf_oracle.c) against fixtures captured from the
+REFERENCE ITSELF (tests/golden/make_golden.py).  Bit-for-bit: on x86-64 both sides do
+the same IEEE operations in the same order and call the same glibc exp/log."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import golden_helpers as gh
+import oracle_helpers as oh
+from roadsurf_amd import abi
+
+SPK = 120
+
+
+def _knots(z, n=None):
+    return {k[5:]: z[k] for k in z.files if k.startswith("knot_")}
+
+
+def test_scenarios_48h_bit_exact():
+    z = gh.load("e2e_scenarios.npz")
+    K = _knots(z)
+    L = 48 * SPK + 1
+    f = gh.expand_knots(K, L, SPK)
+    s = abi.default_settings(L); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
+    out, _, _ = oh.run_oracle("port", f, s, p, l)
+    idx = z["out_index"]
+    for k in oh.F64_OUT:
+        assert np.array_equal(out[k][:, idx], z[f"out_{k}"]), k
+    # the scenarios do what they were built for
+    assert (z["out_tsurf"][5] == -9999.0).any() and not (z["out_tsurf"][0] == -9999.0).any()
+    assert z["out_snow"][7].max() > 5 and z["out_ice"][1].max() > 0.5 and z["out_deposit"][3].max() > 0.05
+
+
+def test_feature_cases_bit_exact():
+    z = gh.load("e2e_features.npz")
+    K = _knots(z)
+    L = 12 * SPK + 1
+    f2 = gh.expand_knots(K, L, SPK)
+    f2["tsurfobs"][:, :360] = f2["tair"][:, :360] - 0.7
+    f2["tsurfobs"][::2, 100:150] = -9999.9
+    p = abi.default_parameters()
+    ls = []
+    for i in range(6):
+        li = abi.default_local(); li.InitLenI = 360
+        li.tair_relax = float(z["tair_relax"][i]); li.VZ_relax = 3.0; li.RH_relax = 85.0
+        ls.append(li)
+    idx = z["out_index"]
+
+    def check(tag, f, s):
+        out, _, _ = oh.run_oracle("port", f, s, p, ls)
+        for k in oh.F64_OUT:
+            assert np.array_equal(out[k][:, idx], z[f"{tag}_{k}"]), (tag, k)
+
+    s = abi.default_settings(L); s.use_relaxation = 1
+    check("relax", f2, s)
+    s = abi.default_settings(L); s.tsurfOutputDepth = 0.05
+    check("depthset", f2, s)
+    f3 = {k: v.copy() for k, v in f2.items()}
+    f3["depth"][:] = 0.0; f3["depth"][::2] = 0.12; f3["depth"][1::4] = 7.0
+    check("deptharr", f3, abi.default_settings(L))
+    s = abi.default_settings(L); s.force_tsurf = 1
+    check("force", f2, s)
+    s = abi.default_settings(L); s.NLayers = 9
+    check("nl9", f2, s)
+
+
+def test_init_products_bit_exact():
+    z = gh.load("init_products.npz")
+    zs = gh.load("e2e_scenarios.npz")
+    f = gh.expand_knots(_knots(zs), 48 * SPK + 1, SPK)
+    port = oh.load("port")
+    l = abi.default_local(); l.InitLenI = 1
+    for tag, nl, mod in (("nl15", 15, False), ("nl8", 8, False), ("nl32", 32, False), ("nl15mod", 15, True)):
+        s = abi.default_settings(48 * SPK + 1); s.NLayers = nl
+        p = abi.default_parameters()
+        if mod:
+            p.RhoB1 = 1.9; p.Silt2 = 0.0; p.ZMom = 0.2; p.ZeroDisp = 0.5; p.Poro1 = 0.15; p.TClimG = 4.0
+        ip, op, keep = oh.point_pointers(f, 1)
+        arrs = [np.zeros(nl + 2) for _ in range(6)]
+        logs = np.zeros(4); ts = C.c_double()
+        port.oracle_probe_init(C.byref(ip), C.byref(op), C.byref(s), C.byref(p), C.byref(l),
+                               *[a.ctypes.data_as(abi.c_double_p) for a in arrs],
+                               logs.ctypes.data_as(abi.c_double_p), C.byref(ts))
+        for nm, a in zip(("zdpth", "dyc", "dyk", "cc", "conddz", "tmp"), arrs):
+            assert np.array_equal(a, z[f"{tag}_{nm}"]), (tag, nm)
+        assert np.array_equal(logs, z[f"{tag}_logs"]) and ts.value == z[f"{tag}_tsurf"][0]
+    # the oracle's layer grid for NLayers = 15
+    survey = [0, 3.02999997511506081e-02, 6.47199992090463638e-02, 1.04907998815178871e-01,
+              1.53171198442578316e-01, 2.12739674374461174e-01, 2.88135541602969170e-01,
+              3.85689759626984596e-01, 5.14265662059187889e-01, 6.86271915212273598e-01,
+              9.19080657884478569e-01, 1.23701289482414722e+00, 1.67411803267896175e+00,
+              2.27806521393358707e+00, 3.11559125594794750e+00, 4.28012775070965290e+00]
+    assert list(z["nl15_zdpth"][:16]) == survey
+
+
+def test_blcond_known_answers_bit_exact():
+    z = gh.load("blcond_known_answers.npz")
+    port = oh.load("port")
+    port.oracle_probe_blcond.argtypes = [C.POINTER(abi.InputSettings), C.POINTER(abi.InputParameters)] + \
+        [C.c_double] * 5 + [abi.c_double_p] * 3 + [abi.c_int32_p]
+    s = abi.default_settings(100); p = abi.default_parameters()
+    iters = []
+    for i in range(len(z["tsurf"])):
+        b, le, ev, it = C.c_double(), C.c_double(), C.c_double(), C.c_int32()
+        port.oracle_probe_blcond(C.byref(s), C.byref(p), z["tsurf"][i], z["tair"][i], z["vz"][i],
+                                 z["rh"][i], z["wat"][i], C.byref(b), C.byref(le), C.byref(ev), C.byref(it))
+        assert (b.value, le.value, ev.value) == (z["blcond"][i], z["le"][i], z["evap"][i]), i
+        iters.append(it.value)
+    # both regimes of the fixed-point iteration are covered: exit at the minimum 5 and later
+    assert min(iters) == 5 and max(iters) > 6
+
+
+@pytest.mark.skipif(not oh.have_ref(), reason="reference build not available")
+def test_port_equals_reference_on_random_workload():
+    n, L = 400, 2881
+    f = oh.synth_forcing(n, L, seed=31337)
+    s = abi.default_settings(L); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
+    a, fa, _ = oh.run_oracle("ref", f, s, p, l)
+    b, fb, _ = oh.run_oracle("port", f, s, p, l)
+    for k in oh.F64_OUT:
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(fa["vz"], fb["vz"])  # VZ(1) side effect
