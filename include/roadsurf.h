@@ -317,6 +317,10 @@ int rs_hip_expand_forcing(RsPlan *plan, const RsSynthSpec *spec,
                           const double *knots, int32_t k0, int32_t nknots,
                           const RsForcing *f, int32_t t0, int32_t nsteps);
 
+/* Test hook: y[i] = device exp (fn 0) / log (fn 1) of x[i], device pointers
+ * (roadsurf_amd/csrc/rs_math.hpp; tests/test_hip_math.py). */
+int rs_hip_test_math(RsPlan *plan, int32_t fn, int64_t n, const double *x, double *y);
+
 /* Kernel flavour: 0 auto (register profile when NLayers == 15, else LDS
  * profile), 1 register profile, 2 LDS profile. */
 int rs_hip_set_variant(RsPlan *plan, int32_t variant);

@@ -855,3 +855,9 @@ void oracle_probe_blcond(const InputSettings *s, const InputParameters *P, doubl
   *iters = CalcBLCondAndLE(&M);
   *BLCond = M.BLCond; *LE = M.LE; *Evap = M.Evap;
 }
+
+/* y[i] = libm exp (fn 0) / log (fn 1) of x[i]: the very functions the reference
+ * calls.  (numpy may use its own SIMD exp/log, so tests go through this.) */
+void oracle_libm_map(int fn, long n, const double *x, double *y) {
+  for (long i = 0; i < n; ++i) y[i] = fn == 0 ? exp(x[i]) : log(x[i]);
+}

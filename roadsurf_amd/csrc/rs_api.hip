@@ -358,6 +358,13 @@ int rs_hip_sync(RsPlan *pl) {
   return 0;
 }
 
+int rs_hip_test_math(RsPlan *pl, int32_t fn, int64_t n, const double *x, double *y) {
+  if (!pl || !x || !y || n < 1 || fn < 0 || fn > 1) return set_err("rs_hip_test_math: bad arguments");
+  HIP_OK(hipSetDevice(pl->device));
+  HIP_OK(rs_launch_math_test(fn, n, x, y, pl->stream));
+  return 0;
+}
+
 int rs_hip_synth_knots(RsPlan *pl, const RsSynthSpec *spec, double *knots, int32_t k0,
                        int32_t nknots) {
   if (!pl || !spec || !knots || nknots < 1 || k0 < 0)

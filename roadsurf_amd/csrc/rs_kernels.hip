@@ -147,7 +147,8 @@ __device__ __forceinline__ void store_outputs(const RsOutputs &o, int32_t i, int
 /* The time loop of runsimulation (examples/example1/src/Simulation.f90:57-115)
  * for one point over absolute indices [t0, t0+nsteps). */
 template <bool FULL, class Prof>
-__device__ __forceinline__ void time_loop(const StepArgs &a, int64_t p, Prof &T, Scalars &s) {
+__device__ __forceinline__ void time_loop(const StepArgs &a, const MathTab &mt, int64_t p, Prof &T,
+                                          Scalars &s) {
   int32_t slot = a.cslot;
   const RsConstants &c0 = g_consts[slot];
   const double tbot = a.pp.tbottom[p];
@@ -204,7 +205,7 @@ __device__ __forceinline__ void time_loop(const StepArgs &a, int64_t p, Prof &T,
           }
           if (i > initlen) {
             const double den = (double)(4.f * 3600.f);
-            const double e = rs_exp(-((c.DTSecs * i) - (c.DTSecs * initlen)) / den);
+            const double e = rs_exp(mt, -((c.DTSecs * i) - (c.DTSecs * initlen)) / den);
             tair = tair - (tairR - s.tair_end) * e;
             vz = vz - (vzR - s.vz_end) * e;
             rhz = rhz - (rhR - s.rh_end) * e;
@@ -217,31 +218,37 @@ __device__ __forceinline__ void time_loop(const StepArgs &a, int64_t p, Prof &T,
        * relaxation; the pre-step surface temperature uses depth(SimLen) only */
       if (FULL) s.tsurf = surface_temperature(c, T, tbot, f.depth);
     }
-    model_step(c, s, T, tbot, tair, vz, rhz, prec_ts, f.sw, f.lw, f.phase, f.hour, f.depth);
+    model_step(c, mt, s, T, tbot, tair, vz, rhz, prec_ts, f.sw, f.lw, f.phase, f.hour, f.depth);
     store_outputs(a.o, i, p, s, true);
   }
 }
 
 template <int NL, bool FULL, int WPE>
 __global__ void __launch_bounds__(kBlock, WPE) step_kernel_reg(const StepArgs a) {
+  __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
+  const MathTab mt = fill_math_tables(math_lds);
+  __syncthreads();
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= a.npoints) return;
   RegProfile<NL> T;
   Scalars s;
   load_state(a.state, a.np_pad, p, T, s);
-  time_loop<FULL>(a, p, T, s);
+  time_loop<FULL>(a, mt, p, T, s);
   store_state(a.state, a.np_pad, p, T, s);
 }
 
 template <bool FULL, int WPE>
 __global__ void __launch_bounds__(kBlock, WPE) step_kernel_lds(const StepArgs a) {
   extern __shared__ double lds[]; /* [NLayers][kBlock] */
+  __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
+  const MathTab mt = fill_math_tables(math_lds);
+  __syncthreads();
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= a.npoints) return; /* no barriers below: each lane owns its column */
   LdsProfile T{lds + threadIdx.x, g_consts[a.cslot].NLayers};
   Scalars s;
   load_state(a.state, a.np_pad, p, T, s);
-  time_loop<FULL>(a, p, T, s);
+  time_loop<FULL>(a, mt, p, T, s);
   store_state(a.state, a.np_pad, p, T, s);
 }
 
@@ -366,6 +373,17 @@ __global__ void __launch_bounds__(kBlock) expand_kernel(const ExpandArgs a) {
   }
 }
 
+/* Unit-test kernel for rs_exp / rs_log (tests/test_hip_math.py). fn: 0 exp, 1 log. */
+__global__ void __launch_bounds__(kBlock) math_test_kernel(int fn, int64_t n, const double *x,
+                                                           double *y) {
+  __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
+  const MathTab mt = fill_math_tables(math_lds);
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  y[i] = fn == 0 ? rs_exp(mt, x[i]) : rs_log(mt, x[i]);
+}
+
 __global__ void __launch_bounds__(kBlock) count_failed_kernel(const double *st, int64_t np_pad,
                                                               int64_t npoints,
                                                               unsigned long long *out) {
@@ -381,8 +399,20 @@ __global__ void __launch_bounds__(kBlock) count_failed_kernel(const double *st, 
 
 static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + RS_BLOCK - 1) / RS_BLOCK)); }
 
+hipError_t rs_launch_math_test(int fn, int64_t n, const double *x, double *y, hipStream_t stream) {
+  hipLaunchKernelGGL(rs::math_test_kernel, grid_for(n), dim3(RS_BLOCK), 0, stream, fn, n, x, y);
+  return hipGetLastError();
+}
+
 hipError_t rs_upload_constants(int slot, const RsConstants *c, hipStream_t stream) {
   if (slot < 0 || slot >= RS_CONST_SLOTS) return hipErrorInvalidValue;
+  /* transcendental tables (same for every plan; cheap enough to refresh) */
+  hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(rs::c_gl_exp_tab), rs_gl_exp_tab,
+                                        sizeof(rs_gl_exp_tab), 0, hipMemcpyHostToDevice, stream);
+  if (e != hipSuccess) return e;
+  e = hipMemcpyToSymbolAsync(HIP_SYMBOL(rs::c_gl_log_tab), rs_gl_log_tab, sizeof(rs_gl_log_tab), 0,
+                             hipMemcpyHostToDevice, stream);
+  if (e != hipSuccess) return e;
   return hipMemcpyToSymbolAsync(HIP_SYMBOL(rs::g_consts), c, sizeof(RsConstants),
                                 (size_t)slot * sizeof(RsConstants), hipMemcpyHostToDevice, stream);
 }

@@ -81,9 +81,9 @@ __device__ __forceinline__ double surface_temperature(const RsConstants &c, cons
 }
 
 /* src/Cond.f90:143-249 + src/Storage.f90:9-29 */
-__device__ __forceinline__ void precipitation_to_storage(const RsConstants &c, Scalars &s,
-                                                         int32_t phase, double &prec_ts,
-                                                         double tair, double rhz) {
+__device__ __forceinline__ void precipitation_to_storage(const RsConstants &c, const MathTab &mt,
+                                                         Scalars &s, int32_t phase,
+                                                         double &prec_ts, double tair, double rhz) {
   double rain = R4(0.0), snow = R4(0.0);
   bool interpret = true;
   if ((double)phase > c.MissValI) {
@@ -106,7 +106,7 @@ __device__ __forceinline__ void precipitation_to_storage(const RsConstants &c, S
       snow = R4(0.0);
     } else {
       const double pexp = R4(22.0) - R4(2.7) * tair - R4(0.20) * rhz;
-      const double prain = R4(1.0) / (R4(1.0) + rs_exp(pexp));
+      const double prain = R4(1.0) / (R4(1.0) + rs_exp(mt, pexp));
       if (prain < c.PLimSnow) {
         snow = prec_ts;
         rain = R4(0.0);
@@ -125,9 +125,10 @@ __device__ __forceinline__ void precipitation_to_storage(const RsConstants &c, S
 
 /* src/BoundaryLayer.f90:3-109 (+ calcRaero :112-131, CalcLE :134-190).
  * Outputs: blcond, le (LE_Flux), evap (EvapmmTS). */
-__device__ __forceinline__ void boundary_layer(const RsConstants &c, double tsurf, double tair,
-                                               double vz, double rhz, double wat, double &blcond,
-                                               double &le, double &evap) {
+__device__ __forceinline__ void boundary_layer(const RsConstants &c, const MathTab &mt,
+                                               double tsurf, double tair, double vz, double rhz,
+                                               double wat, double &blcond, double &le,
+                                               double &evap) {
   const double ConvLim = R4(0.001);
   const double TaK = tair + R4(273.15);
   const double AirDens = R4(100000.0) / (R4(287.05) * TaK);
@@ -154,7 +155,7 @@ __device__ __forceinline__ void boundary_layer(const RsConstants &c, double tsur
       PSIH = R4(4.7) * Stab;
       PSIM = PSIH;
     } else {
-      PSIH = R4(-2.0) * rs_log((R4(1.0) + sqrt(R4(1.0) - R4(16.0) * Stab)) / R4(2.0));
+      PSIH = R4(-2.0) * rs_log(mt, (R4(1.0) + sqrt(R4(1.0) - R4(16.0) * Stab)) / R4(2.0));
       PSIM = R4(0.6) * PSIH;
     }
     if ((j >= 5) && (fabs(BLCond - BLCond_Old) < ConvLim)) break;
@@ -166,13 +167,13 @@ __device__ __forceinline__ void boundary_layer(const RsConstants &c, double tsur
 
   double ESurf, ESat;
   if (tsurf < 0)
-    ESurf = R4(0.61078) * rs_exp(R4(21.875) * tsurf / (tsurf + R4(265.5)));
+    ESurf = R4(0.61078) * rs_exp(mt, R4(21.875) * tsurf / (tsurf + R4(265.5)));
   else
-    ESurf = R4(0.61078) * rs_exp(R4(17.269) * tsurf / (tsurf + R4(237.3)));
+    ESurf = R4(0.61078) * rs_exp(mt, R4(17.269) * tsurf / (tsurf + R4(237.3)));
   if (tair < 0)
-    ESat = R4(0.61078) * rs_exp(R4(21.875) * tair / (tair + R4(265.5)));
+    ESat = R4(0.61078) * rs_exp(mt, R4(21.875) * tair / (tair + R4(265.5)));
   else
-    ESat = R4(0.61078) * rs_exp(R4(17.269) * tair / (tair + R4(237.3)));
+    ESat = R4(0.61078) * rs_exp(mt, R4(17.269) * tair / (tair + R4(237.3)));
   double hum = R4(0.01) * rhz;
   if (hum > R4(1.0)) hum = R4(1.0);
   const double EAir = hum * ESat;
@@ -396,12 +397,12 @@ __device__ __forceinline__ void road_condition(const RsConstants &c, Scalars &s,
  * SetCurrentValues / relaxation / lastValues), T is Tmp(1..N) possibly with obs
  * forcing applied, s.tsurf is up to date.  depth_i is modelInput%depth(i). */
 template <class Prof>
-__device__ __forceinline__ void model_step(const RsConstants &c, Scalars &s, Prof &T, double tbot,
-                                           double tair, double vz, double rhz, double prec_ts,
-                                           double sw, double lw, int32_t phase, int32_t hour,
-                                           double depth_i) {
+__device__ __forceinline__ void model_step(const RsConstants &c, const MathTab &mt, Scalars &s,
+                                           Prof &T, double tbot, double tair, double vz,
+                                           double rhz, double prec_ts, double sw, double lw,
+                                           int32_t phase, int32_t hour, double depth_i) {
   const int N = T.nlayers();
-  precipitation_to_storage(c, s, phase, prec_ts, tair, rhz);
+  precipitation_to_storage(c, mt, s, phase, prec_ts, tair, rhz);
 
   /* SetDayDependendVariables, src/BalanceModel.f90:354-387 */
   double calm, trffric;
@@ -415,7 +416,7 @@ __device__ __forceinline__ void model_step(const RsConstants &c, Scalars &s, Pro
   if (vz < calm) vz = calm;
 
   double blcond, le, evap;
-  boundary_layer(c, s.tsurf, tair, vz, rhz, s.wat, blcond, le, evap);
+  boundary_layer(c, mt, s.tsurf, tair, vz, rhz, s.wat, blcond, le, evap);
 
   /* CalcRNet, src/BalanceModel.f90:282-307 (SwRadCof = LwRadCof = 1.0 off the
    * coupling path; x*1.0 is exact so the factors are kept out) */

@@ -35,6 +35,7 @@ def test_golden_scenarios_on_gpu():
             got = res[k][:, idx]
             assert np.array_equal(want == -9999.0, got == -9999.0), k
             assert np.abs(np.where(want == -9999.0, 0, got - want)).max() < TOL, k
+            assert np.array_equal(want, got), (k, "within tolerance but not bit-identical")
 
 
 def test_golden_feature_cases_on_gpu():
@@ -57,6 +58,7 @@ def test_golden_feature_cases_on_gpu():
         res, _ = device.run_points(f, s, p, ls)
         for k in oh.F64_OUT:
             assert np.abs(res[k][:, idx] - z[f"{tag}_{k}"]).max() < TOL, (tag, k)
+            assert np.array_equal(res[k][:, idx], z[f"{tag}_{k}"]), (tag, k, "not bit-identical")
 
     s = abi.default_settings(L); s.use_relaxation = 1
     check("relax", f2, s)

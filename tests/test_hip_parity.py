@@ -1,8 +1,12 @@
 """GPU parity: HIP path (through the C-ABI) vs the CPU oracle on identical forcing.
 
-Tolerances (BASELINE.json north_star): max|dTsurf| < 1e-6 K over 48 h; we hold the
-storages (mm) to the same absolute 1e-6.  Everything except exp/log is IEEE-exact
-and in the reference's evaluation order, so the observed differences are ~1e-12.
+Contract (BASELINE.json north_star): max|dTsurf| < 1e-6 K over 48 h (we hold the storages,
+mm, to the same 1e-6).  What we actually require is stronger: BIT EQUALITY.  Every operation
+on the path is IEEE-exact in the reference's evaluation order, and the device exp/log return
+glibc's bits (roadsurf_amd/csrc/rs_math.hpp explains why nothing less survives 1e6 points:
+melt-out steps branch on the sign of a rounding residual).  Bit equality presumes the host
+libm runs its FMA variants (any x86-64 CPU since 2013); on another host the 1e-6 gate still
+has to hold and the count of non-identical points is printed.
 """
 import numpy as np
 import pytest
@@ -14,6 +18,10 @@ pytestmark = pytest.mark.gpu
 
 TOL_K = 1e-6
 TOL_MM = 1e-6
+try:
+    HOST_HAS_FMA = " fma " in open("/proc/cpuinfo").read()
+except OSError:
+    HOST_HAS_FMA = False
 
 
 def _oracle_kind():
@@ -32,6 +40,9 @@ def _compare(res, ora, tag):
     assert worst["tsurf"] < TOL_K, (tag, worst)
     for k in ("snow", "water", "ice", "deposit", "ice2"):
         assert worst[k] < TOL_MM, (tag, worst)
+    if HOST_HAS_FMA:
+        for k in oh.F64_OUT:
+            assert np.array_equal(res[k], ora[k]), f"{tag}: {k} is within tolerance but not bit-identical"
     return worst
 
 
@@ -134,3 +145,21 @@ def test_other_layer_counts_and_timestep():
     ora, _, _ = oh.run_oracle(kind, f, s, p, l)
     res, _ = device.run_points(f, s, p, l)
     _compare(res, ora, "dt60")
+
+
+def test_bit_identity_at_scale_8192_points():
+    """The melt-out branch (src/Storage.f90:149-162) turns any last-bit difference into
+    1e-3..0.2 K; with OCML's exp/log 9 of these 8192 points left the 1e-6 K gate.  With
+    glibc-exact exp/log every one of them is bit-identical to the reference."""
+    from roadsurf_amd import device
+    n, L = 8192, 5761
+    f = oh.synth_forcing(n, L, seed=20240110, point_offset=100000)
+    s = abi.default_settings(L); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
+    ora, _, _ = oh.run_oracle(_oracle_kind(), f, s, p, l)
+    res, _ = device.run_points(f, s, p, l)
+    d = np.maximum.reduce([np.abs(res[k] - ora[k]) for k in oh.F64_OUT])
+    nonident = int((d.max(1) != 0).sum())
+    print("points not bit-identical:", nonident, "max |dTsurf|:", np.abs(res["tsurf"] - ora["tsurf"]).max())
+    assert np.abs(res["tsurf"] - ora["tsurf"]).max() < TOL_K
+    if HOST_HAS_FMA:
+        assert nonident == 0
