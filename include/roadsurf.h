@@ -321,6 +321,14 @@ int rs_hip_expand_forcing(RsPlan *plan, const RsSynthSpec *spec,
  * (roadsurf_amd/csrc/rs_math.hpp; tests/test_hip_math.py). */
 int rs_hip_test_math(RsPlan *plan, int32_t fn, int64_t n, const double *x, double *y);
 
+/* How this build divides: 0 = compiler's IEEE expansion everywhere (-DRS_IEEE_DIV),
+ * 1 = bare Newton sequence for normal-range operands (default, same bits, see
+ * rs_math.hpp), 2 = both evaluated and compared (-DRS_DIV_CHECK).  In mode 2
+ * rs_hip_div_mismatch_count returns how many call-site evaluations disagreed
+ * since the library was loaded (0 in the other modes). */
+int rs_hip_division_mode(void);
+int64_t rs_hip_div_mismatch_count(RsPlan *plan);
+
 /* Kernel flavour: 0 auto (register profile when NLayers == 15, else LDS
  * profile), 1 register profile, 2 LDS profile. */
 int rs_hip_set_variant(RsPlan *plan, int32_t variant);

@@ -358,6 +358,24 @@ int rs_hip_sync(RsPlan *pl) {
   return 0;
 }
 
+int64_t rs_hip_div_mismatch_count(RsPlan *pl) {
+  if (!pl) return -1;
+  if (hipSetDevice(pl->device) != hipSuccess) return -1;
+  unsigned long long n = 0;
+  if (rs_read_div_mismatch(&n, pl->stream) != hipSuccess) return -1;
+  return (int64_t)n;
+}
+
+int rs_hip_division_mode(void) {
+#if defined(RS_IEEE_DIV)
+  return 0;
+#elif defined(RS_DIV_CHECK)
+  return 2;
+#else
+  return 1;
+#endif
+}
+
 int rs_hip_test_math(RsPlan *pl, int32_t fn, int64_t n, const double *x, double *y) {
   if (!pl || !x || !y || n < 1 || fn < 0 || fn > 1) return set_err("rs_hip_test_math: bad arguments");
   HIP_OK(hipSetDevice(pl->device));

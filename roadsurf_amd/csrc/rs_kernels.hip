@@ -54,7 +54,7 @@ struct LdsProfile {
   __device__ __forceinline__ void set(int j, double x) { col[(j - 1) * kBlock] = x; }
 };
 
-template <class Prof>
+template <bool FULL, class Prof>
 __device__ __forceinline__ void load_state(const double *__restrict__ st, int64_t np, int64_t p,
                                            Prof &T, Scalars &s) {
   const int N = T.nlayers();
@@ -73,12 +73,16 @@ __device__ __forceinline__ void load_state(const double *__restrict__ st, int64_
   s.albedo = st[(int64_t)RS_ST_ALBEDO * np + p];
   s.verycold = st[(int64_t)RS_ST_VERYCOLD * np + p] != 0.0;
   s.failed = st[(int64_t)RS_ST_FAILED * np + p] != 0.0;
-  s.tair_end = st[(int64_t)RS_ST_TAIR_END * np + p];
-  s.vz_end = st[(int64_t)RS_ST_VZ_END * np + p];
-  s.rh_end = st[(int64_t)RS_ST_RH_END * np + p];
+  if (FULL) { /* relaxation anchors: untouched by the LEAN variant */
+    s.tair_end = st[(int64_t)RS_ST_TAIR_END * np + p];
+    s.vz_end = st[(int64_t)RS_ST_VZ_END * np + p];
+    s.rh_end = st[(int64_t)RS_ST_RH_END * np + p];
+  } else {
+    s.tair_end = s.vz_end = s.rh_end = 0.0;
+  }
 }
 
-template <class Prof>
+template <bool FULL, class Prof>
 __device__ __forceinline__ void store_state(double *__restrict__ st, int64_t np, int64_t p,
                                             const Prof &T, const Scalars &s) {
   const int N = T.nlayers();
@@ -97,28 +101,45 @@ __device__ __forceinline__ void store_state(double *__restrict__ st, int64_t np,
   st[(int64_t)RS_ST_ALBEDO * np + p] = s.albedo;
   st[(int64_t)RS_ST_VERYCOLD * np + p] = s.verycold ? 1.0 : 0.0;
   st[(int64_t)RS_ST_FAILED * np + p] = s.failed ? 1.0 : 0.0;
-  st[(int64_t)RS_ST_TAIR_END * np + p] = s.tair_end;
-  st[(int64_t)RS_ST_VZ_END * np + p] = s.vz_end;
-  st[(int64_t)RS_ST_RH_END * np + p] = s.rh_end;
+  if (FULL) {
+    st[(int64_t)RS_ST_TAIR_END * np + p] = s.tair_end;
+    st[(int64_t)RS_ST_VZ_END * np + p] = s.vz_end;
+    st[(int64_t)RS_ST_RH_END * np + p] = s.rh_end;
+  }
 }
 
+/* The kernel arguments are read through the kernarg segment pointer (constant
+ * address space: scalar loads) and that pointer is laundered once per time
+ * step.  Effect: the 17 stream pointers + strides are s_load-ed at their point
+ * of use instead of living in ~45 SGPRs for the whole time loop (SGPR spills go
+ * to VGPR lanes and every use of a spilled value costs a v_readlane). */
+typedef const StepArgs __attribute__((address_space(4))) *KernArgs;
+
+__device__ __forceinline__ KernArgs kernargs() {
+  return (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+}
+
+/* Addressing: `base` pointers below are wave-uniform (row pointer + first point
+ * of the workgroup), `lane` is the 32-bit index of the point inside the
+ * workgroup, so every access is global_load/store saddr + 32-bit voffset with no
+ * 64-bit per-lane arithmetic. */
 template <bool FULL>
-__device__ __forceinline__ Forcing load_forcing(const RsForcing &f, int64_t row, int64_t p,
+__device__ __forceinline__ Forcing load_forcing(KernArgs ka, int64_t row0, uint32_t lane,
                                                 int32_t k) {
   Forcing o;
-  const int64_t off = row + p;
-  o.tair = f.tair[off];
-  o.vz = f.vz[off];
-  o.rhz = f.rhz[off];
-  o.prec = f.prec[off];
-  o.sw = f.sw[off];
-  o.lw = f.lw[off];
-  o.phase = f.precphase[off];
-  o.hour = f.hour_pstride ? f.hour[off] : f.hour[k];
+  const int64_t row = (int64_t)k * ka->f.t_stride + row0;
+  o.tair = (ka->f.tair + row)[lane];
+  o.vz = (ka->f.vz + row)[lane];
+  o.rhz = (ka->f.rhz + row)[lane];
+  o.prec = (ka->f.prec + row)[lane];
+  o.sw = (ka->f.sw + row)[lane];
+  o.lw = (ka->f.lw + row)[lane];
+  o.phase = (ka->f.precphase + row)[lane];
+  o.hour = ka->f.hour_pstride ? (ka->f.hour + row)[lane] : ka->f.hour[k];
   if (FULL) {
-    o.tdew = f.tdew ? f.tdew[off] : 0.0;
-    o.tsurfobs = f.tsurfobs ? f.tsurfobs[off] : R4(-9999.9);
-    o.depth = f.depth ? f.depth[off] : R4(-9999.9);
+    o.tdew = ka->f.tdew ? (ka->f.tdew + row)[lane] : 0.0;
+    o.tsurfobs = ka->f.tsurfobs ? (ka->f.tsurfobs + row)[lane] : R4(-9999.9);
+    o.depth = ka->f.depth ? (ka->f.depth + row)[lane] : R4(-9999.9);
   } else {
     o.tdew = 0.0;
     o.tsurfobs = R4(-9999.9);
@@ -127,67 +148,69 @@ __device__ __forceinline__ Forcing load_forcing(const RsForcing &f, int64_t row,
   return o;
 }
 
-__device__ __forceinline__ void store_outputs(const RsOutputs &o, int32_t i, int64_t p,
+__device__ __forceinline__ void store_outputs(KernArgs ka, int32_t i, int64_t row0, uint32_t lane,
                                               const Scalars &s, bool valid) {
   int64_t r = (int64_t)(i - 1);
-  if (o.decimate > 1) {
-    if (r % o.decimate != 0) return;
-    r /= o.decimate;
+  const int32_t dec = ka->o.decimate;
+  if (dec > 1) {
+    if (r % dec != 0) return;
+    r /= dec;
   }
-  const int64_t off = (r - o.row0) * o.t_stride + p;
+  const int64_t row = (r - ka->o.row0) * ka->o.t_stride + row0;
   const double miss = R4(-9999.0); /* src/Initialization.f90:404-411 */
-  o.tsurf[off] = valid ? s.tsurf : miss;
-  o.snow[off] = valid ? s.snow : miss;
-  o.water[off] = valid ? s.wat : miss;
-  o.ice[off] = valid ? s.ice : miss;
-  o.deposit[off] = valid ? s.dep : miss;
-  o.ice2[off] = valid ? s.ice2 : miss;
+  (ka->o.tsurf + row)[lane] = valid ? s.tsurf : miss;
+  (ka->o.snow + row)[lane] = valid ? s.snow : miss;
+  (ka->o.water + row)[lane] = valid ? s.wat : miss;
+  (ka->o.ice + row)[lane] = valid ? s.ice : miss;
+  (ka->o.deposit + row)[lane] = valid ? s.dep : miss;
+  (ka->o.ice2 + row)[lane] = valid ? s.ice2 : miss;
 }
 
 /* The time loop of runsimulation (examples/example1/src/Simulation.f90:57-115)
  * for one point over absolute indices [t0, t0+nsteps). */
 template <bool FULL, class Prof>
-__device__ __forceinline__ void time_loop(const StepArgs &a, const MathTab &mt, int64_t p, Prof &T,
-                                          Scalars &s) {
-  int32_t slot = a.cslot;
-  const RsConstants &c0 = g_consts[slot];
-  const double tbot = a.pp.tbottom[p];
+__device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s) {
+  KernArgs ka = kernargs();
+  const uint32_t lane = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * kBlock; /* first point of this workgroup */
+  const int32_t nsteps = ka->nsteps, t0 = ka->t0;
+  const double tbot = (ka->pp.tbottom + row0)[lane];
   int32_t initlen = 0;
   bool relax = false;
   double tairR = 0, vzR = 0, rhR = 0;
   if (FULL) {
-    initlen = a.pp.initlen ? a.pp.initlen[p] : 0;
-    if (c0.use_relaxation && a.pp.tair_relax) {
+    initlen = ka->pp.initlen ? (ka->pp.initlen + row0)[lane] : 0;
+    if (g_consts[ka->cslot].use_relaxation && ka->pp.tair_relax) {
       /* setInputParam, src/InputOutput.f90:19-26: targets pass through REAL(4) */
-      tairR = (double)(float)a.pp.tair_relax[p];
-      vzR = (double)(float)a.pp.vz_relax[p];
-      rhR = (double)(float)a.pp.rh_relax[p];
+      tairR = (double)(float)(ka->pp.tair_relax + row0)[lane];
+      vzR = (double)(float)(ka->pp.vz_relax + row0)[lane];
+      rhR = (double)(float)(ka->pp.rh_relax + row0)[lane];
       relax = !(tairR < R4(-100.0) || tairR > R4(100.0) || vzR < R4(0.0) || vzR > R4(100.0) ||
                 rhR < R4(0.0) || rhR > 110);
     }
   }
 
-  Forcing nxt = load_forcing<FULL>(a.f, 0, p, 0);
-  for (int32_t k = 0; k < a.nsteps; ++k) {
-    asm volatile("" : "+s"(slot));
-    const RsConstants &c = g_consts[slot];
-    const int32_t i = a.t0 + k;
-    Forcing f = nxt;
-    if (k + 1 < a.nsteps) nxt = load_forcing<FULL>(a.f, (int64_t)(k + 1) * a.f.t_stride, p, k + 1);
+  Forcing nxt = load_forcing<FULL>(ka, row0, lane, 0);
+  for (int32_t k = 0; k < nsteps; ++k) {
+    asm volatile("" : "+s"(ka));
+    const RsConstants &c = g_consts[ka->cslot];
+    const int32_t i = t0 + k;
+    const Forcing f = nxt;
 
     if (s.failed) { /* loop has exited in the reference: outputs stay -9999.0 */
-      store_outputs(a.o, i, p, s, false);
+      if (k + 1 < nsteps) nxt = load_forcing<FULL>(ka, row0, lane, k + 1);
+      store_outputs(ka, i, row0, lane, s, false);
       continue;
     }
     double tair = f.tair, vz = f.vz, rhz = f.rhz;
     /* src/Initialization.f90:121-123: VZ(1) is raised to 0.4 in the input array */
     if (i == 1 && vz < R4(0.4)) vz = R4(0.4);
-    const double prec_ts = f.prec / 3600 * c.DTSecs; /* src/InputOutput.f90:111,186 */
+    const double prec_ts = rs_div(f.prec, 3600.0) * c.DTSecs; /* src/InputOutput.f90:111,186 */
 
     if (i < c.SimLen) {
       Forcing chk = f;
       chk.vz = vz;
-      if (check_values(chk, s.tsurf, FULL && a.f.tdew != nullptr)) s.failed = true;
+      if (check_values(chk, s.tsurf, FULL && ka->f.tdew != nullptr)) s.failed = true;
       if (FULL) {
         /* SetCurrentValues obs forcing, src/InputOutput.f90:116-148 */
         if ((i <= initlen || c.force_tsurf) && f.tsurfobs > R4(-100.0)) {
@@ -205,7 +228,7 @@ __device__ __forceinline__ void time_loop(const StepArgs &a, const MathTab &mt, 
           }
           if (i > initlen) {
             const double den = (double)(4.f * 3600.f);
-            const double e = rs_exp(mt, -((c.DTSecs * i) - (c.DTSecs * initlen)) / den);
+            const double e = rs_exp(mt, rs_div(-((c.DTSecs * i) - (c.DTSecs * initlen)), den));
             tair = tair - (tairR - s.tair_end) * e;
             vz = vz - (vzR - s.vz_end) * e;
             rhz = rhz - (rhR - s.rh_end) * e;
@@ -218,8 +241,18 @@ __device__ __forceinline__ void time_loop(const StepArgs &a, const MathTab &mt, 
        * relaxation; the pre-step surface temperature uses depth(SimLen) only */
       if (FULL) s.tsurf = surface_temperature(c, T, tbot, f.depth);
     }
-    model_step(c, mt, s, T, tbot, tair, vz, rhz, prec_ts, f.sw, f.lw, f.phase, f.hour, f.depth);
-    store_outputs(a.o, i, p, s, true);
+    if (!FULL) { /* TmpNw(1:2) == Tmp(1:2) whenever observation forcing cannot act */
+      s.tnw1 = T.get(1);
+      s.tnw2 = T.get(2);
+    }
+    const Fluxes fx =
+        model_step_fluxes(c, mt, s, tair, vz, rhz, prec_ts, f.sw, f.lw, f.phase, f.hour);
+    /* next index's forcing: issued here, half a step before its first use, so the
+     * HBM latency hides under the ground/storage half without holding 14 VGPRs
+     * across the boundary-layer iteration */
+    if (k + 1 < nsteps) nxt = load_forcing<FULL>(ka, row0, lane, k + 1);
+    model_step_ground(c, s, T, tbot, tair, fx, f.depth);
+    store_outputs(ka, i, row0, lane, s, true);
   }
 }
 
@@ -232,9 +265,9 @@ __global__ void __launch_bounds__(kBlock, WPE) step_kernel_reg(const StepArgs a)
   if (p >= a.npoints) return;
   RegProfile<NL> T;
   Scalars s;
-  load_state(a.state, a.np_pad, p, T, s);
-  time_loop<FULL>(a, mt, p, T, s);
-  store_state(a.state, a.np_pad, p, T, s);
+  load_state<FULL>(a.state, a.np_pad, p, T, s);
+  time_loop<FULL>(mt, T, s);
+  store_state<FULL>(a.state, a.np_pad, p, T, s);
 }
 
 template <bool FULL, int WPE>
@@ -247,9 +280,9 @@ __global__ void __launch_bounds__(kBlock, WPE) step_kernel_lds(const StepArgs a)
   if (p >= a.npoints) return; /* no barriers below: each lane owns its column */
   LdsProfile T{lds + threadIdx.x, g_consts[a.cslot].NLayers};
   Scalars s;
-  load_state(a.state, a.np_pad, p, T, s);
-  time_loop<FULL>(a, mt, p, T, s);
-  store_state(a.state, a.np_pad, p, T, s);
+  load_state<FULL>(a.state, a.np_pad, p, T, s);
+  time_loop<FULL>(mt, T, s);
+  store_state<FULL>(a.state, a.np_pad, p, T, s);
 }
 
 /* Device part of Initialization (src/Initialization.f90:65-147): initial
@@ -399,6 +432,13 @@ __global__ void __launch_bounds__(kBlock) count_failed_kernel(const double *st, 
 
 static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + RS_BLOCK - 1) / RS_BLOCK)); }
 
+hipError_t rs_read_div_mismatch(unsigned long long *out, hipStream_t stream) {
+  hipError_t e = hipMemcpyFromSymbolAsync(out, HIP_SYMBOL(rs::g_div_mismatch), sizeof(*out), 0,
+                                          hipMemcpyDeviceToHost, stream);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(stream);
+}
+
 hipError_t rs_launch_math_test(int fn, int64_t n, const double *x, double *y, hipStream_t stream) {
   hipLaunchKernelGGL(rs::math_test_kernel, grid_for(n), dim3(RS_BLOCK), 0, stream, fn, n, x, y);
   return hipGetLastError();
@@ -426,7 +466,7 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
   if (variant == RS_VARIANT_AUTO) variant = (NL == 15) ? RS_VARIANT_REG : RS_VARIANT_LDS;
   if (variant == RS_VARIANT_REG) {
     if (NL != 15) return hipErrorInvalidValue;
-    if (wpe == 0) wpe = 2;
+    if (wpe == 0) wpe = 4;
 #define RS_REG(W)                                                                        \
   if (wpe == W) {                                                                        \
     if (full)                                                                            \
@@ -434,10 +474,10 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
     else                                                                                 \
       hipLaunchKernelGGL((rs::step_kernel_reg<15, false, W>), g, b, 0, stream, a);       \
   }
-    RS_REG(1) RS_REG(2) RS_REG(3) RS_REG(4)
+    RS_REG(2) RS_REG(3) RS_REG(4)
   } else {
     const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
-    if (wpe == 0) wpe = 3;
+    if (wpe == 0) wpe = 4;
 #define RS_LDS(W)                                                                        \
   if (wpe == W) {                                                                        \
     if (full)                                                                            \
@@ -445,7 +485,7 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
     else                                                                                 \
       hipLaunchKernelGGL((rs::step_kernel_lds<false, W>), g, b, lds, stream, a);         \
   }
-    RS_LDS(2) RS_LDS(3) RS_LDS(4)
+    RS_LDS(3) RS_LDS(4)
   }
   return hipGetLastError();
 }

@@ -29,9 +29,9 @@
  * bits.  tests/test_hip_math.py checks bit equality against libm on 1e6 arguments.
  * Cost: exp ~22, log ~30-60 VALU instructions (OCML: 45 / 97).
  *
- * Out-of-domain arguments (|x| >= 512 for exp; x <= 0, subnormal, inf, nan for
- * log) cannot be produced by the model (CheckValues bounds the inputs) and
- * take OCML's functions.
+ * Out-of-domain arguments cannot be produced by the model (CheckValues bounds
+ * the inputs): exp saturates to inf/0 for |x| >= 512 instead of glibc's gradual
+ * over/underflow; log handles 0, negatives, inf, nan and subnormals like glibc.
  */
 #pragma once
 #include <hip/hip_runtime.h>
@@ -62,6 +62,76 @@ __device__ __forceinline__ MathTab fill_math_tables(double *lds) {
   return t;
 }
 
+/* ---- correctly rounded division and square root for NORMAL-RANGE operands ----
+ *
+ * hipcc expands an IEEE fp64 `a / b` to: 2 x v_div_scale_f64, v_rcp_f64, two
+ * Newton steps on the reciprocal (4 fma), q = a*r, rem = fma(-b, q, a),
+ * v_div_fmas_f64 (= fma(rem, r, q) plus un-scaling), v_div_fixup_f64 (0, inf,
+ * nan) — 11 VALU instructions + wait states, ~46 times per point-step.
+ * v_div_scale only rescales when an operand or the quotient nears the ends of
+ * the exponent range, and v_div_fixup only patches 0/inf/nan operands.  Every
+ * division on this path has operands of moderate magnitude (temperatures,
+ * fluxes, storages, O(1e-10..1e10); denominators bounded away from 0 by the
+ * model's own guards and by CheckValues), so the bare sequence below returns
+ * the same bits in 8 instructions.  Likewise sqrt (argument 1 - 16*Stab >= 1).
+ *
+ * This is an assumption about the DATA, so it is checked, not trusted: the
+ * library built with -DRS_DIV_CHECK evaluates both forms at every call site and
+ * counts disagreements in a device counter; tests/test_hip_fastdiv.py runs the
+ * 1 M-point x 48 h workload through that build and requires the count to be 0.
+ * -DRS_IEEE_DIV switches every call site back to the compiler's expansion. */
+__device__ unsigned long long g_div_mismatch = 0ull;
+
+__device__ __forceinline__ double div_bare(double a, double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  const double q = a * r;
+  const double rem = __builtin_fma(-b, q, a);
+  return __builtin_fma(rem, r, q);
+}
+
+__device__ __forceinline__ double sqrt_bare(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+}
+
+__device__ __forceinline__ double rs_div(double a, double b) {
+#if defined(RS_IEEE_DIV)
+  return a / b;
+#elif defined(RS_DIV_CHECK)
+  const double q = a / b, f = div_bare(a, b);
+  if (__double_as_longlong(q) != __double_as_longlong(f) && !(q != q && f != f))
+    atomicAdd(&g_div_mismatch, 1ull);
+  return q;
+#else
+  return div_bare(a, b);
+#endif
+}
+
+__device__ __forceinline__ double rs_sqrt(double x) {
+#if defined(RS_IEEE_DIV)
+  return ::sqrt(x);
+#elif defined(RS_DIV_CHECK)
+  const double q = ::sqrt(x), f = sqrt_bare(x);
+  if (__double_as_longlong(q) != __double_as_longlong(f) && !(q != q && f != f))
+    atomicAdd(&g_div_mismatch, 1ull);
+  return q;
+#else
+  return sqrt_bare(x);
+#endif
+}
+
 __device__ __forceinline__ double gl_d(uint64_t bits) { return __longlong_as_double((long long)bits); }
 
 /* glibc 2.35 sysdeps/ieee754/dbl-64/e_exp.c as built for x86-64 + FMA. */
@@ -73,7 +143,10 @@ __device__ __forceinline__ double rs_exp(const MathTab &mt, double x) {
   const uint32_t abstop = (uint32_t)(ix >> 52) & 0x7ffu;
   if (__builtin_expect(abstop - 0x3c9u > 0x3eu, 0)) {
     if (abstop < 0x3c9u) return 1.0 + x; /* |x| < 2^-54 */
-    return ::exp(x);                     /* |x| >= 512, inf, nan: outside the model's domain */
+    /* |x| >= 512, inf, nan: outside the model's domain (CheckValues keeps every
+     * argument within +-300).  Saturate instead of glibc's gradual over/underflow. */
+    if (x != x) return x;
+    return (x > 0.0) ? __builtin_inf() : 0.0;
   }
   /* x = ln2/N*k + r, k integer, |r| <= ln2/2N */
   double kd = __builtin_fma(x, gl_d(RS_GL_EXP_INVLN2N), gl_d(RS_GL_EXP_SHIFT));
@@ -100,8 +173,8 @@ __device__ __forceinline__ double rs_log(const MathTab &mt, double x) {
 #ifdef RS_OCML_LOG
   return ::log(x);
 #endif
-  const uint64_t ix = (uint64_t)__double_as_longlong(x);
-  const uint32_t hi32 = (uint32_t)(ix >> 32);
+  uint64_t ix = (uint64_t)__double_as_longlong(x);
+  uint32_t hi32 = (uint32_t)(ix >> 32);
   if (hi32 - 0x3fee0000u < 0x00030900u) {
     /* 1 - 2^-4 <= x < 1 + 0x1.09p-4: polynomial in r = x - 1 with a double-double head */
     if (ix == 0x3ff0000000000000ull) return 0.0;
@@ -130,8 +203,14 @@ __device__ __forceinline__ double rs_log(const MathTab &mt, double x) {
     const double y = __builtin_fma(p, r3, lo);
     return hi + y;
   }
-  if (__builtin_expect((uint32_t)(hi32 >> 16) - 0x0010u >= 0x7ff0u - 0x0010u, 0))
-    return ::log(x); /* x <= 0, subnormal, inf, nan: outside the model's domain */
+  if (__builtin_expect((uint32_t)(hi32 >> 16) - 0x0010u >= 0x7ff0u - 0x0010u, 0)) {
+    /* x <= 0, subnormal, inf, nan: outside the model's domain (its argument is >= 1) */
+    if (ix * 2 == 0) return -__builtin_inf();
+    if (ix == 0x7ff0000000000000ull) return x;
+    if ((hi32 & 0x80000000u) || (hi32 & 0x7ff00000u) == 0x7ff00000u) return __builtin_nan("");
+    ix = (uint64_t)__double_as_longlong(x * 0x1p52) - (52ull << 52); /* subnormal: normalise */
+    hi32 = (uint32_t)(ix >> 32);
+  }
   /* x = 2^k z, z in [OFF, 2 OFF), OFF = 0x3fe6000000000000 */
   const uint32_t tmp_hi = hi32 - 0x3fe60000u;
   const uint32_t i = (tmp_hi >> 13) & 127u;

@@ -66,7 +66,7 @@ __device__ __forceinline__ double temp_at_depth(const RsConstants &c, const Prof
     if (!found && depth > zk && depth <= zk1) {
       const double tk = T.get(k);
       const double tk1 = (k == N) ? tbot : T.get(k + 1);
-      r = tk + (depth - zk) * (tk1 - tk) / (zk1 - zk);
+      r = tk + rs_div((depth - zk) * (tk1 - tk), zk1 - zk);
       found = true;
     }
   }
@@ -106,7 +106,7 @@ __device__ __forceinline__ void precipitation_to_storage(const RsConstants &c, c
       snow = R4(0.0);
     } else {
       const double pexp = R4(22.0) - R4(2.7) * tair - R4(0.20) * rhz;
-      const double prain = R4(1.0) / (R4(1.0) + rs_exp(mt, pexp));
+      const double prain = rs_div(R4(1.0), R4(1.0) + rs_exp(mt, pexp));
       if (prain < c.PLimSnow) {
         snow = prec_ts;
         rain = R4(0.0);
@@ -131,8 +131,8 @@ __device__ __forceinline__ void boundary_layer(const RsConstants &c, const MathT
                                                double &evap) {
   const double ConvLim = R4(0.001);
   const double TaK = tair + R4(273.15);
-  const double AirDens = R4(100000.0) / (R4(287.05) * TaK);
-  const double AirHCap = R4(1005.0) + ((TaK - R4(250.0)) * (TaK - R4(250.0))) / R4(3364.);
+  const double AirDens = rs_div(R4(100000.0), R4(287.05) * TaK);
+  const double AirHCap = R4(1005.0) + rs_div((TaK - R4(250.0)) * (TaK - R4(250.0)), R4(3364.));
   const double AirVCap = AirHCap * AirDens;
   const double PsychC = R4(0.1) * (R4(0.00063) * TaK + R4(0.47496));
   const double WatDen = R4(-0.0050) * tsurf * tsurf + R4(0.0079) * tsurf + R4(1000.0028);
@@ -147,41 +147,40 @@ __device__ __forceinline__ void boundary_layer(const RsConstants &c, const MathT
   double BLCond = 0.0, BLCond_Old;
   for (int j = 1; j <= 40; ++j) {
     BLCond_Old = BLCond;
-    const double UStar = vkvz / (c.logUstar + PSIM);
-    BLCond = avk * UStar / (c.logCond + PSIH);
-    double Stab = stab_num * BLCond * dT / (stab_den0 * (UStar * UStar * UStar));
+    const double UStar = rs_div(vkvz, c.logUstar + PSIM);
+    BLCond = rs_div(avk * UStar, c.logCond + PSIH);
+    double Stab = rs_div(stab_num * BLCond * dT, stab_den0 * (UStar * UStar * UStar));
     if (Stab > 1) Stab = 1;
     if (Stab > 0) {
       PSIH = R4(4.7) * Stab;
       PSIM = PSIH;
     } else {
-      PSIH = R4(-2.0) * rs_log(mt, (R4(1.0) + sqrt(R4(1.0) - R4(16.0) * Stab)) / R4(2.0));
+      PSIH = R4(-2.0) * rs_log(mt, (R4(1.0) + rs_sqrt(R4(1.0) - R4(16.0) * Stab)) / R4(2.0));
       PSIM = R4(0.6) * PSIH;
     }
     if ((j >= 5) && (fabs(BLCond - BLCond_Old) < ConvLim)) break;
   }
   blcond = BLCond;
 
-  double RAero = (c.logMom + PSIM) * (c.logHeat + PSIH) / (c.VK_Const * c.VK_Const * vz);
+  double RAero = rs_div((c.logMom + PSIM) * (c.logHeat + PSIH), c.VK_Const * c.VK_Const * vz);
   if (RAero > R4(30.0)) RAero = R4(30.);
 
-  double ESurf, ESat;
-  if (tsurf < 0)
-    ESurf = R4(0.61078) * rs_exp(mt, R4(21.875) * tsurf / (tsurf + R4(265.5)));
-  else
-    ESurf = R4(0.61078) * rs_exp(mt, R4(17.269) * tsurf / (tsurf + R4(237.3)));
-  if (tair < 0)
-    ESat = R4(0.61078) * rs_exp(mt, R4(21.875) * tair / (tair + R4(265.5)));
-  else
-    ESat = R4(0.61078) * rs_exp(mt, R4(17.269) * tair / (tair + R4(237.3)));
+  /* Magnus formula over ice (T < 0) or water: one exp per temperature, the
+   * coefficients are selected instead of the whole expression being branched */
+  const double as = (tsurf < 0) ? R4(21.875) : R4(17.269);
+  const double bs = (tsurf < 0) ? R4(265.5) : R4(237.3);
+  const double ESurf = R4(0.61078) * rs_exp(mt, rs_div(as * tsurf, tsurf + bs));
+  const double aa = (tair < 0) ? R4(21.875) : R4(17.269);
+  const double ba = (tair < 0) ? R4(265.5) : R4(237.3);
+  const double ESat = R4(0.61078) * rs_exp(mt, rs_div(aa * tair, tair + ba));
   double hum = R4(0.01) * rhz;
   if (hum > R4(1.0)) hum = R4(1.0);
   const double EAir = hum * ESat;
-  le = (AirDens * AirHCap * (ESurf - EAir)) / (PsychC * RAero);
+  le = rs_div(AirDens * AirHCap * (ESurf - EAir), PsychC * RAero);
   if (tsurf >= R4(0.0))
-    evap = (le / (c.LVap * WatDen)) * R4(1000.0) * c.DTSecs;
+    evap = rs_div(le, c.LVap * WatDen) * R4(1000.0) * c.DTSecs;
   else
-    evap = (le / (c.LFus * WatDen)) * R4(1000.0) * c.DTSecs;
+    evap = rs_div(le, c.LFus * WatDen) * R4(1000.0) * c.DTSecs;
   if ((le > R4(0.0)) && (wat <= R4(0.0))) {
     le = R4(0.0);
     evap = R4(0.0);
@@ -228,7 +227,7 @@ __device__ __forceinline__ void melting(Scalars &s, Prof &T, double hstor, doubl
       T.set(2, s.t4melt + R4(0.01));
     } else {
       const double QLeftOver = QAvail - s.q2melt;
-      T.set(1, s.t4melt + (QLeftOver / hs1));
+      T.set(1, s.t4melt + rs_div(QLeftOver, hs1));
       T.set(2, s.t4melt + R4(0.01));
     }
   } else {
@@ -287,7 +286,7 @@ __device__ __forceinline__ void road_condition(const RsConstants &c, Scalars &s,
     double WatSnowRat;
     const double RDummy = ext + s.snow;
     if (RDummy > R4(0.001))
-      WatSnowRat = ext / RDummy;
+      WatSnowRat = rs_div(ext, RDummy);
     else
       WatSnowRat = R4(0.0);
     if (s.snow > R4(0.0)) {
@@ -297,7 +296,7 @@ __device__ __forceinline__ void road_condition(const RsConstants &c, Scalars &s,
         s.dep = R4(0.0);
       }
       if ((s.q2melt > R4(0.0)) && (s.tsurf >= c.TLimMeltSnow)) {
-        const double Melted = (s.q2melt * c.DTSecs) / (c.WatMHeat * c.WatDens);
+        const double Melted = rs_div(s.q2melt * c.DTSecs, c.WatMHeat * c.WatDens);
         s.snow = s.snow - R4(1000.) * Melted;
         s.wat = s.wat + R4(1000.) * Melted;
       }
@@ -331,7 +330,7 @@ __device__ __forceinline__ void road_condition(const RsConstants &c, Scalars &s,
   }
   if ((s.snow <= R4(0.)) && (s.ice > R4(0.))) {
     if ((s.q2melt > R4(0.0)) && (s.tsurf >= c.TLimMeltIce)) {
-      const double Melted = (s.q2melt * c.DTSecs) / (c.WatMHeat * c.WatDens);
+      const double Melted = rs_div(s.q2melt * c.DTSecs, c.WatMHeat * c.WatDens);
       s.ice = s.ice - R4(1000.) * Melted;
       s.ice2 = s.ice2 - R4(1000.) * Melted;
       s.wat = s.wat + R4(1000.) * Melted;
@@ -364,11 +363,11 @@ __device__ __forceinline__ void road_condition(const RsConstants &c, Scalars &s,
   /* NewMeltFreezeHeat, src/Storage.f90:409-432 */
   s.q2melt = R4(0.0);
   if (s.snow > R4(0.0)) {
-    s.q2melt = c.WatMHeat * c.WatDens * (s.snow / R4(1000.)) / c.DTSecs;
+    s.q2melt = rs_div(c.WatMHeat * c.WatDens * rs_div(s.snow, R4(1000.)), c.DTSecs);
     s.t4melt = c.TLimMeltSnow;
   }
   if ((s.snow <= R4(0.0)) && (s.ice > R4(0.0))) {
-    s.q2melt = c.WatMHeat * c.WatDens * (s.ice / R4(1000.)) / c.DTSecs;
+    s.q2melt = rs_div(c.WatMHeat * c.WatDens * rs_div(s.ice, R4(1000.)), c.DTSecs);
     s.t4melt = c.TLimMeltIce;
   }
   if (s.q2melt < R4(0.0)) s.q2melt = R4(0.0);
@@ -383,7 +382,7 @@ __device__ __forceinline__ void road_condition(const RsConstants &c, Scalars &s,
       alb = c.AlbSnow;
     } else if (s.ice > R4(0.01) || s.dep > R4(0.01)) {
       if (IceSum < IceMax)
-        alb = c.AlbDry + (IceSum / IceMax) * (c.AlbSnow - c.AlbDry);
+        alb = c.AlbDry + rs_div(IceSum, IceMax) * (c.AlbSnow - c.AlbDry);
       else
         alb = c.AlbSnow;
     }
@@ -392,52 +391,65 @@ __device__ __forceinline__ void road_condition(const RsConstants &c, Scalars &s,
 }
 
 /* roadModelOneStep (examples/example1/src/Simulation.f90:120-172) with
- * BalanceModelOneStep (src/BalanceModel.f90:7-86) inlined.
+ * BalanceModelOneStep (src/BalanceModel.f90:7-86) inlined, in two halves so that
+ * the caller can issue the next time index's forcing loads between them.
  * On entry: tair/vz/rhz/prec_ts are the current atm values (after
  * SetCurrentValues / relaxation / lastValues), T is Tmp(1..N) possibly with obs
- * forcing applied, s.tsurf is up to date.  depth_i is modelInput%depth(i). */
-template <class Prof>
-__device__ __forceinline__ void model_step(const RsConstants &c, const MathTab &mt, Scalars &s,
-                                           Prof &T, double tbot, double tair, double vz,
-                                           double rhz, double prec_ts, double sw, double lw,
-                                           int32_t phase, int32_t hour, double depth_i) {
-  const int N = T.nlayers();
+ * forcing applied, s.tsurf is up to date. */
+struct Fluxes {
+  double blcond, le, evap, rnet, trffric;
+};
+
+/* first half: precipitation -> storages, day/night, boundary layer, net radiation */
+__device__ __forceinline__ Fluxes model_step_fluxes(const RsConstants &c, const MathTab &mt,
+                                                    Scalars &s, double tair, double vz, double rhz,
+                                                    double prec_ts, double sw, double lw,
+                                                    int32_t phase, int32_t hour) {
+  Fluxes fx;
   precipitation_to_storage(c, mt, s, phase, prec_ts, tair, rhz);
 
   /* SetDayDependendVariables, src/BalanceModel.f90:354-387 */
-  double calm, trffric;
+  double calm;
   if (((double)hour >= c.NightOn) || ((double)hour <= c.NightOff)) {
     calm = c.CalmLimNgt;
-    trffric = c.TrfFricNgt;
+    fx.trffric = c.TrfFricNgt;
   } else {
     calm = c.CalmLimDay;
-    trffric = c.TrFfricDay;
+    fx.trffric = c.TrFfricDay;
   }
   if (vz < calm) vz = calm;
 
-  double blcond, le, evap;
-  boundary_layer(c, mt, s.tsurf, tair, vz, rhz, s.wat, blcond, le, evap);
+  boundary_layer(c, mt, s.tsurf, tair, vz, rhz, s.wat, fx.blcond, fx.le, fx.evap);
 
   /* CalcRNet, src/BalanceModel.f90:282-307 (SwRadCof = LwRadCof = 1.0 off the
    * coupling path; x*1.0 is exact so the factors are kept out) */
   const double TsurfK = s.tsurf + R4(273.15);
   const double TsurfK2 = TsurfK * TsurfK;
   const double RBB = c.Emiss * c.SB_Const * (TsurfK2 * TsurfK2);
-  const double RNet = (R4(1.) - s.albedo) * sw + c.Emiss * lw - RBB;
+  fx.rnet = (R4(1.) - s.albedo) * sw + c.Emiss * lw - RBB;
+  return fx;
+}
 
+/* second half: ground profile, melting, new surface temperature, storages.
+ * depth_i is modelInput%depth(i). */
+template <class Prof>
+__device__ __forceinline__ void model_step_ground(const RsConstants &c, Scalars &s, Prof &T,
+                                                  double tbot, double tair, const Fluxes &fx,
+                                                  double depth_i) {
+  const int N = T.nlayers();
   /* CalcHCapHCond + calcCapDZCondDZ + calcProfile fused
    * (src/BalanceModel.f90:189-251, 132-155, 90-129) */
   const double t1old = T.get(1), t2old = T.get(2);
-  const double Sens = blcond * (tair - t1old);
-  double Gprev = RNet - le + trffric + Sens;
+  const double Sens = fx.blcond * (tair - t1old);
+  double Gprev = fx.rnet - fx.le + fx.trffric + Sens;
   double hs1 = 0.0;
 #pragma unroll
   for (int j = 1; j <= N; ++j) {
     const double tj = T.get(j);
     const double tstale = (j == 1) ? s.tnw1 : (j == 2) ? s.tnw2 : tj;
     const double vsh = layer_vsh(c, j, tstale);
-    if (j == 1) hs1 = vsh * c.HSfac1 / c.twoDT;
-    const double capDZ = -(1.0 / (c.DyC[j] * vsh));
+    if (j == 1) hs1 = rs_div(vsh * c.HSfac1, c.twoDT);
+    const double capDZ = -rs_div(1.0, c.DyC[j] * vsh);
     const double tnext = (j == N) ? tbot : T.get(j + 1);
     const double G = c.condDZ[j] * (tnext - tj);
     T.set(j, tj + c.DTSecs * (capDZ * (G - Gprev)));
@@ -457,7 +469,7 @@ __device__ __forceinline__ void model_step(const RsConstants &c, const MathTab &
   const double depth = (c.tsurfOutputDepth >= R4(0.0)) ? c.tsurfOutputDepth : depth_i;
   s.tsurf = surface_temperature(c, T, tbot, depth);
 
-  road_condition(c, s, evap);
+  road_condition(c, s, fx.evap);
 }
 
 /* CheckValues, src/InputOutput.f90:45-84 (sky-view checks excluded) */
