@@ -61,6 +61,19 @@ def cpu_baseline(sample_points: int, simlen: int, seed: int):
     }
 
 
+def measured_traffic(points: int, chunk: int):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (profiles/r01_traffic.json), valid for the configuration it was collected on."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        t = json.load(open(path))
+    except (OSError, ValueError):
+        return None, None
+    if t.get("points") != points or t.get("chunk_steps") != chunk:
+        return None, None
+    return t.get("traffic_bytes_per_launch"), t.get("derived")
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,17 +99,24 @@ def main() -> None:
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     device.require_gpu()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if ndev >= world:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL; used for barrier + MAX only
+        else:  # rehearsal: more ranks than GPUs on this box -> ranks share cards, gloo for control
+            print(f"[bench] {world} ranks on {ndev} GPU(s): sharing devices, gloo control plane",
+                  file=sys.stderr)
+            dist.init_process_group("gloo")
 
     spk = 120                      # 3600 s / DTSecs 30 s
     simlen = args.hours * spk + 1  # examples/example1/src/InputSettings.cpp:98
     settings = abi.default_settings(simlen)
     params = abi.default_parameters()
     n = args.points
-    plan = device.Plan(n, settings, params, local_rank)
+    plan = device.Plan(n, settings, params, dev_index)
     if args.variant:
         plan.set_variant(args.variant)
     npad = plan.np_pad
@@ -135,7 +155,9 @@ def main() -> None:
         one_pass()
     fence()
     elapsed = time.perf_counter() - t_start
-    elapsed = sharding.max_over_ranks(elapsed, dist if world > 1 else None, dev)
+    elapsed = sharding.max_over_ranks(
+        elapsed, dist if world > 1 else None,
+        dev if (world > 1 and dist.get_backend() == "nccl") else None)
     step_ms, nlaunch = plan.timing_step_ms()
     nfail = plan.failed_count()
 
@@ -146,6 +168,7 @@ def main() -> None:
     units_per_launch = units_per_pass * args.steps / max(nlaunch, 1)
     achieved = ALGO_BYTES_PER_UNIT * units_per_launch / avg_launch_s / 1e9
 
+    traffic, valu = measured_traffic(n, chunk)
     if rank == 0:
         line = {
             "metric": "point_timesteps_per_s",
@@ -177,7 +200,10 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
+                                  "per launch of 2.4e8 units)" if traffic else None,
+                "valu": valu,
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "launches": nlaunch,
                 "units_per_launch": units_per_launch,
