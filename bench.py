@@ -84,6 +84,9 @@ def main() -> None:
     ap.add_argument("--chunk", type=int, default=240, help="time indices per step-kernel launch")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 register profile, 2 LDS profile")
     ap.add_argument("--seed", type=int, default=20240110)
+    ap.add_argument("--overlap", action="store_true",
+                    help="double-buffer: expand window c+1 on a side stream while stepping window c "
+                         "(measured: no gain, the step kernel owns the whole register file; DESIGN.md 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4096)
     args = ap.parse_args()
@@ -124,21 +127,42 @@ def main() -> None:
     offset, _ = sharding.weak_shard(n, rank)
     spec, knots = plan.synth_knots(args.seed, nknots, point_offset=offset, steps_per_knot=spk)
     chunk = min(args.chunk, simlen)
-    win = device.ForcingWindow.empty(chunk, npad, dev, optional=())
+    overlap = args.overlap
+    nbuf = 2 if overlap else 1
+    wins = [device.ForcingWindow.empty(chunk, npad, dev, optional=()) for _ in range(nbuf)]
     out = device.OutputWindow.empty(chunk, npad, dev)
     # index-1 window for the init kernel: needs TsurfObs(1)
     win0 = device.ForcingWindow.empty(1, npad, dev, optional=("tsurfobs",))
     pp = plan.point_params(plan.uniform_tbottom(2024, 1, 10))
+    main = plan.stream
+    side = torch.cuda.Stream(dev) if overlap else main
+    starts = list(range(1, simlen + 1, chunk))
+    ev_filled = [torch.cuda.Event() for _ in range(nbuf)]    # window b holds fresh forcing
+    ev_consumed = [torch.cuda.Event() for _ in range(nbuf)]  # step kernel is done with window b
 
     def one_pass():
+        """init -> per window: expand (HBM-bound, side stream) || step (VALU-bound, main stream).
+        Double-buffered: expansion of window c+1 overlaps stepping of window c."""
         plan.expand(spec, knots, win0, 1, 1)
         plan.init_state(win0, pp)
-        t0 = 1
-        while t0 <= simlen:
+        if not overlap:
+            for t0 in starts:
+                ns = min(chunk, simlen - t0 + 1)
+                plan.expand(spec, knots, wins[0], t0, ns)
+                plan.step(wins[0], out, pp, t0, ns, out_row0=t0 - 1)
+            return
+        side.wait_stream(main)
+        for c, t0 in enumerate(starts):
+            b = c % 2
             ns = min(chunk, simlen - t0 + 1)
-            plan.expand(spec, knots, win, t0, ns)
-            plan.step(win, out, pp, t0, ns, out_row0=t0 - 1)
-            t0 += ns
+            if c >= 2:
+                side.wait_event(ev_consumed[b])
+            plan.expand(spec, knots, wins[b], t0, ns, stream=side)
+            ev_filled[b].record(side)
+            main.wait_event(ev_filled[b])
+            plan.step(wins[b], out, pp, t0, ns, out_row0=t0 - 1)
+            ev_consumed[b].record(main)
+        main.wait_stream(side)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -189,6 +213,7 @@ def main() -> None:
                 "points_per_gpu": n,
                 "simlen": simlen,
                 "chunk_steps": chunk,
+                "overlap_expand_with_step": overlap,
                 "kernel_variant": args.variant,
                 "parallelism": f"points sharded over {world} GPU(s), no collectives",
                 "failed_points": int(nfail),

@@ -317,6 +317,14 @@ int rs_hip_expand_forcing(RsPlan *plan, const RsSynthSpec *spec,
                           const double *knots, int32_t k0, int32_t nknots,
                           const RsForcing *f, int32_t t0, int32_t nsteps);
 
+/* Same, enqueued on another HIP stream (hipStream_t) than the plan's: lets a caller
+ * overlap the HBM-bound expansion of window c+1 with the VALU-bound stepping of
+ * window c (double-buffered windows, dependencies by HIP events on the caller's side). */
+int rs_hip_expand_forcing_on(RsPlan *plan, const RsSynthSpec *spec,
+                             const double *knots, int32_t k0, int32_t nknots,
+                             const RsForcing *f, int32_t t0, int32_t nsteps,
+                             void *stream);
+
 /* Test hook: y[i] = device exp (fn 0) / log (fn 1) of x[i], device pointers
  * (roadsurf_amd/csrc/rs_math.hpp; tests/test_hip_math.py). */
 int rs_hip_test_math(RsPlan *plan, int32_t fn, int64_t n, const double *x, double *y);

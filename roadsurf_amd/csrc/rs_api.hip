@@ -399,8 +399,9 @@ int rs_hip_synth_knots(RsPlan *pl, const RsSynthSpec *spec, double *knots, int32
   return 0;
 }
 
-int rs_hip_expand_forcing(RsPlan *pl, const RsSynthSpec *spec, const double *knots, int32_t k0,
-                          int32_t nknots, const RsForcing *f, int32_t t0, int32_t nsteps) {
+int rs_hip_expand_forcing_on(RsPlan *pl, const RsSynthSpec *spec, const double *knots, int32_t k0,
+                             int32_t nknots, const RsForcing *f, int32_t t0, int32_t nsteps,
+                             void *stream) {
   if (!pl || !spec || !knots || !f) return set_err("rs_hip_expand_forcing: bad arguments");
   if (check_forcing(pl, f, "rs_hip_expand_forcing")) return -1;
   if (nsteps < 1 || nsteps > 65535 || t0 < 1)
@@ -426,8 +427,14 @@ int rs_hip_expand_forcing(RsPlan *pl, const RsSynthSpec *spec, const double *kno
   a.start_hour = spec->start_hour;
   a.kfirst = kfirst;
   a.nsteps = nsteps;
-  HIP_OK(rs_launch_expand(a, (t0 + nsteps - 2) / spk - kfirst + 1, pl->stream));
+  HIP_OK(rs_launch_expand(a, (t0 + nsteps - 2) / spk - kfirst + 1, (hipStream_t)stream));
   return 0;
+}
+
+int rs_hip_expand_forcing(RsPlan *pl, const RsSynthSpec *spec, const double *knots, int32_t k0,
+                          int32_t nknots, const RsForcing *f, int32_t t0, int32_t nsteps) {
+  if (!pl) return set_err("rs_hip_expand_forcing: bad arguments");
+  return rs_hip_expand_forcing_on(pl, spec, knots, k0, nknots, f, t0, nsteps, pl->stream);
 }
 
 } /* extern "C" */

@@ -186,11 +186,14 @@ class Plan:
                                             0, nknots), "rs_hip_synth_knots")
         return spec, knots
 
-    def expand(self, spec, knots, window: ForcingWindow, t0: int, nsteps: int) -> None:
+    def expand(self, spec, knots, window: ForcingWindow, t0: int, nsteps: int,
+               stream: torch.cuda.Stream | None = None) -> None:
         f = window.struct(0)
-        lib.check(self.L.rs_hip_expand_forcing(self._h, C.byref(spec), C.c_void_p(knots.data_ptr()),
-                                               0, knots.shape[0], C.byref(f), t0, nsteps),
-                  "rs_hip_expand_forcing")
+        st = (stream or self.stream).cuda_stream
+        lib.check(self.L.rs_hip_expand_forcing_on(self._h, C.byref(spec),
+                                                  C.c_void_p(knots.data_ptr()), 0, knots.shape[0],
+                                                  C.byref(f), t0, nsteps, C.c_void_p(st)),
+                  "rs_hip_expand_forcing_on")
 
 
 def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputParameters,
