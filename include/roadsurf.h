@@ -168,6 +168,11 @@ typedef struct RsConstants {
   int32_t SimLen;
   int32_t use_relaxation;
   int32_t force_tsurf;
+  int32_t use_coupling;    /* settings%use_coupling; per point it is switched off without a
+                              usable observation (src/InputOutput.f90:34-36) */
+  int32_t cplLenI;         /* int(coupling_minutes*60/DTs)   src/Coupling.f90:516-517 */
+  double cplLenR;          /* coupling_minutes*60/DTs        src/Coupling.f90:512 */
+  double cplReduction;     /* couplingEffectReduction        src/Coupling.f90:84-87 */
   double DTSecs;
   double Tph;              /* DTSecs/3600.0  src/Initialization.f90:92 */
   double tsurfOutputDepth; /* <0: use depth(i) */
@@ -254,6 +259,12 @@ typedef struct RsPointParams {
   const double *tbottom;  /* Tmp(NLayers+1), src/Initialization.f90:267 */
   const int32_t *initlen; /* LocalParameters.InitLenI */
   const double *tair_relax, *vz_relax, *rh_relax; /* may be NULL if !use_relaxation */
+  /* LocalParameters.couplingIndexI / couplingTsurf; may be NULL if !use_coupling.  With
+   * coupling the step window must be the whole series (t0 = 1, nsteps = SimLen): a point
+   * replays its coupling window up to 25 times (src/Coupling.f90:61-78,324), so the window
+   * has to stay addressable. */
+  const int32_t *coupling_index;
+  const double *coupling_tsurf;
 } RsPointParams;
 
 const char *rs_last_error(void);

@@ -60,3 +60,30 @@ gcc -O2 -fPIC -fopenmp -c "$HERE/harness.c" -o "$TMP/obj/harness.o"
 $FC -shared -o "$OUT/libroadsurf_ref.so" "$TMP"/obj/*.o -fopenmp -lgomp 2>/dev/null || \
 $FC -shared -o "$OUT/libroadsurf_ref.so" "$TMP"/obj/*.o -L/usr/lib/gcc/x86_64-linux-gnu/11 -lgomp
 echo "built $OUT/libroadsurf_ref.so"
+
+# ---- second variant: coupling as the reference INTENDS it --------------------------
+# The reference relies on undefined behaviour for coupling: setInputParam stores the
+# observation (coupling%obsI(1), obsTsurf(1), NObs; src/InputOutput.f90:30-33) and THEN
+# `allocator` is called with `type(couplingVariables), intent(OUT) :: coupling`
+# (src/Initialization.f90:96,150-157).  An INTENT(OUT) dummy becomes undefined on entry;
+# gfortran (the documented compiler) happens to leave the non-allocatable components alone,
+# flang re-initialises the whole object, so in the strict build above obsI(1) = 0,
+# obsTsurf(1) = 0 and the coupling window is [1,0]: coupling never runs (and, because
+# use_coupling stays .true., observation forcing is disabled too, src/InputOutput.f90:120-121).
+# That is faithfully what libroadsurf_ref.so does.  To pin the coupling ALGORITHM we also
+# build libroadsurf_ref_cpl.so from the same sources with ONE token changed in the temp
+# copy of Initialization.f90: that dummy's INTENT(OUT) -> INTENT(INOUT), i.e. gfortran's
+# observable behaviour.  Nothing else differs; non-coupled runs are bit-identical between
+# the two libraries (tests/test_oracle_vs_golden.py).
+rm "$TMP/src/Initialization.f90"
+sed '/^Subroutine allocator/,/^end Subroutine/ s/type(couplingVariables), intent(OUT) :: coupling/type(couplingVariables), intent(INOUT) :: coupling/' \
+    "$REF/src/Initialization.f90" > "$TMP/src/Initialization.f90"
+if cmp -s "$REF/src/Initialization.f90" "$TMP/src/Initialization.f90"; then
+  echo "build_ref: allocator intent line not found - reference changed?" >&2; exit 1
+fi
+[ "$(diff "$REF/src/Initialization.f90" "$TMP/src/Initialization.f90" | grep -c '^>')" = "1" ]
+cd "$TMP/src"
+$FC $FFLAGS -module-dir "$TMP/obj" -I. -c Initialization.f90 -o "$TMP/obj/Initialization.o"
+$FC -shared -o "$OUT/libroadsurf_ref_cpl.so" "$TMP"/obj/*.o -fopenmp -lgomp 2>/dev/null || \
+$FC -shared -o "$OUT/libroadsurf_ref_cpl.so" "$TMP"/obj/*.o -L/usr/lib/gcc/x86_64-linux-gnu/11 -lgomp
+echo "built $OUT/libroadsurf_ref_cpl.so"

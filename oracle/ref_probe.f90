@@ -77,3 +77,43 @@ subroutine ref_probe_blcond(inputParam, dtsecs, tsurfave, tair, vz, rhz, srfwat,
    le = atm%LE_Flux
    evap = ev
 end subroutine ref_probe_blcond
+
+!> Coupling set-up as the reference's Initialization leaves it (src/Coupling.f90:486-534).
+subroutine ref_probe_coupling_init(inPointers, outPointers, inSettings, inputParam, localParam, &
+                                   ivals, rvals) bind(C, name='ref_probe_coupling_init')
+   use, intrinsic :: iso_c_binding
+   use RoadSurfVariables
+   use RoadSurf
+   implicit none
+   type(InputPointers), intent(in) :: inPointers
+   type(OutputPointers), intent(inout) :: outPointers
+   type(InputSettings), intent(in) :: inSettings
+   type(InputParameters), intent(in) :: inputParam
+   type(LocalParameters), intent(in) :: localParam
+   integer(c_int), intent(out) :: ivals(8)
+   real(c_double), intent(out) :: rvals(4)
+   type(InputArrays) :: modelInput
+   type(OutputArrays) :: modelOutput
+   type(PhysicalParameters) :: phy
+   type(GroundVariables) :: ground
+   type(SurfaceVariables) :: surf
+   type(AtmVariables) :: atm
+   type(CouplingVariables) :: coupling
+   type(ModelSettings) :: settings
+   type(RoadCondParameters) :: condParam
+   call ConnectFortran2Carrays(inPointers, modelInput, outPointers, modelOutput)
+   call Initialization(modelInput, inSettings, settings, modelOutput, atm, surf, inputParam, &
+                       localParam, coupling, phy, ground, condParam)
+   ivals(1) = merge(1, 0, settings%use_coupling)
+   ivals(2) = coupling%obsI(1)
+   ivals(3) = coupling%couplingStartI(1)
+   ivals(4) = coupling%couplingEndI(1)
+   ivals(5) = coupling%NObs
+   ivals(6) = coupling%CoupPhaseN
+   ivals(7) = merge(1, 0, coupling%Coupling_failed)
+   ivals(8) = merge(1, 0, settings%use_relaxation)
+   rvals(1) = coupling%lastTsurfObs
+   rvals(2) = coupling%obsTsurf(1)
+   rvals(3) = atm%TairR
+   rvals(4) = coupling%RadCoeff
+end subroutine ref_probe_coupling_init

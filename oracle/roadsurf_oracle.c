@@ -59,9 +59,16 @@ typedef struct {
       WatMHeat, PorEvaF, DampWearF, TLimFreeze, TLimMeltSnow, TLimMeltIce,
       TLimMeltDep, TLimDew, TLimColdH, TLimColdL, WetSnowFormR, WetSnowMeltR,
       PLimSnow, PLimRain, WWetLim, WWearLim, Snow2IceFac;
-  /* coupling members read on the non-coupled path (src/Coupling.f90:144-169) */
+  /* coupling (src/CouplingVariables.f90.inc); NObs = CoupPhaseN = 1 in this model version */
   double SwRadCof, LwRadCof, lastTsurfObs;
   int inCouplingPhase;
+  int Coupling_iterations, start_coupling_again, Coupling_failed, couplingStartI, couplingEndI,
+      saveDatai, VeryColdSave, coupling_minutes;
+  double TsurfNearestAbove, TsurfNearestBelow, RadCoeff, RadCoefNearestAbove, RadCoefNearestBelow,
+      RadCoeffPrevious, SW_correction, LW_correction, Tsurf_end_coup1, couplingEffectReduction;
+  double TsurfAveSave, SrfWatmmsSave, SrfIce2mmsSave, SrfDepmmsSave, SrfSnowmmsSave, AlbedoSave;
+  double TmpSave[MAXL + 2];
+  int skyview_on;
   /* wear factors (src/WearingFactors.f90.inc) */
   double SnowTran, DepWear, IceWear, IceWear2, WatWear;
 } Model;
@@ -553,6 +560,197 @@ static void CalcAlbedo(Model *m) {
   }
 }
 
+/* ---- coupling: src/Coupling.f90 ------------------------------------------------ */
+
+/* src/Coupling.f90:172-210.  SrfIcemms is NOT saved (the reference saves Ice2 twice,
+ * :194-195); the SW/SW_dir/LW window copies only matter when something mutates those
+ * inputs (sky view), see uploadDataForCoupling. */
+static void saveDataForCoupling(Model *m, int datai) {
+  m->saveDatai = datai;
+  m->TsurfAveSave = m->TsurfAve;
+  m->SrfWatmmsSave = m->Wat;
+  m->SrfIce2mmsSave = m->Ice2;
+  m->SrfDepmmsSave = m->Dep;
+  m->SrfSnowmmsSave = m->Snow;
+  m->AlbedoSave = m->Albedo;
+  m->VeryColdSave = m->VeryCold;
+  memcpy(m->TmpSave, m->Tmp, sizeof(double) * (m->NLayers + 2));
+}
+
+/* src/Coupling.f90:213-255 (Tmp restored, TmpNw not; SrfIcemms not restored) */
+static void uploadDataForCoupling(Model *m, int *datai) {
+  *datai = m->saveDatai;
+  m->TsurfAve = m->TsurfAveSave;
+  m->Wat = m->SrfWatmmsSave;
+  m->Ice2 = m->SrfIce2mmsSave;
+  m->Dep = m->SrfDepmmsSave;
+  m->Snow = m->SrfSnowmmsSave;
+  m->Albedo = m->AlbedoSave;
+  m->VeryCold = m->VeryColdSave;
+  memcpy(m->Tmp, m->TmpSave, sizeof(double) * (m->NLayers + 2));
+}
+
+/* src/Coupling.f90:259-289 */
+static void snowIceCheck(Model *m) {
+  const double obs = m->lastTsurfObs;
+  if (obs > m->TLimMeltSnow && m->Snow > R4(0.00)) {
+    m->Wat = m->Wat + m->Snow;
+    m->Snow = R4(0.00);
+  }
+  if (obs > m->TLimMeltIce && m->Ice > R4(0.00)) {
+    m->Wat = m->Wat + m->Ice;
+    m->Ice = R4(0.00);
+  }
+  if (obs > m->TLimMeltIce && m->Ice2 > R4(0.00)) m->Ice2 = R4(0.00);
+  if (obs > m->TLimMeltDep && m->Dep > R4(0.00)) {
+    m->Wat = m->Wat + m->Dep;
+    m->Dep = R4(0.00);
+  }
+}
+
+/* src/Coupling.f90:10-96 */
+static void CouplingOperations1(Model *m, const InputPointers *in, int *i) {
+  const double DTs = m->DTSecs;
+  m->inCouplingPhase = 0;
+  if (*i >= m->couplingStartI && *i <= m->couplingEndI) m->inCouplingPhase = 1;
+  if (*i == m->couplingStartI && m->Coupling_iterations == 0) {
+    saveDataForCoupling(m, *i);
+    m->SwRadCof = R4(1.0);
+    m->LwRadCof = R4(1.0);
+    m->SW_correction = R4(0.0);
+    m->LW_correction = R4(0.0);
+  }
+  if (m->start_coupling_again) {
+    uploadDataForCoupling(m, i);
+    m->start_coupling_again = 0;
+    if (in->c_SW[*i - 1] > in->c_LW[*i - 1] && !m->skyview_on) {
+      m->SwRadCof = m->RadCoeff;
+      m->LwRadCof = R4(1.0);
+    } else {
+      m->SwRadCof = R4(1.0);
+      m->LwRadCof = m->RadCoeff;
+    }
+  }
+  if (*i > m->couplingEndI) {
+    m->SwRadCof = R4(1.0) + m->SW_correction * exp(-((DTs * *i) - (DTs * m->couplingEndI)) /
+                                                       m->couplingEffectReduction);
+    m->LwRadCof = R4(1.0) + m->LW_correction * exp(-((DTs * *i) - (DTs * m->couplingEndI)) /
+                                                       m->couplingEffectReduction);
+  }
+  if (m->inCouplingPhase) snowIceCheck(m);
+}
+
+/* src/Coupling.f90:292-481.  TsurfAve and LastTsurfObs make a round trip through
+ * Kelvin (+273.16, -273.16): the rounding it leaves behind is part of the result. */
+static void Coupling_control(Model *m) {
+  double TDifAbove, TDifBelow;
+  m->start_coupling_again = 0;
+  m->TsurfAve = m->TsurfAve + R4(273.16);
+  m->lastTsurfObs = m->lastTsurfObs + R4(273.16);
+  if (!m->Coupling_failed) {
+    if (m->Coupling_iterations == 0) m->Tsurf_end_coup1 = m->TsurfAve;
+    if (m->Coupling_iterations == 25) {
+      if (fabs(m->Tsurf_end_coup1 - m->lastTsurfObs) < fabs(m->TsurfAve - m->lastTsurfObs))
+        m->start_coupling_again = 1;
+      m->SwRadCof = R4(1.0); m->LwRadCof = R4(1.0);
+      m->SW_correction = R4(0.0); m->LW_correction = R4(0.0);
+      m->RadCoeff = R4(1.0);
+      m->Coupling_failed = 1;
+    } else if (m->lastTsurfObs < -100) {
+      m->SwRadCof = R4(1.0); m->LwRadCof = R4(1.0);
+      m->SW_correction = R4(0.0); m->LW_correction = R4(0.0);
+      m->RadCoeff = R4(1.0);
+      m->Coupling_failed = 1;
+      m->start_coupling_again = 1;
+    } else if (m->TsurfAve < R4(170.0) || m->TsurfAve > R4(400.0) || m->Coupling_failed) {
+      m->SwRadCof = R4(1.0); m->LwRadCof = R4(1.0);
+      m->SW_correction = R4(0.0); m->LW_correction = R4(0.0);
+      m->Coupling_failed = 1;
+      m->start_coupling_again = 1;
+      m->RadCoeff = R4(1.0);
+    } else if (m->TsurfAve - m->lastTsurfObs > R4(0.1)) {
+      if (m->TsurfNearestAbove < -100) {
+        m->TsurfNearestAbove = m->TsurfAve;
+        m->RadCoefNearestAbove = m->RadCoeff;
+      } else if (m->TsurfNearestAbove - m->lastTsurfObs > m->TsurfAve - m->lastTsurfObs) {
+        m->TsurfNearestAbove = m->TsurfAve;
+        m->RadCoefNearestAbove = m->RadCoeff;
+      }
+      m->start_coupling_again = 1;
+      if (m->TsurfNearestAbove > -100 && m->TsurfNearestBelow > -100) {
+        TDifAbove = m->TsurfNearestAbove - m->lastTsurfObs;
+        TDifBelow = m->lastTsurfObs - m->TsurfNearestBelow;
+        m->RadCoeff = m->RadCoefNearestAbove -
+                      TDifAbove / (TDifAbove + TDifBelow) * (m->RadCoefNearestAbove - m->RadCoefNearestBelow);
+      } else {
+        m->RadCoeff = R4(0.5) * m->RadCoeff;
+      }
+      if (fabs(m->RadCoeff - m->RadCoeffPrevious) < R4(0.00005)) {
+        m->TsurfNearestAbove = -9999;
+        m->TsurfNearestBelow = -9999;
+      }
+      if (m->RadCoeff < R4(0.01)) {
+        m->RadCoeff = R4(1.0);
+        m->Coupling_failed = 1;
+        m->SwRadCof = R4(1.0); m->LwRadCof = R4(1.0);
+        m->SW_correction = R4(0.0); m->LW_correction = R4(0.0);
+      }
+      m->RadCoeffPrevious = m->RadCoeff;
+    } else if (m->lastTsurfObs - m->TsurfAve > R4(0.1)) {
+      if (m->TsurfNearestBelow < -100) {
+        m->TsurfNearestBelow = m->TsurfAve;
+        m->RadCoefNearestBelow = m->RadCoeff;
+      } else if (m->TsurfNearestBelow - m->lastTsurfObs < m->TsurfAve - m->lastTsurfObs) {
+        m->TsurfNearestBelow = m->TsurfAve;
+        m->RadCoefNearestBelow = m->RadCoeff;
+      }
+      m->start_coupling_again = 1;
+      if (m->TsurfNearestAbove > -100 && m->TsurfNearestBelow > -100) {
+        TDifAbove = m->TsurfNearestAbove - m->lastTsurfObs;
+        TDifBelow = m->lastTsurfObs - m->TsurfNearestBelow;
+        m->RadCoeff = m->RadCoefNearestAbove -
+                      TDifAbove / (TDifAbove + TDifBelow) * (m->RadCoefNearestAbove - m->RadCoefNearestBelow);
+      } else {
+        m->RadCoeff = R4(2.0) * m->RadCoeff;
+      }
+      if (fabs(m->RadCoeff - m->RadCoeffPrevious) < R4(0.00005)) {
+        m->TsurfNearestAbove = -9999;
+        m->TsurfNearestBelow = -9999;
+      }
+      m->RadCoeffPrevious = m->RadCoeff;
+    } else {
+      if (m->RadCoeff > R4(3.0)) {
+        m->Coupling_failed = 1;
+        m->RadCoeff = R4(1.0);
+        m->SwRadCof = R4(1.0); m->LwRadCof = R4(1.0);
+        m->SW_correction = R4(0.0); m->LW_correction = R4(0.0);
+      }
+      m->SW_correction = m->SwRadCof - R4(1.0);
+      m->LW_correction = m->LwRadCof - R4(1.0);
+      m->Coupling_failed = 0;
+      m->Coupling_iterations = -1;
+      m->TsurfNearestAbove = R4(-9999.0);
+      m->TsurfNearestBelow = R4(-9999.0);
+      m->RadCoeff = R4(1.0);
+      m->RadCoefNearestAbove = R4(-9999.0);
+      m->RadCoefNearestBelow = R4(-9999.0);
+      m->RadCoeffPrevious = R4(1.0);
+      /* CoupPhaseN < NObs never holds (NObs = 1) */
+    }
+  }
+  m->TsurfAve = m->TsurfAve - R4(273.16);
+  m->lastTsurfObs = m->lastTsurfObs - R4(273.16);
+}
+
+/* src/Coupling.f90:98-141 */
+static void CheckEndCoupling(Model *m, int i) {
+  if (m->use_coupling && i == m->couplingEndI && !m->Coupling_failed) {
+    if (m->Coupling_iterations == 0) m->Tsurf_end_coup1 = m->TsurfAve;
+    Coupling_control(m);
+    m->Coupling_iterations = m->Coupling_iterations + 1;
+  }
+}
+
 /* examples/example1/src/Simulation.f90:120-172, sky-view branch excluded
  * (taken only when 0 <= sky_view < 1) */
 static void roadModelOneStep(Model *m, const InputPointers *in, int i /*1-based*/) {
@@ -582,7 +780,7 @@ static void CheckValues(Model *m, const InputPointers *in, const LocalParameters
   if (m->TsurfAve < R4(-100.0) || m->TsurfAve > R4(100.0)) m->failed = 1;
 }
 
-/* src/InputOutput.f90:86-149 (non-coupled: use_coupling is false here) */
+/* src/InputOutput.f90:86-149 */
 static void SetCurrentValues(Model *m, const InputPointers *in, int i) {
   const int k = i - 1;
   m->Tair = in->c_tair[k];
@@ -591,7 +789,7 @@ static void SetCurrentValues(Model *m, const InputPointers *in, int i) {
   m->PrecInTStep = in->c_prec[k] / 3600 * m->DTSecs;
   m->Tmp[0] = m->Tair;
   if (i <= m->InitLenI || m->force_tsurf) {
-    if (in->c_TSurfObs[k] > R4(-100.0)) {
+    if (in->c_TSurfObs[k] > R4(-100.0) && (!m->use_coupling || i < m->couplingStartI)) {
       double depth;
       m->Tmp[1] = in->c_TSurfObs[k];
       m->Tmp[2] = in->c_TSurfObs[k];
@@ -712,10 +910,9 @@ static void Initialization(Model *m, OutputPointers *out, const InputPointers *i
     m->use_relaxation = 0;
   m->lastTsurfObs = lp->couplingTsurf;
   if (lp->couplingTsurf < -100 || lp->couplingIndexI < 1) m->use_coupling = 0;
-  if (m->use_coupling) {
-    fprintf(stderr, "roadsurf_oracle: coupling is not restated yet (SURVEY.md 8f rank 2)\n");
-    abort();
-  }
+  m->coupling_minutes = s->coupling_minutes;
+  m->couplingEffectReduction = s->couplingEffectReduction;
+  m->skyview_on = (lp->sky_view < R4(1.0) && lp->sky_view > R4(-0.01));
   /* initVariablesAndParameters :65-147 */
   m->failed = 0;
   m->Tph = m->DTSecs / R4(3600.0);
@@ -751,7 +948,26 @@ static void Initialization(Model *m, OutputPointers *out, const InputPointers *i
   CalcHCapHCond(m);
   calcCapDZCondDZ(m);
   /* initCoupling src/Coupling.f90:144-169 */
-  m->SwRadCof = R4(1.0); m->LwRadCof = R4(1.0); m->inCouplingPhase = 0;
+  m->Coupling_iterations = 0;
+  m->TsurfNearestAbove = R4(-9999.0); m->TsurfNearestBelow = R4(-9999.0);
+  m->RadCoeff = R4(1.0);
+  m->RadCoefNearestAbove = R4(-9999.0); m->RadCoefNearestBelow = R4(-9999.0);
+  m->RadCoeffPrevious = R4(1.0);
+  m->SwRadCof = R4(1.0); m->LwRadCof = R4(1.0);
+  m->start_coupling_again = 0; m->Coupling_failed = 0;
+  m->SW_correction = R4(0.0); m->LW_correction = R4(0.0);
+  m->inCouplingPhase = 0;
+  /* initCouplingTimes src/Coupling.f90:486-534 */
+  m->couplingStartI = -99; m->couplingEndI = -99;
+  if (m->use_coupling && lp->couplingIndexI > -1) {
+    m->couplingEndI = lp->couplingIndexI;
+    if (lp->couplingIndexI <= (m->coupling_minutes * 60) / m->DTSecs)
+      m->couplingStartI = 1;
+    else
+      m->couplingStartI = lp->couplingIndexI - (int)((m->coupling_minutes * 60) / m->DTSecs);
+  } else {
+    m->use_coupling = 0;
+  }
   /* condInit :479-557 */
   m->WatDens = P->WatDens; m->WatMHeat = P->WatMHeat; m->PorEvaF = P->PorEvaF;
   m->DampWearF = P->DampWearF;
@@ -777,6 +993,7 @@ static void Initialization(Model *m, OutputPointers *out, const InputPointers *i
   else
     m->TsurfAve = (m->Tmp[1] + m->Tmp[2]) / R4(2.0);
   CalcBLCondAndLE(m); /* :138-139 */
+  if (m->lastTsurfObs < -100) m->Coupling_failed = 1; /* :142-144 */
 }
 
 /* examples/example1/src/Simulation.f90:4-117 */
@@ -796,10 +1013,12 @@ void runsimulation(OutputPointers *out, const InputPointers *in, const InputSett
   i = 1;
   while (i < m->SimLen && !m->failed) {
     CheckValues(m, in, lp, i);
+    if (m->use_coupling) CouplingOperations1(m, in, &i);
     SetCurrentValues(m, in, i);
     if (m->use_relaxation) RelaxationOperations(m, i);
     roadModelOneStep(m, in, i);
     SaveOutput(m, out, i);
+    CheckEndCoupling(m, i);
     i = i + 1;
   }
   if (!m->failed) {

@@ -269,6 +269,14 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
                     (pl->c.use_relaxation && pp->tair_relax != nullptr) || (f->tdew != nullptr);
   if (pl->c.use_relaxation && pp->tair_relax && (!pp->vz_relax || !pp->rh_relax || !pp->initlen))
     return set_err("rs_hip_step: relaxation needs tair_relax, vz_relax, rh_relax and initlen");
+  const bool coupled = pl->c.use_coupling && pp->coupling_index != nullptr;
+  if (coupled) {
+    if (!pp->coupling_tsurf) return set_err("rs_hip_step: coupling needs coupling_index and coupling_tsurf");
+    if (t0 != 1 || nsteps != pl->c.SimLen)
+      return set_err("rs_hip_step: with coupling the window must be the whole series "
+                     "(t0 = 1, nsteps = SimLen = %d): coupling windows are replayed", pl->c.SimLen);
+    if (o->decimate != 1) return set_err("rs_hip_step: coupling needs decimate == 1");
+  }
   rs::StepArgs a;
   a.cslot = pl->cslot;
   a.f = *f;
@@ -293,7 +301,10 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
     pl->ev_used += 2;
     HIP_OK(hipEventRecord(e0, pl->stream));
   }
-  HIP_OK(rs_launch_step(a, pl->c.NLayers, full, pl->variant, pl->stream));
+  if (coupled)
+    HIP_OK(rs_launch_step_coupled(a, pl->c.NLayers, pl->stream));
+  else
+    HIP_OK(rs_launch_step(a, pl->c.NLayers, full, pl->variant, pl->stream));
   if (pl->timing) HIP_OK(hipEventRecord(e1, pl->stream));
   return 0;
 }

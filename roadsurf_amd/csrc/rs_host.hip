@@ -128,8 +128,11 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
   const int L = consts->SimLen;
   /* tile sizes: bounded pinned staging (~0.5 GB) whatever n and SimLen are */
   const char *ep = getenv("ROADSURF_HIP_TILE_POINTS"), *et = getenv("ROADSURF_HIP_CHUNK_STEPS");
-  const int P = std::min<int64_t>(n, ep ? std::max(1, atoi(ep)) : 16384);
-  const int TC = std::min(L, et ? std::max(1, atoi(et)) : 256);
+  /* with coupling a point replays its window, so the whole series is one window
+   * (rs_hip_step enforces it) and the point tile shrinks to keep staging bounded */
+  const bool coupled = consts->use_coupling != 0;
+  const int P = std::min<int64_t>(n, ep ? std::max(1, atoi(ep)) : (coupled ? 4096 : 16384));
+  const int TC = coupled ? L : std::min(L, et ? std::max(1, atoi(et)) : 256);
   const int Ppad = (P + RS_BLOCK - 1) / RS_BLOCK * RS_BLOCK;
 
   int ndev = 0;
@@ -153,10 +156,10 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
   HOK(d_i32tp.alloc(tp_elems * 2 * sizeof(int32_t)));
   HOK(d_out_tp.alloc(tp_elems * 6 * sizeof(double)));
   HOK(d_out_pt.alloc(in_elems * 6 * sizeof(double)));
-  HOK(d_pp64.alloc((size_t)Ppad * 4 * sizeof(double)));
-  HOK(d_pp32.alloc((size_t)Ppad * sizeof(int32_t)));
-  std::vector<double> pp64((size_t)Ppad * 4);
-  std::vector<int32_t> pp32(Ppad);
+  HOK(d_pp64.alloc((size_t)Ppad * 5 * sizeof(double)));
+  HOK(d_pp32.alloc((size_t)Ppad * 2 * sizeof(int32_t)));
+  std::vector<double> pp64((size_t)Ppad * 5);
+  std::vector<int32_t> pp32((size_t)Ppad * 2);
 
   int rc = 0;
   for (int64_t p0 = 0; p0 < n && rc == 0; p0 += P) {
@@ -173,7 +176,9 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
       pp64[(size_t)Ppad + p] = localParam[p0 + p].tair_relax;
       pp64[(size_t)2 * Ppad + p] = localParam[p0 + p].VZ_relax;
       pp64[(size_t)3 * Ppad + p] = localParam[p0 + p].RH_relax;
+      pp64[(size_t)4 * Ppad + p] = localParam[p0 + p].couplingTsurf;
       pp32[p] = localParam[p0 + p].InitLenI;
+      pp32[(size_t)Ppad + p] = localParam[p0 + p].couplingIndexI;
     }
     HOK(hipMemcpyAsync(d_pp64.p, pp64.data(), pp64.size() * sizeof(double),
                        hipMemcpyHostToDevice, stream));
@@ -185,6 +190,8 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
     pp.vz_relax = (double *)d_pp64.p + 2 * (size_t)Ppad;
     pp.rh_relax = (double *)d_pp64.p + 3 * (size_t)Ppad;
     pp.initlen = (int32_t *)d_pp32.p;
+    pp.coupling_tsurf = coupled ? (double *)d_pp64.p + 4 * (size_t)Ppad : nullptr;
+    pp.coupling_index = coupled ? (int32_t *)d_pp32.p + Ppad : nullptr;
 
     for (int t0 = 1; t0 <= L; t0 += TC) {
       const int len = std::min(TC, L - t0 + 1);

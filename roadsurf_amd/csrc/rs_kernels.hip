@@ -256,6 +256,304 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
   }
 }
 
+/* ---- coupling: src/Coupling.f90 -------------------------------------------------
+ * Per-point state machine that re-runs the point's coupling window with a scaled
+ * short- or long-wave input until the simulated surface temperature at the end of
+ * the window matches the last observation (secant / halving / doubling, <= 25
+ * replays).  On the device every lane carries its OWN time index: a replay sets it
+ * back to the window start (src/Coupling.f90:61-78), so forcing reads and output
+ * writes are per-lane gathers/scatters into the (whole-series) windows, and a wave
+ * runs until its slowest lane is through.  The saved state of
+ * saveDataForCoupling (:172-210) is parked in the HBM state block. */
+struct Coupling {
+  double tabove, tbelow, radcoeff, rcabove, rcbelow, rcprev, swcof, lwcof, swcorr, lwcorr,
+      tend1, lastobs;
+  int32_t iter, cs, ce; /* Coupling_iterations, couplingStartI, couplingEndI */
+  bool again, failed, on;
+};
+
+/* Coupling_control, src/Coupling.f90:292-481 (called with Coupling_failed == .false.).
+ * TsurfAve and LastTsurfObs make a round trip through Kelvin (+273.16, -273.16); the
+ * rounding that leaves behind is part of the reference's result. */
+__device__ __forceinline__ void coupling_control(Coupling &q, double &tsurf) {
+  q.again = false;
+  tsurf = tsurf + R4(273.16);
+  q.lastobs = q.lastobs + R4(273.16);
+  if (q.iter == 0) q.tend1 = tsurf;
+  if (q.iter == 25) {
+    if (fabs(q.tend1 - q.lastobs) < fabs(tsurf - q.lastobs)) q.again = true;
+    q.swcof = R4(1.0); q.lwcof = R4(1.0); q.swcorr = R4(0.0); q.lwcorr = R4(0.0);
+    q.radcoeff = R4(1.0);
+    q.failed = true;
+  } else if (q.lastobs < -100) {
+    q.swcof = R4(1.0); q.lwcof = R4(1.0); q.swcorr = R4(0.0); q.lwcorr = R4(0.0);
+    q.radcoeff = R4(1.0);
+    q.failed = true;
+    q.again = true;
+  } else if (tsurf < R4(170.0) || tsurf > R4(400.0)) {
+    q.swcof = R4(1.0); q.lwcof = R4(1.0); q.swcorr = R4(0.0); q.lwcorr = R4(0.0);
+    q.failed = true;
+    q.again = true;
+    q.radcoeff = R4(1.0);
+  } else if (tsurf - q.lastobs > R4(0.1)) {
+    if (q.tabove < -100) {
+      q.tabove = tsurf;
+      q.rcabove = q.radcoeff;
+    } else if (q.tabove - q.lastobs > tsurf - q.lastobs) {
+      q.tabove = tsurf;
+      q.rcabove = q.radcoeff;
+    }
+    q.again = true;
+    if (q.tabove > -100 && q.tbelow > -100) {
+      const double da = q.tabove - q.lastobs, db = q.lastobs - q.tbelow;
+      q.radcoeff = q.rcabove - da / (da + db) * (q.rcabove - q.rcbelow);
+    } else {
+      q.radcoeff = R4(0.5) * q.radcoeff;
+    }
+    if (fabs(q.radcoeff - q.rcprev) < R4(0.00005)) {
+      q.tabove = -9999;
+      q.tbelow = -9999;
+    }
+    if (q.radcoeff < R4(0.01)) {
+      q.radcoeff = R4(1.0);
+      q.failed = true;
+      q.swcof = R4(1.0); q.lwcof = R4(1.0); q.swcorr = R4(0.0); q.lwcorr = R4(0.0);
+    }
+    q.rcprev = q.radcoeff;
+  } else if (q.lastobs - tsurf > R4(0.1)) {
+    if (q.tbelow < -100) {
+      q.tbelow = tsurf;
+      q.rcbelow = q.radcoeff;
+    } else if (q.tbelow - q.lastobs < tsurf - q.lastobs) {
+      q.tbelow = tsurf;
+      q.rcbelow = q.radcoeff;
+    }
+    q.again = true;
+    if (q.tabove > -100 && q.tbelow > -100) {
+      const double da = q.tabove - q.lastobs, db = q.lastobs - q.tbelow;
+      q.radcoeff = q.rcabove - da / (da + db) * (q.rcabove - q.rcbelow);
+    } else {
+      q.radcoeff = R4(2.0) * q.radcoeff;
+    }
+    if (fabs(q.radcoeff - q.rcprev) < R4(0.00005)) {
+      q.tabove = -9999;
+      q.tbelow = -9999;
+    }
+    q.rcprev = q.radcoeff;
+  } else {
+    if (q.radcoeff > R4(3.0)) {
+      q.failed = true;
+      q.radcoeff = R4(1.0);
+      q.swcof = R4(1.0); q.lwcof = R4(1.0); q.swcorr = R4(0.0); q.lwcorr = R4(0.0);
+    }
+    q.swcorr = q.swcof - R4(1.0);
+    q.lwcorr = q.lwcof - R4(1.0);
+    q.failed = false;
+    q.iter = -1;
+    q.tabove = R4(-9999.0); q.tbelow = R4(-9999.0);
+    q.radcoeff = R4(1.0);
+    q.rcabove = R4(-9999.0); q.rcbelow = R4(-9999.0);
+    q.rcprev = R4(1.0);
+  }
+  tsurf = tsurf - R4(273.16);
+  q.lastobs = q.lastobs - R4(273.16);
+}
+
+__device__ __forceinline__ void load_coupling(const double *st, int64_t np, int64_t p, Coupling &q) {
+  q.iter = (int32_t)st[(int64_t)RS_ST_CPL_ITER * np + p];
+  const int32_t fl = (int32_t)st[(int64_t)RS_ST_CPL_FLAGS * np + p];
+  q.again = fl & 1; q.failed = (fl >> 1) & 1;
+  q.tabove = st[(int64_t)RS_ST_CPL_TABOVE * np + p]; q.tbelow = st[(int64_t)RS_ST_CPL_TBELOW * np + p];
+  q.radcoeff = st[(int64_t)RS_ST_CPL_RADCOEFF * np + p];
+  q.rcabove = st[(int64_t)RS_ST_CPL_RCABOVE * np + p]; q.rcbelow = st[(int64_t)RS_ST_CPL_RCBELOW * np + p];
+  q.rcprev = st[(int64_t)RS_ST_CPL_RCPREV * np + p];
+  q.swcof = st[(int64_t)RS_ST_CPL_SWCOF * np + p]; q.lwcof = st[(int64_t)RS_ST_CPL_LWCOF * np + p];
+  q.swcorr = st[(int64_t)RS_ST_CPL_SWCORR * np + p]; q.lwcorr = st[(int64_t)RS_ST_CPL_LWCORR * np + p];
+  q.tend1 = st[(int64_t)RS_ST_CPL_TEND1 * np + p];
+  q.lastobs = st[(int64_t)RS_ST_CPL_LASTOBS * np + p];
+}
+
+__device__ __forceinline__ void store_coupling(double *st, int64_t np, int64_t p, const Coupling &q) {
+  st[(int64_t)RS_ST_CPL_ITER * np + p] = (double)q.iter;
+  const int32_t keep = ((int32_t)st[(int64_t)RS_ST_CPL_FLAGS * np + p]) & 4;
+  st[(int64_t)RS_ST_CPL_FLAGS * np + p] = (double)(keep | (q.again ? 1 : 0) | (q.failed ? 2 : 0));
+  st[(int64_t)RS_ST_CPL_TABOVE * np + p] = q.tabove; st[(int64_t)RS_ST_CPL_TBELOW * np + p] = q.tbelow;
+  st[(int64_t)RS_ST_CPL_RADCOEFF * np + p] = q.radcoeff;
+  st[(int64_t)RS_ST_CPL_RCABOVE * np + p] = q.rcabove; st[(int64_t)RS_ST_CPL_RCBELOW * np + p] = q.rcbelow;
+  st[(int64_t)RS_ST_CPL_RCPREV * np + p] = q.rcprev;
+  st[(int64_t)RS_ST_CPL_SWCOF * np + p] = q.swcof; st[(int64_t)RS_ST_CPL_LWCOF * np + p] = q.lwcof;
+  st[(int64_t)RS_ST_CPL_SWCORR * np + p] = q.swcorr; st[(int64_t)RS_ST_CPL_LWCORR * np + p] = q.lwcorr;
+  st[(int64_t)RS_ST_CPL_TEND1 * np + p] = q.tend1;
+  st[(int64_t)RS_ST_CPL_LASTOBS * np + p] = q.lastobs;
+}
+
+/* Per-lane gather of the forcing of absolute index i (window row i - t0). */
+__device__ __forceinline__ Forcing gather_forcing(KernArgs ka, int64_t p, int32_t i, int32_t t0) {
+  Forcing o;
+  const int64_t off = (int64_t)(i - t0) * ka->f.t_stride + p;
+  o.tair = ka->f.tair[off]; o.vz = ka->f.vz[off]; o.rhz = ka->f.rhz[off];
+  o.prec = ka->f.prec[off]; o.sw = ka->f.sw[off]; o.lw = ka->f.lw[off];
+  o.phase = ka->f.precphase[off];
+  o.hour = ka->f.hour_pstride ? ka->f.hour[off] : ka->f.hour[i - t0];
+  o.tdew = ka->f.tdew ? ka->f.tdew[off] : 0.0;
+  o.tsurfobs = ka->f.tsurfobs ? ka->f.tsurfobs[off] : R4(-9999.9);
+  o.depth = ka->f.depth ? ka->f.depth[off] : R4(-9999.9);
+  return o;
+}
+
+/* runsimulation's loop with coupling (examples/example1/src/Simulation.f90:57-115):
+ * CheckValues -> CouplingOperations1 (may rewind i) -> SetCurrentValues -> relaxation ->
+ * roadModelOneStep -> SaveOutput -> CheckEndCoupling. */
+template <class Prof>
+__device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Prof &Tstale,
+                                                  Scalars &s, Coupling &q, double *st, int64_t np,
+                                                  int64_t p) {
+  KernArgs ka = kernargs();
+  const uint32_t lane = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * kBlock;
+  const RsConstants &c = g_consts[ka->cslot];
+  const int N = T.nlayers();
+  const int32_t t0 = ka->t0, tend = ka->t0 + ka->nsteps;
+  const double tbot = ka->pp.tbottom[p];
+  const int32_t initlen = ka->pp.initlen ? ka->pp.initlen[p] : 0;
+  bool relax = false;
+  double tairR = 0, vzR = 0, rhR = 0;
+  if (c.use_relaxation && ka->pp.tair_relax) {
+    tairR = (double)(float)ka->pp.tair_relax[p];
+    vzR = (double)(float)ka->pp.vz_relax[p];
+    rhR = (double)(float)ka->pp.rh_relax[p];
+    relax = !(tairR < R4(-100.0) || tairR > R4(100.0) || vzR < R4(0.0) || vzR > R4(100.0) ||
+              rhR < R4(0.0) || rhR > 110);
+  }
+  /* setInputParam + initCouplingTimes, src/InputOutput.f90:30-36, src/Coupling.f90:486-534 */
+  const int32_t cidx = ka->pp.coupling_index[p];
+  q.on = c.use_coupling && !(ka->pp.coupling_tsurf[p] < -100 || cidx < 1);
+  q.cs = -99; q.ce = -99;
+  if (q.on) {
+    q.ce = cidx;
+    q.cs = ((double)cidx <= c.cplLenR) ? 1 : cidx - c.cplLenI;
+  }
+  (void)lane; (void)row0;
+
+  int32_t i = t0;
+  bool stale_all = false; /* first step after a restore: TmpNw is the pre-restore profile */
+  while (i < tend) {
+    if (s.failed) { /* the reference's loop has exited: remaining outputs stay -9999.0 */
+      store_outputs(ka, i, p, 0u, s, false);
+      ++i;
+      continue;
+    }
+    Forcing f = gather_forcing(ka, p, i, t0);
+    if (i == 1 && f.vz < R4(0.4)) f.vz = R4(0.4);
+    CouplingInputs cp;
+    if (i < c.SimLen) {
+      if (check_values(f, s.tsurf, ka->f.tdew != nullptr)) s.failed = true;
+      if (q.on) {
+        /* CouplingOperations1, src/Coupling.f90:10-96 */
+        bool in_phase = (i >= q.cs && i <= q.ce);
+        if (i == q.cs && q.iter == 0) {
+          /* saveDataForCoupling :172-210 */
+          st[(int64_t)RS_ST_CPL_SAVE_TSURF * np + p] = s.tsurf;
+          st[(int64_t)RS_ST_CPL_SAVE_WAT * np + p] = s.wat;
+          st[(int64_t)RS_ST_CPL_SAVE_ICE2 * np + p] = s.ice2;
+          st[(int64_t)RS_ST_CPL_SAVE_DEP * np + p] = s.dep;
+          st[(int64_t)RS_ST_CPL_SAVE_SNOW * np + p] = s.snow;
+          st[(int64_t)RS_ST_CPL_SAVE_ALBEDO * np + p] = s.albedo;
+          const int32_t fl = ((int32_t)st[(int64_t)RS_ST_CPL_FLAGS * np + p]) & 3;
+          st[(int64_t)RS_ST_CPL_FLAGS * np + p] = (double)(fl | (s.verycold ? 4 : 0));
+          for (int j = 1; j <= N; ++j) st[(int64_t)(RS_ST_CPL_SAVE_TMP0 + j - 1) * np + p] = T.get(j);
+          q.swcof = R4(1.0); q.lwcof = R4(1.0); q.swcorr = R4(0.0); q.lwcorr = R4(0.0);
+        }
+        if (q.again) {
+          /* uploadDataForCoupling :213-255: back to the window start; SrfIcemms, Q2Melt,
+           * T4Melt and TmpNw are NOT restored */
+          i = q.cs;
+          s.tsurf = st[(int64_t)RS_ST_CPL_SAVE_TSURF * np + p];
+          s.wat = st[(int64_t)RS_ST_CPL_SAVE_WAT * np + p];
+          s.ice2 = st[(int64_t)RS_ST_CPL_SAVE_ICE2 * np + p];
+          s.dep = st[(int64_t)RS_ST_CPL_SAVE_DEP * np + p];
+          s.snow = st[(int64_t)RS_ST_CPL_SAVE_SNOW * np + p];
+          s.albedo = st[(int64_t)RS_ST_CPL_SAVE_ALBEDO * np + p];
+          s.verycold = (((int32_t)st[(int64_t)RS_ST_CPL_FLAGS * np + p]) & 4) != 0;
+          for (int j = 1; j <= N; ++j) {
+            Tstale.set(j, T.get(j)); /* TmpNw keeps the end-of-window profile */
+            T.set(j, st[(int64_t)(RS_ST_CPL_SAVE_TMP0 + j - 1) * np + p]);
+          }
+          stale_all = true;
+          q.again = false;
+          f = gather_forcing(ka, p, i, t0);
+          if (i == 1 && f.vz < R4(0.4)) f.vz = R4(0.4);
+          /* sky view is not on this path, so the SW branch is selectable (:68-76) */
+          if (f.sw > f.lw) {
+            q.swcof = q.radcoeff;
+            q.lwcof = R4(1.0);
+          } else {
+            q.swcof = R4(1.0);
+            q.lwcof = q.radcoeff;
+          }
+        }
+        if (i > q.ce) {
+          const double e = rs_exp(mt, rs_div(-((c.DTSecs * i) - (c.DTSecs * q.ce)), c.cplReduction));
+          q.swcof = R4(1.0) + q.swcorr * e;
+          q.lwcof = R4(1.0) + q.lwcorr * e;
+        }
+        if (in_phase) {
+          /* snowIceCheck :259-289 */
+          if (q.lastobs > c.TLimMeltSnow && s.snow > R4(0.00)) { s.wat = s.wat + s.snow; s.snow = R4(0.00); }
+          if (q.lastobs > c.TLimMeltIce && s.ice > R4(0.00)) { s.wat = s.wat + s.ice; s.ice = R4(0.00); }
+          if (q.lastobs > c.TLimMeltIce && s.ice2 > R4(0.00)) s.ice2 = R4(0.00);
+          if (q.lastobs > c.TLimMeltDep && s.dep > R4(0.00)) { s.wat = s.wat + s.dep; s.dep = R4(0.00); }
+        }
+        cp.in_phase = in_phase;
+      }
+      /* SetCurrentValues obs forcing, src/InputOutput.f90:116-148 */
+      if ((i <= initlen || c.force_tsurf) && f.tsurfobs > R4(-100.0) && (!q.on || i < q.cs)) {
+        T.set(1, f.tsurfobs);
+        T.set(2, f.tsurfobs);
+        const double depth = (c.tsurfOutputDepth >= R4(0.0)) ? c.tsurfOutputDepth : f.depth;
+        s.tsurf = surface_temperature(c, T, tbot, depth);
+      }
+    } else {
+      /* lastValues, src/InputOutput.f90:169-198 */
+      s.tsurf = surface_temperature(c, T, tbot, f.depth);
+      cp.in_phase = false; /* coupling%inCouplingPhase keeps its last value: index SimLen-1 */
+      if (q.on) cp.in_phase = (c.SimLen - 1 >= q.cs && c.SimLen - 1 <= q.ce);
+    }
+    double tair = f.tair, vz = f.vz, rhz = f.rhz;
+    const double prec_ts = rs_div(f.prec, 3600.0) * c.DTSecs;
+    if (i < c.SimLen && relax) {
+      if (i == initlen) { s.tair_end = tair; s.vz_end = vz; s.rh_end = rhz; }
+      if (i > initlen) {
+        const double den = (double)(4.f * 3600.f);
+        const double e = rs_exp(mt, rs_div(-((c.DTSecs * i) - (c.DTSecs * initlen)), den));
+        tair = tair - (tairR - s.tair_end) * e;
+        vz = vz - (vzR - s.vz_end) * e;
+        rhz = rhz - (rhR - s.rh_end) * e;
+        if (rhz > R4(100.)) rhz = R4(100.0);
+      }
+    }
+    cp.sw_cof = q.swcof; cp.lw_cof = q.lwcof; cp.last_tsurf_obs = q.lastobs;
+    const Fluxes fx = model_step_fluxes(c, mt, s, tair, vz, rhz, prec_ts, f.sw, f.lw, f.phase,
+                                        f.hour, cp);
+    if (stale_all) {
+      /* observation forcing cannot follow a restore (i >= couplingStartI), so TmpNw(1:2)
+       * are the stale values too */
+      model_step_ground(c, s, T, tbot, tair, fx, f.depth, cp, &Tstale);
+      stale_all = false;
+    } else {
+      model_step_ground(c, s, T, tbot, tair, fx, f.depth, cp);
+    }
+    store_outputs(ka, i, p, 0u, s, true);
+    /* CheckEndCoupling + CouplingOperations2, src/Coupling.f90:98-141 */
+    if (i < c.SimLen && q.on && i == q.ce && !q.failed) {
+      if (q.iter == 0) q.tend1 = s.tsurf;
+      coupling_control(q, s.tsurf);
+      q.iter = q.iter + 1;
+    }
+    ++i;
+  }
+}
+
 template <int NL, bool FULL, int WPE>
 __global__ void __launch_bounds__(kBlock, WPE) step_kernel_reg(const StepArgs a) {
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
@@ -283,6 +581,26 @@ __global__ void __launch_bounds__(kBlock, WPE) step_kernel_lds(const StepArgs a)
   load_state<FULL>(a.state, a.np_pad, p, T, s);
   time_loop<FULL>(mt, T, s);
   store_state<FULL>(a.state, a.np_pad, p, T, s);
+}
+
+/* Coupled variant: LDS profile (any NLayers), FULL feature set + coupling. */
+__global__ void __launch_bounds__(kBlock, 2) step_kernel_coupled(const StepArgs a) {
+  extern __shared__ double lds[]; /* [2][NLayers][kBlock]: profile, stale TmpNw */
+  __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
+  const MathTab mt = fill_math_tables(math_lds);
+  __syncthreads();
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= a.npoints) return;
+  const int NLc = g_consts[a.cslot].NLayers;
+  LdsProfile T{lds + threadIdx.x, NLc};
+  LdsProfile Tstale{lds + (size_t)NLc * kBlock + threadIdx.x, NLc};
+  Scalars s;
+  Coupling q;
+  load_state<true>(a.state, a.np_pad, p, T, s);
+  load_coupling(a.state, a.np_pad, p, q);
+  time_loop_coupled(mt, T, Tstale, s, q, a.state, a.np_pad, p);
+  store_state<true>(a.state, a.np_pad, p, T, s);
+  store_coupling(a.state, a.np_pad, p, q);
 }
 
 /* Device part of Initialization (src/Initialization.f90:65-147): initial
@@ -344,6 +662,21 @@ __global__ void __launch_bounds__(kBlock) init_kernel(const InitArgs a) {
   st[(int64_t)RS_ST_TAIR_END * np + p] = R4(-99.9); /* src/Initialization.f90:377-379 */
   st[(int64_t)RS_ST_VZ_END * np + p] = R4(-99.9);
   st[(int64_t)RS_ST_RH_END * np + p] = R4(-99.9);
+  /* initCoupling, src/Coupling.f90:144-169 */
+  st[(int64_t)RS_ST_CPL_ITER * np + p] = 0.0;
+  st[(int64_t)RS_ST_CPL_FLAGS * np + p] = 0.0;
+  st[(int64_t)RS_ST_CPL_TABOVE * np + p] = R4(-9999.0);
+  st[(int64_t)RS_ST_CPL_TBELOW * np + p] = R4(-9999.0);
+  st[(int64_t)RS_ST_CPL_RADCOEFF * np + p] = R4(1.0);
+  st[(int64_t)RS_ST_CPL_RCABOVE * np + p] = R4(-9999.0);
+  st[(int64_t)RS_ST_CPL_RCBELOW * np + p] = R4(-9999.0);
+  st[(int64_t)RS_ST_CPL_RCPREV * np + p] = R4(1.0);
+  st[(int64_t)RS_ST_CPL_SWCOF * np + p] = R4(1.0);
+  st[(int64_t)RS_ST_CPL_LWCOF * np + p] = R4(1.0);
+  st[(int64_t)RS_ST_CPL_SWCORR * np + p] = R4(0.0);
+  st[(int64_t)RS_ST_CPL_LWCORR * np + p] = R4(0.0);
+  st[(int64_t)RS_ST_CPL_TEND1 * np + p] = 0.0;
+  st[(int64_t)RS_ST_CPL_LASTOBS * np + p] = a.pp.coupling_tsurf ? a.pp.coupling_tsurf[p] : R4(-9999.0);
 }
 
 /* Hourly knots of the synthetic workload, [knot][RS_KNOT_FIELDS][np_pad]. */
@@ -455,6 +788,12 @@ hipError_t rs_upload_constants(int slot, const RsConstants *c, hipStream_t strea
   if (e != hipSuccess) return e;
   return hipMemcpyToSymbolAsync(HIP_SYMBOL(rs::g_consts), c, sizeof(RsConstants),
                                 (size_t)slot * sizeof(RsConstants), hipMemcpyHostToDevice, stream);
+}
+
+hipError_t rs_launch_step_coupled(const rs::StepArgs &a, int NL, hipStream_t stream) {
+  const size_t lds = 2 * (size_t)NL * RS_BLOCK * sizeof(double);
+  hipLaunchKernelGGL(rs::step_kernel_coupled, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
+  return hipGetLastError();
 }
 
 hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,

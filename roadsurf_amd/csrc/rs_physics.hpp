@@ -207,10 +207,11 @@ __device__ __forceinline__ double layer_vsh(const RsConstants &c, int j, double 
  * The TsurfAve assignment at :389-394 is overwritten unconditionally at
  * src/BalanceModel.f90:78-84 and is dropped. */
 template <class Prof>
-__device__ __forceinline__ void melting(Scalars &s, Prof &T, double hstor, double hs1) {
+__device__ __forceinline__ void melting(Scalars &s, Prof &T, double hstor, double hs1,
+                                        bool in_coupling_phase, double last_tsurf_obs) {
   if ((s.snow > R4(0.0)) || (s.ice > R4(0.0)) || (s.ice2 > R4(0.0))) {
-    /* inCouplingPhase is .false. off the coupling path (src/Coupling.f90:165) */
-    if ((hstor <= R4(0.00001)) || (s.tsurf <= s.t4melt) || (s.q2melt <= 0)) {
+    if ((hstor <= R4(0.00001)) || (s.tsurf <= s.t4melt) || (s.q2melt <= 0) ||
+        (in_coupling_phase && last_tsurf_obs < s.t4melt)) {
       if (s.tsurf < R4(0.5)) {
         s.q2melt = R4(0.0);
         return;
@@ -400,11 +401,19 @@ struct Fluxes {
   double blcond, le, evap, rnet, trffric;
 };
 
+/* What the coupling machinery feeds into a step (src/BalanceModel.f90:44-45,71-73);
+ * off the coupling path: coefficients 1.0, not in a coupling phase. */
+struct CouplingInputs {
+  double sw_cof = 1.0, lw_cof = 1.0, last_tsurf_obs = 0.0;
+  bool in_phase = false;
+};
+
 /* first half: precipitation -> storages, day/night, boundary layer, net radiation */
 __device__ __forceinline__ Fluxes model_step_fluxes(const RsConstants &c, const MathTab &mt,
                                                     Scalars &s, double tair, double vz, double rhz,
                                                     double prec_ts, double sw, double lw,
-                                                    int32_t phase, int32_t hour) {
+                                                    int32_t phase, int32_t hour,
+                                                    const CouplingInputs &cp = CouplingInputs()) {
   Fluxes fx;
   precipitation_to_storage(c, mt, s, phase, prec_ts, tair, rhz);
 
@@ -422,11 +431,11 @@ __device__ __forceinline__ Fluxes model_step_fluxes(const RsConstants &c, const 
   boundary_layer(c, mt, s.tsurf, tair, vz, rhz, s.wat, fx.blcond, fx.le, fx.evap);
 
   /* CalcRNet, src/BalanceModel.f90:282-307 (SwRadCof = LwRadCof = 1.0 off the
-   * coupling path; x*1.0 is exact so the factors are kept out) */
+   * coupling path; x*1.0 is exact, so the compiler drops the factors there) */
   const double TsurfK = s.tsurf + R4(273.15);
   const double TsurfK2 = TsurfK * TsurfK;
   const double RBB = c.Emiss * c.SB_Const * (TsurfK2 * TsurfK2);
-  fx.rnet = (R4(1.) - s.albedo) * sw + c.Emiss * lw - RBB;
+  fx.rnet = (R4(1.) - s.albedo) * sw * cp.sw_cof + c.Emiss * lw * cp.lw_cof - RBB;
   return fx;
 }
 
@@ -435,7 +444,9 @@ __device__ __forceinline__ Fluxes model_step_fluxes(const RsConstants &c, const 
 template <class Prof>
 __device__ __forceinline__ void model_step_ground(const RsConstants &c, Scalars &s, Prof &T,
                                                   double tbot, double tair, const Fluxes &fx,
-                                                  double depth_i) {
+                                                  double depth_i,
+                                                  const CouplingInputs &cp = CouplingInputs(),
+                                                  const Prof *stale_all = nullptr) {
   const int N = T.nlayers();
   /* CalcHCapHCond + calcCapDZCondDZ + calcProfile fused
    * (src/BalanceModel.f90:189-251, 132-155, 90-129) */
@@ -446,7 +457,10 @@ __device__ __forceinline__ void model_step_ground(const RsConstants &c, Scalars 
 #pragma unroll
   for (int j = 1; j <= N; ++j) {
     const double tj = T.get(j);
-    const double tstale = (j == 1) ? s.tnw1 : (j == 2) ? s.tnw2 : tj;
+    /* TmpNw(j) as CalcHCapHCond sees it (src/BalanceModel.f90:215): equal to Tmp(j) except
+     * for layers 1-2 after observation forcing, and for EVERY layer on the first step after
+     * a coupling restore (Tmp is restored, TmpNw is not: src/Coupling.f90:245-247) */
+    const double tstale = stale_all ? stale_all->get(j) : (j == 1) ? s.tnw1 : (j == 2) ? s.tnw2 : tj;
     const double vsh = layer_vsh(c, j, tstale);
     if (j == 1) hs1 = rs_div(vsh * c.HSfac1, c.twoDT);
     const double capDZ = -rs_div(1.0, c.DyC[j] * vsh);
@@ -461,7 +475,7 @@ __device__ __forceinline__ void model_step_ground(const RsConstants &c, Scalars 
   const double TN1Ave = (T.get(1) + R4(3.) * T.get(2)) / R4(4.);
   const double hstor = hs1 * (TN1Ave - T1Ave);
 
-  melting(s, T, hstor, hs1);
+  melting(s, T, hstor, hs1, cp.in_phase, cp.last_tsurf_obs);
 
   /* Tmp = TmpNw; new TsurfAve (src/BalanceModel.f90:60-84) */
   s.tnw1 = T.get(1);

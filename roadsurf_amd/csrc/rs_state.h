@@ -31,7 +31,29 @@ enum RsStateSlot {
   RS_ST_TAIR_END,                /* atm%TairInitEnd (relaxation) */
   RS_ST_VZ_END,                  /* atm%VZInitEnd */
   RS_ST_RH_END,                  /* atm%RhzInitEnd */
-  RS_NSTATE
+  /* ---- coupling (src/CouplingVariables.f90.inc); touched only by the coupled kernel ---- */
+  RS_ST_CPL_ITER,                /* Coupling_iterations */
+  RS_ST_CPL_FLAGS,               /* bit0 start_coupling_again, bit1 Coupling_failed, bit2 VeryColdSave */
+  RS_ST_CPL_TABOVE,              /* TsurfNearestAbove */
+  RS_ST_CPL_TBELOW,              /* TsurfNearestBelow */
+  RS_ST_CPL_RADCOEFF,            /* RadCoeff */
+  RS_ST_CPL_RCABOVE,             /* RadCoefNearestAbove */
+  RS_ST_CPL_RCBELOW,             /* RadCoefNearestBelow */
+  RS_ST_CPL_RCPREV,              /* RadCoeffPrevious */
+  RS_ST_CPL_SWCOF,               /* SWRadCof */
+  RS_ST_CPL_LWCOF,               /* LWRadCof */
+  RS_ST_CPL_SWCORR,              /* SW_correction */
+  RS_ST_CPL_LWCORR,              /* LW_correction */
+  RS_ST_CPL_TEND1,               /* Tsurf_end_coup1 */
+  RS_ST_CPL_LASTOBS,             /* lastTsurfObs */
+  RS_ST_CPL_SAVE_TSURF,          /* TSurfAveSave */
+  RS_ST_CPL_SAVE_WAT,            /* SrfWatmmsSave */
+  RS_ST_CPL_SAVE_ICE2,           /* SrfIce2mmsSave (SrfIcemms is never saved, src/Coupling.f90:194-195) */
+  RS_ST_CPL_SAVE_DEP,            /* SrfDepmmsSave */
+  RS_ST_CPL_SAVE_SNOW,           /* SrfSnowmmsSave */
+  RS_ST_CPL_SAVE_ALBEDO,         /* AlbedoSave */
+  RS_ST_CPL_SAVE_TMP0,           /* TmpSave(1..NLayers) at the next RS_MAX_LAYERS slots */
+  RS_NSTATE = RS_ST_CPL_SAVE_TMP0 + RS_MAX_LAYERS
 };
 
 #endif

@@ -116,18 +116,21 @@ class Plan:
         self.close()
 
     # -- per-point parameters -------------------------------------------------
-    def point_params(self, tbottom, initlen=None, tair_relax=None, vz_relax=None, rh_relax=None):
+    def point_params(self, tbottom, initlen=None, tair_relax=None, vz_relax=None, rh_relax=None,
+                     coupling_index=None, coupling_tsurf=None):
         """tbottom: float (uniform) or tensor[np_pad]; others tensors or None."""
         if not torch.is_tensor(tbottom):
             tbottom = torch.full((self.np_pad,), float(tbottom), dtype=torch.float64,
                                  device=self.device)
-        keep = (tbottom, initlen, tair_relax, vz_relax, rh_relax)
+        keep = (tbottom, initlen, tair_relax, vz_relax, rh_relax, coupling_index, coupling_tsurf)
         pp = lib.RsPointParams()
         pp.tbottom = _ptr(tbottom)
         pp.initlen = _ptr(initlen)
         pp.tair_relax = _ptr(tair_relax)
         pp.vz_relax = _ptr(vz_relax)
         pp.rh_relax = _ptr(rh_relax)
+        pp.coupling_index = _ptr(coupling_index)
+        pp.coupling_tsurf = _ptr(coupling_tsurf)
         self._pp_keep = keep
         return pp
 
@@ -216,8 +219,9 @@ def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputPara
         local = [local] * n
     initlen = np.array([l.InitLenI for l in local], np.int32)
     relax_on = settings.use_relaxation == 1
+    coupled = settings.use_coupling == 1
     need_full = (not lean_if_possible) or initlen.max() > 1 or settings.force_tsurf == 1 or \
-        relax_on or settings.tsurfOutputDepth >= 0 or (forcing["depth"] >= 0).any()
+        relax_on or coupled or settings.tsurfOutputDepth >= 0 or (forcing["depth"] >= 0).any()
 
     def pad_t(a, dtype):  # [n, L] -> device [L, npad]
         t = torch.zeros((L, npad), dtype=dtype, device=dev)
@@ -245,12 +249,14 @@ def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputPara
             tb, pp_vec(initlen.tolist(), torch.int32),
             pp_vec([l.tair_relax for l in local], torch.float64) if relax_on else None,
             pp_vec([l.VZ_relax for l in local], torch.float64) if relax_on else None,
-            pp_vec([l.RH_relax for l in local], torch.float64) if relax_on else None)
+            pp_vec([l.RH_relax for l in local], torch.float64) if relax_on else None,
+            pp_vec([l.couplingIndexI for l in local], torch.int32) if coupled else None,
+            pp_vec([l.couplingTsurf for l in local], torch.float64) if coupled else None)
     else:
         pp = plan.point_params(tb)
     out = OutputWindow.empty(L, npad, dev)
     plan.init_state(win, pp)
-    chunk = chunk or L
+    chunk = L if coupled else (chunk or L)
     t0 = 1
     while t0 <= L:
         ns = min(chunk, L - t0 + 1)

@@ -79,7 +79,8 @@ module RoadSurfHip
 
    !> Mirror of `RsConstants` in include/roadsurf.h (same order, same types).
    type, bind(C), public :: RsConstants
-      integer(c_int) :: NLayers, SimLen, use_relaxation, force_tsurf
+      integer(c_int) :: NLayers, SimLen, use_relaxation, force_tsurf, use_coupling, cplLenI
+      real(c_double) :: cplLenR, cplReduction
       real(c_double) :: DTSecs, Tph, tsurfOutputDepth, twoDT
       real(c_double) :: ZDpth(0:RS_MAX_LAYERS + 1)
       real(c_double) :: DyC(0:RS_MAX_LAYERS + 1)
@@ -188,6 +189,12 @@ contains
       c%SimLen = inSettings%SimLen
       c%use_relaxation = merge(1, 0, inSettings%use_relaxation == 1)
       c%force_tsurf = merge(1, 0, inSettings%force_tsurf == 1)
+      c%use_coupling = merge(1, 0, inSettings%use_coupling == 1)
+      ! length of the coupling window in steps, as a real (for the comparison) and
+      ! truncated (for the start index): src/Coupling.f90:512,516-517
+      c%cplLenR = inSettings%coupling_minutes*60/inSettings%DTSecs
+      c%cplLenI = int(inSettings%coupling_minutes*60/inSettings%DTSecs)
+      c%cplReduction = inSettings%couplingEffectReduction
       c%DTSecs = inSettings%DTSecs
       c%Tph = inSettings%DTSecs/3600.0          ! src/Initialization.f90:92
       c%tsurfOutputDepth = inSettings%tsurfOutputDepth
@@ -364,15 +371,6 @@ contains
       end if
 
       do p = 1, n
-         ! coupling switches itself off without a usable observation
-         ! (src/InputOutput.f90:34-36); a usable one needs the coupling replay,
-         ! which is not on the device yet (SURVEY.md 8f rank 2)
-         if (inSettings%use_coupling == 1 .and. .not. (localParam(p)%couplingTsurf < -100 .or. &
-                                                         localParam(p)%couplingIndexI < 1)) then
-            call fail('runsimulation_batch: coupling (use_coupling=1 with a valid observation) is not supported yet', &
-                      status, -2)
-            return
-         end if
          if (localParam(p)%sky_view < 1.0 .and. localParam(p)%sky_view > -0.01) then
             call fail('runsimulation_batch: sky-view radiation (0 <= sky_view < 1) is not supported yet', status, -3)
             return

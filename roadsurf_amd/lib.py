@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("ROADSURF_HIP_LIB") or os.path.join(_HERE, "lib", "lib
 
 RS_MAX_LAYERS = abi.RS_MAX_LAYERS
 RS_KNOT_FIELDS = 9
-RS_NSTATE = RS_MAX_LAYERS + 16
+RS_NSTATE = RS_MAX_LAYERS + 16 + 20 + RS_MAX_LAYERS
 
 _tbl = C.c_double * (RS_MAX_LAYERS + 2)
 
@@ -26,7 +26,8 @@ _tbl = C.c_double * (RS_MAX_LAYERS + 2)
 class RsConstants(C.Structure):
     _fields_ = (
         [("NLayers", C.c_int32), ("SimLen", C.c_int32), ("use_relaxation", C.c_int32),
-         ("force_tsurf", C.c_int32),
+         ("force_tsurf", C.c_int32), ("use_coupling", C.c_int32), ("cplLenI", C.c_int32),
+         ("cplLenR", C.c_double), ("cplReduction", C.c_double),
          ("DTSecs", C.c_double), ("Tph", C.c_double), ("tsurfOutputDepth", C.c_double),
          ("twoDT", C.c_double),
          ("ZDpth", _tbl), ("DyC", _tbl), ("condDZ", _tbl), ("WCont", _tbl), ("dryCap", _tbl)]
@@ -61,7 +62,8 @@ class RsOutputs(C.Structure):
 
 
 class RsPointParams(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("tbottom", "initlen", "tair_relax", "vz_relax", "rh_relax")]
+    _fields_ = [(n, C.c_void_p) for n in ("tbottom", "initlen", "tair_relax", "vz_relax", "rh_relax",
+                                          "coupling_index", "coupling_tsurf")]
 
 
 class RsSynthSpec(C.Structure):

@@ -127,6 +127,32 @@ def main():
             idx, save[f"{c}_{k}"] = thin(o[k])
     save["out_index"] = idx
     np.savez_compressed(os.path.join(HERE, "e2e_features.npz"), **save)
+    # ---- (i'') coupling: from the reference built with working coupling -------------
+    # (oracle/build_ref.sh: the strict amdflang build wipes the observation in `allocator`)
+    L3 = 24 * SPK + 1
+    K3 = {k: (v[:, :26].copy() if v.ndim == 2 else v.copy()) for k, v in K.items()}
+    f3 = gh.expand_knots(K3, L3, SPK)
+    base3 = oh.run_oracle("ref", f3, abi.default_settings(L3), p, l)[0]
+    f3["tsurfobs"][:, :] = np.where(base3["tsurf"] == -9999.0, -9999.9, base3["tsurf"] + 0.3)
+    offs = np.array([0.0, 0.5, -2.0, 6.0, -6.0, 15.0, 0.05, -0.5])
+    ls3 = []
+    for i in range(8):
+        li = abi.default_local(); li.InitLenI = 1440; li.couplingIndexI = 1440
+        li.couplingTsurf = float(base3["tsurf"][i, 1439] + offs[i])
+        li.tair_relax = float(f3["tair"][i, 1440]) + 1.0; li.VZ_relax = 3.0; li.RH_relax = 80.0
+        ls3.append(li)
+    ls3[4].couplingTsurf = -9999.0  # a point without a usable observation
+    s3 = abi.default_settings(L3); s3.use_coupling = 1; s3.use_relaxation = 1
+    o3 = oh.run_oracle("ref_cpl", f3, s3, p, ls3)[0]
+    save = {f"knot_{k}": v for k, v in K3.items()}
+    save["coupling_tsurf"] = np.array([x.couplingTsurf for x in ls3])
+    save["tair_relax"] = np.array([x.tair_relax for x in ls3])
+    save["tsurfobs"] = f3["tsurfobs"][:, ::KEEP].copy()
+    save["base_tsurf_full"] = base3["tsurf"]
+    for k in oh.F64_OUT:
+        idx, save[f"cpl_{k}"] = thin(o3[k])
+    save["out_index"] = idx
+    np.savez_compressed(os.path.join(HERE, "e2e_coupling.npz"), **save)
     # ---- (iii) init products ------------------------------------------------------
     ref = oh.load("ref")
     save = {}

@@ -25,6 +25,8 @@ from roadsurf_amd import abi  # noqa: E402
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 PORT_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libroadsurf_ref.so")
+#: same sources, `allocator`'s coupling dummy INTENT(INOUT): coupling as gfortran runs it
+REF_CPL_SO = os.path.join(ORACLE_DIR, "_ref", "libroadsurf_ref_cpl.so")
 
 F64_IN = ("tair", "tdew", "vz", "rhz", "prec", "sw", "lw", "sw_dir", "lw_net", "tsurfobs", "depth")
 I32_AXIS = ("year", "month", "day", "hour", "minute", "second")
@@ -53,13 +55,14 @@ _libs: dict[str, C.CDLL] = {}
 
 
 def load(kind: str) -> C.CDLL:
-    """kind: 'port' (C restatement) or 'ref' (reference Fortran)."""
+    """kind: 'port' (C restatement), 'ref' (reference Fortran, strict build) or 'ref_cpl'
+    (reference Fortran with working coupling, see oracle/build_ref.sh)."""
     if kind in _libs:
         return _libs[kind]
-    path = PORT_SO if kind == "port" else REF_SO
+    path = {"port": PORT_SO, "ref": REF_SO, "ref_cpl": REF_CPL_SO}[kind]
     if kind == "port" and not os.path.exists(path):
         build_port()
-    if kind == "ref" and not os.path.exists(path):
+    if kind.startswith("ref") and not os.path.exists(path):
         if os.path.isdir("/root/reference/src"):
             build_ref()
         else:

@@ -100,10 +100,6 @@ def test_batch_rejects_unsupported_rows_loudly():
     st = C.c_int32(0)
     L.runsimulation_batch(1, C.byref(op), C.byref(ip), C.byref(s), C.byref(p), C.byref(l), C.byref(st))
     assert st.value == -3 and "sky-view" in lib.last_error()
-    l = abi.default_local(); l.couplingIndexI = 100; l.couplingTsurf = -2.0
-    s.use_coupling = 1
-    L.runsimulation_batch(1, C.byref(op), C.byref(ip), C.byref(s), C.byref(p), C.byref(l), C.byref(st))
-    assert st.value == -2 and "coupling" in lib.last_error()
 
 
 def test_device_synth_equals_host_twin():

@@ -1,0 +1,109 @@
+"""GPU: coupling (src/Coupling.f90) — per-point replay of the coupling window with scaled
+radiation until the simulated surface temperature meets the last observation.
+
+Oracle: the reference built with working coupling (oracle/build_ref.sh explains why the
+strict amdflang build has inert coupling: an INTENT(OUT) dummy wipes the observation), or the
+C restatement, which is bit-identical to that build (tests/test_oracle_vs_golden.py)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_helpers as oh
+from roadsurf_amd import abi, lib
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def _kind():
+    return "ref_cpl" if os.path.exists(oh.REF_CPL_SO) else "port"
+
+
+def _cases(n, L, seed):
+    f = oh.synth_forcing(n, L, seed=seed)
+    s0 = abi.default_settings(L); p = abi.default_parameters(); l0 = abi.default_local(); l0.InitLenI = 1
+    base, _, _ = oh.run_oracle("port", f, s0, p, l0)
+    rs = np.random.RandomState(seed)
+    out = []
+    for case in range(4):
+        s = abi.default_settings(L); s.use_coupling = 1
+        if case == 1:
+            s.use_relaxation = 1
+        if case == 2:
+            s.coupling_minutes = 60
+        ls = []
+        f2 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in f.items()}
+        for i in range(n):
+            li = abi.default_local()
+            ci = L // 2 if case != 3 else int(rs.randint(50, L - 60))
+            li.InitLenI = ci if case != 2 else 1
+            li.couplingIndexI = ci
+            off = rs.choice([0.0, 0.05, 0.5, -0.5, 2.0, -2.0, 6.0, -6.0, 15.0, -15.0])
+            li.couplingTsurf = float(base["tsurf"][i, ci - 1] + off)
+            if i % 50 == 0:
+                li.couplingTsurf = -9999.0       # no usable observation: coupling off for the point
+            if i % 51 == 0:
+                li.couplingIndexI = 0
+            li.tair_relax = float(f["tair"][i, min(ci, L - 1)]) + 1.0; li.VZ_relax = 3.0; li.RH_relax = 80.0
+            ls.append(li)
+        if case != 2:
+            f2["tsurfobs"][:, :] = base["tsurf"] + 0.3
+        out.append((f2, s, p, ls))
+    return out, base
+
+
+def test_coupled_runs_match_oracle_bitwise():
+    from roadsurf_amd import device
+    n, L = 384, 2881
+    cases, base = _cases(n, L, 4242)
+    for k, (f2, s, p, ls) in enumerate(cases):
+        ora, _, _ = oh.run_oracle(_kind(), f2, s, p, ls)
+        res, _ = device.run_points(f2, s, p, ls)
+        worst = max(float(np.abs(res[q] - ora[q]).max()) for q in oh.F64_OUT)
+        nonid = sum(int((res[q] != ora[q]).sum()) for q in oh.F64_OUT)
+        moved = int((np.abs(ora["tsurf"] - base["tsurf"]).max(1) > 1e-3).sum())
+        print(f"case {k}: max|diff| {worst:.3e}, non-identical values {nonid}, points moved by coupling {moved}")
+        assert worst < TOL
+        assert nonid == 0
+        assert moved > n // 2  # coupling really acts in these cases
+
+
+def test_coupling_through_the_c_abi_batch_entry():
+    L = lib.load()
+    n, SL = 300, 1441
+    cases, _ = _cases(n, SL, 77)
+    f2, s, p, ls = cases[1]
+    ora, _, _ = oh.run_oracle(_kind(), f2, s, p, ls)
+    g = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in f2.items()}
+    out = {k: np.full((n, SL), np.nan) for k in oh.F64_OUT}
+    ips = (abi.InputPointers * n)(); ops = (abi.OutputPointers * n)(); keep = []
+    for pt in range(n):
+        ip, op, kp = oh.point_pointers(g, pt, out)
+        ips[pt], ops[pt] = ip, op
+        keep.append(kp)
+    larr = (abi.LocalParameters * n)(*ls)
+    st = C.c_int32(99)
+    L.runsimulation_batch(n, ops, ips, C.byref(s), C.byref(p), larr, C.byref(st))
+    assert st.value == 0, lib.last_error()
+    for k in oh.F64_OUT:
+        assert np.array_equal(out[k], ora[k]), k
+
+
+def test_coupling_window_must_be_whole_series():
+    from roadsurf_amd import device
+    n, L = 64, 721
+    cases, _ = _cases(n, L, 5)
+    f2, s, p, ls = cases[0]
+    plan = device.Plan(n, s, p, 0)
+    import torch
+    dev = plan.device
+    win = device.ForcingWindow.empty(100, plan.np_pad, dev)
+    out = device.OutputWindow.empty(100, plan.np_pad, dev)
+    z = torch.zeros(plan.np_pad, dtype=torch.int32, device=dev)
+    zd = torch.zeros(plan.np_pad, dtype=torch.float64, device=dev)
+    pp = plan.point_params(0.0, z, None, None, None, z, zd)
+    with pytest.raises(RuntimeError, match="whole series"):
+        plan.step(win, out, pp, 1, 100)
+    plan.close()

@@ -2,6 +2,7 @@
 REFERENCE ITSELF (tests/golden/make_golden.py).  Bit-for-bit: on x86-64 both sides do
 the same IEEE operations in the same order and call the same glibc exp/log."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -65,6 +66,36 @@ def test_feature_cases_bit_exact():
     check("nl9", f2, s)
 
 
+def _coupling_case():
+    z = gh.load("e2e_coupling.npz")
+    K = _knots(z)
+    L = 24 * SPK + 1
+    f = gh.expand_knots(K, L, SPK)
+    base = z["base_tsurf_full"]
+    f["tsurfobs"][:, :] = np.where(base == -9999.0, -9999.9, base + 0.3)
+    ls = []
+    for i in range(8):
+        li = abi.default_local(); li.InitLenI = 1440; li.couplingIndexI = 1440
+        li.couplingTsurf = float(z["coupling_tsurf"][i])
+        li.tair_relax = float(z["tair_relax"][i]); li.VZ_relax = 3.0; li.RH_relax = 80.0
+        ls.append(li)
+    s = abi.default_settings(L); s.use_coupling = 1; s.use_relaxation = 1
+    return z, f, s, abi.default_parameters(), ls
+
+
+def test_coupling_bit_exact():
+    """Fixture from the reference built with working coupling (see oracle/build_ref.sh)."""
+    z, f, s, p, ls = _coupling_case()
+    out, _, _ = oh.run_oracle("port", f, s, p, ls)
+    idx = z["out_index"]
+    for k in oh.F64_OUT:
+        assert np.array_equal(out[k][:, idx], z[f"cpl_{k}"]), k
+    # coupling pulled the simulated temperature at the observation index onto the observation
+    got = out["tsurf"][:, 1439]; obs = z["coupling_tsurf"]
+    ok = [i for i in range(8) if obs[i] > -100 and abs(obs[i] - z["base_tsurf_full"][i, 1439]) < 7 and got[i] != -9999.0]
+    assert len(ok) >= 4 and all(abs(got[i] - obs[i]) <= 0.1 + 1e-9 for i in ok)
+
+
 def test_init_products_bit_exact():
     z = gh.load("init_products.npz")
     zs = gh.load("e2e_scenarios.npz")
@@ -121,3 +152,31 @@ def test_port_equals_reference_on_random_workload():
     for k in oh.F64_OUT:
         assert np.array_equal(a[k], b[k]), k
     assert np.array_equal(fa["vz"], fb["vz"])  # VZ(1) side effect
+
+
+@pytest.mark.skipif(not os.path.exists(oh.REF_CPL_SO), reason="coupling-enabled reference build not available")
+def test_port_equals_reference_with_coupling():
+    n, L = 300, 2881
+    f = oh.synth_forcing(n, L, seed=4242)
+    p = abi.default_parameters(); l0 = abi.default_local(); l0.InitLenI = 1
+    base, _, _ = oh.run_oracle("port", f, abi.default_settings(L), p, l0)
+    rs = np.random.RandomState(3)
+    ls = []
+    for i in range(n):
+        li = abi.default_local(); ci = int(rs.randint(50, L - 60))
+        li.InitLenI = ci; li.couplingIndexI = ci
+        li.couplingTsurf = float(base["tsurf"][i, ci - 1] + rs.choice([0.0, 0.5, -2.0, 6.0, -15.0]))
+        li.tair_relax = float(f["tair"][i, ci]) + 1.0; li.VZ_relax = 3.0; li.RH_relax = 80.0
+        ls.append(li)
+    f["tsurfobs"][:, :] = base["tsurf"] + 0.3
+    s = abi.default_settings(L); s.use_coupling = 1; s.use_relaxation = 1
+    a, _, _ = oh.run_oracle("ref_cpl", f, s, p, ls)
+    b, _, _ = oh.run_oracle("port", f, s, p, ls)
+    for k in oh.F64_OUT:
+        assert np.array_equal(a[k], b[k]), k
+    # and the two reference builds agree wherever coupling is off
+    s2 = abi.default_settings(L); s2.use_relaxation = 1
+    c, _, _ = oh.run_oracle("ref", f, s2, p, ls)
+    d, _, _ = oh.run_oracle("ref_cpl", f, s2, p, ls)
+    for k in oh.F64_OUT:
+        assert np.array_equal(c[k], d[k]), k
