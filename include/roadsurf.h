@@ -210,6 +210,18 @@ typedef struct RsConstants {
 void rs_build_constants(const InputSettings *inSettings,
                         const InputParameters *inputParam, RsConstants *out,
                         int32_t *status);
+/* Time-only part of the solar position (src/SunPosition.f90:196-260 and :70-121,124-125):
+ * for n time stamps writes table[k*4 + {0,1,2,3}] = apparent right ascension (rad, in
+ * [0,2pi]), mean sidereal time at Greenwich (rad), sin and cos of the declination.
+ * Fortran, host libm. */
+void rs_sun_table(int32_t n, const int32_t *year, const int32_t *month,
+                  const int32_t *day, const int32_t *hour, const int32_t *minute,
+                  const int32_t *second, double *table);
+/* Per-point geometry (src/SunPosition.f90:126-128,133): sin/cos of the latitude and the
+ * longitude in radians, evaluated as the reference does.  Fortran, host libm. */
+void rs_point_geometry(int32_t n, const LocalParameters *localParam,
+                       double *sin_lat, double *cos_lat, double *lon_rad);
+
 /* Bottom boundary temperature Tmp(NLayers+1) for a start date
  * (src/Initialization.f90:266-268, src/BalanceModel.f90:325-351). Fortran. */
 double rs_bottom_temperature(const InputParameters *inputParam,
@@ -242,6 +254,11 @@ typedef struct RsForcing {
   const int32_t *hour;
   int64_t t_stride;     /* elements between consecutive time indices */
   int32_t hour_pstride; /* 0 shared axis, 1 per point */
+  /* sky view (src/ModRadiation.f90): direct short-wave and net long-wave streams, and the
+   * time-only solar quantities of rs_sun_table, [nsteps][4] = {ra, stG, sin decl, cos decl}
+   * on a time axis shared by all points.  NULL when no point has 0 <= sky_view < 1. */
+  const double *sw_dir, *lw_net;
+  const double *sun;
 } RsForcing;
 
 typedef struct RsOutputs {
@@ -265,6 +282,12 @@ typedef struct RsPointParams {
    * has to stay addressable. */
   const int32_t *coupling_index;
   const double *coupling_tsurf;
+  /* sky view: LocalParameters.sky_view, the geometry of rs_point_geometry and the local
+   * horizon table [360][npoints_padded] (degree of azimuth is the slow axis; NULL = all 0).
+   * NULL sky_view = no point uses the sky-view branch. */
+  const double *sky_view, *sin_lat, *cos_lat, *lon_rad;
+  const double *horizons;
+  double albedo_surroundings; /* InputParameters.Albedo_surroundings */
 } RsPointParams;
 
 const char *rs_last_error(void);
@@ -365,11 +388,20 @@ int64_t rs_hip_plan_npoints_padded(const RsPlan *plan);
  * H2D, kernels and D2H happen inside, tiled over points.  tbottom[n] is
  * computed by the Fortran caller.  Returns 0 or <0.
  * ---------------------------------------------------------------------- */
+typedef struct RsHostExtras {
+  /* sky view: NULL/0 when no point has 0 <= sky_view < 1 */
+  const double *sun;      /* rs_sun_table of the shared time axis, [SimLen][4] */
+  const double *sin_lat;  /* rs_point_geometry, [n] each */
+  const double *cos_lat;
+  const double *lon_rad;
+  double albedo_surroundings;
+} RsHostExtras;
+
 int rs_host_run_batch(int32_t n, OutputPointers *outPointers,
                       const InputPointers *inPointers,
                       const RsConstants *consts,
                       const LocalParameters *localParam, const double *tbottom,
-                      int32_t device);
+                      const RsHostExtras *extras, int32_t device);
 
 #define RS_ABI_VERSION 1
 int rs_abi_version(void);

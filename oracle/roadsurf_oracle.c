@@ -68,7 +68,10 @@ typedef struct {
       RadCoeffPrevious, SW_correction, LW_correction, Tsurf_end_coup1, couplingEffectReduction;
   double TsurfAveSave, SrfWatmmsSave, SrfIce2mmsSave, SrfDepmmsSave, SrfSnowmmsSave, AlbedoSave;
   double TmpSave[MAXL + 2];
+  double *SWSave, *SWDirSave, *LWSave; /* window copies, src/Coupling.f90:204-208 */
   int skyview_on;
+  const InputParameters *P;
+  const LocalParameters *lp;
   /* wear factors (src/WearingFactors.f90.inc) */
   double SnowTran, DepWear, IceWear, IceWear2, WatWear;
 } Model;
@@ -565,7 +568,18 @@ static void CalcAlbedo(Model *m) {
 /* src/Coupling.f90:172-210.  SrfIcemms is NOT saved (the reference saves Ice2 twice,
  * :194-195); the SW/SW_dir/LW window copies only matter when something mutates those
  * inputs (sky view), see uploadDataForCoupling. */
-static void saveDataForCoupling(Model *m, int datai) {
+static void saveDataForCoupling(Model *m, const InputPointers *in, int datai) {
+  const int len = m->couplingEndI - m->couplingStartI + 1;
+  if (len > 0 && !m->SWSave) {
+    m->SWSave = (double *)malloc(sizeof(double) * len);
+    m->SWDirSave = (double *)malloc(sizeof(double) * len);
+    m->LWSave = (double *)malloc(sizeof(double) * len);
+  }
+  for (int k = 0; k < len; ++k) { /* :204-208 */
+    m->SWSave[k] = in->c_SW[m->couplingStartI + k - 1];
+    m->SWDirSave[k] = in->c_SW_dir[m->couplingStartI + k - 1];
+    m->LWSave[k] = in->c_LW[m->couplingStartI + k - 1];
+  }
   m->saveDatai = datai;
   m->TsurfAveSave = m->TsurfAve;
   m->SrfWatmmsSave = m->Wat;
@@ -578,7 +592,13 @@ static void saveDataForCoupling(Model *m, int datai) {
 }
 
 /* src/Coupling.f90:213-255 (Tmp restored, TmpNw not; SrfIcemms not restored) */
-static void uploadDataForCoupling(Model *m, int *datai) {
+static void uploadDataForCoupling(Model *m, const InputPointers *in, int *datai) {
+  const int len = m->couplingEndI - m->couplingStartI + 1;
+  for (int k = 0; k < len && m->SWSave; ++k) { /* :249-253: undo in-place sky-view edits */
+    in->c_SW[m->couplingStartI + k - 1] = m->SWSave[k];
+    in->c_SW_dir[m->couplingStartI + k - 1] = m->SWDirSave[k];
+    in->c_LW[m->couplingStartI + k - 1] = m->LWSave[k];
+  }
   *datai = m->saveDatai;
   m->TsurfAve = m->TsurfAveSave;
   m->Wat = m->SrfWatmmsSave;
@@ -614,14 +634,14 @@ static void CouplingOperations1(Model *m, const InputPointers *in, int *i) {
   m->inCouplingPhase = 0;
   if (*i >= m->couplingStartI && *i <= m->couplingEndI) m->inCouplingPhase = 1;
   if (*i == m->couplingStartI && m->Coupling_iterations == 0) {
-    saveDataForCoupling(m, *i);
+    saveDataForCoupling(m, in, *i);
     m->SwRadCof = R4(1.0);
     m->LwRadCof = R4(1.0);
     m->SW_correction = R4(0.0);
     m->LW_correction = R4(0.0);
   }
   if (m->start_coupling_again) {
-    uploadDataForCoupling(m, i);
+    uploadDataForCoupling(m, in, i);
     m->start_coupling_again = 0;
     if (in->c_SW[*i - 1] > in->c_LW[*i - 1] && !m->skyview_on) {
       m->SwRadCof = m->RadCoeff;
@@ -751,10 +771,152 @@ static void CheckEndCoupling(Model *m, int i) {
   }
 }
 
-/* examples/example1/src/Simulation.f90:120-172, sky-view branch excluded
- * (taken only when 0 <= sky_view < 1) */
+/* ---- sky view: src/SunPosition.f90, src/ModRadiation.f90 -------------------------- */
+
+/* src/SunPosition.f90:196-260.  REAL() without a kind is REAL(4): the day fraction is
+ * accumulated in single precision. */
+static double JulianEphemerisDay(const InputPointers *in, int idx /*1-based*/) {
+  const int mmyr = in->c_year[idx - 1], mmmon = in->c_month[idx - 1], mmday = in->c_day[idx - 1];
+  const int mmhr = in->c_hour[idx - 1], mmmin = in->c_minute[idx - 1], mmsec = in->c_second[idx - 1];
+  const double Dyr = R4(365.25);
+  double yr, mo, A, B, day;
+  if (mmmon <= 2) {
+    yr = (double)(float)(mmyr - 1);
+    mo = (double)(float)(mmmon + 12);
+  } else {
+    yr = (double)(float)mmyr;
+    mo = (double)(float)mmmon;
+  }
+  {
+    float d = (float)mmday + (float)mmhr / 24.f;
+    d = d + (float)mmmin / (24.f * 60.f);
+    d = d + (float)mmsec / (24.f * 60.f * 60.f);
+    day = (double)d;
+  }
+  A = trunc(yr / R4(100.));
+  B = R4(2.) - A + trunc(A / R4(4.));
+  return trunc(Dyr * (yr + 4716)) + trunc(R4(30.6001) * (mo + R4(1.))) + day + B - 1.5245e3;
+}
+
+/* src/SunPosition.f90:20-194.  Returns 0, or 1 where the reference would `stop`. */
+static int calcElevationAzimuth(double JDE, double lat, double lon, double *elevation_angle,
+                                double *azimuth_angle) {
+  const double pi = 4 * atan(1.0);
+  const double Dyr = R4(365.25);
+  double T, ml, ma, ecc, sunc, al, tilt, eps, ra, declination, stG;
+  double cos_declination, sin_declination, lat_radians, sin_lat, cos_lat, cos_dec_lat, sin_dec_lat;
+  double hour_angle_corr, cosah, cos_elev, chi, cosele, precos;
+  T = (JDE - R4(2451545.0)) / (Dyr * R4(100.));
+  ml = R4(280.46645) + R4(36000.76983) * T + R4(0.0003032) * T * T;
+  if (ml < R4(0.)) ml = ml - R4(360.) * (trunc(ml / R4(360.)) - R4(1.));
+  if (ml > R4(360.)) ml = ml - R4(360.) * trunc(ml / R4(360.));
+  ma = R4(357.52910) + R4(35999.05030) * T - R4(0.0001559) * T * T - R4(0.00000048) * T * T * T;
+  if (ma < R4(0.)) ma = ma - R4(360.) * (trunc(ma / R4(360.)) - R4(1.));
+  if (ma > R4(360.)) ma = ma - R4(360.) * trunc(ma / R4(360.));
+  ecc = R4(0.016708617) - R4(0.000042037) * T - R4(0.0000001236) * T * T;
+  (void)ecc;
+  sunc = (R4(1.913600) - R4(0.004817) * T - R4(0.000014) * T * T) * sin(ma * pi / R4(180.)) +
+         (R4(0.019993) - R4(0.000101) * T) * sin(R4(2.) * ma * pi / R4(180.)) +
+         R4(0.000290) * sin(R4(3.) * ma * pi / R4(180.));
+  al = ml + sunc - R4(0.00569) - R4(0.00478) * sin((R4(125.04) - R4(1934.136) * T) * pi / R4(180.));
+  al = al * pi / R4(180.);
+  tilt = R4(23.43929111) - R4(0.013004166) * T - R4(0.001638888) * T * T + R4(0.005036111) * T * T * T;
+  eps = tilt + R4(0.00256) * cos((R4(125.04) - R4(1934.136) * T) * pi / R4(180.));
+  eps = eps * pi / R4(180.);
+  ra = atan2(cos(eps) * sin(al), cos(al));
+  if (ra < R4(0.)) ra = ra - R4(2.) * pi * (trunc(ra / (R4(2.) * pi)) - R4(1.));
+  if (ra > R4(2.) * pi) ra = ra - R4(2.) * pi * trunc(ra / (R4(2.) * pi));
+  declination = asin(sin(eps) * sin(al));
+  stG = R4(280.46061837) + R4(360.98564736629) * (JDE - R4(2451545.0)) + R4(0.000387933) * T * T -
+        T * T * T / R4(38710000.);
+  if (stG < R4(0.)) stG = stG - R4(360.) * (trunc(stG / R4(360.)) - R4(1.));
+  if (stG > R4(360.)) stG = stG - R4(360.) * trunc(stG / R4(360.));
+  stG = stG * pi / R4(180.);
+  cos_declination = cos(declination);
+  sin_declination = sin(declination);
+  lat_radians = pi * lat / R4(180.);
+  sin_lat = sin(lat_radians);
+  cos_lat = cos(lat_radians);
+  cos_dec_lat = cos_declination * cos_lat;
+  sin_dec_lat = sin_declination * sin_lat;
+  hour_angle_corr = (stG + lon * pi / R4(180.) - ra);
+  if (ra < R4(0.))
+    hour_angle_corr = hour_angle_corr - R4(2.) * pi * (trunc(hour_angle_corr / (R4(2.) * pi)) - R4(1.));
+  if (ra > R4(2.) * pi)
+    hour_angle_corr = hour_angle_corr - R4(2.) * pi * trunc(hour_angle_corr / (R4(2.) * pi));
+  cosah = cos(hour_angle_corr);
+  cos_elev = sin_dec_lat + cos_dec_lat * cosah;
+  if (cos_elev >= R4(1.0) && cos_elev < R4(1.001)) {
+    chi = R4(0.);
+  } else if (cos_elev >= R4(1.001)) {
+    return 1;
+  } else if (cos_elev > R4(-1.001) && cos_elev <= R4(-1.0)) {
+    chi = pi;
+  } else {
+    chi = acos(cos_elev);
+  }
+  *elevation_angle = R4(90.0) - chi * (R4(180.) / pi);
+  if (hour_angle_corr < R4(0.))
+    hour_angle_corr = 2 * pi + hour_angle_corr;
+  else if (hour_angle_corr > 2 * pi)
+    hour_angle_corr = hour_angle_corr - 2 * pi;
+  if (*elevation_angle > 0) {
+    cosele = cos((pi / R4(2.0)) - chi);
+    if (cosele >= R4(-0.0001) && cosele < R4(0.0001)) {
+      *azimuth_angle = R4(-9999.9);
+    } else {
+      precos = (sin_declination * cos_lat - cos_declination * sin_lat * cosah) / cosele;
+      if (precos >= R4(1.0) && precos < R4(1.001)) {
+        *azimuth_angle = R4(0.0);
+      } else if (precos >= R4(1.001)) {
+        return 1;
+      } else if (precos > R4(-1.001) && precos <= R4(-1.0)) {
+        *azimuth_angle = pi;
+      } else {
+        *azimuth_angle = acos(precos);
+      }
+    }
+    if (hour_angle_corr < pi) *azimuth_angle = 2 * pi - *azimuth_angle;
+    *azimuth_angle = *azimuth_angle * (R4(180.) / pi);
+  } else {
+    *azimuth_angle = R4(-9999.9);
+    *elevation_angle = R4(-9999.9);
+  }
+  return 0;
+}
+
+/* src/ModRadiation.f90:7-73: writes SW(i), SW_dir(i), LW(i) in the caller's arrays. */
+static void ModRadiationBySurroundings(const InputPointers *in, const InputParameters *P,
+                                       const LocalParameters *lp, int i) {
+  const int k = i - 1;
+  double sun_elevation = 0, sun_azim = 0, dif_SW, LW_surroundings, SW_ref, shadow_fac, horizon;
+  int azim_idx;
+  dif_SW = in->c_SW[k] - in->c_SW_dir[k];
+  LW_surroundings = in->c_LW_net[k] - in->c_LW[k];
+  if (calcElevationAzimuth(JulianEphemerisDay(in, i), lp->lat, lp->lon, &sun_elevation, &sun_azim)) {
+    fprintf(stderr, "roadsurf_oracle: the reference would STOP here (zenith/azimuth problem)\n");
+    abort();
+  }
+  azim_idx = (int)lround(sun_azim); /* NINT */
+  if (azim_idx == 360) azim_idx = 0;
+  /* the reference indexes local_horizons(azim_idx+1) also for the missing value -9999.9
+   * (index -9999: out of bounds, whatever memory holds); the value is unused then because
+   * sun_elevation is -9999.9 too.  We read nothing in that case. */
+  horizon = (azim_idx >= 0 && azim_idx < 360) ? in->c_local_horizons[azim_idx] : R4(0.);
+  shadow_fac = (horizon > sun_elevation) ? R4(0.0) : R4(1.0);
+  if (sun_elevation > R4(0.0)) {
+    in->c_SW_dir[k] = in->c_SW_dir[k] * shadow_fac;
+    SW_ref = P->Albedo_surroundings * in->c_SW_dir[k] + P->Albedo_surroundings * dif_SW;
+    dif_SW = lp->sky_view * dif_SW + (R4(1.0) - lp->sky_view) * SW_ref;
+    in->c_SW[k] = dif_SW + in->c_SW_dir[k];
+  }
+  in->c_LW[k] = lp->sky_view * in->c_LW[k] + (R4(1.0) - lp->sky_view) * (-LW_surroundings);
+}
+
+/* examples/example1/src/Simulation.f90:120-172 */
 static void roadModelOneStep(Model *m, const InputPointers *in, int i /*1-based*/) {
   PrecipitationToStorage(m, in->c_PrecPhase[i - 1]);
+  if (m->skyview_on) ModRadiationBySurroundings(in, m->P, m->lp, i);
   BalanceModelOneStep(m, in->c_SW[i - 1], in->c_LW[i - 1], in->c_hour[i - 1],
                       in->c_Depth[i - 1]);
   WearFactors(m);
@@ -913,6 +1075,8 @@ static void Initialization(Model *m, OutputPointers *out, const InputPointers *i
   m->coupling_minutes = s->coupling_minutes;
   m->couplingEffectReduction = s->couplingEffectReduction;
   m->skyview_on = (lp->sky_view < R4(1.0) && lp->sky_view > R4(-0.01));
+  m->P = P;
+  m->lp = lp;
   /* initVariablesAndParameters :65-147 */
   m->failed = 0;
   m->Tph = m->DTSecs / R4(3600.0);
@@ -1005,10 +1169,6 @@ void runsimulation(OutputPointers *out, const InputPointers *in, const InputSett
     fprintf(stderr, "roadsurf_oracle: NLayers out of range\n");
     abort();
   }
-  if (lp->sky_view < R4(1.0) && lp->sky_view > R4(-0.01)) {
-    fprintf(stderr, "roadsurf_oracle: sky-view branch is not restated yet (SURVEY.md 8f rank 3)\n");
-    abort();
-  }
   Initialization(m, out, in, s, P, lp);
   i = 1;
   while (i < m->SimLen && !m->failed) {
@@ -1038,6 +1198,7 @@ void runsimulation(OutputPointers *out, const InputPointers *in, const InputSett
     roadModelOneStep(m, in, L);
     SaveOutput(m, out, i);
   }
+  free(m->SWSave); free(m->SWDirSave); free(m->LWSave);
 }
 
 /* ---- known-answer probes (tests only) ---------------------------------- */
@@ -1079,4 +1240,15 @@ void oracle_probe_blcond(const InputSettings *s, const InputParameters *P, doubl
  * calls.  (numpy may use its own SIMD exp/log, so tests go through this.) */
 void oracle_libm_map(int fn, long n, const double *x, double *y) {
   for (long i = 0; i < n; ++i) y[i] = fn == 0 ? exp(x[i]) : log(x[i]);
+}
+
+/* Solar elevation/azimuth for one time stamp and location (known-answer tests). */
+int oracle_probe_sun(int year, int month, int day, int hour, int minute, int second, double lat,
+                     double lon, double *elevation, double *azimuth, double *jde) {
+  int32_t y = year, mo = month, d = day, h = hour, mi = minute, se = second;
+  InputPointers in;
+  memset(&in, 0, sizeof(in));
+  in.c_year = &y; in.c_month = &mo; in.c_day = &d; in.c_hour = &h; in.c_minute = &mi; in.c_second = &se;
+  *jde = JulianEphemerisDay(&in, 1);
+  return calcElevationAzimuth(*jde, lat, lon, elevation, azimuth);
 }

@@ -269,6 +269,13 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
                     (pl->c.use_relaxation && pp->tair_relax != nullptr) || (f->tdew != nullptr);
   if (pl->c.use_relaxation && pp->tair_relax && (!pp->vz_relax || !pp->rh_relax || !pp->initlen))
     return set_err("rs_hip_step: relaxation needs tair_relax, vz_relax, rh_relax and initlen");
+  const bool skyview = pp->sky_view != nullptr;
+  if (skyview) {
+    if (!pp->sin_lat || !pp->cos_lat || !pp->lon_rad || !f->sw_dir || !f->lw_net || !f->sun)
+      return set_err("rs_hip_step: sky view needs sin_lat, cos_lat, lon_rad, sw_dir, lw_net and sun");
+    if (f->hour_pstride)
+      return set_err("rs_hip_step: sky view needs a time axis shared by all points");
+  }
   const bool coupled = pl->c.use_coupling && pp->coupling_index != nullptr;
   if (coupled) {
     if (!pp->coupling_tsurf) return set_err("rs_hip_step: coupling needs coupling_index and coupling_tsurf");
@@ -301,8 +308,11 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
     pl->ev_used += 2;
     HIP_OK(hipEventRecord(e0, pl->stream));
   }
-  if (coupled)
+  if (coupled || skyview) {
+    if (!pp->coupling_index && pl->c.use_coupling)
+      return set_err("rs_hip_step: use_coupling is set: pass coupling_index/coupling_tsurf");
     HIP_OK(rs_launch_step_coupled(a, pl->c.NLayers, pl->stream));
+  }
   else
     HIP_OK(rs_launch_step(a, pl->c.NLayers, full, pl->variant, pl->stream));
   if (pl->timing) HIP_OK(hipEventRecord(e1, pl->stream));

@@ -83,7 +83,7 @@ int fail(const char *what, hipError_t e) {
     if (e_ != hipSuccess) return fail(#expr, e_);   \
   } while (0)
 
-enum { F_TAIR, F_TDEW, F_VZ, F_RHZ, F_PREC, F_SW, F_LW, F_OBS, F_DEPTH, NF64 };
+enum { F_TAIR, F_TDEW, F_VZ, F_RHZ, F_PREC, F_SW, F_LW, F_OBS, F_DEPTH, F_SWDIR, F_LWNET, NF64 };
 
 inline const double *in_f64(const InputPointers &ip, int f) {
   switch (f) {
@@ -95,6 +95,8 @@ inline const double *in_f64(const InputPointers &ip, int f) {
     case F_SW: return ip.c_SW;
     case F_LW: return ip.c_LW;
     case F_OBS: return ip.c_TSurfObs;
+    case F_SWDIR: return ip.c_SW_dir;
+    case F_LWNET: return ip.c_LW_net;
     default: return ip.c_Depth;
   }
 }
@@ -120,7 +122,7 @@ int rs_host_default_device(void) {
 
 int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointers *inPointers,
                       const RsConstants *consts, const LocalParameters *localParam,
-                      const double *tbottom, int32_t device) {
+                      const double *tbottom, const RsHostExtras *extras, int32_t device) {
   if (n < 1 || !outPointers || !inPointers || !consts || !localParam || !tbottom) {
     rs_host_set_error("rs_host_run_batch: bad arguments");
     return -1;
@@ -131,6 +133,8 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
   /* with coupling a point replays its window, so the whole series is one window
    * (rs_hip_step enforces it) and the point tile shrinks to keep staging bounded */
   const bool coupled = consts->use_coupling != 0;
+  const bool skyview = extras && extras->sun;
+  const int nf64 = skyview ? NF64 : NF64 - 2; /* SW_dir / LW_net travel only for sky view */
   const int P = std::min<int64_t>(n, ep ? std::max(1, atoi(ep)) : (coupled ? 4096 : 16384));
   const int TC = coupled ? L : std::min(L, et ? std::max(1, atoi(et)) : 256);
   const int Ppad = (P + RS_BLOCK - 1) / RS_BLOCK * RS_BLOCK;
@@ -147,19 +151,30 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
   const size_t in_elems = (size_t)P * TC, tp_elems = (size_t)Ppad * TC;
   Pinned h_in, h_out, h_i32;
   Dev d_pt, d_tp, d_i32pt, d_i32tp, d_out_tp, d_out_pt, d_pp64, d_pp32;
-  HOK(h_in.alloc(in_elems * NF64 * sizeof(double)));
+  HOK(h_in.alloc(in_elems * nf64 * sizeof(double)));
   HOK(h_out.alloc(in_elems * 6 * sizeof(double)));
   HOK(h_i32.alloc(in_elems * 2 * sizeof(int32_t)));
-  HOK(d_pt.alloc(in_elems * NF64 * sizeof(double)));
-  HOK(d_tp.alloc(tp_elems * NF64 * sizeof(double)));
+  HOK(d_pt.alloc(in_elems * nf64 * sizeof(double)));
+  HOK(d_tp.alloc(tp_elems * nf64 * sizeof(double)));
   HOK(d_i32pt.alloc(in_elems * 2 * sizeof(int32_t)));
   HOK(d_i32tp.alloc(tp_elems * 2 * sizeof(int32_t)));
   HOK(d_out_tp.alloc(tp_elems * 6 * sizeof(double)));
   HOK(d_out_pt.alloc(in_elems * 6 * sizeof(double)));
-  HOK(d_pp64.alloc((size_t)Ppad * 5 * sizeof(double)));
+  constexpr int NPP64 = 9; /* tbottom, 3 relaxation targets, couplingTsurf, sky_view, sin/cos lat, lon */
+  HOK(d_pp64.alloc((size_t)Ppad * NPP64 * sizeof(double)));
   HOK(d_pp32.alloc((size_t)Ppad * 2 * sizeof(int32_t)));
-  std::vector<double> pp64((size_t)Ppad * 5);
+  std::vector<double> pp64((size_t)Ppad * NPP64);
   std::vector<int32_t> pp32((size_t)Ppad * 2);
+  Dev d_sun, d_hz_pt, d_hz;
+  Pinned h_hz;
+  if (skyview) {
+    HOK(d_sun.alloc((size_t)L * 4 * sizeof(double)));
+    HOK(hipMemcpyAsync(d_sun.p, extras->sun, (size_t)L * 4 * sizeof(double), hipMemcpyHostToDevice,
+                       stream));
+    HOK(h_hz.alloc((size_t)P * 360 * sizeof(double)));
+    HOK(d_hz_pt.alloc((size_t)P * 360 * sizeof(double)));
+    HOK(d_hz.alloc((size_t)Ppad * 360 * sizeof(double)));
+  }
 
   int rc = 0;
   for (int64_t p0 = 0; p0 < n && rc == 0; p0 += P) {
@@ -177,6 +192,14 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
       pp64[(size_t)2 * Ppad + p] = localParam[p0 + p].VZ_relax;
       pp64[(size_t)3 * Ppad + p] = localParam[p0 + p].RH_relax;
       pp64[(size_t)4 * Ppad + p] = localParam[p0 + p].couplingTsurf;
+      pp64[(size_t)5 * Ppad + p] = localParam[p0 + p].sky_view;
+      if (skyview) {
+        pp64[(size_t)6 * Ppad + p] = extras->sin_lat[p0 + p];
+        pp64[(size_t)7 * Ppad + p] = extras->cos_lat[p0 + p];
+        pp64[(size_t)8 * Ppad + p] = extras->lon_rad[p0 + p];
+        std::memcpy((double *)h_hz.p + (size_t)p * 360, inPointers[p0 + p].c_local_horizons,
+                    360 * sizeof(double));
+      }
       pp32[p] = localParam[p0 + p].InitLenI;
       pp32[(size_t)Ppad + p] = localParam[p0 + p].couplingIndexI;
     }
@@ -192,6 +215,20 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
     pp.initlen = (int32_t *)d_pp32.p;
     pp.coupling_tsurf = coupled ? (double *)d_pp64.p + 4 * (size_t)Ppad : nullptr;
     pp.coupling_index = coupled ? (int32_t *)d_pp32.p + Ppad : nullptr;
+    pp.sky_view = pp.sin_lat = pp.cos_lat = pp.lon_rad = pp.horizons = nullptr;
+    pp.albedo_surroundings = 0.0;
+    if (skyview) {
+      pp.sky_view = (double *)d_pp64.p + 5 * (size_t)Ppad;
+      pp.sin_lat = (double *)d_pp64.p + 6 * (size_t)Ppad;
+      pp.cos_lat = (double *)d_pp64.p + 7 * (size_t)Ppad;
+      pp.lon_rad = (double *)d_pp64.p + 8 * (size_t)Ppad;
+      pp.albedo_surroundings = extras->albedo_surroundings;
+      /* horizon table [point][360] -> [360][point] */
+      HOK(hipMemcpyAsync(d_hz_pt.p, h_hz.p, (size_t)m * 360 * sizeof(double), hipMemcpyHostToDevice,
+                         stream));
+      HOK(transpose((const double *)d_hz_pt.p, (double *)d_hz.p, m, 360, 360, mp, stream));
+      pp.horizons = (double *)d_hz.p;
+    }
 
     for (int t0 = 1; t0 <= L; t0 += TC) {
       const int len = std::min(TC, L - t0 + 1);
@@ -201,17 +238,17 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
 #pragma omp parallel for schedule(static)
       for (int p = 0; p < m; ++p) {
         const InputPointers &ip = inPointers[p0 + p];
-        for (int f = 0; f < NF64; ++f)
+        for (int f = 0; f < nf64; ++f)
           std::memcpy(hin + ((size_t)f * m + p) * len, in_f64(ip, f) + (t0 - 1),
                       (size_t)len * sizeof(double));
         std::memcpy(hi + (size_t)p * len, ip.c_PrecPhase + (t0 - 1), (size_t)len * sizeof(int32_t));
         std::memcpy(hi + ((size_t)m + p) * len, ip.c_hour + (t0 - 1), (size_t)len * sizeof(int32_t));
       }
-      HOK(hipMemcpyAsync(d_pt.p, hin, (size_t)NF64 * m * len * sizeof(double),
+      HOK(hipMemcpyAsync(d_pt.p, hin, (size_t)nf64 * m * len * sizeof(double),
                          hipMemcpyHostToDevice, stream));
       HOK(hipMemcpyAsync(d_i32pt.p, hi, (size_t)2 * m * len * sizeof(int32_t),
                          hipMemcpyHostToDevice, stream));
-      for (int f = 0; f < NF64; ++f)
+      for (int f = 0; f < nf64; ++f)
         HOK(transpose((const double *)d_pt.p + (size_t)f * m * len,
                       (double *)d_tp.p + (size_t)f * mp * TC, m, len, len, mp, stream));
       for (int f = 0; f < 2; ++f)
@@ -227,6 +264,15 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
       fo.hour = (int32_t *)d_i32tp.p + fs;
       fo.t_stride = mp;
       fo.hour_pstride = 1;
+      fo.sw_dir = fo.lw_net = fo.sun = nullptr;
+      if (skyview) {
+        fo.sw_dir = b + F_SWDIR * fs;
+        fo.lw_net = b + F_LWNET * fs;
+        fo.sun = (double *)d_sun.p + (size_t)(t0 - 1) * 4;
+        /* the time axis is shared (checked by the Fortran caller): hour as a shared axis */
+        fo.hour = (int32_t *)d_i32pt.p + (size_t)m * len; /* point 0's row of the [p][t] copy */
+        fo.hour_pstride = 0;
+      }
       RsOutputs oo;
       double *ob = (double *)d_out_tp.p;
       oo.tsurf = ob; oo.snow = ob + fs; oo.water = ob + 2 * fs; oo.ice = ob + 3 * fs;

@@ -426,14 +426,27 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Pr
               rhR < R4(0.0) || rhR > 110);
   }
   /* setInputParam + initCouplingTimes, src/InputOutput.f90:30-36, src/Coupling.f90:486-534 */
-  const int32_t cidx = ka->pp.coupling_index[p];
-  q.on = c.use_coupling && !(ka->pp.coupling_tsurf[p] < -100 || cidx < 1);
+  const int32_t cidx = ka->pp.coupling_index ? ka->pp.coupling_index[p] : 0;
+  q.on = c.use_coupling && ka->pp.coupling_index &&
+         !(ka->pp.coupling_tsurf[p] < -100 || cidx < 1);
   q.cs = -99; q.ce = -99;
   if (q.on) {
     q.ce = cidx;
     q.cs = ((double)cidx <= c.cplLenR) ? 1 : cidx - c.cplLenI;
   }
   (void)lane; (void)row0;
+  /* sky view, examples/example1/src/Simulation.f90:154-156 */
+  double skyv = R4(1.0), sinlat = 0, coslat = 0, lonrad = 0;
+  bool sky_on = false;
+  if (ka->pp.sky_view) {
+    skyv = ka->pp.sky_view[p];
+    sky_on = (skyv < R4(1.0) && skyv > R4(-0.01));
+    if (sky_on) {
+      sinlat = ka->pp.sin_lat[p];
+      coslat = ka->pp.cos_lat[p];
+      lonrad = ka->pp.lon_rad[p];
+    }
+  }
 
   int32_t i = t0;
   bool stale_all = false; /* first step after a restore: TmpNw is the pre-restore profile */
@@ -446,8 +459,18 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Pr
     Forcing f = gather_forcing(ka, p, i, t0);
     if (i == 1 && f.vz < R4(0.4)) f.vz = R4(0.4);
     CouplingInputs cp;
+    double sw_dir = 0.0, lw_net = 0.0;
+    if (ka->f.sw_dir) {
+      const int64_t off = (int64_t)(i - t0) * ka->f.t_stride + p;
+      sw_dir = ka->f.sw_dir[off];
+      lw_net = ka->f.lw_net[off];
+    }
     if (i < c.SimLen) {
       if (check_values(f, s.tsurf, ka->f.tdew != nullptr)) s.failed = true;
+      if (sky_on && (sw_dir < R4(-0.1) || sw_dir > R4(4000.0) || lw_net < R4(-1000.0) ||
+                     lw_net > R4(1000.0)))
+        s.failed = true; /* src/InputOutput.f90:68-74 */
+      if (sw_dir > f.sw) sw_dir = f.sw; /* :75-77 */
       if (q.on) {
         /* CouplingOperations1, src/Coupling.f90:10-96 */
         bool in_phase = (i >= q.cs && i <= q.ce);
@@ -483,8 +506,16 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Pr
           q.again = false;
           f = gather_forcing(ka, p, i, t0);
           if (i == 1 && f.vz < R4(0.4)) f.vz = R4(0.4);
-          /* sky view is not on this path, so the SW branch is selectable (:68-76) */
-          if (f.sw > f.lw) {
+          if (ka->f.sw_dir) {
+            /* the restored window holds the arrays as CheckValues left them in the first
+             * pass: SW_dir already clamped to SW (src/Coupling.f90:204-208,249-253) */
+            const int64_t off = (int64_t)(i - t0) * ka->f.t_stride + p;
+            sw_dir = ka->f.sw_dir[off];
+            lw_net = ka->f.lw_net[off];
+            if (sw_dir > f.sw) sw_dir = f.sw;
+          }
+          /* short-wave scaling only without sky view (:68-76) */
+          if (f.sw > f.lw && !sky_on) {
             q.swcof = q.radcoeff;
             q.lwcof = R4(1.0);
           } else {
@@ -533,7 +564,17 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Pr
       }
     }
     cp.sw_cof = q.swcof; cp.lw_cof = q.lwcof; cp.last_tsurf_obs = q.lastobs;
-    const Fluxes fx = model_step_fluxes(c, mt, s, tair, vz, rhz, prec_ts, f.sw, f.lw, f.phase,
+    double sw_in = f.sw, lw_in = f.lw;
+    if (sky_on) {
+      /* the reference runs this between PrecipitationToStorage and BalanceModelOneStep
+       * (Simulation.f90:151-162); the two do not share data, so the order is free */
+      if (!sky_view_radiation(ka->f.sun + (int64_t)(i - t0) * 4, sinlat, coslat, lonrad, skyv,
+                              ka->pp.albedo_surroundings,
+                              ka->pp.horizons ? ka->pp.horizons + p : nullptr, np, sw_in, sw_dir,
+                              lw_in, lw_net))
+        s.failed = true; /* the reference would `stop` the process here */
+    }
+    const Fluxes fx = model_step_fluxes(c, mt, s, tair, vz, rhz, prec_ts, sw_in, lw_in, f.phase,
                                         f.hour, cp);
     if (stale_all) {
       /* observation forcing cannot follow a restore (i >= couplingStartI), so TmpNw(1:2)

@@ -486,7 +486,82 @@ __device__ __forceinline__ void model_step_ground(const RsConstants &c, Scalars 
   road_condition(c, s, fx.evap);
 }
 
-/* CheckValues, src/InputOutput.f90:45-84 (sky-view checks excluded) */
+/* Sky view / local horizon: the per-point, per-step remainder of calcElevationAzimuth
+ * (src/SunPosition.f90:123-193) and ModRadiationBySurroundings (src/ModRadiation.f90:7-73).
+ * sun[4] = {ra, stG, sin decl, cos decl} comes from the host (rs_sun_table, libm).  The
+ * solar position only ever acts through discrete outcomes (sun above the horizon line or
+ * not, which degree of azimuth, elevation > 0), so the device cos/acos need not reproduce
+ * libm's last bit: a different outcome needs the elevation within ~1e-14 deg of the horizon
+ * value or the azimuth within ~1e-13 deg of a half degree.  Returns false where the
+ * reference would `stop` (|cos| >= 1.001: cannot happen for real inputs). */
+__device__ __forceinline__ bool sky_view_radiation(const double *sun, double sin_lat,
+                                                   double cos_lat, double lon_rad, double sky_view,
+                                                   double albedo_surr, const double *horizons,
+                                                   int64_t hstride, double &sw, double &sw_dir,
+                                                   double &lw, double lw_net) {
+  const double pi = 3.141592653589793; /* 4*atan(1.0_8) */
+  const double ra = sun[0], stG = sun[1], sin_decl = sun[2], cos_decl = sun[3];
+  const double cos_dec_lat = cos_decl * cos_lat;
+  const double sin_dec_lat = sin_decl * sin_lat;
+  double hac = (stG + lon_rad - ra);
+  const double cosah = ::cos(hac);
+  const double cos_elev = sin_dec_lat + cos_dec_lat * cosah;
+  double chi;
+  if (cos_elev >= R4(1.0) && cos_elev < R4(1.001)) {
+    chi = R4(0.);
+  } else if (cos_elev >= R4(1.001)) {
+    return false;
+  } else if (cos_elev > R4(-1.001) && cos_elev <= R4(-1.0)) {
+    chi = pi;
+  } else {
+    chi = ::acos(cos_elev);
+  }
+  double elevation = R4(90.0) - chi * (R4(180.) / pi);
+  if (hac < R4(0.))
+    hac = 2 * pi + hac;
+  else if (hac > 2 * pi)
+    hac = hac - 2 * pi;
+  double azimuth;
+  if (elevation > 0) {
+    const double cosele = ::cos((pi / R4(2.0)) - chi);
+    if (cosele >= R4(-0.0001) && cosele < R4(0.0001)) {
+      azimuth = R4(-9999.9);
+    } else {
+      const double precos = (sin_decl * cos_lat - cos_decl * sin_lat * cosah) / cosele;
+      if (precos >= R4(1.0) && precos < R4(1.001))
+        azimuth = R4(0.0);
+      else if (precos >= R4(1.001))
+        return false;
+      else if (precos > R4(-1.001) && precos <= R4(-1.0))
+        azimuth = pi;
+      else
+        azimuth = ::acos(precos);
+    }
+    if (hac < pi) azimuth = 2 * pi - azimuth;
+    azimuth = azimuth * (R4(180.) / pi);
+  } else {
+    azimuth = R4(-9999.9);
+    elevation = R4(-9999.9);
+  }
+  /* ModRadiationBySurroundings */
+  double dif_sw = sw - sw_dir;
+  const double lw_surroundings = lw_net - lw;
+  int azim_idx = (int)__builtin_round(azimuth); /* NINT */
+  if (azim_idx == 360) azim_idx = 0;
+  double horizon = R4(0.);
+  if (horizons && azim_idx >= 0 && azim_idx < 360) horizon = horizons[(int64_t)azim_idx * hstride];
+  const double shadow_fac = (horizon > elevation) ? R4(0.0) : R4(1.0);
+  if (elevation > R4(0.0)) {
+    sw_dir = sw_dir * shadow_fac;
+    const double sw_ref = albedo_surr * sw_dir + albedo_surr * dif_sw;
+    dif_sw = sky_view * dif_sw + (R4(1.0) - sky_view) * sw_ref;
+    sw = dif_sw + sw_dir;
+  }
+  lw = sky_view * lw + (R4(1.0) - sky_view) * (-lw_surroundings);
+  return true;
+}
+
+/* CheckValues, src/InputOutput.f90:45-84 (sky-view checks: see the general kernel) */
 __device__ __forceinline__ bool check_values(const Forcing &f, double tsurf, bool has_tdew) {
   bool bad = f.tair < R4(-90.0) || f.tair > R4(100.0) || f.rhz < R4(-0.1) || f.rhz > R4(120.0) ||
              f.vz < R4(-1.0) || f.vz > R4(100.0) || f.sw < R4(-0.1) || f.sw > R4(4000.0) ||

@@ -62,6 +62,11 @@ class ForcingWindow:
         f.hour = C.c_void_p(h[row].data_ptr())
         f.t_stride = self.t_stride
         f.hour_pstride = 1 if self.hour_per_point else 0
+        for n in ("sw_dir", "lw_net"):
+            t = self.tensors.get(n)
+            setattr(f, n, None if t is None else C.c_void_p(t[row].data_ptr()))
+        sun = self.tensors.get("sun")  # [nsteps, 4]
+        f.sun = None if sun is None else C.c_void_p(sun[row].data_ptr())
         return f
 
 
@@ -117,7 +122,7 @@ class Plan:
 
     # -- per-point parameters -------------------------------------------------
     def point_params(self, tbottom, initlen=None, tair_relax=None, vz_relax=None, rh_relax=None,
-                     coupling_index=None, coupling_tsurf=None):
+                     coupling_index=None, coupling_tsurf=None, sky=None):
         """tbottom: float (uniform) or tensor[np_pad]; others tensors or None."""
         if not torch.is_tensor(tbottom):
             tbottom = torch.full((self.np_pad,), float(tbottom), dtype=torch.float64,
@@ -131,6 +136,12 @@ class Plan:
         pp.rh_relax = _ptr(rh_relax)
         pp.coupling_index = _ptr(coupling_index)
         pp.coupling_tsurf = _ptr(coupling_tsurf)
+        if sky is not None:  # dict: sky_view, sin_lat, cos_lat, lon_rad, horizons (tensors)
+            pp.sky_view = _ptr(sky["sky_view"]); pp.sin_lat = _ptr(sky["sin_lat"])
+            pp.cos_lat = _ptr(sky["cos_lat"]); pp.lon_rad = _ptr(sky["lon_rad"])
+            pp.horizons = _ptr(sky.get("horizons"))
+            pp.albedo_surroundings = float(self.params.Albedo_surroundings)
+            keep = keep + (sky,)
         self._pp_keep = keep
         return pp
 
@@ -220,8 +231,10 @@ def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputPara
     initlen = np.array([l.InitLenI for l in local], np.int32)
     relax_on = settings.use_relaxation == 1
     coupled = settings.use_coupling == 1
+    skyv = np.array([l.sky_view for l in local])
+    sky_on = bool(((skyv < 1.0) & (skyv > -0.01)).any())
     need_full = (not lean_if_possible) or initlen.max() > 1 or settings.force_tsurf == 1 or \
-        relax_on or coupled or settings.tsurfOutputDepth >= 0 or (forcing["depth"] >= 0).any()
+        relax_on or coupled or sky_on or settings.tsurfOutputDepth >= 0 or (forcing["depth"] >= 0).any()
 
     def pad_t(a, dtype):  # [n, L] -> device [L, npad]
         t = torch.zeros((L, npad), dtype=dtype, device=dev)
@@ -234,6 +247,29 @@ def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputPara
         tens[k] = pad_t(forcing[k], torch.float64) if need_full else None
     tens["precphase"] = pad_t(forcing["precphase"], torch.int32)
     tens["hour"] = torch.from_numpy(np.ascontiguousarray(forcing["hour"])).to(dev)
+    sky = None
+    if sky_on:
+        Lh = lib.load()
+        tens["sw_dir"] = pad_t(forcing["sw_dir"], torch.float64)
+        tens["lw_net"] = pad_t(forcing["lw_net"], torch.float64)
+        sun = np.zeros((L, 4))
+        ax = [np.ascontiguousarray(forcing[k], np.int32) for k in ("year", "month", "day", "hour", "minute", "second")]
+        Lh.rs_sun_table(L, *[C.c_void_p(a.ctypes.data) for a in ax], C.c_void_p(sun.ctypes.data))
+        tens["sun"] = torch.from_numpy(sun).to(dev)
+        larr = (abi.LocalParameters * n)(*local)
+        geo = [np.zeros(n) for _ in range(3)]
+        Lh.rs_point_geometry(n, larr, *[C.c_void_p(g.ctypes.data) for g in geo])
+
+        def vec(a):
+            t = torch.zeros((npad,), dtype=torch.float64, device=dev)
+            t[:n] = torch.from_numpy(np.ascontiguousarray(a))
+            return t
+        sky = {"sky_view": vec(skyv), "sin_lat": vec(geo[0]), "cos_lat": vec(geo[1]), "lon_rad": vec(geo[2])}
+        hz = forcing.get("local_horizons")
+        if hz is not None:
+            h = torch.zeros((360, npad), dtype=torch.float64, device=dev)
+            h[:, :n] = torch.from_numpy(np.ascontiguousarray(hz)).to(dev).T
+            sky["horizons"] = h
     win = ForcingWindow(L, npad, tens)
     if year_month_day is None:
         year_month_day = (int(forcing["year"][0]), int(forcing["month"][0]), int(forcing["day"][0]))
@@ -251,7 +287,8 @@ def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputPara
             pp_vec([l.VZ_relax for l in local], torch.float64) if relax_on else None,
             pp_vec([l.RH_relax for l in local], torch.float64) if relax_on else None,
             pp_vec([l.couplingIndexI for l in local], torch.int32) if coupled else None,
-            pp_vec([l.couplingTsurf for l in local], torch.float64) if coupled else None)
+            pp_vec([l.couplingTsurf for l in local], torch.float64) if coupled else None,
+            sky)
     else:
         pp = plan.point_params(tb)
     out = OutputWindow.empty(L, npad, dev)

@@ -100,17 +100,24 @@ module RoadSurfHip
       real(c_double) :: wSnowTran, wSnow2Ice, wIce, wIce2, wDep, wWat
    end type RsConstants
 
+   !> Mirror of `RsHostExtras` in include/roadsurf.h.
+   type, bind(C), public :: RsHostExtras
+      type(c_ptr) :: sun, sin_lat, cos_lat, lon_rad
+      real(c_double) :: albedo_surroundings
+   end type RsHostExtras
+
    interface
       !> C shim, roadsurf_amd/csrc/rs_host.hip
-      function rs_host_run_batch(n, outPointers, inPointers, consts, localParam, tbottom, device) &
+      function rs_host_run_batch(n, outPointers, inPointers, consts, localParam, tbottom, extras, device) &
          bind(C, name='rs_host_run_batch') result(rc)
-         import :: c_int, c_double, OutputPointers, InputPointers, RsConstants, LocalParameters
+         import :: c_int, c_double, OutputPointers, InputPointers, RsConstants, LocalParameters, RsHostExtras
          integer(c_int), value :: n
          type(OutputPointers), intent(inout) :: outPointers(*)
          type(InputPointers), intent(in) :: inPointers(*)
          type(RsConstants), intent(in) :: consts
          type(LocalParameters), intent(in) :: localParam(*)
          real(c_double), intent(in) :: tbottom(*)
+         type(RsHostExtras), intent(in) :: extras
          integer(c_int), value :: device
          integer(c_int) :: rc
       end function rs_host_run_batch
@@ -127,7 +134,7 @@ module RoadSurfHip
    end interface
 
    public :: rs_build_constants, rs_bottom_temperature, runsimulation, runsimulation_batch
-   public :: rs_fortran_sizeof
+   public :: rs_fortran_sizeof, rs_sun_table, rs_point_geometry
 
 contains
 
@@ -336,6 +343,81 @@ contains
                                                   inputParam%Omega*(-170) - (c%ZDpth(c%NLayers + 1)/inputParam%DampDpth))
    end function rs_bottom_temperature
 
+   !> Time-only solar quantities after Meeus, "Astronomical Algorithms" ch. 7, 12, 22, 25, as
+   !! the reference evaluates them (src/SunPosition.f90:70-125, 241-258).  Default-REAL
+   !! literals and REAL() conversions are deliberately left at default kind: the reference
+   !! accumulates the day fraction in single precision and rounds its coefficients to REAL(4).
+   subroutine rs_sun_table(n, year, month, day, hour, minute, second, table) bind(C, name='rs_sun_table')
+      integer(c_int), value :: n
+      integer(c_int), intent(in) :: year(n), month(n), day(n), hour(n), minute(n), second(n)
+      real(c_double), intent(out) :: table(4, n)
+      real(8), parameter :: pi = 4*atan(1.0_8)
+      real(8) :: cy, yr, mo, dayf, ca, cb, jde, t, lmean, anom, centre, lapp, obl, ra, decl, sidereal, node
+      integer :: k
+      cy = 365.25
+      do k = 1, n
+         ! Julian Ephemeris Day
+         if (month(k) <= 2) then
+            yr = real(year(k) - 1)
+            mo = real(month(k) + 12)
+         else
+            yr = real(year(k))
+            mo = real(month(k))
+         end if
+         dayf = real(day(k)) + real(hour(k))/24. + real(minute(k))/(24.*60.) + real(second(k))/(24.*60.*60.)
+         ca = dint(yr/100.)
+         cb = 2. - ca + dint(ca/4.)
+         jde = dint(cy*(yr + 4716)) + dint(30.6001*(mo + 1.)) + dayf + cb - 1.5245d3
+         t = (jde - 2451545.0)/(cy*100.)
+         ! geometric mean longitude and mean anomaly, reduced to [0, 360]
+         lmean = 280.46645 + 36000.76983*t + 0.0003032*t*t
+         if (lmean < 0.) lmean = lmean - 360.*(aint(lmean/360.) - 1.)
+         if (lmean > 360.) lmean = lmean - 360.*aint(lmean/360.)
+         anom = 357.52910 + 35999.05030*t - 0.0001559*t*t - 0.00000048*t*t*t
+         if (anom < 0.) anom = anom - 360.*(aint(anom/360.) - 1.)
+         if (anom > 360.) anom = anom - 360.*aint(anom/360.)
+         ! equation of centre, apparent longitude, obliquity with nutation term
+         centre = (1.913600 - 0.004817*t - 0.000014*t*t)*sin(anom*pi/180.) &
+                  + (0.019993 - 0.000101*t)*sin(2.*anom*pi/180.) &
+                  + 0.000290*sin(3.*anom*pi/180.)
+         node = (125.04 - 1934.136*t)*pi/180.
+         lapp = lmean + centre - 0.00569 - 0.00478*sin(node)
+         lapp = lapp*pi/180.
+         obl = 23.43929111 - 0.013004166*t - 0.001638888*t*t + 0.005036111*t*t*t
+         obl = obl + 0.00256*cos(node)
+         obl = obl*pi/180.
+         ! right ascension in [0, 2 pi], declination
+         ra = atan2(cos(obl)*sin(lapp), cos(lapp))
+         if (ra < 0.) ra = ra - 2.*pi*(aint(ra/(2.*pi)) - 1.)
+         if (ra > 2.*pi) ra = ra - 2.*pi*aint(ra/(2.*pi))
+         decl = asin(sin(obl)*sin(lapp))
+         ! mean sidereal time at Greenwich
+         sidereal = 280.46061837 + 360.98564736629*(jde - 2451545.0) + 0.000387933*t*t - t*t*t/38710000.
+         if (sidereal < 0.) sidereal = sidereal - 360.*(aint(sidereal/360.) - 1.)
+         if (sidereal > 360.) sidereal = sidereal - 360.*aint(sidereal/360.)
+         table(1, k) = ra
+         table(2, k) = sidereal*pi/180.
+         table(3, k) = sin(decl)
+         table(4, k) = cos(decl)
+      end do
+   end subroutine rs_sun_table
+
+   !> sin/cos of the latitude and longitude in radians (src/SunPosition.f90:126-128,133).
+   subroutine rs_point_geometry(n, localParam, sin_lat, cos_lat, lon_rad) bind(C, name='rs_point_geometry')
+      integer(c_int), value :: n
+      type(LocalParameters), intent(in) :: localParam(n)
+      real(c_double), intent(out) :: sin_lat(n), cos_lat(n), lon_rad(n)
+      real(8), parameter :: pi = 4*atan(1.0_8)
+      real(8) :: latr
+      integer :: p
+      do p = 1, n
+         latr = pi*localParam(p)%lat/180.
+         sin_lat(p) = sin(latr)
+         cos_lat(p) = cos(latr)
+         lon_rad(p) = localParam(p)%lon*pi/180.
+      end do
+   end subroutine rs_point_geometry
+
    subroutine fail(msg, status, code)
       character(len=*), intent(in) :: msg
       integer(c_int), intent(out) :: status
@@ -356,13 +438,17 @@ contains
       integer(c_int), intent(out) :: status
 
       type(RsConstants) :: consts
-      real(c_double), allocatable :: tbottom(:)
-      integer(c_int), pointer :: yy(:), mm(:), dd(:)
+      type(RsHostExtras) :: extras
+      real(c_double), allocatable, target :: tbottom(:), sun(:, :), slat(:), clat(:), lrad(:)
+      integer(c_int), pointer :: yy(:), mm(:), dd(:), hh(:), mi(:), ss(:), other(:)
+      logical :: any_sky
+      integer :: k, nt
       real(c_double), pointer :: vz(:)
       integer :: p
       integer(c_int) :: rc
 
       status = 0
+      any_sky = .false.
       if (n < 1) return
       call rs_build_constants(inSettings, inputParam, consts, rc)
       if (rc /= 0) then
@@ -371,10 +457,7 @@ contains
       end if
 
       do p = 1, n
-         if (localParam(p)%sky_view < 1.0 .and. localParam(p)%sky_view > -0.01) then
-            call fail('runsimulation_batch: sky-view radiation (0 <= sky_view < 1) is not supported yet', status, -3)
-            return
-         end if
+         if (localParam(p)%sky_view < 1.0 .and. localParam(p)%sky_view > -0.01) any_sky = .true.
          if (inPointers(p)%inputLen < inSettings%SimLen .or. outPointers(p)%outputLen < inSettings%SimLen) then
             call fail('runsimulation_batch: inputLen/outputLen shorter than SimLen', status, -4)
             return
@@ -393,7 +476,39 @@ contains
          if (vz(1) < 0.4) vz(1) = 0.4
       end do
 
-      rc = rs_host_run_batch(n, outPointers, inPointers, consts, localParam, tbottom, rs_host_default_device())
+      extras%sun = c_null_ptr; extras%sin_lat = c_null_ptr; extras%cos_lat = c_null_ptr
+      extras%lon_rad = c_null_ptr; extras%albedo_surroundings = inputParam%Albedo_surroundings
+      if (any_sky) then
+         ! the solar quantities that depend on time only are computed here, on the host, for
+         ! the time axis of point 1; the device path needs that axis to be shared by all points
+         nt = inSettings%SimLen
+         call c_f_pointer(inPointers(1)%c_year, yy, [nt]); call c_f_pointer(inPointers(1)%c_month, mm, [nt])
+         call c_f_pointer(inPointers(1)%c_day, dd, [nt]); call c_f_pointer(inPointers(1)%c_hour, hh, [nt])
+         call c_f_pointer(inPointers(1)%c_minute, mi, [nt]); call c_f_pointer(inPointers(1)%c_second, ss, [nt])
+         do p = 2, n
+            do k = 1, 6
+               select case (k)
+               case (1); call c_f_pointer(inPointers(p)%c_year, other, [nt]); if (any(other /= yy)) rc = -1
+               case (2); call c_f_pointer(inPointers(p)%c_month, other, [nt]); if (any(other /= mm)) rc = -1
+               case (3); call c_f_pointer(inPointers(p)%c_day, other, [nt]); if (any(other /= dd)) rc = -1
+               case (4); call c_f_pointer(inPointers(p)%c_hour, other, [nt]); if (any(other /= hh)) rc = -1
+               case (5); call c_f_pointer(inPointers(p)%c_minute, other, [nt]); if (any(other /= mi)) rc = -1
+               case (6); call c_f_pointer(inPointers(p)%c_second, other, [nt]); if (any(other /= ss)) rc = -1
+               end select
+            end do
+            if (rc /= 0) then
+               call fail('runsimulation_batch: sky view needs one time axis shared by all points of the batch', status, -5)
+               return
+            end if
+         end do
+         allocate (sun(4, nt), slat(n), clat(n), lrad(n))
+         call rs_sun_table(int(nt, c_int), yy, mm, dd, hh, mi, ss, sun)
+         call rs_point_geometry(n, localParam, slat, clat, lrad)
+         extras%sun = c_loc(sun); extras%sin_lat = c_loc(slat); extras%cos_lat = c_loc(clat)
+         extras%lon_rad = c_loc(lrad)
+      end if
+      rc = rs_host_run_batch(n, outPointers, inPointers, consts, localParam, tbottom, extras, &
+                             rs_host_default_device())
       if (rc /= 0) status = rc
       deallocate (tbottom)
    end subroutine runsimulation_batch

@@ -51,6 +51,7 @@ class RsForcing(C.Structure):
         [(n, C.c_void_p) for n in ("tair", "tdew", "vz", "rhz", "prec", "sw", "lw",
                                    "tsurfobs", "depth", "precphase", "hour")]
         + [("t_stride", C.c_int64), ("hour_pstride", C.c_int32)]
+        + [(n, C.c_void_p) for n in ("sw_dir", "lw_net", "sun")]
     )
 
 
@@ -63,7 +64,14 @@ class RsOutputs(C.Structure):
 
 class RsPointParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("tbottom", "initlen", "tair_relax", "vz_relax", "rh_relax",
-                                          "coupling_index", "coupling_tsurf")]
+                                          "coupling_index", "coupling_tsurf", "sky_view",
+                                          "sin_lat", "cos_lat", "lon_rad", "horizons")] + \
+               [("albedo_surroundings", C.c_double)]
+
+
+class RsHostExtras(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("sun", "sin_lat", "cos_lat", "lon_rad")] + \
+               [("albedo_surroundings", C.c_double)]
 
 
 class RsSynthSpec(C.Structure):
@@ -75,6 +83,7 @@ class RsSynthSpec(C.Structure):
 EXPORTS = (
     "rs_default_parameters", "rs_default_settings", "rs_default_local",
     "runsimulation", "runsimulation_batch", "rs_build_constants", "rs_bottom_temperature",
+    "rs_sun_table", "rs_point_geometry",
     "rs_last_error", "rs_hip_device_count", "rs_hip_plan_create", "rs_hip_plan_destroy",
     "rs_hip_plan_npoints", "rs_hip_plan_npoints_padded", "rs_hip_plan_state_bytes",
     "rs_hip_init_state", "rs_hip_step", "rs_hip_state_download", "rs_hip_state_upload",
@@ -156,7 +165,11 @@ def load() -> C.CDLL:
     L.rs_hip_timing_step_ms.restype = C.c_double
     L.rs_host_run_batch.argtypes = [C.c_int32, P(abi.OutputPointers), P(abi.InputPointers),
                                     P(RsConstants), P(abi.LocalParameters), P(C.c_double),
-                                    C.c_int32]
+                                    P(RsHostExtras), C.c_int32]
+    L.rs_sun_table.argtypes = [C.c_int32] + [C.c_void_p] * 7
+    L.rs_sun_table.restype = None
+    L.rs_point_geometry.argtypes = [C.c_int32, P(abi.LocalParameters)] + [C.c_void_p] * 3
+    L.rs_point_geometry.restype = None
     for n in ("rs_abi_sizeof", "rs_fortran_sizeof"):
         getattr(L, n).argtypes = [C.c_int]
         getattr(L, n).restype = C.c_int64

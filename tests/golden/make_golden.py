@@ -153,6 +153,32 @@ def main():
         idx, save[f"cpl_{k}"] = thin(o3[k])
     save["out_index"] = idx
     np.savez_compressed(os.path.join(HERE, "e2e_coupling.npz"), **save)
+    # ---- (i-sky) sky view / local horizons (src/ModRadiation.f90, src/SunPosition.f90) ---
+    L4 = 24 * SPK + 1
+    K4 = {k: (v[:, :26].copy() if v.ndim == 2 else v.copy()) for k, v in K.items()}
+    K4["sw"] = K4["sw"] * 2.5
+    f4 = gh.expand_knots(K4, L4, SPK, start=(2024, 5, 15, 0, 0, 0))
+    rs4 = np.random.RandomState(11)
+    fac4 = np.array([0.2, 0.5, 0.8, 1.1, 0.6, 0.9, 0.4, 0.7])
+    f4["sw_dir"] = np.ascontiguousarray(f4["sw"] * fac4[:, None])
+    f4["lw_net"] = np.full((8, L4), -55.0)
+    hz4 = np.round(rs4.uniform(0, 30, (8, 360)), 1); hz4[0] = 0.0
+    f4["local_horizons"] = np.ascontiguousarray(hz4)
+    lat4 = np.array([60.43, 69.9, 61.0, -33.9, 0.5, 45.0, 64.2, 59.9])
+    lon4 = np.array([22.84, 27.0, 25.7, 151.2, -78.5, 7.6, 29.1, 10.7])
+    sv4 = np.array([0.99, 0.75, 0.3, 0.5, 0.0, 1.0, 0.6, 0.85])
+    ls4 = []
+    for i in range(8):
+        li = abi.default_local(); li.InitLenI = 1; li.lat = float(lat4[i]); li.lon = float(lon4[i])
+        li.sky_view = float(sv4[i]); ls4.append(li)
+    o4, fm4, _ = oh.run_oracle("ref", f4, abi.default_settings(L4), p, ls4)
+    save = {f"knot_{k}": v for k, v in K4.items()}
+    save.update(lat=lat4, lon=lon4, sky_view=sv4, horizons=hz4, sw_dir_factor=fac4)
+    for k in oh.F64_OUT:
+        idx, save[f"sky_{k}"] = thin(o4[k])
+    save["out_index"] = idx
+    save["sw_after"] = fm4["sw"][:, ::KEEP].copy()  # the reference's in-place edit of the input
+    np.savez_compressed(os.path.join(HERE, "e2e_skyview.npz"), **save)
     # ---- (iii) init products ------------------------------------------------------
     ref = oh.load("ref")
     save = {}

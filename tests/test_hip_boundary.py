@@ -89,17 +89,21 @@ def test_runsimulation_batch_matches_oracle(monkeypatch):
     assert (out["tsurf"][5] == -9999.0).sum() == SL - 701
 
 
-def test_batch_rejects_unsupported_rows_loudly():
+def test_batch_rejects_bad_arguments_loudly():
     L = lib.load()
     n, SL = 1, 241
     f = oh.synth_forcing(n, SL, seed=3)
     out = {k: np.full((n, SL), np.nan) for k in oh.F64_OUT}
     ip, op, hz = _pointers(f, out, 0)
-    s = abi.default_settings(SL); p = abi.default_parameters()
-    l = abi.default_local(); l.sky_view = 0.7
+    s = abi.default_settings(SL); p = abi.default_parameters(); l = abi.default_local()
     st = C.c_int32(0)
+    s.NLayers = 40
     L.runsimulation_batch(1, C.byref(op), C.byref(ip), C.byref(s), C.byref(p), C.byref(l), C.byref(st))
-    assert st.value == -3 and "sky-view" in lib.last_error()
+    assert st.value == -1 and "NLayers" in lib.last_error()
+    s.NLayers = 15
+    ip.inputLen = 100
+    L.runsimulation_batch(1, C.byref(op), C.byref(ip), C.byref(s), C.byref(p), C.byref(l), C.byref(st))
+    assert st.value == -4 and "shorter than SimLen" in lib.last_error()
 
 
 def test_device_synth_equals_host_twin():

@@ -83,6 +83,16 @@ def test_golden_coupling_on_gpu():
         assert np.array_equal(res[k][:, idx], z[f"cpl_{k}"]), k
 
 
+def test_golden_skyview_on_gpu():
+    from roadsurf_amd import device
+    from test_oracle_vs_golden import _skyview_case
+    z, f, s, p, ls = _skyview_case()
+    res, _ = device.run_points(f, s, p, ls)
+    idx = z["out_index"]
+    for k in oh.F64_OUT:
+        assert np.array_equal(res[k][:, idx], z[f"sky_{k}"]), k
+
+
 def _synthetic_pass(plan, spec, knots, simlen, chunk, sample_cols, pp):
     """One full pass; returns (checksum, sampled outputs [6][simlen][ncols], mins, maxs)."""
     import torch

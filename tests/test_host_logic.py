@@ -73,3 +73,37 @@ def test_shards_partition_the_points():
         for (o1, c1), (o2, _) in zip(spans[:-1], spans[1:]):
             assert o1 + c1 == o2
     assert sharding.weak_shard(1000, 3) == (3000, 1000)
+
+
+def test_fortran_sun_table_against_oracle_solar_position():
+    """rs_sun_table + rs_point_geometry (Fortran host) recombine to the oracle's elevation:
+    cos(zenith) = sin(decl) sin(lat) + cos(decl) cos(lat) cos(stG + lon - ra)."""
+    import oracle_helpers as oh
+    L = lib.load()
+    port = oh.load("port")
+    port.oracle_probe_sun.argtypes = [C.c_int] * 6 + [C.c_double] * 2 + [abi.c_double_p] * 3
+    rs = np.random.RandomState(0)
+    n = 200
+    y = np.full(n, 2024, np.int32); mo = rs.randint(1, 13, n).astype(np.int32)
+    d = rs.randint(1, 29, n).astype(np.int32); h = rs.randint(0, 24, n).astype(np.int32)
+    mi = rs.randint(0, 60, n).astype(np.int32); se = (30 * rs.randint(0, 2, n)).astype(np.int32)
+    tab = np.zeros((n, 4))
+    L.rs_sun_table(n, *[C.c_void_p(a.ctypes.data) for a in (y, mo, d, h, mi, se)], C.c_void_p(tab.ctypes.data))
+    ls = []
+    for k in range(n):
+        l = abi.default_local(); l.lat = float(rs.uniform(-80, 80)); l.lon = float(rs.uniform(-180, 180)); ls.append(l)
+    larr = (abi.LocalParameters * n)(*ls)
+    g = [np.zeros(n) for _ in range(3)]
+    L.rs_point_geometry(n, larr, *[C.c_void_p(a.ctypes.data) for a in g])
+    for k in range(n):
+        el, az, jde = C.c_double(), C.c_double(), C.c_double()
+        assert port.oracle_probe_sun(int(y[k]), int(mo[k]), int(d[k]), int(h[k]), int(mi[k]), int(se[k]),
+                                     ls[k].lat, ls[k].lon, C.byref(el), C.byref(az), C.byref(jde)) == 0
+        ra, stg, sd, cd = tab[k]
+        assert 0.0 <= ra <= 2 * np.pi + 1e-12
+        cosz = sd * g[0][k] + (cd * g[1][k]) * np.cos((stg + g[2][k]) - ra)
+        elev = 90.0 - np.degrees(np.arccos(np.clip(cosz, -1, 1)))
+        if el.value > -9000:
+            assert abs(elev - el.value) < 1e-9
+        else:
+            assert elev <= 1e-9

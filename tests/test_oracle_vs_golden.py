@@ -96,6 +96,31 @@ def test_coupling_bit_exact():
     assert len(ok) >= 4 and all(abs(got[i] - obs[i]) <= 0.1 + 1e-9 for i in ok)
 
 
+def _skyview_case():
+    z = gh.load("e2e_skyview.npz")
+    K = _knots(z)
+    L = 24 * SPK + 1
+    f = gh.expand_knots(K, L, SPK, start=(2024, 5, 15, 0, 0, 0))
+    f["sw_dir"] = np.ascontiguousarray(f["sw"] * z["sw_dir_factor"][:, None])
+    f["lw_net"] = np.full((8, L), -55.0)
+    f["local_horizons"] = np.ascontiguousarray(z["horizons"])
+    ls = []
+    for i in range(8):
+        li = abi.default_local(); li.InitLenI = 1; li.lat = float(z["lat"][i]); li.lon = float(z["lon"][i])
+        li.sky_view = float(z["sky_view"][i]); ls.append(li)
+    return z, f, abi.default_settings(L), abi.default_parameters(), ls
+
+
+def test_skyview_bit_exact():
+    z, f, s, p, ls = _skyview_case()
+    out, fm, _ = oh.run_oracle("port", f, s, p, ls)
+    idx = z["out_index"]
+    for k in oh.F64_OUT:
+        assert np.array_equal(out[k][:, idx], z[f"sky_{k}"]), k
+    assert np.array_equal(fm["sw"][:, ::12], z["sw_after"])  # same in-place edit of SW
+    assert (fm["sw"] != f["sw"]).mean() > 0.05
+
+
 def test_init_products_bit_exact():
     z = gh.load("init_products.npz")
     zs = gh.load("e2e_scenarios.npz")
