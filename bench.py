@@ -34,6 +34,19 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s 
 ALGO_BYTES_PER_UNIT = 100.0    # 52 B read + 48 B written per point-timestep
 
 
+def effective_cpus() -> int:
+    """CPUs this process may actually use: affinity mask AND cgroup v2 quota (the GPU box gives a
+    16-CPU share of a 256-thread host; OpenMP's default of 256 threads would oversubscribe it)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(sample_points: int, simlen: int, seed: int):
     """Reference Fortran (oracle/_ref, kind 'reference') or, if absent, the C port,
     OpenMP over points on this box's host cores, on a bounded sample of the workload."""
@@ -47,9 +60,10 @@ def cpu_baseline(sample_points: int, simlen: int, seed: int):
     l = abi.default_local()
     l.InitLenI = 1
     f = oh.synth_forcing(sample_points, simlen, seed=seed)
-    oh.run_oracle(kind, {k: (v[:64] if v.ndim == 2 else v) for k, v in f.items()}, s, p, l)  # warm
+    oh.run_oracle(kind, {k: (v[:64] if v.ndim == 2 else v) for k, v in f.items()}, s, p, l,
+                  nthreads=effective_cpus())  # warm
     t = time.perf_counter()
-    _, _, threads = oh.run_oracle(kind, f, s, p, l, copy_inputs=False)
+    _, _, threads = oh.run_oracle(kind, f, s, p, l, nthreads=effective_cpus(), copy_inputs=False)
     dt = time.perf_counter() - t
     return {
         "value": sample_points * simlen / dt,
@@ -88,7 +102,7 @@ def main() -> None:
                     help="double-buffer: expand window c+1 on a side stream while stepping window c "
                          "(measured: no gain, the step kernel owns the whole register file; DESIGN.md 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=4096)
+    ap.add_argument("--cpu-sample", type=int, default=16384)
     args = ap.parse_args()
 
     import torch

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <omp.h>
 
 #include "../../include/roadsurf.h"
 #include "rs_kernels.h"
@@ -69,6 +70,26 @@ struct Pinned {
   }
   hipError_t alloc(size_t n) { return hipHostMalloc(&p, n, hipHostMallocDefault); }
 };
+
+/* Host worker threads for the row gather/scatter: the CPUs this process may actually use
+ * (affinity mask AND cgroup v2 cpu.max quota), not the machine's core count: a container
+ * with a 16-CPU quota on a 256-thread host runs 10x slower with 256 OpenMP threads. */
+int host_threads() {
+  const char *e = getenv("ROADSURF_HIP_HOST_THREADS");
+  if (e && atoi(e) > 0) return atoi(e);
+  int n = omp_get_num_procs();
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    long long quota = -1, period = 0;
+    char q[32];
+    if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+      quota = atoll(q);
+      const int c = (int)((quota + period - 1) / period);
+      if (c > 0 && c < n) n = c;
+    }
+    fclose(f);
+  }
+  return n < 1 ? 1 : n;
+}
 
 int fail(const char *what, hipError_t e) {
   char buf[256];
@@ -176,6 +197,7 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
     HOK(d_hz.alloc((size_t)Ppad * 360 * sizeof(double)));
   }
 
+  const int nthreads = host_threads();
   int rc = 0;
   for (int64_t p0 = 0; p0 < n && rc == 0; p0 += P) {
     const int m = (int)std::min<int64_t>(P, n - p0);
@@ -235,7 +257,7 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
       /* gather rows into pinned staging [field][p][len] */
       double *hin = (double *)h_in.p;
       int32_t *hi = (int32_t *)h_i32.p;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nthreads)
       for (int p = 0; p < m; ++p) {
         const InputPointers &ip = inPointers[p0 + p];
         for (int f = 0; f < nf64; ++f)
@@ -289,7 +311,7 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
                          hipMemcpyDeviceToHost, stream));
       HOK(hipStreamSynchronize(stream));
       const double *hout = (const double *)h_out.p;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nthreads)
       for (int p = 0; p < m; ++p)
         for (int f = 0; f < 6; ++f)
           std::memcpy(out_f64(outPointers[p0 + p], f) + (t0 - 1), hout + ((size_t)f * m + p) * len,

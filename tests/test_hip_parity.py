@@ -163,3 +163,39 @@ def test_bit_identity_at_scale_8192_points():
     assert np.abs(res["tsurf"] - ora["tsurf"]).max() < TOL_K
     if HOST_HAS_FMA:
         assert nonident == 0
+
+
+def test_output_decimation_matches_driver_semantics():
+    """decimate = k keeps indices 1, 1+k, 1+2k, ... (what the reference driver writes with
+    outputStep, examples/example1/src/roadrunner.cpp:290,303) and equals the full series there."""
+    import torch
+    from roadsurf_amd import device
+    n, L, k = 300, 1441, 120
+    f = oh.synth_forcing(n, L, seed=21)
+    s = abi.default_settings(L); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
+    full, _ = device.run_points(f, s, p, l)
+    plan = device.Plan(n, s, p, 0)
+    dev = plan.device
+    npad = plan.np_pad
+
+    def pad_t(a, dtype):
+        t = torch.zeros((L, npad), dtype=dtype, device=dev)
+        t[:, :n] = torch.from_numpy(np.ascontiguousarray(a)).to(dev).T
+        return t
+    tens = {q: pad_t(f[q], torch.float64) for q in ("tair", "vz", "rhz", "prec", "sw", "lw", "tsurfobs")}
+    tens["tdew"] = None; tens["depth"] = None
+    tens["precphase"] = pad_t(f["precphase"], torch.int32)
+    tens["hour"] = torch.from_numpy(f["hour"]).to(dev)
+    win = device.ForcingWindow(L, npad, tens)
+    nrows = (L - 1) // k + 1
+    out = device.OutputWindow.empty(nrows, npad, dev, decimate=k)
+    pp = plan.point_params(plan.uniform_tbottom(2024, 1, 10))
+    plan.init_state(win, pp)
+    # two launches, boundaries not aligned with the output stride
+    plan.step(win, out, pp, 1, 500, window_row=0, out_row0=0)
+    plan.step(win, out, pp, 501, L - 500, window_row=500, out_row0=0)
+    plan.sync()
+    for q in oh.F64_OUT:
+        got = out.tensors[q][:, :n].T.cpu().numpy()
+        assert np.array_equal(got, full[q][:, ::k]), q
+    plan.close()
