@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/roadsurf.h"
@@ -35,6 +36,8 @@ static int set_err(const char *fmt, ...) {
   } while (0)
 
 static bool g_slot_used[64][RS_CONST_SLOTS];
+static std::mutex g_slot_mutex; /* runsimulation is called concurrently from driver threads
+                                    (examples/example1/src/roadrunner.cpp:490-497) */
 
 struct RsPlan {
   int device = 0;
@@ -171,16 +174,22 @@ RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints, const RsConstants *c
   }
   (void)hipMemsetAsync(pl->state, 0, bytes, pl->stream);
   /* claim a slot of the per-device __constant__ table */
-  for (int sidx = 0; sidx < RS_CONST_SLOTS; ++sidx)
-    if (!g_slot_used[device][sidx]) {
-      g_slot_used[device][sidx] = true;
-      pl->cslot = sidx;
-      break;
-    }
+  {
+    std::lock_guard<std::mutex> lock(g_slot_mutex);
+    for (int sidx = 0; sidx < RS_CONST_SLOTS; ++sidx)
+      if (!g_slot_used[device][sidx]) {
+        g_slot_used[device][sidx] = true;
+        pl->cslot = sidx;
+        break;
+      }
+  }
   if (pl->cslot < 0 || rs_upload_constants(pl->cslot, &pl->c, pl->stream) != hipSuccess) {
     set_err("rs_hip_plan_create: no free constant slot (max %d plans per device) or upload failed",
             RS_CONST_SLOTS);
-    if (pl->cslot >= 0) g_slot_used[device][pl->cslot] = false;
+    if (pl->cslot >= 0) {
+      std::lock_guard<std::mutex> lock(g_slot_mutex);
+      g_slot_used[device][pl->cslot] = false;
+    }
     (void)hipFree(pl->state);
     (void)hipFree(pl->counter);
     delete pl;
@@ -194,7 +203,10 @@ void rs_hip_plan_destroy(RsPlan *pl) {
   (void)hipSetDevice(pl->device);
   (void)hipStreamSynchronize(pl->stream);
   for (hipEvent_t e : pl->ev) (void)hipEventDestroy(e);
-  if (pl->cslot >= 0) g_slot_used[pl->device][pl->cslot] = false;
+  if (pl->cslot >= 0) {
+    std::lock_guard<std::mutex> lock(g_slot_mutex);
+    g_slot_used[pl->device][pl->cslot] = false;
+  }
   (void)hipFree(pl->state);
   (void)hipFree(pl->counter);
   delete pl;

@@ -133,3 +133,32 @@ def test_device_synth_equals_host_twin():
         assert np.array_equal(got[k].T, host[k]), k
     assert np.array_equal(hours, host["hour"])
     plan.close()
+
+
+def test_runsimulation_is_reentrant_from_driver_threads():
+    """The reference driver runs one runsimulation per worker thread
+    (examples/example1/src/roadrunner.cpp:490-497); so must the drop-in."""
+    import threading
+    L = lib.load()
+    n, SL = 12, 721
+    f = oh.synth_forcing(n, SL, seed=8)
+    s = abi.default_settings(SL); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
+    ora, _, _ = oh.run_oracle(_kind(), f, s, p, l)
+    g = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in f.items()}
+    out = {k: np.full((n, SL), np.nan) for k in oh.F64_OUT}
+    args = [_pointers(g, out, pt) for pt in range(n)]
+    errs = []
+
+    def work(lo, hi):
+        try:
+            for pt in range(lo, hi):
+                ip, op, _ = args[pt]
+                L.runsimulation(C.byref(op), C.byref(ip), C.byref(s), C.byref(p), C.byref(l))
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(i * 3, i * 3 + 3)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs
+    for k in oh.F64_OUT:
+        assert np.array_equal(out[k], ora[k]), k
