@@ -101,6 +101,9 @@ def main() -> None:
     ap.add_argument("--overlap", action="store_true",
                     help="double-buffer: expand window c+1 on a side stream while stepping window c "
                          "(measured: no gain, the step kernel owns the whole register file; DESIGN.md 6)")
+    ap.add_argument("--f32", action="store_true",
+                    help="BASELINE config 5 flavour: fp32 state/forcing/outputs/arithmetic "
+                         "(tolerance-gated, not the parity path); default is fp64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16384)
     args = ap.parse_args()
@@ -136,6 +139,9 @@ def main() -> None:
     plan = device.Plan(n, settings, params, dev_index)
     if args.variant:
         plan.set_variant(args.variant)
+    wdtype = torch.float32 if args.f32 else torch.float64
+    if args.f32:
+        plan.set_precision(32)
     npad = plan.np_pad
     nknots = args.hours + 2
     offset, _ = sharding.weak_shard(n, rank)
@@ -143,10 +149,10 @@ def main() -> None:
     chunk = min(args.chunk, simlen)
     overlap = args.overlap
     nbuf = 2 if overlap else 1
-    wins = [device.ForcingWindow.empty(chunk, npad, dev, optional=()) for _ in range(nbuf)]
-    out = device.OutputWindow.empty(chunk, npad, dev)
+    wins = [device.ForcingWindow.empty(chunk, npad, dev, optional=(), dtype=wdtype) for _ in range(nbuf)]
+    out = device.OutputWindow.empty(chunk, npad, dev, dtype=wdtype)
     # index-1 window for the init kernel: needs TsurfObs(1)
-    win0 = device.ForcingWindow.empty(1, npad, dev, optional=("tsurfobs",))
+    win0 = device.ForcingWindow.empty(1, npad, dev, optional=("tsurfobs",), dtype=wdtype)
     pp = plan.point_params(plan.uniform_tbottom(2024, 1, 10))
     main = plan.stream
     side = torch.cuda.Stream(dev) if overlap else main
@@ -204,9 +210,10 @@ def main() -> None:
     # dominant kernel: step kernel, HIP events on its own stream around every launch
     avg_launch_s = step_ms / 1e3 / max(nlaunch, 1)
     units_per_launch = units_per_pass * args.steps / max(nlaunch, 1)
-    achieved = ALGO_BYTES_PER_UNIT * units_per_launch / avg_launch_s / 1e9
+    algo_bytes = 52.0 if args.f32 else ALGO_BYTES_PER_UNIT  # fp32: 6 x 4 + 4 read, 6 x 4 written
+    achieved = algo_bytes * units_per_launch / avg_launch_s / 1e9
 
-    traffic, valu = measured_traffic(n, chunk)
+    traffic, valu = (None, None) if args.f32 else measured_traffic(n, chunk)
     if rank == 0:
         line = {
             "metric": "point_timesteps_per_s",
@@ -219,11 +226,11 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f32" if args.f32 else "f64",
             "data": "synthetic",
             "config": {
                 "workload": f"{n} synthetic points per GPU x {args.hours} h (SimLen {simlen}, "
-                            f"DTSecs 30, NLayers 15), fp64, outputs every time index",
+                            f"DTSecs 30, NLayers 15), {'fp32' if args.f32 else 'fp64'}, outputs every time index",
                 "points_per_gpu": n,
                 "simlen": simlen,
                 "chunk_steps": chunk,

@@ -363,6 +363,13 @@ int rs_hip_expand_forcing_on(RsPlan *plan, const RsSynthSpec *spec,
  * (roadsurf_amd/csrc/rs_math.hpp; tests/test_hip_math.py). */
 int rs_hip_test_math(RsPlan *plan, int32_t fn, int64_t n, const double *x, double *y);
 
+/* Arithmetic flavour of a plan: 64 (default; the parity path) or 32 (BASELINE config 5:
+ * fp32 state/forcing/outputs/arithmetic, LEAN feature set, tolerance-gated against fp64).
+ * With 32 the `double *` members of RsForcing/RsOutputs point to FLOAT arrays of the same
+ * [t][p] layout (precphase/hour stay int32, tbottom stays double), and the state block
+ * holds floats.  Set before rs_hip_init_state. */
+int rs_hip_set_precision(RsPlan *plan, int32_t bits);
+
 /* How this build divides: 0 = compiler's IEEE expansion everywhere (-DRS_IEEE_DIV),
  * 1 = bare Newton sequence for normal-range operands (default, same bits, see
  * rs_math.hpp), 2 = both evaluated and compared (-DRS_DIV_CHECK).  In mode 2

@@ -48,6 +48,7 @@ struct RsPlan {
   unsigned long long *counter = nullptr;
   int variant = RS_VARIANT_AUTO;
   int cslot = -1;
+  bool f32 = false; /* single-precision flavour: windows and state hold floats */
   std::vector<hipEvent_t> ev; /* start/stop pairs */
   size_t ev_used = 0;
   bool timing = false;
@@ -218,6 +219,14 @@ size_t rs_hip_plan_state_bytes(const RsPlan *pl) {
   return pl ? (size_t)RS_NSTATE * pl->np_pad * sizeof(double) : 0;
 }
 
+int rs_hip_set_precision(RsPlan *pl, int32_t bits) {
+  if (!pl || (bits != 32 && bits != 64)) return set_err("rs_hip_set_precision: bits must be 32 or 64");
+  HIP_OK(hipSetDevice(pl->device));
+  if (bits == 32) HIP_OK(rs32_upload_constants(pl->cslot, &pl->c, pl->stream));
+  pl->f32 = (bits == 32);
+  return 0;
+}
+
 int rs_hip_set_variant(RsPlan *pl, int32_t variant) {
   if (!pl || variant < 0 || variant % 10 > 2 || variant / 10 > 4)
     return set_err("rs_hip_set_variant: bad arguments");
@@ -250,7 +259,12 @@ int rs_hip_init_state(RsPlan *pl, const RsForcing *f, const RsPointParams *pp) {
   a.state = pl->state;
   a.npoints = pl->npoints;
   a.np_pad = pl->np_pad;
-  HIP_OK(rs_launch_init(a, pl->stream));
+  if (pl->f32) {
+    if (f->depth) return set_err("rs_hip_init_state: the fp32 flavour has no output-depth support");
+    HIP_OK(rs32_launch_init(a, pl->stream));
+  } else {
+    HIP_OK(rs_launch_init(a, pl->stream));
+  }
   return 0;
 }
 
@@ -320,7 +334,12 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
     pl->ev_used += 2;
     HIP_OK(hipEventRecord(e0, pl->stream));
   }
-  if (coupled || skyview) {
+  if (pl->f32) {
+    if (full || coupled || skyview)
+      return set_err("rs_hip_step: the fp32 flavour supports the LEAN feature set only (no Tdew, "
+                     "observation forcing, depth, relaxation, coupling, sky view)");
+    HIP_OK(rs32_launch_step(a, pl->c.NLayers, pl->variant, pl->stream));
+  } else if (coupled || skyview) {
     if (!pp->coupling_index && pl->c.use_coupling)
       return set_err("rs_hip_step: use_coupling is set: pass coupling_index/coupling_tsurf");
     HIP_OK(rs_launch_step_coupled(a, pl->c.NLayers, pl->stream));
@@ -460,7 +479,12 @@ int rs_hip_expand_forcing_on(RsPlan *pl, const RsSynthSpec *spec, const double *
   a.start_hour = spec->start_hour;
   a.kfirst = kfirst;
   a.nsteps = nsteps;
-  HIP_OK(rs_launch_expand(a, (t0 + nsteps - 2) / spk - kfirst + 1, (hipStream_t)stream));
+  if (pl->f32) {
+    if (f->depth || f->tdew) return set_err("rs_hip_expand_forcing: fp32 windows carry no Tdew/depth");
+    HIP_OK(rs32_launch_expand(a, (t0 + nsteps - 2) / spk - kfirst + 1, (hipStream_t)stream));
+  } else {
+    HIP_OK(rs_launch_expand(a, (t0 + nsteps - 2) / spk - kfirst + 1, (hipStream_t)stream));
+  }
   return 0;
 }
 

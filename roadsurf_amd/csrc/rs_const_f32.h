@@ -1,0 +1,36 @@
+/* rs_const_f32.h - single-precision mirror of RsConstants for the fp32 kernels
+ * (BASELINE config 5).  Same member names, so the type-parameterised physics
+ * (rs_physics_body.inc) compiles against either. */
+#pragma once
+#include "../../include/roadsurf.h"
+
+#define RS_CONST_SCALARS(X)                                                                      \
+  X(DTSecs) X(Tph) X(tsurfOutputDepth) X(twoDT) X(HSfac1) X(logMom) X(logHeat) X(logCond)        \
+  X(logUstar) X(VK_Const) X(ZRefT) X(Grav) X(LVap) X(LFus) X(Emiss) X(SB_Const) X(Albedo0)       \
+  X(NightOn) X(NightOff) X(CalmLimDay) X(CalmLimNgt) X(TrfFricNgt) X(TrFfricDay) X(MaxPormms)    \
+  X(MissValI) X(MinPrecmm) X(MinWatmms) X(MinSnowmms) X(MinDepmms) X(MinIcemms) X(MaxSnowmms)    \
+  X(MaxDepmms) X(MaxIcemms) X(MaxWatmms) X(AlbDry) X(AlbSnow) X(WatDens) X(WatMHeat) X(PorEvaF)  \
+  X(DampWearF) X(TLimFreeze) X(TLimMeltSnow) X(TLimMeltIce) X(TLimMeltDep) X(TLimDew)            \
+  X(TLimColdH) X(TLimColdL) X(WetSnowFormR) X(WetSnowMeltR) X(PLimSnow) X(PLimRain) X(WWetLim)   \
+  X(WWearLim) X(T4Melt0) X(wSnowTran) X(wSnow2Ice) X(wIce) X(wIce2) X(wDep) X(wWat)
+
+struct RsConstantsF {
+  int32_t NLayers, SimLen, use_relaxation, force_tsurf;
+  float ZDpth[RS_MAX_LAYERS + 2], DyC[RS_MAX_LAYERS + 2], condDZ[RS_MAX_LAYERS + 2],
+      WCont[RS_MAX_LAYERS + 2], dryCap[RS_MAX_LAYERS + 2];
+#define X(n) float n;
+  RS_CONST_SCALARS(X)
+#undef X
+};
+
+static inline void rs_constants_to_f32(const RsConstants &c, RsConstantsF &f) {
+  f.NLayers = c.NLayers; f.SimLen = c.SimLen; f.use_relaxation = c.use_relaxation;
+  f.force_tsurf = c.force_tsurf;
+  for (int i = 0; i < RS_MAX_LAYERS + 2; ++i) {
+    f.ZDpth[i] = (float)c.ZDpth[i]; f.DyC[i] = (float)c.DyC[i]; f.condDZ[i] = (float)c.condDZ[i];
+    f.WCont[i] = (float)c.WCont[i]; f.dryCap[i] = (float)c.dryCap[i];
+  }
+#define X(n) f.n = (float)c.n;
+  RS_CONST_SCALARS(X)
+#undef X
+}

@@ -57,3 +57,9 @@ hipError_t rs_launch_knots(const rs::KnotArgs &a, int32_t nknots, hipStream_t st
 hipError_t rs_launch_expand(const rs::ExpandArgs &a, int32_t nintervals, hipStream_t stream);
 hipError_t rs_launch_count_failed(const double *st, int64_t np_pad, int64_t npoints,
                                   unsigned long long *out, hipStream_t stream);
+
+/* fp32 flavour (rs_kernels_f32.hip) */
+hipError_t rs32_upload_constants(int slot, const RsConstants *c, hipStream_t stream);
+hipError_t rs32_launch_step(const rs::StepArgs &a, int NL, int variant, hipStream_t stream);
+hipError_t rs32_launch_init(const rs::InitArgs &a, hipStream_t stream);
+hipError_t rs32_launch_expand(const rs::ExpandArgs &a, int32_t nintervals, hipStream_t stream);

@@ -39,8 +39,9 @@
 
 namespace rs {
 
-__constant__ uint64_t c_gl_exp_tab[256] = {0};
-__constant__ uint64_t c_gl_log_tab[256] = {0};
+/* static: this header is included by more than one translation unit */
+static __constant__ uint64_t c_gl_exp_tab[256] = {0};
+static __constant__ uint64_t c_gl_log_tab[256] = {0};
 
 /* LDS copies of the tables; filled by fill_math_tables() at kernel start. */
 struct MathTab {
@@ -80,7 +81,7 @@ __device__ __forceinline__ MathTab fill_math_tables(double *lds) {
  * counts disagreements in a device counter; tests/test_hip_fastdiv.py runs the
  * 1 M-point x 48 h workload through that build and requires the count to be 0.
  * -DRS_IEEE_DIV switches every call site back to the compiler's expansion. */
-__device__ unsigned long long g_div_mismatch = 0ull;
+static __device__ unsigned long long g_div_mismatch = 0ull;
 
 __device__ __forceinline__ double div_bare(double a, double b) {
   double r = __builtin_amdgcn_rcp(b);
@@ -131,6 +132,17 @@ __device__ __forceinline__ double rs_sqrt(double x) {
   return sqrt_bare(x);
 #endif
 }
+
+__device__ __forceinline__ double rs_fabs(double x) { return __builtin_fabs(x); }
+__device__ __forceinline__ float rs_fabs(float x) { return __builtin_fabsf(x); }
+
+/* fp32 flavour (BASELINE config 5, tolerance-gated, NOT the parity path): hardware
+ * transcendental and reciprocal approximations (~1 ulp), no tables. */
+struct MathTab;
+__device__ __forceinline__ float rs_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float rs_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float rs_exp(const MathTab &, float x) { return __expf(x); }
+__device__ __forceinline__ float rs_log(const MathTab &, float x) { return __logf(x); }
 
 __device__ __forceinline__ double gl_d(uint64_t bits) { return __longlong_as_double((long long)bits); }
 

@@ -42,13 +42,14 @@ class ForcingWindow:
     hour_per_point: bool = False
 
     @classmethod
-    def empty(cls, nsteps: int, np_pad: int, device, optional=("tdew", "tsurfobs", "depth")):
+    def empty(cls, nsteps: int, np_pad: int, device, optional=("tdew", "tsurfobs", "depth"),
+              dtype=torch.float64):
         t = {}
         for n in F64_FORCING:
             if n in ("tdew", "tsurfobs", "depth") and n not in optional:
                 t[n] = None
             else:
-                t[n] = torch.empty((nsteps, np_pad), dtype=torch.float64, device=device)
+                t[n] = torch.empty((nsteps, np_pad), dtype=dtype, device=device)
         t["precphase"] = torch.empty((nsteps, np_pad), dtype=torch.int32, device=device)
         t["hour"] = torch.empty((nsteps,), dtype=torch.int32, device=device)
         return cls(nsteps, np_pad, t)
@@ -78,8 +79,8 @@ class OutputWindow:
     decimate: int = 1
 
     @classmethod
-    def empty(cls, nrows: int, np_pad: int, device, decimate: int = 1):
-        t = {n: torch.empty((nrows, np_pad), dtype=torch.float64, device=device) for n in OUT_FIELDS}
+    def empty(cls, nrows: int, np_pad: int, device, decimate: int = 1, dtype=torch.float64):
+        t = {n: torch.empty((nrows, np_pad), dtype=dtype, device=device) for n in OUT_FIELDS}
         return cls(nrows, np_pad, t, decimate)
 
     def struct(self, row0: int) -> lib.RsOutputs:
@@ -159,6 +160,10 @@ class Plan:
         o = out.struct((t0 - 1 + out.decimate - 1) // out.decimate if out_row0 is None else out_row0)
         lib.check(self.L.rs_hip_step(self._h, C.byref(f), C.byref(o), C.byref(pp), t0, nsteps),
                   "rs_hip_step")
+
+    def set_precision(self, bits: int) -> None:
+        """32: fp32 flavour (LEAN features, float windows); 64: the parity path."""
+        lib.check(self.L.rs_hip_set_precision(self._h, bits), "rs_hip_set_precision")
 
     def set_variant(self, v: int) -> None:
         lib.check(self.L.rs_hip_set_variant(self._h, v), "rs_hip_set_variant")

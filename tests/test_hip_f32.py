@@ -1,0 +1,53 @@
+"""GPU: the fp32 flavour (BASELINE.json configs[4], "fp32 kernels with fp64 tolerance gate").
+
+fp32 cannot follow the fp64 reference point by point: the storage logic branches on the SIGN of
+rounding residuals (roadsurf_amd/csrc/rs_math.hpp), so a fraction of the points takes the other
+side of a melt-out branch and carries a transient of up to ~0.2 K.  The gate is therefore on
+the DISTRIBUTION of |fp32 - fp64 oracle| over 4 096 points x 48 h (measured values in
+brackets, tolerances ~3x above them):
+    Tsurf  rms < 1e-3 K [3e-4]   99.9th percentile < 1e-3 K [2.8e-4]   max < 0.5 K [0.17]
+    fraction of point-steps off by more than 0.05 K < 1e-4 [9e-6]
+    storages  rms < 5e-4 mm [8e-5]   99.9th percentile < 5e-4 mm [8e-5]   max < 0.1 mm [0.024]"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_helpers as oh
+from roadsurf_amd import abi
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+def test_fp32_distribution_gate_against_fp64_oracle():
+    from f32_experiment import run_f32
+    n, L, seed = 4096, 5761, 20240110
+    f = oh.synth_forcing(n, L, seed=seed)
+    s = abi.default_settings(L); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
+    ora, _, _ = oh.run_oracle("port", f, s, p, l)
+    res = run_f32(n, L, seed)
+    d = np.abs(res["tsurf"] - ora["tsurf"])
+    print("tsurf rms %.2e p99.9 %.2e max %.2e frac>0.05K %.2e" %
+          (np.sqrt((d ** 2).mean()), np.percentile(d, 99.9), d.max(), (d > 0.05).mean()))
+    assert np.sqrt((d ** 2).mean()) < 1e-3 and np.percentile(d, 99.9) < 1e-3 and d.max() < 0.5
+    assert (d > 0.05).mean() < 1e-4
+    for k in ("snow", "water", "ice", "deposit", "ice2"):
+        e = np.abs(res[k] - ora[k])
+        assert np.sqrt((e ** 2).mean()) < 5e-4 and np.percentile(e, 99.9) < 5e-4 and e.max() < 0.1, k
+
+
+def test_fp32_rejects_non_lean_features():
+    import torch
+    from roadsurf_amd import device
+    s = abi.default_settings(100); p = abi.default_parameters()
+    plan = device.Plan(64, s, p, 0)
+    plan.set_precision(32)
+    dev = plan.device
+    win = device.ForcingWindow.empty(10, plan.np_pad, dev, optional=("tdew",), dtype=torch.float32)
+    out = device.OutputWindow.empty(10, plan.np_pad, dev, dtype=torch.float32)
+    pp = plan.point_params(5.0)
+    with pytest.raises(RuntimeError, match="LEAN feature set"):
+        plan.step(win, out, pp, 1, 10)
+    plan.close()

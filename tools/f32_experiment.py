@@ -1,0 +1,41 @@
+"""fp32 flavour vs fp64 oracle: error distribution + throughput (BASELINE config 5 study)."""
+import os, sys, time
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np, torch
+import oracle_helpers as oh
+from roadsurf_amd import abi, device
+
+def run_f32(n, L, seed, offset=0, spk=120, chunk=480):
+    s = abi.default_settings(L); p = abi.default_parameters()
+    plan = device.Plan(n, s, p, 0); plan.set_precision(32)
+    dev = plan.device
+    spec, knots = plan.synth_knots(seed, (L - 1) // spk + 2, point_offset=offset, steps_per_knot=spk)
+    win = device.ForcingWindow.empty(chunk, plan.np_pad, dev, optional=(), dtype=torch.float32)
+    win0 = device.ForcingWindow.empty(1, plan.np_pad, dev, optional=("tsurfobs",), dtype=torch.float32)
+    out = device.OutputWindow.empty(L, plan.np_pad, dev, dtype=torch.float32)
+    pp = plan.point_params(plan.uniform_tbottom(2024, 1, 10))
+    plan.expand(spec, knots, win0, 1, 1); plan.init_state(win0, pp)
+    t0 = 1
+    while t0 <= L:
+        ns = min(chunk, L - t0 + 1)
+        plan.expand(spec, knots, win, t0, ns); plan.step(win, out, pp, t0, ns, out_row0=0)
+        t0 += ns
+    plan.sync()
+    res = {k: out.tensors[k][:, :n].T.contiguous().cpu().numpy().astype(np.float64) for k in device.OUT_FIELDS}
+    plan.close()
+    return res
+
+if __name__ == "__main__":
+    n, L, seed = 4096, int(sys.argv[1]) if len(sys.argv) > 1 else 5761, 20240110
+    f = oh.synth_forcing(n, L, seed=seed)
+    s = abi.default_settings(L); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
+    ora, _, _ = oh.run_oracle("port", f, s, p, l)
+    res = run_f32(n, L, seed)
+    for k in oh.F64_OUT:
+        d = np.abs(res[k] - ora[k])
+        per_point = d.max(1)
+        print(f"{k:8s} max {d.max():.3e}  rms {np.sqrt((d**2).mean()):.3e}  p50 {np.percentile(d,50):.2e} "
+              f"p99 {np.percentile(d,99):.2e} p99.9 {np.percentile(d,99.9):.2e}  points with max>0.05: {(per_point>0.05).mean()*100:.2f}%  >0.5: {(per_point>0.5).mean()*100:.2f}%")
+    dt = np.abs(res['tsurf'] - ora['tsurf'])
+    print('fraction of (point,step) with |dTsurf| > 0.05 K:', (dt > 0.05).mean())
