@@ -13,6 +13,27 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _ensure_built():
+    """Build the in-tree libraries when they are missing (fresh checkout): the product library
+    cross-compiles without a GPU; on the GPU box the prebuilt .so files travel with the snapshot."""
+    import subprocess
+    lib_so = os.path.join(ROOT, "roadsurf_amd", "lib", "libroadsurf_hip.so")
+    if not os.path.exists(lib_so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "roadsurf_amd")], stdout=subprocess.DEVNULL)
+    chk = os.path.join(ROOT, "roadsurf_amd", "lib", "libroadsurf_hip_divcheck.so")
+    if not os.path.exists(chk):
+        subprocess.call(["make", "-C", os.path.join(ROOT, "roadsurf_amd"), "divcheck"], stdout=subprocess.DEVNULL)
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/src") and not os.path.exists(
+            os.path.join(ROOT, "oracle", "_ref", "libroadsurf_ref_cpl.so")):
+        subprocess.check_call(["bash", os.path.join(ROOT, "oracle", "build_ref.sh")], stdout=subprocess.DEVNULL)
+
+
+def pytest_sessionstart(session):
+    _ensure_built()
+
+
 @pytest.fixture(scope="session")
 def hip_lib():
     from roadsurf_amd import lib
