@@ -410,6 +410,78 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers,
                       const LocalParameters *localParam, const double *tbottom,
                       const RsHostExtras *extras, int32_t device);
 
+/* ------------------------------------------------------------------------
+ * Layer 4: the reference DRIVER's data path on the device.
+ *
+ * What examples/example1 does on the host for every point before and after
+ * `runsimulation` — and what makes a step-resolution boundary PCIe-bound — happens here
+ * on the GPU, so only the RAW series (hourly NWP / observations) cross the bus inbound and
+ * only the decimated outputs come back:
+ *   JsonSource ctor      Tdew <-> RH completion of the raw series
+ *                        (JsonSource.cpp:288-295, MeteorologyTools.cpp:12-51)
+ *   JsonSource::interpolate   raw times -> simulation times, per variable, with the
+ *                        reference's missing-value rules (JsonSource.cpp:49-176)
+ *   DataHandler::GetWeather   later sources overwrite earlier ones where they have data
+ *                        (DataHandler.cpp:75-84, JsonSource.cpp:323-373; PrecPhase and
+ *                        Depth are NOT carried over there, so they stay missing)
+ *   read_input           completeness check, relaxation targets, coupling index/observation
+ *                        and the blanking of TSurfObs inside the coupling window
+ *                        (roadrunner.cpp:156-278)
+ *   runsimulation        the hot path (layers 1-3)
+ *   save_output          every (outputStep*60/DTSecs)-th index (roadrunner.cpp:285-315)
+ * Out of scope: JSON/text parsing and writing (host work, roadsurf_amd/driver.py has a
+ * reader/writer for the reference's schema).
+ * Restriction: all points of one source share that source's raw time axis.
+ * ---------------------------------------------------------------------- */
+#define RS_MAX_SOURCES 4
+
+/* One data source after parsing (JsonSource.cpp:182-316).  Arrays are HOST pointers,
+ * [n_points][n_times] row-major (one contiguous series per point, as the reference's
+ * InputData holds them); NULL = the variable is absent from this source (all missing,
+ * -9999.9).  PrecipitationForm is not listed: the reference reads it but never hands it
+ * on (JsonSource.cpp:323-373 does not copy PrecPhase). */
+typedef struct RsRawSource {
+  int32_t n_times;
+  int32_t is_observation;   /* DataHandler.cpp:65-66: counts for GetLatestObsIndex */
+  const int64_t *times;     /* [n_times] epoch seconds */
+  const double *tair, *rhz, *tdew, *vz, *prec, *lw_net, *lw, *sw, *sw_dir, *tsurfobs;
+} RsRawSource;
+
+typedef struct RsDriverInput {
+  int32_t n_points;
+  int32_t n_sources;            /* 1..RS_MAX_SOURCES, applied in this order */
+  const RsRawSource *sources;
+  int64_t start_time;           /* InputSettings.start_time; simulation index k (0-based) is at
+                                   start_time + k*int(DTSecs)  (JsonSource.cpp:199-205) */
+  int64_t forecast_time;        /* InputSettings.forecast_time (roadrunner.cpp:168-169) */
+  /* local calendar of the simulation times, [SimLen] each (JsonSource.cpp:297-308) */
+  const int32_t *year, *month, *day, *hour, *minute, *second;
+  const double *horizons;       /* [n_points][360] local horizon angles, or NULL (all 0) */
+} RsDriverInput;
+
+/* Per-point status: 0 simulated; 1..6 a mandatory variable is missing at `missing_index`
+ * (tair, Rhz, prec, SW, LW, VZ: the order roadrunner.cpp:188-229 tests them in) and the
+ * point is skipped like the reference skips it (outputs stay -9999.0); 7 the relaxation
+ * index equals SimLen (the reference reads one past its arrays there, roadrunner.cpp:246-248). */
+typedef struct RsDriverOutput {
+  int32_t n_out;                /* number of kept indices: ceil(SimLen / step) */
+  double *tsurf, *snow, *water, *ice, *deposit, *ice2; /* host [n_points][n_out]; NULL = not wanted */
+  int32_t *status;              /* [n_points] */
+  int32_t *missing_index;       /* [n_points] 0-based index of the first missing value, else -1 */
+} RsDriverOutput;
+
+/* local[n_points]: in lat, lon, sky_view (others ignored); out InitLenI, tair_relax,
+ * VZ_relax, RH_relax, couplingIndexI, couplingTsurf as read_input leaves them.
+ * Returns 0 or <0 (rs_last_error). */
+int rs_driver_run(const RsDriverInput *in, const InputSettings *settings,
+                  const InputParameters *params, LocalParameters *local,
+                  const RsDriverOutput *out, int32_t device);
+/* Test hook: only the input side.  merged = host [10][n_points][SimLen] in the order tair,
+ * tdew, VZ, Rhz, prec, SW, LW, SW_dir, LW_net, TSurfObs: what read_input returns. */
+int rs_driver_expand(const RsDriverInput *in, const InputSettings *settings,
+                     LocalParameters *local, double *merged, int32_t *status,
+                     int32_t *missing_index, int32_t device);
+
 #define RS_ABI_VERSION 1
 int rs_abi_version(void);
 /* sizeof of the boundary structs as the C side / the Fortran side see them

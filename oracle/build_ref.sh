@@ -87,3 +87,12 @@ $FC $FFLAGS -module-dir "$TMP/obj" -I. -c Initialization.f90 -o "$TMP/obj/Initia
 $FC -shared -o "$OUT/libroadsurf_ref_cpl.so" "$TMP"/obj/*.o -fopenmp -lgomp 2>/dev/null || \
 $FC -shared -o "$OUT/libroadsurf_ref_cpl.so" "$TMP"/obj/*.o -L/usr/lib/gcc/x86_64-linux-gnu/11 -lgomp
 echo "built $OUT/libroadsurf_ref_cpl.so"
+
+# ---- the driver's one self-contained C++ file -----------------------------------------
+# examples/example1/src/MeteorologyTools.cpp (CalcTdewOrRH) needs only <cmath>; it pins
+# oracle/driver_oracle.c's restatement.  The rest of the driver (JsonSource.cpp,
+# roadrunner.cpp) needs jsoncpp, which this image lacks: unbuildable, see driver_oracle.c.
+# Strict flags (the reference's own are -funsafe-math-optimizations ..., Makefile:6).
+g++ -O2 -fPIC -shared -ffp-contract=off -I"$REF/examples/example1/src" \
+    "$REF/examples/example1/src/MeteorologyTools.cpp" -o "$OUT/libroadrunner_tools_ref.so"
+echo "built $OUT/libroadrunner_tools_ref.so"

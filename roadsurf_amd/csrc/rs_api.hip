@@ -308,7 +308,6 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
     if (t0 != 1 || nsteps != pl->c.SimLen)
       return set_err("rs_hip_step: with coupling the window must be the whole series "
                      "(t0 = 1, nsteps = SimLen = %d): coupling windows are replayed", pl->c.SimLen);
-    if (o->decimate != 1) return set_err("rs_hip_step: coupling needs decimate == 1");
   }
   rs::StepArgs a;
   a.cslot = pl->cslot;

@@ -1,0 +1,88 @@
+/* rs_devutil.hpp — small device/host helpers shared by the host-array layers (internal). */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace rsu {
+
+constexpr int TS = 32; /* transpose tile */
+
+/* src[r][c] (rows x cols, leading dim ld_src) -> dst[c][r] (leading dim ld_dst) */
+template <typename T>
+__global__ void __launch_bounds__(TS * 8) transpose_kernel(const T *__restrict__ src,
+                                                           T *__restrict__ dst, int rows, int cols,
+                                                           int64_t ld_src, int64_t ld_dst) {
+  __shared__ T tile[TS][TS + 1];
+  const int c0 = blockIdx.x * TS, r0 = blockIdx.y * TS;
+  for (int j = threadIdx.y; j < TS; j += 8) {
+    const int r = r0 + j, c = c0 + threadIdx.x;
+    if (r < rows && c < cols) tile[j][threadIdx.x] = src[(int64_t)r * ld_src + c];
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < TS; j += 8) {
+    const int c = c0 + j, r = r0 + threadIdx.x;
+    if (r < rows && c < cols) dst[(int64_t)c * ld_dst + r] = tile[threadIdx.x][j];
+  }
+}
+
+template <typename T>
+inline hipError_t transpose(const T *src, T *dst, int rows, int cols, int64_t ld_src,
+                            int64_t ld_dst, hipStream_t s) {
+  if (rows < 1 || cols < 1) return hipSuccess;
+  dim3 g((cols + TS - 1) / TS, (rows + TS - 1) / TS), b(TS, 8);
+  hipLaunchKernelGGL(transpose_kernel<T>, g, b, 0, s, src, dst, rows, cols, ld_src, ld_dst);
+  return hipGetLastError();
+}
+
+struct Dev {
+  void *p = nullptr;
+  Dev() = default;
+  Dev(const Dev &) = delete;
+  Dev &operator=(const Dev &) = delete;
+  ~Dev() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+  }
+  hipError_t alloc(size_t n) {
+    release();
+    return hipMalloc(&p, n ? n : 8);
+  }
+  template <typename T>
+  T *as() const { return static_cast<T *>(p); }
+};
+struct Pinned {
+  void *p = nullptr;
+  Pinned() = default;
+  Pinned(const Pinned &) = delete;
+  Pinned &operator=(const Pinned &) = delete;
+  ~Pinned() {
+    if (p) (void)hipHostFree(p);
+  }
+  hipError_t alloc(size_t n) { return hipHostMalloc(&p, n ? n : 8, hipHostMallocDefault); }
+};
+
+/* Host worker threads for row gather/scatter: the CPUs this process may actually use
+ * (OpenMP's view AND the cgroup v2 cpu.max quota), not the machine's core count: a container
+ * with a 16-CPU quota on a 256-thread host runs 10x slower with 256 OpenMP threads. */
+inline int host_threads(int omp_procs) {
+  const char *e = getenv("ROADSURF_HIP_HOST_THREADS");
+  if (e && atoi(e) > 0) return atoi(e);
+  int n = omp_procs;
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    long long period = 0;
+    char q[32];
+    if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+      const long long quota = atoll(q);
+      const int c = (int)((quota + period - 1) / period);
+      if (c > 0 && c < n) n = c;
+    }
+    fclose(f);
+  }
+  return n < 1 ? 1 : n;
+}
+
+}  // namespace rsu

@@ -1,0 +1,821 @@
+/*
+ * rs_driver.hip — layer 4 of include/roadsurf.h: the reference DRIVER's data path
+ * (examples/example1/src: JsonSource.cpp, DataHandler.cpp, MeteorologyTools.cpp,
+ * roadrunner.cpp read_input/save_output) with the per-value work on the device.
+ *
+ * Data flow per tile of points:
+ *   raw host series [point][time] --H2D--> LDS-tiled transpose --> raw[time][point] in HBM
+ *   humidity_fill_kernel       Tdew <-> RH completion           (JsonSource.cpp:288-295)
+ *   scan_raw_kernel            per variable: first missing index, latest observation,
+ *                              latest road-temperature observation (one pass over the series)
+ *   finalize_kernel            read_input's decisions per point    (roadrunner.cpp:186-275)
+ *   per time chunk:
+ *     expand_raw_kernel        JsonSource::interpolate + GetWeather overlay, written as the
+ *                              [t][point] windows the step kernels read
+ *     step kernel              (layers 1-3), outputs decimated in the kernel
+ *   outputs [row][point] --transpose--> [point][row] --D2H--> caller
+ *
+ * JsonSource::interpolate walks the raw and the simulation time axes together; which raw
+ * interval a simulation index falls into, and whether it copies or interpolates there,
+ * depends on the TIMES only.  All points of a source share its time axis, so the walk is
+ * run once per source on the host (build_plan: the reference's loop, statement for
+ * statement, quirks included) and the device applies the resulting per-index plan to every
+ * point's data with the reference's arithmetic and missing-value tests.
+ *
+ * The kernels are streaming (HBM-bound): one variable per blockIdx.y, one point per lane,
+ * time in the loop, the two raw neighbours cached in registers and re-read only when the
+ * plan moves to another raw interval.
+ */
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/roadsurf.h"
+#include "rs_devutil.hpp"
+#include "rs_kernels.h"
+
+extern "C" void rs_host_set_error(const char *msg);
+
+namespace {
+
+using rsu::Dev;
+using rsu::transpose;
+
+constexpr int NFLD = 10;
+/* order of `merged` in rs_driver_expand and of the window buffers */
+enum { R_TAIR, R_TDEW, R_VZ, R_RHZ, R_PREC, R_SW, R_LW, R_SWDIR, R_LWNET, R_OBS };
+enum { K_NONE = 0, K_COPY = 1, K_INTERP = 2 };
+
+struct PlanStep {
+  int32_t kind; /* K_* */
+  int32_t rp;   /* rawPos */
+  double num;   /* simtime[simPos] - rawtime[rawPos]      (JsonSource.cpp:116 ff.) */
+  double den;   /* rawtime[rawPos+1] - rawtime[rawPos] */
+};
+
+struct SrcDev {
+  const double *fld[NFLD]; /* [n_times][np_pad], nullptr = variable absent */
+  const PlanStep *plan;    /* [SimLen] */
+  int32_t n_times;
+  int32_t is_obs;
+};
+
+struct SrcSet {
+  SrcDev src[RS_MAX_SOURCES];
+  int32_t nsrc;
+  int32_t simlen;
+  int64_t np_pad;
+  int64_t npoints;
+};
+
+/* examples/example1/src/InputData.cpp:5-26: every series starts out missing */
+__device__ __forceinline__ double miss_r() { return -9999.9; }
+/* JsonSource.cpp:92-111,323-345: `> -100.0`, except LW_net `> -1000.0` */
+__device__ __forceinline__ double threshold(int fld) { return fld == R_LWNET ? -1000.0 : -100.0; }
+
+/* Value of one variable of one source at one simulation index: JsonSource::interpolate
+ * (JsonSource.cpp:86-170) followed by GetWeather's own test (JsonSource.cpp:337-356).
+ * a, b = raw[rawPos], raw[rawPos+1]. */
+__device__ __forceinline__ bool source_value(const PlanStep &st, double a, double b, double thr,
+                                             double &v) {
+  if (st.kind == K_COPY) {
+    v = a;
+    return a > thr;
+  }
+  if (!(a > thr && b > thr)) return false;
+  /* raw[rawPos] + (simtime-rawtime[rawPos]) * (raw[rawPos+1]-raw[rawPos]) / (rawtime[rawPos+1]-rawtime[rawPos]) */
+  v = a + st.num * (b - a) / st.den;
+  return v > thr;
+}
+
+/* Sequential pass over simulation indices [i0, i1) of one variable of one point.
+ * visit(i, merged value, bitmask of the sources that supplied a value). */
+template <class Visit>
+__device__ __forceinline__ void walk_field(const SrcSet &S, int fld, int64_t p, int32_t i0,
+                                           int32_t i1, Visit &&visit) {
+  const double thr = threshold(fld);
+  double a[RS_MAX_SOURCES], b[RS_MAX_SOURCES];
+  int32_t cur[RS_MAX_SOURCES];
+#pragma unroll
+  for (int s = 0; s < RS_MAX_SOURCES; ++s) {
+    a[s] = b[s] = 0.0;
+    cur[s] = -2;
+  }
+  for (int32_t i = i0; i < i1; ++i) {
+    double v = miss_r();
+    uint32_t mask = 0;
+#pragma unroll
+    for (int s = 0; s < RS_MAX_SOURCES; ++s) {
+      if (s >= S.nsrc) continue;
+      const double *x = S.src[s].fld[fld];
+      if (!x) continue;
+      const PlanStep st = S.src[s].plan[i]; /* uniform: scalar loads */
+      if (st.kind == K_NONE) continue;
+      if (st.rp != cur[s]) {
+        a[s] = x[(int64_t)st.rp * S.np_pad + p];
+        b[s] = x[(int64_t)(st.rp + 1) * S.np_pad + p];
+        cur[s] = st.rp;
+      }
+      double vs;
+      if (source_value(st, a[s], b[s], thr, vs)) { /* DataHandler.cpp:75-84: later sources win */
+        v = vs;
+        mask |= 1u << s;
+      }
+    }
+    visit(i, v, mask);
+  }
+}
+
+/* Random access to the merged value (used for the relaxation targets). */
+__device__ __forceinline__ double merged_at(const SrcSet &S, int fld, int64_t p, int32_t i) {
+  const double thr = threshold(fld);
+  double v = miss_r();
+  for (int s = 0; s < S.nsrc; ++s) {
+    const double *x = S.src[s].fld[fld];
+    if (!x) continue;
+    const PlanStep st = S.src[s].plan[i];
+    if (st.kind == K_NONE) continue;
+    const double a = x[(int64_t)st.rp * S.np_pad + p], b = x[(int64_t)(st.rp + 1) * S.np_pad + p];
+    double vs;
+    if (source_value(st, a, b, thr, vs)) v = vs;
+  }
+  return v;
+}
+
+/* roadrunner.cpp:42-45 */
+__device__ __forceinline__ bool is_missing(double v) { return (v != v) || v < -9000; }
+
+struct ScanArgs {
+  SrcSet S;
+  int32_t *first_missing; /* [6][np_pad]: tair, Rhz, prec, SW, LW, VZ (roadrunner.cpp:188-229) */
+  int32_t *last_obs;      /* [np_pad] DataHandler::GetLatestObsIndex, -1 if none */
+  int32_t *cpl_i;         /* [np_pad] last index with a road temperature observation, -1 */
+  double *cpl_t;          /* [np_pad] that observation */
+};
+
+__global__ void __launch_bounds__(RS_BLOCK) scan_raw_kernel(const ScanArgs A) {
+  const int64_t p = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
+  if (p >= A.S.npoints) return;
+  const int y = blockIdx.y;
+  const int L = A.S.simlen;
+  if (y < 6) {
+    const int fld = (y == 0) ? R_TAIR : (y == 1) ? R_RHZ : (y == 2) ? R_PREC : (y == 3) ? R_SW
+                  : (y == 4) ? R_LW : R_VZ;
+    uint32_t obsmask = 0;
+    for (int s = 0; s < A.S.nsrc; ++s)
+      if (A.S.src[s].is_obs) obsmask |= 1u << s;
+    int32_t first = L, last = -1;
+    walk_field(A.S, fld, p, 0, L, [&](int32_t i, double v, uint32_t mask) {
+      if (first == L && is_missing(v)) first = i;
+      /* JsonSource.cpp:412-416: `for i = SimLen..1: if tair[i-1] > -100 return i`, on the
+       * source's OWN interpolated series; DataHandler.cpp:118-137 takes the max over the
+       * observation sources */
+      if (mask & obsmask) last = i + 1;
+    });
+    A.first_missing[(int64_t)y * A.S.np_pad + p] = first;
+    if (y == 0) A.last_obs[p] = last;
+  } else {
+    int32_t ci = -1;
+    double ct = miss_r();
+    /* roadrunner.cpp:256-261: last index whose TSurfObs is neither missing nor < -100 */
+    walk_field(A.S, R_OBS, p, 0, L, [&](int32_t i, double v, uint32_t) {
+      if (!(is_missing(v) || v < -100)) {
+        ci = i;
+        ct = v;
+      }
+    });
+    A.cpl_i[p] = ci;
+    A.cpl_t[p] = ct;
+  }
+}
+
+struct FinalArgs {
+  SrcSet S;
+  const int32_t *first_missing, *last_obs, *cpl_i;
+  const double *cpl_t;
+  int32_t use_relaxation, use_coupling, cplLen, default_initlen;
+  /* out, [np_pad] */
+  int32_t *status, *missing_index, *initlen, *cpl_index, *cpl_hi;
+  double *tair_relax, *vz_relax, *rh_relax, *cpl_tsurf;
+};
+
+/* read_input after GetWeather, roadrunner.cpp:186-275 */
+__global__ void __launch_bounds__(RS_BLOCK) finalize_kernel(const FinalArgs A) {
+  const int64_t p = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
+  if (p >= A.S.np_pad) return;
+  const int L = A.S.simlen;
+  int32_t status = 0, mi = L;
+  if (p < A.S.npoints) {
+    for (int k = 0; k < 6; ++k) {
+      const int32_t fm = A.first_missing[(int64_t)k * A.S.np_pad + p];
+      if (fm < mi) { /* strict: at equal index the earlier test in the reference's order wins */
+        mi = fm;
+        status = k + 1;
+      }
+    }
+  }
+  int32_t initlen = A.default_initlen; /* roadrunner.cpp:168-169 */
+  double tr = miss_r(), vr = miss_r(), rr = miss_r();
+  int32_t cidx = -9999, chi = -1;
+  double ctsurf = miss_r();
+  if (p < A.S.npoints && status == 0) {
+    if (A.use_relaxation == 1) { /* roadrunner.cpp:235-250 */
+      const int32_t idx = A.last_obs[p];
+      if (idx > -1) {
+        initlen = idx;
+        if (idx >= L) {
+          status = 7; /* the reference reads data.tair[SimLen] here */
+        } else {
+          tr = merged_at(A.S, R_TAIR, p, idx);
+          vr = merged_at(A.S, R_VZ, p, idx);
+          rr = merged_at(A.S, R_RHZ, p, idx);
+        }
+      }
+    }
+    if (A.use_coupling == 1 && status == 0) { /* roadrunner.cpp:253-275 */
+      const int32_t i = A.cpl_i[p];
+      if (i >= A.cplLen) {
+        ctsurf = A.cpl_t[p];
+        cidx = i;
+        chi = i;
+      }
+    }
+  }
+  A.status[p] = status;
+  A.missing_index[p] = (status >= 1 && status <= 6) ? mi : -1;
+  A.initlen[p] = initlen;
+  A.tair_relax[p] = tr;
+  A.vz_relax[p] = vr;
+  A.rh_relax[p] = rr;
+  A.cpl_index[p] = cidx;
+  A.cpl_tsurf[p] = ctsurf;
+  A.cpl_hi[p] = chi;
+}
+
+struct ExpandRawArgs {
+  SrcSet S;
+  double *out[NFLD]; /* [nsteps][stride] windows; nullptr = not wanted */
+  const int32_t *status; /* [np_pad] or nullptr */
+  const int32_t *cpl_hi; /* [np_pad] or nullptr */
+  int32_t cplLen;
+  int32_t i0, nsteps; /* 0-based first simulation index of the window */
+  int64_t stride;
+};
+
+__global__ void __launch_bounds__(RS_BLOCK) expand_raw_kernel(const ExpandRawArgs A) {
+  const int64_t p = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
+  const int fld = blockIdx.y;
+  double *out = A.out[fld];
+  if (p >= A.S.npoints || !out) return;
+  out += p;
+  /* a point read_input rejects is not simulated by the reference (roadrunner.cpp:393): a
+   * missing air temperature makes CheckValues stop its lane at the first index (its output
+   * rows are blanked afterwards, blank_rejected_kernel) */
+  const bool rejected = A.status && A.status[p] != 0 && fld == R_TAIR;
+  /* roadrunner.cpp:266-273: no road temperature input inside the coupling window */
+  int32_t clr_lo = 0, clr_hi = -1;
+  if (fld == R_OBS && A.cpl_hi) {
+    clr_hi = A.cpl_hi[p];
+    clr_lo = clr_hi - A.cplLen; /* exclusive */
+    if (clr_hi < 0) clr_lo = clr_hi;
+  }
+  const int32_t i0 = A.i0;
+  const int64_t stride = A.stride;
+  walk_field(A.S, fld, p, i0, i0 + A.nsteps, [&](int32_t i, double v, uint32_t) {
+    if (rejected) v = miss_r();
+    if (i > clr_lo && i <= clr_hi) v = miss_r();
+    out[(int64_t)(i - i0) * stride] = v;
+  });
+}
+
+/* A point read_input rejects is never handed to runsimulation (roadrunner.cpp:393): all its
+ * output rows read -9999.0 (OutputData.cpp:5-13).  Its lanes did run - stopped by CheckValues
+ * at the first index, which still writes that index's row (src/InputOutput.f90:55-82 sets the
+ * flag, examples/example1/src/Simulation.f90:100 leaves the loop after SaveOutput). */
+__global__ void __launch_bounds__(RS_BLOCK) blank_rejected_kernel(double *out, int64_t stride,
+                                                                  int32_t nrows, int64_t npoints,
+                                                                  const int32_t *status) {
+  const int64_t p = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
+  if (p >= npoints || status[p] == 0) return;
+  for (int f = 0; f < 6; ++f)
+    for (int32_t r = 0; r < nrows; ++r) out[((int64_t)f * nrows + r) * stride + p] = -9999.0;
+}
+
+__global__ void __launch_bounds__(RS_BLOCK) fill_i32_kernel(int32_t *x, int64_t n, int32_t v) {
+  const int64_t i = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
+  if (i < n) x[i] = v;
+}
+__global__ void __launch_bounds__(RS_BLOCK) fill_f64_kernel(double *x, int64_t n, double v) {
+  const int64_t i = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
+  if (i < n) x[i] = v;
+}
+
+inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + RS_BLOCK - 1) / RS_BLOCK)); }
+
+/* ---- host side ------------------------------------------------------------------ */
+
+int fail_msg(const char *msg, int code) {
+  rs_host_set_error(msg);
+  return code;
+}
+int fail_hip(const char *what, hipError_t e) {
+  char buf[300];
+  snprintf(buf, sizeof(buf), "rs_driver: %s: %s", what, hipGetErrorString(e));
+  rs_host_set_error(buf);
+  return -10;
+}
+#define HOK(expr)                                     \
+  do {                                                \
+    hipError_t e_ = (expr);                           \
+    if (e_ != hipSuccess) return fail_hip(#expr, e_); \
+  } while (0)
+
+/* The time walk of JsonSource::interpolate (JsonSource.cpp:49-85,113-114,171-175) without
+ * the data: which raw interval each simulation index uses and how. */
+void build_plan(const int64_t *rawtime, int rawLen, const std::vector<int64_t> &simtime,
+                std::vector<PlanStep> &plan) {
+  const int simLen = (int)simtime.size();
+  plan.assign(simLen, PlanStep{K_NONE, 0, 0.0, 1.0});
+  if (rawLen == 0) return; /* JsonSource.cpp:233-237 */
+  int rawPos = 0, simPos = 0;
+  if (rawtime[0] < simtime[0]) {
+    for (rawPos = 0; rawPos < rawLen; ++rawPos)
+      if (rawtime[rawPos] >= simtime[0]) break;
+    rawPos = rawPos - 1;
+    simPos = 0;
+  } else if (simtime[0] < rawtime[0]) {
+    for (simPos = 0; simPos < simLen; ++simPos)
+      if (simtime[simPos] >= rawtime[0]) break;
+    rawPos = 0;
+  }
+  while (rawPos + 1 < rawLen && simPos < simLen) {
+    if (std::llabs(simtime[simPos] - rawtime[rawPos]) < 0.01) {
+      plan[simPos] = PlanStep{K_COPY, rawPos, 0.0, 1.0};
+      simPos++;
+    } else if (std::llabs(simtime[simPos] - rawtime[rawPos + 1]) < 0.01) {
+      rawPos++;
+    } else {
+      plan[simPos] = PlanStep{K_INTERP, rawPos, (double)(simtime[simPos] - rawtime[rawPos]),
+                              (double)(rawtime[rawPos + 1] - rawtime[rawPos])};
+      simPos++;
+    }
+  }
+}
+
+const double *raw_field(const RsRawSource &s, int fld) {
+  switch (fld) {
+    case R_TAIR: return s.tair;
+    case R_TDEW: return s.tdew;
+    case R_VZ: return s.vz;
+    case R_RHZ: return s.rhz;
+    case R_PREC: return s.prec;
+    case R_SW: return s.sw;
+    case R_LW: return s.lw;
+    case R_SWDIR: return s.sw_dir;
+    case R_LWNET: return s.lw_net;
+    default: return s.tsurfobs;
+  }
+}
+
+struct Common {
+  int n = 0, nsrc = 0, L = 0, DT = 0;
+  int default_initlen = 0, cplLen = 0;
+  std::vector<int64_t> simtime;
+  std::vector<std::vector<PlanStep>> plans;
+};
+
+int prepare(const RsDriverInput *in, const InputSettings *st, Common &c) {
+  if (!in || !st || in->n_points < 1 || in->n_sources < 1 || in->n_sources > RS_MAX_SOURCES ||
+      !in->sources)
+    return fail_msg("rs_driver: bad arguments (n_points >= 1, 1 <= n_sources <= RS_MAX_SOURCES)", -1);
+  if (st->SimLen < 1 || !(st->DTSecs >= 1.0))
+    return fail_msg("rs_driver: SimLen >= 1 and DTSecs >= 1 required", -1);
+  c.n = in->n_points;
+  c.nsrc = in->n_sources;
+  c.L = st->SimLen;
+  c.DT = (int)st->DTSecs; /* JsonSource takes `const int DTSecs` */
+  c.simtime.resize(c.L);
+  for (int k = 0; k < c.L; ++k) c.simtime[k] = in->start_time + (int64_t)k * c.DT;
+  /* roadrunner.cpp:168-169: time_t / double, truncated */
+  c.default_initlen = 1 + (int)((double)(in->forecast_time - in->start_time) / st->DTSecs);
+  /* roadrunner.cpp:263: static_cast<int>(coupling_minutes * 60 / DTSecs) */
+  c.cplLen = (int)((double)(st->coupling_minutes * 60) / st->DTSecs);
+  c.plans.resize(c.nsrc);
+  for (int s = 0; s < c.nsrc; ++s) {
+    const RsRawSource &rs = in->sources[s];
+    if (rs.n_times < 0 || (rs.n_times > 0 && !rs.times))
+      return fail_msg("rs_driver: source without a time axis", -1);
+    build_plan(rs.times, rs.n_times, c.simtime, c.plans[s]);
+  }
+  return 0;
+}
+
+/* Device copies of one tile's raw data + plans. */
+struct TileRaw {
+  Dev plan[RS_MAX_SOURCES];
+  Dev fld[RS_MAX_SOURCES][NFLD];
+  Dev stage; /* [m][n_times] landing buffer for the H2D copy */
+  SrcSet S{};
+};
+
+int upload_tile(const RsDriverInput *in, const Common &c, int64_t p0, int m, int64_t mp,
+                TileRaw &T, hipStream_t stream) {
+  T.S.nsrc = c.nsrc;
+  T.S.simlen = c.L;
+  T.S.np_pad = mp;
+  T.S.npoints = m;
+  int maxnt = 1;
+  for (int s = 0; s < c.nsrc; ++s) maxnt = std::max(maxnt, in->sources[s].n_times);
+  HOK(T.stage.alloc((size_t)m * maxnt * sizeof(double)));
+  for (int s = 0; s < c.nsrc; ++s) {
+    const RsRawSource &rs = in->sources[s];
+    SrcDev &d = T.S.src[s];
+    d.n_times = rs.n_times;
+    d.is_obs = rs.is_observation;
+    HOK(T.plan[s].alloc((size_t)c.L * sizeof(PlanStep)));
+    HOK(hipMemcpyAsync(T.plan[s].p, c.plans[s].data(), (size_t)c.L * sizeof(PlanStep),
+                       hipMemcpyHostToDevice, stream));
+    d.plan = T.plan[s].as<PlanStep>();
+    for (int f = 0; f < NFLD; ++f) {
+      const double *h = raw_field(rs, f);
+      d.fld[f] = nullptr;
+      /* Tdew and RH can be completed from each other: both exist if either does */
+      const bool derived = (f == R_TDEW && rs.rhz && rs.tair) || (f == R_RHZ && rs.tdew && rs.tair);
+      if ((!h && !derived) || rs.n_times == 0) continue;
+      const size_t ne = (size_t)rs.n_times * mp;
+      HOK(T.fld[s][f].alloc(ne * sizeof(double)));
+      double *dst = T.fld[s][f].as<double>();
+      if (h) {
+        HOK(hipMemcpyAsync(T.stage.p, h + (size_t)p0 * rs.n_times,
+                           (size_t)m * rs.n_times * sizeof(double), hipMemcpyHostToDevice, stream));
+        HOK(transpose(T.stage.as<double>(), dst, m, rs.n_times, rs.n_times, mp, stream));
+      } else {
+        hipLaunchKernelGGL(fill_f64_kernel, grid1((int64_t)ne), dim3(RS_BLOCK), 0, stream, dst,
+                           (int64_t)ne, -9999.9);
+        HOK(hipGetLastError());
+      }
+      d.fld[f] = dst;
+    }
+    /* JsonSource.cpp:288-295 (needs the math tables: the caller has created a plan) */
+    if (d.fld[R_TAIR] && d.fld[R_TDEW] && d.fld[R_RHZ])
+      HOK(rs_launch_humidity_fill(d.fld[R_TAIR], const_cast<double *>(d.fld[R_TDEW]),
+                                  const_cast<double *>(d.fld[R_RHZ]), (int64_t)rs.n_times * mp,
+                                  stream));
+  }
+  return 0;
+}
+
+/* Per-point decisions of read_input for one tile (device arrays, [mp]). */
+struct TileDecisions {
+  Dev first_missing, last_obs, cpl_i, cpl_t;
+  Dev status, missing_index, initlen, cpl_index, cpl_hi, tair_relax, vz_relax, rh_relax, cpl_tsurf;
+};
+
+int decide_tile(const Common &c, const InputSettings *st, const TileRaw &T, TileDecisions &D,
+                hipStream_t stream) {
+  const int64_t mp = T.S.np_pad;
+  HOK(D.first_missing.alloc((size_t)6 * mp * sizeof(int32_t)));
+  HOK(D.last_obs.alloc(mp * sizeof(int32_t)));
+  HOK(D.cpl_i.alloc(mp * sizeof(int32_t)));
+  HOK(D.cpl_t.alloc(mp * sizeof(double)));
+  for (Dev *d : {&D.status, &D.missing_index, &D.initlen, &D.cpl_index, &D.cpl_hi})
+    HOK(d->alloc(mp * sizeof(int32_t)));
+  for (Dev *d : {&D.tair_relax, &D.vz_relax, &D.rh_relax, &D.cpl_tsurf})
+    HOK(d->alloc(mp * sizeof(double)));
+  ScanArgs sa;
+  sa.S = T.S;
+  sa.first_missing = D.first_missing.as<int32_t>();
+  sa.last_obs = D.last_obs.as<int32_t>();
+  sa.cpl_i = D.cpl_i.as<int32_t>();
+  sa.cpl_t = D.cpl_t.as<double>();
+  hipLaunchKernelGGL(scan_raw_kernel, dim3((unsigned)(mp / RS_BLOCK), 7), dim3(RS_BLOCK), 0, stream,
+                     sa);
+  HOK(hipGetLastError());
+  FinalArgs fa;
+  fa.S = T.S;
+  fa.first_missing = sa.first_missing;
+  fa.last_obs = sa.last_obs;
+  fa.cpl_i = sa.cpl_i;
+  fa.cpl_t = sa.cpl_t;
+  fa.use_relaxation = st->use_relaxation;
+  fa.use_coupling = st->use_coupling;
+  fa.cplLen = c.cplLen;
+  fa.default_initlen = c.default_initlen;
+  fa.status = D.status.as<int32_t>();
+  fa.missing_index = D.missing_index.as<int32_t>();
+  fa.initlen = D.initlen.as<int32_t>();
+  fa.cpl_index = D.cpl_index.as<int32_t>();
+  fa.cpl_hi = D.cpl_hi.as<int32_t>();
+  fa.tair_relax = D.tair_relax.as<double>();
+  fa.vz_relax = D.vz_relax.as<double>();
+  fa.rh_relax = D.rh_relax.as<double>();
+  fa.cpl_tsurf = D.cpl_tsurf.as<double>();
+  hipLaunchKernelGGL(finalize_kernel, grid1(mp), dim3(RS_BLOCK), 0, stream, fa);
+  HOK(hipGetLastError());
+  return 0;
+}
+
+/* Copy the decisions back into the caller's LocalParameters / status arrays the way
+ * read_input leaves them. */
+int report_tile(const Common &c, const InputSettings *st, const TileDecisions &D, int64_t p0, int m,
+                LocalParameters *local, int32_t *status, int32_t *missing_index,
+                hipStream_t stream) {
+  std::vector<int32_t> hs(m), hm(m), hi(m), hc(m);
+  std::vector<double> tr(m), vr(m), rr(m), ct(m);
+  HOK(hipMemcpyAsync(hs.data(), D.status.p, m * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  HOK(hipMemcpyAsync(hm.data(), D.missing_index.p, m * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  HOK(hipMemcpyAsync(hi.data(), D.initlen.p, m * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  HOK(hipMemcpyAsync(hc.data(), D.cpl_index.p, m * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  HOK(hipMemcpyAsync(tr.data(), D.tair_relax.p, m * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HOK(hipMemcpyAsync(vr.data(), D.vz_relax.p, m * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HOK(hipMemcpyAsync(rr.data(), D.rh_relax.p, m * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HOK(hipMemcpyAsync(ct.data(), D.cpl_tsurf.p, m * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HOK(hipStreamSynchronize(stream));
+  for (int p = 0; p < m; ++p) {
+    if (status) status[p0 + p] = hs[p];
+    if (missing_index) missing_index[p0 + p] = hm[p];
+    if (!local) continue;
+    LocalParameters &l = local[p0 + p];
+    l.InitLenI = c.default_initlen; /* roadrunner.cpp:169, before anything can fail */
+    if (hs[p] >= 1 && hs[p] <= 6) continue; /* read_input returned early */
+    if (st->use_relaxation == 1) {
+      l.tair_relax = tr[p];
+      l.VZ_relax = vr[p];
+      l.RH_relax = rr[p];
+      l.InitLenI = hi[p];
+    }
+    if (st->use_coupling == 1 && hs[p] == 0) {
+      l.couplingTsurf = ct[p];
+      l.couplingIndexI = hc[p];
+    }
+  }
+  return 0;
+}
+
+int check_device(int32_t device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail_msg("rs_driver: no HIP device visible - this library has no CPU path", -9);
+  if (device < 0 || device >= ndev) return fail_msg("rs_driver: device index out of range", -9);
+  return 0;
+}
+
+struct StreamGuard {
+  hipStream_t s = nullptr;
+  ~StreamGuard() {
+    if (s) (void)hipStreamDestroy(s);
+  }
+};
+struct PlanGuard {
+  RsPlan *p = nullptr;
+  ~PlanGuard() {
+    if (p) rs_hip_plan_destroy(p);
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int rs_driver_expand(const RsDriverInput *in, const InputSettings *st, LocalParameters *local,
+                     double *merged, int32_t *status, int32_t *missing_index, int32_t device) {
+  Common c;
+  if (int rc = prepare(in, st, c)) return rc;
+  if (!merged) return fail_msg("rs_driver_expand: merged is required", -1);
+  if (int rc = check_device(device)) return rc;
+  HOK(hipSetDevice(device));
+  StreamGuard sg;
+  HOK(hipStreamCreate(&sg.s));
+  /* the math tables live with the plans' constants: make one (any valid constants do) */
+  InputSettings s15 = *st;
+  InputParameters prm;
+  rs_default_parameters(&prm, st->DTSecs);
+  RsConstants consts;
+  int32_t rc32 = 0;
+  rs_build_constants(&s15, &prm, &consts, &rc32);
+  if (rc32 != 0) return fail_msg("rs_driver_expand: bad settings", -1);
+  const int P = std::min(c.n, 4096);
+  for (int64_t p0 = 0; p0 < c.n; p0 += P) {
+    const int m = (int)std::min<int64_t>(P, c.n - p0);
+    PlanGuard pg;
+    pg.p = rs_hip_plan_create(device, m, &consts, sg.s);
+    if (!pg.p) return -11;
+    const int64_t mp = rs_hip_plan_npoints_padded(pg.p);
+    TileRaw T;
+    if (int rc = upload_tile(in, c, p0, m, mp, T, sg.s)) return rc;
+    TileDecisions D;
+    if (int rc = decide_tile(c, st, T, D, sg.s)) return rc;
+    if (int rc = report_tile(c, st, D, p0, m, local, status, missing_index, sg.s)) return rc;
+    Dev win, pt;
+    HOK(win.alloc((size_t)NFLD * c.L * mp * sizeof(double)));
+    HOK(pt.alloc((size_t)m * c.L * sizeof(double)));
+    ExpandRawArgs ea;
+    ea.S = T.S;
+    for (int f = 0; f < NFLD; ++f) ea.out[f] = win.as<double>() + (size_t)f * c.L * mp;
+    ea.status = nullptr; /* the test hook shows what read_input returns, rejected or not */
+    ea.cpl_hi = st->use_coupling == 1 ? D.cpl_hi.as<int32_t>() : nullptr;
+    ea.cplLen = c.cplLen;
+    ea.i0 = 0;
+    ea.nsteps = c.L;
+    ea.stride = mp;
+    hipLaunchKernelGGL(expand_raw_kernel, dim3((unsigned)(mp / RS_BLOCK), NFLD), dim3(RS_BLOCK), 0,
+                       sg.s, ea);
+    HOK(hipGetLastError());
+    for (int f = 0; f < NFLD; ++f) {
+      HOK(transpose((const double *)ea.out[f], pt.as<double>(), c.L, m, mp, c.L, sg.s));
+      HOK(hipMemcpyAsync(merged + ((size_t)f * c.n + p0) * c.L, pt.p, (size_t)m * c.L * sizeof(double),
+                         hipMemcpyDeviceToHost, sg.s));
+    }
+    HOK(hipStreamSynchronize(sg.s));
+  }
+  return 0;
+}
+
+int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputParameters *params,
+                  LocalParameters *local, const RsDriverOutput *out, int32_t device) {
+  Common c;
+  if (int rc = prepare(in, st, c)) return rc;
+  if (!params || !local || !out) return fail_msg("rs_driver_run: params, local and out are required", -1);
+  if (!in->year || !in->month || !in->day || !in->hour || !in->minute || !in->second)
+    return fail_msg("rs_driver_run: the calendar arrays of the simulation times are required", -1);
+  /* roadrunner.cpp:290: int step = outputStep*60/DTSecs */
+  const int step = (int)((double)(st->outputStep * 60) / st->DTSecs);
+  if (step < 1) return fail_msg("rs_driver_run: outputStep*60/DTSecs < 1", -1);
+  const int n_out = (c.L + step - 1) / step;
+  if (out->n_out != n_out) {
+    char b[160];
+    snprintf(b, sizeof(b), "rs_driver_run: n_out must be ceil(SimLen/step) = %d (step %d)", n_out, step);
+    return fail_msg(b, -1);
+  }
+  RsConstants consts;
+  int32_t rc32 = 0;
+  rs_build_constants(st, params, &consts, &rc32);
+  if (rc32 != 0)
+    return fail_msg("rs_driver_run: bad settings (NLayers in 5..32, SimLen >= 1, DTSecs > 0)", -1);
+  if (int rc = check_device(device)) return rc;
+  HOK(hipSetDevice(device));
+  StreamGuard sg;
+  HOK(hipStreamCreate(&sg.s));
+  hipStream_t stream = sg.s;
+
+  const int L = c.L;
+  const bool coupled = st->use_coupling == 1;
+  bool skyview = false;
+  for (int p = 0; p < c.n; ++p)
+    if (local[p].sky_view < 1.0 && local[p].sky_view > (double)-0.01f) skyview = true;
+  const double tbottom = rs_bottom_temperature(params, &consts, in->year[0], in->month[0], in->day[0]);
+
+  const char *ep = getenv("ROADSURF_HIP_TILE_POINTS"), *et = getenv("ROADSURF_HIP_CHUNK_STEPS");
+  const int P = (int)std::min<int64_t>(c.n, ep ? std::max(1, atoi(ep)) : (coupled ? 16384 : 131072));
+  const int TC = coupled ? L : std::min(L, et ? std::max(1, atoi(et)) : 256);
+
+  /* shared axes */
+  Dev d_hour, d_sun;
+  HOK(d_hour.alloc((size_t)L * sizeof(int32_t)));
+  HOK(hipMemcpyAsync(d_hour.p, in->hour, (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  std::vector<double> sun, slat, clat, lrad;
+  if (skyview) {
+    sun.resize((size_t)L * 4);
+    rs_sun_table(L, in->year, in->month, in->day, in->hour, in->minute, in->second, sun.data());
+    HOK(d_sun.alloc(sun.size() * sizeof(double)));
+    HOK(hipMemcpyAsync(d_sun.p, sun.data(), sun.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    slat.resize(c.n);
+    clat.resize(c.n);
+    lrad.resize(c.n);
+    rs_point_geometry(c.n, local, slat.data(), clat.data(), lrad.data());
+  }
+
+  for (int64_t p0 = 0; p0 < c.n; p0 += P) {
+    const int m = (int)std::min<int64_t>(P, c.n - p0);
+    PlanGuard pg;
+    pg.p = rs_hip_plan_create(device, m, &consts, stream);
+    if (!pg.p) return -11;
+    const int64_t mp = rs_hip_plan_npoints_padded(pg.p);
+    TileRaw T;
+    if (int rc = upload_tile(in, c, p0, m, mp, T, stream)) return rc;
+    TileDecisions D;
+    if (int rc = decide_tile(c, st, T, D, stream)) return rc;
+    if (int rc = report_tile(c, st, D, p0, m, local, out->status, out->missing_index, stream)) return rc;
+
+    /* per-point parameters */
+    Dev d_tb, d_geo, d_hz, d_hzpt;
+    HOK(d_tb.alloc(mp * sizeof(double)));
+    hipLaunchKernelGGL(fill_f64_kernel, grid1(mp), dim3(RS_BLOCK), 0, stream, d_tb.as<double>(), mp,
+                       tbottom);
+    HOK(hipGetLastError());
+    RsPointParams pp;
+    std::memset(&pp, 0, sizeof(pp));
+    pp.tbottom = d_tb.as<double>();
+    pp.initlen = D.initlen.as<int32_t>();
+    if (st->use_relaxation == 1) {
+      pp.tair_relax = D.tair_relax.as<double>();
+      pp.vz_relax = D.vz_relax.as<double>();
+      pp.rh_relax = D.rh_relax.as<double>();
+    }
+    if (coupled) {
+      pp.coupling_index = D.cpl_index.as<int32_t>();
+      pp.coupling_tsurf = D.cpl_tsurf.as<double>();
+    }
+    if (skyview) {
+      HOK(d_geo.alloc((size_t)4 * mp * sizeof(double)));
+      std::vector<double> g((size_t)4 * mp, 1.0);
+      for (int p = 0; p < m; ++p) {
+        g[p] = local[p0 + p].sky_view;
+        g[(size_t)mp + p] = slat[p0 + p];
+        g[(size_t)2 * mp + p] = clat[p0 + p];
+        g[(size_t)3 * mp + p] = lrad[p0 + p];
+      }
+      HOK(hipMemcpyAsync(d_geo.p, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+      HOK(hipStreamSynchronize(stream)); /* g goes out of scope */
+      pp.sky_view = d_geo.as<double>();
+      pp.sin_lat = d_geo.as<double>() + mp;
+      pp.cos_lat = d_geo.as<double>() + 2 * mp;
+      pp.lon_rad = d_geo.as<double>() + 3 * mp;
+      pp.albedo_surroundings = params->Albedo_surroundings;
+      HOK(d_hz.alloc((size_t)360 * mp * sizeof(double)));
+      if (in->horizons) {
+        HOK(d_hzpt.alloc((size_t)m * 360 * sizeof(double)));
+        HOK(hipMemcpyAsync(d_hzpt.p, in->horizons + (size_t)p0 * 360, (size_t)m * 360 * sizeof(double),
+                           hipMemcpyHostToDevice, stream));
+        HOK(transpose(d_hzpt.as<double>(), d_hz.as<double>(), m, 360, 360, mp, stream));
+      } else {
+        HOK(hipMemsetAsync(d_hz.p, 0, (size_t)360 * mp * sizeof(double), stream));
+      }
+      pp.horizons = d_hz.as<double>();
+    }
+
+    /* windows */
+    const size_t fs = (size_t)mp * TC;
+    Dev d_win, d_phase, d_out, d_outpt;
+    HOK(d_win.alloc((size_t)NFLD * fs * sizeof(double)));
+    HOK(d_phase.alloc(fs * sizeof(int32_t)));
+    hipLaunchKernelGGL(fill_i32_kernel, grid1((int64_t)fs), dim3(RS_BLOCK), 0, stream,
+                       d_phase.as<int32_t>(), (int64_t)fs, -9999); /* InputData.cpp:16 */
+    HOK(hipGetLastError());
+    const size_t os = (size_t)mp * n_out;
+    HOK(d_out.alloc((size_t)6 * os * sizeof(double)));
+    HOK(d_outpt.alloc((size_t)m * n_out * sizeof(double)));
+
+    ExpandRawArgs ea;
+    ea.S = T.S;
+    double *wb = d_win.as<double>();
+    for (int f = 0; f < NFLD; ++f) ea.out[f] = wb + (size_t)f * fs;
+    if (!skyview) ea.out[R_SWDIR] = ea.out[R_LWNET] = nullptr;
+    ea.status = D.status.as<int32_t>();
+    ea.cpl_hi = coupled ? D.cpl_hi.as<int32_t>() : nullptr;
+    ea.cplLen = c.cplLen;
+    ea.stride = mp;
+
+    RsOutputs oo;
+    double *ob = d_out.as<double>();
+    oo.tsurf = ob; oo.snow = ob + os; oo.water = ob + 2 * os; oo.ice = ob + 3 * os;
+    oo.deposit = ob + 4 * os; oo.ice2 = ob + 5 * os;
+    oo.t_stride = mp;
+    oo.decimate = step;
+    oo.row0 = 0;
+
+    for (int t0 = 1; t0 <= L; t0 += TC) {
+      const int len = std::min(TC, L - t0 + 1);
+      ea.i0 = t0 - 1;
+      ea.nsteps = len;
+      hipLaunchKernelGGL(expand_raw_kernel, dim3((unsigned)(mp / RS_BLOCK), NFLD), dim3(RS_BLOCK), 0,
+                         stream, ea);
+      HOK(hipGetLastError());
+      RsForcing fo;
+      std::memset(&fo, 0, sizeof(fo));
+      fo.tair = ea.out[R_TAIR]; fo.tdew = ea.out[R_TDEW]; fo.vz = ea.out[R_VZ];
+      fo.rhz = ea.out[R_RHZ]; fo.prec = ea.out[R_PREC]; fo.sw = ea.out[R_SW]; fo.lw = ea.out[R_LW];
+      fo.tsurfobs = ea.out[R_OBS];
+      fo.depth = nullptr; /* InputData.cpp:18: Depth is never filled by the driver */
+      fo.precphase = d_phase.as<int32_t>();
+      fo.hour = d_hour.as<int32_t>() + (t0 - 1);
+      fo.t_stride = mp;
+      fo.hour_pstride = 0;
+      if (skyview) {
+        fo.sw_dir = ea.out[R_SWDIR];
+        fo.lw_net = ea.out[R_LWNET];
+        fo.sun = d_sun.as<double>() + (size_t)(t0 - 1) * 4;
+      }
+      if (t0 == 1 && rs_hip_init_state(pg.p, &fo, &pp) != 0) return -12;
+      if (rs_hip_step(pg.p, &fo, &oo, &pp, t0, len) != 0) return -13;
+    }
+    hipLaunchKernelGGL(blank_rejected_kernel, grid1(m), dim3(RS_BLOCK), 0, stream, ob, (int64_t)mp,
+                       (int32_t)n_out, (int64_t)m, (const int32_t *)D.status.as<int32_t>());
+    HOK(hipGetLastError());
+    double *dst[6] = {out->tsurf, out->snow, out->water, out->ice, out->deposit, out->ice2};
+    for (int f = 0; f < 6; ++f) {
+      if (!dst[f]) continue;
+      HOK(transpose((const double *)ob + (size_t)f * os, d_outpt.as<double>(), n_out, m, mp, n_out, stream));
+      HOK(hipMemcpyAsync(dst[f] + (size_t)p0 * n_out, d_outpt.p, (size_t)m * n_out * sizeof(double),
+                         hipMemcpyDeviceToHost, stream));
+    }
+    HOK(hipStreamSynchronize(stream));
+  }
+  return 0;
+}
+
+} /* extern "C" */

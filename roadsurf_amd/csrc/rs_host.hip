@@ -23,73 +23,15 @@
 
 #include "../../include/roadsurf.h"
 #include "rs_kernels.h"
+#include "rs_devutil.hpp"
 
 extern "C" void rs_host_set_error(const char *msg);
 
 namespace {
 
-constexpr int TS = 32; /* transpose tile */
-
-/* src[r][c] (rows x cols, leading dim ld_src) -> dst[c][r] (leading dim ld_dst) */
-template <typename T>
-__global__ void __launch_bounds__(TS *8) transpose_kernel(const T *__restrict__ src,
-                                                           T *__restrict__ dst, int rows, int cols,
-                                                           int64_t ld_src, int64_t ld_dst) {
-  __shared__ T tile[TS][TS + 1];
-  const int c0 = blockIdx.x * TS, r0 = blockIdx.y * TS;
-  for (int j = threadIdx.y; j < TS; j += 8) {
-    const int r = r0 + j, c = c0 + threadIdx.x;
-    if (r < rows && c < cols) tile[j][threadIdx.x] = src[(int64_t)r * ld_src + c];
-  }
-  __syncthreads();
-  for (int j = threadIdx.y; j < TS; j += 8) {
-    const int c = c0 + j, r = r0 + threadIdx.x;
-    if (r < rows && c < cols) dst[(int64_t)c * ld_dst + r] = tile[threadIdx.x][j];
-  }
-}
-
-template <typename T>
-hipError_t transpose(const T *src, T *dst, int rows, int cols, int64_t ld_src, int64_t ld_dst,
-                     hipStream_t s) {
-  dim3 g((cols + TS - 1) / TS, (rows + TS - 1) / TS), b(TS, 8);
-  hipLaunchKernelGGL(transpose_kernel<T>, g, b, 0, s, src, dst, rows, cols, ld_src, ld_dst);
-  return hipGetLastError();
-}
-
-struct Dev {
-  void *p = nullptr;
-  ~Dev() {
-    if (p) (void)hipFree(p);
-  }
-  hipError_t alloc(size_t n) { return hipMalloc(&p, n); }
-};
-struct Pinned {
-  void *p = nullptr;
-  ~Pinned() {
-    if (p) (void)hipHostFree(p);
-  }
-  hipError_t alloc(size_t n) { return hipHostMalloc(&p, n, hipHostMallocDefault); }
-};
-
-/* Host worker threads for the row gather/scatter: the CPUs this process may actually use
- * (affinity mask AND cgroup v2 cpu.max quota), not the machine's core count: a container
- * with a 16-CPU quota on a 256-thread host runs 10x slower with 256 OpenMP threads. */
-int host_threads() {
-  const char *e = getenv("ROADSURF_HIP_HOST_THREADS");
-  if (e && atoi(e) > 0) return atoi(e);
-  int n = omp_get_num_procs();
-  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-    long long quota = -1, period = 0;
-    char q[32];
-    if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
-      quota = atoll(q);
-      const int c = (int)((quota + period - 1) / period);
-      if (c > 0 && c < n) n = c;
-    }
-    fclose(f);
-  }
-  return n < 1 ? 1 : n;
-}
+using rsu::Dev;
+using rsu::Pinned;
+using rsu::transpose;
 
 int fail(const char *what, hipError_t e) {
   char buf[256];
@@ -197,7 +139,7 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
     HOK(d_hz.alloc((size_t)Ppad * 360 * sizeof(double)));
   }
 
-  const int nthreads = host_threads();
+  [[maybe_unused]] const int nthreads = rsu::host_threads(omp_get_num_procs());
   int rc = 0;
   for (int64_t p0 = 0; p0 < n && rc == 0; p0 += P) {
     const int m = (int)std::min<int64_t>(P, n - p0);

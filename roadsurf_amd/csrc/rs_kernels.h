@@ -48,6 +48,9 @@ struct ExpandArgs {
 
 hipError_t rs_read_div_mismatch(unsigned long long *out, hipStream_t stream);
 hipError_t rs_launch_math_test(int fn, int64_t n, const double *x, double *y, hipStream_t stream);
+/* raw-series Tdew<->RH completion (needs the math tables: create a plan first) */
+hipError_t rs_launch_humidity_fill(const double *tair, double *tdew, double *rhz, int64_t n,
+                                   hipStream_t stream);
 hipError_t rs_upload_constants(int slot, const RsConstants *c, hipStream_t stream);
 hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
                           hipStream_t stream);

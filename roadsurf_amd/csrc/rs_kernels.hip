@@ -791,6 +791,45 @@ __global__ void __launch_bounds__(kBlock) math_test_kernel(int fn, int64_t n, co
   y[i] = fn == 0 ? rs_exp(mt, x[i]) : rs_log(mt, x[i]);
 }
 
+/* Tdew <-> RH completion of a raw series, examples/example1/src/JsonSource.cpp:288-295 with
+ * CalcTdewOrRH of MeteorologyTools.cpp:12-51.  C++ source: the literals are true doubles here
+ * (unlike the Fortran side's REAL(4) ones).  exp/log are the glibc-exact ones; the divisions
+ * are the compiler's IEEE expansion (denominators can approach 0 on the RH branch). */
+__device__ __forceinline__ double calc_tdew_or_rh(const MathTab &mt, double t, double tdew,
+                                                  double rh) {
+  const double Alphaw = 17.269, Alphai = 21.875, Betaw = 237.3, Betai = 265.5, AFact = 0.61078;
+  const double Alpha = (t >= 0.0) ? Alphaw : Alphai;
+  const double Beta = (t >= 0.0) ? Betaw : Betai;
+  const double EsatT = AFact * rs_exp(mt, Alpha * t / (t + Beta));
+  if (!(tdew != tdew) && tdew > -1000) {
+    const double EsatTD = AFact * rs_exp(mt, Alpha * tdew / (tdew + Beta));
+    const double x = (EsatTD / EsatT) * 100.0;
+    return (100.0 < x) ? 100.0 : x; /* std::min(x, 100.0) */
+  }
+  if (!(rh != rh) && rh > -1) {
+    const double Epr = 0.01 * rh * EsatT;
+    const double XX = rs_log(mt, Epr / AFact);
+    return Beta * XX / (Alpha - XX);
+  }
+  return __builtin_nan("");
+}
+
+__global__ void __launch_bounds__(kBlock) humidity_fill_kernel(const double *__restrict__ tair,
+                                                               double *tdew, double *rhz,
+                                                               int64_t n) {
+  __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
+  const MathTab mt = fill_math_tables(math_lds);
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const double t = tair[i];
+  double td = tdew[i], rh = rhz[i];
+  if (td < -100 && rh > -100 && t > -100) td = calc_tdew_or_rh(mt, t, -9999.9, rh);
+  if (rh < -100 && td > -100 && t > -100) rh = calc_tdew_or_rh(mt, t, td, -9999.9);
+  tdew[i] = td;
+  rhz[i] = rh;
+}
+
 __global__ void __launch_bounds__(kBlock) count_failed_kernel(const double *st, int64_t np_pad,
                                                               int64_t npoints,
                                                               unsigned long long *out) {
@@ -815,6 +854,13 @@ hipError_t rs_read_div_mismatch(unsigned long long *out, hipStream_t stream) {
 
 hipError_t rs_launch_math_test(int fn, int64_t n, const double *x, double *y, hipStream_t stream) {
   hipLaunchKernelGGL(rs::math_test_kernel, grid_for(n), dim3(RS_BLOCK), 0, stream, fn, n, x, y);
+  return hipGetLastError();
+}
+
+hipError_t rs_launch_humidity_fill(const double *tair, double *tdew, double *rhz, int64_t n,
+                                   hipStream_t stream) {
+  hipLaunchKernelGGL(rs::humidity_fill_kernel, grid_for(n), dim3(RS_BLOCK), 0, stream, tair, tdew,
+                     rhz, n);
   return hipGetLastError();
 }
 

@@ -26,7 +26,7 @@ def _ensure_built():
     if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/src") and not os.path.exists(
-            os.path.join(ROOT, "oracle", "_ref", "libroadsurf_ref_cpl.so")):
+            os.path.join(ROOT, "oracle", "_ref", "libroadrunner_tools_ref.so")):
         subprocess.check_call(["bash", os.path.join(ROOT, "oracle", "build_ref.sh")], stdout=subprocess.DEVNULL)
 
 

@@ -1,0 +1,156 @@
+"""CPU: the checker for the driver data path (oracle/driver_oracle.c).
+
+* CalcTdewOrRH restatement vs the reference's own MeteorologyTools.cpp compiled with g++
+  (oracle/_ref/libroadrunner_tools_ref.so): bit for bit.
+* interpolate / GetWeather / read_input: the reference files need jsoncpp and cannot be built
+  here (PARITY UNPINNED, see oracle/driver_oracle.c); they are held to hand-worked cases
+  chosen so that every expected value is exact in binary."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import driver_helpers as dh
+import oracle_helpers as oh
+from roadsurf_amd import abi, driver
+
+M = -9999.9
+
+
+def test_calc_tdew_or_rh_matches_reference_build():
+    if not os.path.exists(dh.TOOLS_REF_SO):
+        if not os.path.isdir("/root/reference/src"):
+            pytest.skip("reference build not available")
+        oh.build_ref()
+    ref = C.CDLL(dh.TOOLS_REF_SO)
+    fn = getattr(ref, "_Z12CalcTdewOrRHddd")
+    fn.restype = C.c_double
+    fn.argtypes = [C.c_double] * 3
+    port = oh.load("port").oracle_calc_tdew_or_rh
+    port.restype = C.c_double
+    port.argtypes = [C.c_double] * 3
+    rs = np.random.RandomState(5)
+    n = 20000
+    t = rs.uniform(-60, 40, n)
+    cases = [(t, t - rs.uniform(0, 30, n), np.full(n, M)),        # Tdew -> RH
+             (t, np.full(n, M), rs.uniform(0.5, 100, n)),         # RH -> Tdew
+             (t, np.full(n, M), rs.uniform(-1.5, 0.5, n)),        # RH <= 0: nan / -inf paths
+             (t, np.full(n, np.nan), np.full(n, np.nan))]
+    for a, b, c in cases:
+        x = np.array([fn(*v) for v in zip(a, b, c)])
+        y = np.array([port(*v) for v in zip(a, b, c)])
+        assert np.array_equal(np.isnan(x), np.isnan(y))
+        ok = ~np.isnan(x)
+        assert np.array_equal(x[ok].view(np.int64), y[ok].view(np.int64))
+
+
+def _settings(L, **kw):
+    s = abi.default_settings(L)
+    for k, v in kw.items():
+        setattr(s, k, v)
+    return s
+
+
+def _one(times, **fields):
+    return driver.RawSource(np.asarray(times, np.int64),
+                            {k: np.asarray(v, np.float64)[None, :] for k, v in fields.items()})
+
+
+def test_interpolate_on_grid_and_edges():
+    t0 = dh.START
+    # raw: hourly, starts one hour BEFORE the simulation; values chosen so k*30/3600*120 is exact
+    src = _one([t0 - 3600, t0, t0 + 3600, t0 + 7200], tair=[-120.0 + 0, 0.0, 120.0, 240.0],
+               vz=[1.0, 1.0, M, 3.0])
+    L = 241  # two hours: the LAST raw time is index 240
+    r = dh.oracle_read_input([src], _settings(L), t0, t0)
+    tair = r["merged"]["tair"][0]
+    k = np.arange(L)
+    # interior: raw[rp] + (k*30 - rawtime)*(b-a)/3600 = k exactly; raw[0] = -120 is 'missing' (<= -100)
+    assert np.array_equal(tair[:240], k[:240].astype(float))
+    # quirk (JsonSource.cpp:84): the walk stops when rawPos reaches the last raw point, so the
+    # simulation index that coincides with the LAST raw time is never filled
+    assert tair[240] == M
+    vz = r["merged"]["vz"][0]
+    assert vz[0] == 1.0                     # exact hit copies
+    assert np.all(vz[1:120] == M)           # a missing neighbour: no interpolation
+    assert np.all(vz[120:240] == M)         # copy of a missing value is skipped too
+    # Rhz is absent altogether: the first failing test (order tair, Rhz, ...) is Rhz at index 0
+    assert r["status"][0] == 2 and r["missing_index"][0] == 0
+
+def test_status_reports_first_missing_in_reference_order():
+    t0 = dh.START
+    full = dict(tair=[1.0, 2.0, 3.0], rhz=[80.0, 80.0, 80.0], prec=[0.0, 0.0, 0.0],
+                sw=[0.0, 0.0, 0.0], lw=[300.0, 300.0, 300.0], vz=[2.0, 2.0, 2.0])
+    tt = [t0, t0 + 3600, t0 + 7200]
+    L = 121
+    r = dh.oracle_read_input([_one(tt, **full)], _settings(L), t0, t0)
+    assert r["status"][0] == 0 and r["missing_index"][0] == -1
+    for code, name in ((1, "tair"), (2, "rhz"), (3, "prec"), (4, "sw"), (5, "lw"), (6, "vz")):
+        f = {k: list(v) for k, v in full.items()}
+        f[name][1] = M      # from index 1 on nothing can be interpolated
+        r = dh.oracle_read_input([_one(tt, **f)], _settings(L), t0, t0)
+        assert (r["status"][0], r["missing_index"][0]) == (code, 1), name
+    # simulation starting before the data: indices before the first raw time stay missing
+    r = dh.oracle_read_input([_one(tt, **full)], _settings(L), t0 - 60, t0)
+    assert (r["status"][0], r["missing_index"][0]) == (1, 0)
+    assert r["merged"]["tair"][0][2] == 1.0
+
+
+def test_off_grid_raw_times_never_advance():
+    """JsonSource.cpp:113-114 only moves to the next raw interval on an EXACT time hit; a raw
+    time that is not a simulation time pins the walk to the interval before it (extrapolation)."""
+    t0 = dh.START
+    src = _one([t0, t0 + 3616, t0 + 7200], tair=[0.0, 113.0, 500.0])
+    L = 241
+    r = dh.oracle_read_input([src], _settings(L), t0, t0)
+    k = np.arange(L, dtype=float)
+    want = 0.0 + (k * 30.0) * 113.0 / 3616.0     # 113/3616 = 1/32 exactly
+    assert np.array_equal(r["merged"]["tair"][0], np.where(want > -100, want, M))
+    assert r["merged"]["tair"][0][240] == 225.0
+
+
+def test_sources_overlay_relaxation_and_coupling():
+    t0 = dh.START
+    L = 481  # four hours
+    hours = [t0 + 3600 * h for h in range(6)]
+    fc = _one(hours, tair=[0.0, 120, 240, 360, 480, 600], rhz=[50.0] * 6, prec=[0.0] * 6,
+              sw=[0.0] * 6, lw=[300.0] * 6, vz=[4.0] * 6, tsurfobs=[M] * 6)
+    ob = _one([t0, t0 + 1800, t0 + 3600, t0 + 5400, t0 + 7200],
+              tair=[1000.0, 1060.0, 1120.0, M, M], tsurfobs=[-3.0, -2.0, -1.0, 0.0, M])
+    ob.is_observation = True
+    s = _settings(L, use_relaxation=1, use_coupling=1, coupling_minutes=60)
+    r = dh.oracle_read_input([fc, ob], s, t0, t0 + 7200)
+    tair = r["merged"]["tair"][0]
+    k = np.arange(L, dtype=float)
+    # observation wins where it has data: indices 0..119 (copy at 0/60, interpolation between;
+    # index 120 is a copy of raw[2]), beyond that the forecast shows through
+    assert np.array_equal(tair[:121], 1000.0 + k[:121])
+    assert np.array_equal(tair[121:], k[121:])
+    lp = r["local"][0]
+    # GetLatestObsIndex: last index with observed tair is 120 -> returns 121
+    assert lp.InitLenI == 121
+    assert lp.tair_relax == 121.0 and lp.VZ_relax == 4.0 and lp.RH_relax == 50.0
+    # road temperature: observed up to index 180 (copy of raw[3] = 0.0): 180 >= 120 = coupling length
+    assert lp.couplingIndexI == 180 and lp.couplingTsurf == 0.0
+    obs = r["merged"]["tsurfobs"][0]
+    assert np.all(obs[61:181] == M)          # blanked: (180-120, 180]
+    assert obs[60] == -2.0 and obs[0] == -3.0
+    assert np.all(obs[181:] == M)
+    # without relaxation the initialisation length comes from the forecast time
+    r2 = dh.oracle_read_input([fc, ob], _settings(L), t0, t0 + 7200)
+    assert r2["local"][0].InitLenI == 1 + 7200 // 30
+
+
+def test_humidity_is_completed_per_source():
+    t0 = dh.START
+    tt = [t0, t0 + 3600, t0 + 7200]
+    port = oh.load("port").oracle_calc_tdew_or_rh
+    port.restype = C.c_double
+    port.argtypes = [C.c_double] * 3
+    a = _one(tt, tair=[5.0, 5.0, 5.0], tdew=[1.0, 1.0, 1.0])
+    b = _one(tt, tair=[-5.0, -5.0, -5.0], rhz=[70.0, 70.0, 70.0])
+    r = dh.oracle_read_input([a], _settings(121), t0, t0)
+    assert np.all(r["merged"]["rhz"][0][:120] == port(5.0, 1.0, M))
+    r = dh.oracle_read_input([b], _settings(121), t0, t0)
+    assert np.all(r["merged"]["tdew"][0][:120] == port(-5.0, M, 70.0))
