@@ -476,6 +476,10 @@ typedef struct RsDriverOutput {
 int rs_driver_run(const RsDriverInput *in, const InputSettings *settings,
                   const InputParameters *params, LocalParameters *local,
                   const RsDriverOutput *out, int32_t device);
+/* rs_driver_run keeps its forcing-window block (up to 64 GB of HBM with coupling) for the next
+ * call, because releasing and re-acquiring that much VRAM costs seconds (the driver wipes it).
+ * This frees it. */
+void rs_driver_release_cache(void);
 /* Test hook: only the input side.  merged = host [10][n_points][SimLen] in the order tair,
  * tdew, VZ, Rhz, prec, SW, LW, SW_dir, LW_net, TSurfObs: what read_input returns. */
 int rs_driver_expand(const RsDriverInput *in, const InputSettings *settings,

@@ -32,6 +32,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <mutex>
 #include <vector>
 
 #include "../../include/roadsurf.h"
@@ -564,6 +566,90 @@ int check_device(int32_t device) {
   return 0;
 }
 
+/* ROADSURF_HIP_DRIVER_TIMING=1: wall time per phase of rs_driver_run on stderr (synchronises) */
+struct PhaseTimer {
+  bool on;
+  hipStream_t s;
+  double t0;
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  static double now() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+  }
+  explicit PhaseTimer(hipStream_t st) : on(getenv("ROADSURF_HIP_DRIVER_TIMING") != nullptr), s(st), t0(now()) {}
+  void lap(int k) {
+    if (!on) return;
+    (void)hipStreamSynchronize(s);
+    const double t = now();
+    acc[k] += t - t0;
+    t0 = t;
+  }
+  void report() const {
+    if (!on) return;
+    fprintf(stderr,
+            "rs_driver_run phases [s]: setup %.3f  upload+transpose %.3f  scan/decide %.3f  alloc/params %.3f  "
+            "expand+step %.3f  outputs %.3f  window alloc %.3f  free %.3f\n", acc[0], acc[1], acc[2], acc[3],
+            acc[4], acc[5], acc[6], acc[7]);
+  }
+};
+
+/* The forcing windows are the one large allocation (up to 64 GB with coupling).  The amdgpu
+ * driver wipes VRAM when it is released, and a hipMalloc that lands on pages still being
+ * wiped waits for them: measured here, a 60 GB hipMalloc right after a 60 GB hipFree takes
+ * 3-6 s, against 0.6 s for the whole simulation.  So the window block is kept per process and
+ * reused by the next call (rs_driver_release_cache frees it); a concurrent second caller gets a
+ * private allocation. */
+struct WindowCache {
+  std::mutex m;
+  void *p = nullptr;
+  size_t bytes = 0;
+  int device = -1;
+  bool busy = false;
+} g_wincache;
+
+struct WindowLease {
+  void *p = nullptr;
+  bool cached = false;
+  ~WindowLease() { release(); }
+  hipError_t acquire(size_t bytes, int device) {
+    std::lock_guard<std::mutex> lk(g_wincache.m);
+    WindowCache &c = g_wincache;
+    if (!c.busy) {
+      if (c.p && (c.device != device || c.bytes < bytes)) {
+        (void)hipFree(c.p);
+        c.p = nullptr;
+        c.bytes = 0;
+      }
+      if (!c.p) {
+        hipError_t e = hipMalloc(&c.p, bytes);
+        if (e != hipSuccess) {
+          c.p = nullptr;
+          return e;
+        }
+        c.bytes = bytes;
+        c.device = device;
+      }
+      c.busy = true;
+      cached = true;
+      p = c.p;
+      return hipSuccess;
+    }
+    cached = false;
+    return hipMalloc(&p, bytes);
+  }
+  void release() {
+    if (!p) return;
+    if (cached) {
+      std::lock_guard<std::mutex> lk(g_wincache.m);
+      g_wincache.busy = false;
+    } else {
+      (void)hipFree(p);
+    }
+    p = nullptr;
+  }
+};
+
 struct StreamGuard {
   hipStream_t s = nullptr;
   ~StreamGuard() {
@@ -635,6 +721,14 @@ int rs_driver_expand(const RsDriverInput *in, const InputSettings *st, LocalPara
   return 0;
 }
 
+void rs_driver_release_cache(void) {
+  std::lock_guard<std::mutex> lk(g_wincache.m);
+  if (g_wincache.busy || !g_wincache.p) return;
+  (void)hipFree(g_wincache.p);
+  g_wincache.p = nullptr;
+  g_wincache.bytes = 0;
+}
+
 int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputParameters *params,
                   LocalParameters *local, const RsDriverOutput *out, int32_t device) {
   Common c;
@@ -670,7 +764,15 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputP
   const double tbottom = rs_bottom_temperature(params, &consts, in->year[0], in->month[0], in->day[0]);
 
   const char *ep = getenv("ROADSURF_HIP_TILE_POINTS"), *et = getenv("ROADSURF_HIP_CHUNK_STEPS");
-  const int P = (int)std::min<int64_t>(c.n, ep ? std::max(1, atoi(ep)) : (coupled ? 16384 : 131072));
+  /* Tile of points: large enough to fill the chip (256 CUs x 4 workgroups of 256 points is
+   * 262144 points per round).  With coupling the windows hold the whole series (a point
+   * replays its coupling window), so the tile follows from a 64 GB window budget. */
+  int64_t Pdef = 524288;
+  if (coupled) {
+    Pdef = (int64_t)(64e9 / ((double)L * NFLD * sizeof(double)));
+    Pdef = std::max<int64_t>(4096, std::min<int64_t>(262144, Pdef / 4096 * 4096));
+  }
+  const int P = (int)std::min<int64_t>(c.n, ep ? std::max(1, atoi(ep)) : Pdef);
   const int TC = coupled ? L : std::min(L, et ? std::max(1, atoi(et)) : 256);
 
   /* shared axes */
@@ -689,6 +791,15 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputP
     rs_point_geometry(c.n, local, slat.data(), clat.data(), lrad.data());
   }
 
+  PhaseTimer pt(stream);
+  pt.lap(0);
+  WindowLease win;
+  {
+    const int64_t Ppad = ((int64_t)P + RS_BLOCK - 1) / RS_BLOCK * RS_BLOCK;
+    const int nwin = skyview ? NFLD : NFLD - 2;
+    HOK(win.acquire((size_t)nwin * Ppad * TC * sizeof(double), device));
+  }
+  pt.lap(6);
   for (int64_t p0 = 0; p0 < c.n; p0 += P) {
     const int m = (int)std::min<int64_t>(P, c.n - p0);
     PlanGuard pg;
@@ -697,9 +808,11 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputP
     const int64_t mp = rs_hip_plan_npoints_padded(pg.p);
     TileRaw T;
     if (int rc = upload_tile(in, c, p0, m, mp, T, stream)) return rc;
+    pt.lap(1);
     TileDecisions D;
     if (int rc = decide_tile(c, st, T, D, stream)) return rc;
     if (int rc = report_tile(c, st, D, p0, m, local, out->status, out->missing_index, stream)) return rc;
+    pt.lap(2);
 
     /* per-point parameters */
     Dev d_tb, d_geo, d_hz, d_hzpt;
@@ -750,8 +863,7 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputP
 
     /* windows */
     const size_t fs = (size_t)mp * TC;
-    Dev d_win, d_phase, d_out, d_outpt;
-    HOK(d_win.alloc((size_t)NFLD * fs * sizeof(double)));
+    Dev d_phase, d_out, d_outpt;
     HOK(d_phase.alloc(fs * sizeof(int32_t)));
     hipLaunchKernelGGL(fill_i32_kernel, grid1((int64_t)fs), dim3(RS_BLOCK), 0, stream,
                        d_phase.as<int32_t>(), (int64_t)fs, -9999); /* InputData.cpp:16 */
@@ -762,9 +874,12 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputP
 
     ExpandRawArgs ea;
     ea.S = T.S;
-    double *wb = d_win.as<double>();
-    for (int f = 0; f < NFLD; ++f) ea.out[f] = wb + (size_t)f * fs;
-    if (!skyview) ea.out[R_SWDIR] = ea.out[R_LWNET] = nullptr;
+    /* window f lives at slot wslot[f] of the leased block (SW_dir / LW_net only with sky view) */
+    double *wb = static_cast<double *>(win.p);
+    for (int f = 0, k = 0; f < NFLD; ++f) {
+      const bool used = skyview || (f != R_SWDIR && f != R_LWNET);
+      ea.out[f] = used ? wb + (size_t)(k++) * fs : nullptr;
+    }
     ea.status = D.status.as<int32_t>();
     ea.cpl_hi = coupled ? D.cpl_hi.as<int32_t>() : nullptr;
     ea.cplLen = c.cplLen;
@@ -778,6 +893,7 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputP
     oo.decimate = step;
     oo.row0 = 0;
 
+    pt.lap(3);
     for (int t0 = 1; t0 <= L; t0 += TC) {
       const int len = std::min(TC, L - t0 + 1);
       ea.i0 = t0 - 1;
@@ -803,6 +919,7 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputP
       if (t0 == 1 && rs_hip_init_state(pg.p, &fo, &pp) != 0) return -12;
       if (rs_hip_step(pg.p, &fo, &oo, &pp, t0, len) != 0) return -13;
     }
+    pt.lap(4);
     hipLaunchKernelGGL(blank_rejected_kernel, grid1(m), dim3(RS_BLOCK), 0, stream, ob, (int64_t)mp,
                        (int32_t)n_out, (int64_t)m, (const int32_t *)D.status.as<int32_t>());
     HOK(hipGetLastError());
@@ -814,7 +931,13 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputP
                          hipMemcpyDeviceToHost, stream));
     }
     HOK(hipStreamSynchronize(stream));
+    pt.lap(5);
+    d_phase.release();
+    d_out.release();
+    d_outpt.release();
+    pt.lap(7);
   }
+  pt.report();
   return 0;
 }
 

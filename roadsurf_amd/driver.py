@@ -136,13 +136,19 @@ def make_input(sources, start_time: int, forecast_time: int, cal: dict | None = 
 
 
 def _locals(n: int, local) -> C.Array:
+    """LocalParameters[n]: None -> defaults, one struct -> replicated, a list, or a ready
+    ctypes array (used as is: it is also where the decisions are written back)."""
+    if isinstance(local, C.Array):
+        if len(local) != n:
+            raise ValueError("local: wrong length")
+        return local
     if local is None:
-        local = []
-        for _ in range(n):
-            lp = abi.default_local()
-            local.append(lp)
-    elif isinstance(local, abi.LocalParameters):
-        local = [local] * n
+        local = abi.default_local()
+    if isinstance(local, abi.LocalParameters):
+        arr = (abi.LocalParameters * n)()
+        tmpl = bytes(local)
+        C.memmove(arr, tmpl * n, len(tmpl) * n)
+        return arr
     return (abi.LocalParameters * n)(*local)
 
 

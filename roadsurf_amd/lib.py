@@ -89,7 +89,7 @@ EXPORTS = (
     "rs_hip_init_state", "rs_hip_step", "rs_hip_state_download", "rs_hip_state_upload",
     "rs_hip_failed_count", "rs_hip_sync", "rs_hip_synth_knots", "rs_hip_expand_forcing", "rs_hip_expand_forcing_on",
     "rs_hip_set_variant", "rs_hip_set_precision", "rs_hip_test_math", "rs_hip_division_mode", "rs_hip_div_mismatch_count", "rs_hip_timing_reset", "rs_hip_timing_step_ms",
-    "rs_host_run_batch", "rs_driver_run", "rs_driver_expand", "rs_abi_version", "rs_abi_sizeof", "rs_fortran_sizeof",
+    "rs_host_run_batch", "rs_driver_run", "rs_driver_expand", "rs_driver_release_cache", "rs_abi_version", "rs_abi_sizeof", "rs_fortran_sizeof",
 )
 
 _lib = None
