@@ -154,3 +154,60 @@ def test_humidity_is_completed_per_source():
     assert np.all(r["merged"]["rhz"][0][:120] == port(5.0, 1.0, M))
     r = dh.oracle_read_input([b], _settings(121), t0, t0)
     assert np.all(r["merged"]["tdew"][0][:120] == port(-5.0, M, 70.0))
+
+
+# ---- host-side file formats and argument handling of roadsurf_amd/driver.py (no GPU) ----------
+
+def test_json_reader_and_writer_follow_the_reference_schema(tmp_path):
+    import json
+    stations = [
+        {"statId": 101, "lat": 60.4, "lon": 22.8, "time": ["2024-01-10 00:00", "2024-01-10 01:00"],
+         "Temperature 2m": [-3.0, -2.5], "Humidity": [90, None], "WindSpeed": [2.0, 3.0],
+         "PrecipitationForm": [1, 1], "RoadTemperature": [-4.0, -3.5]},
+        {"statId": 102, "lat": 61.0, "lon": 23.5, "time": ["2024-01-10 00:00", "2024-01-10 01:00"],
+         "Temperature 2m": [1.0, 1.5], "DewPoint": [0.0, 0.5], "WindSpeed": [5.0, 6.0]},
+    ]
+    path = tmp_path / "obs.json"
+    path.write_text(json.dumps(stations))
+    src, ids, lats, lons = driver.read_json_source(str(path), is_observation=True)
+    assert ids == [101, 102] and lats[1] == 61.0 and lons[0] == 22.8
+    assert src.is_observation and list(src.times) == [dh.START, dh.START + 3600]
+    assert set(src.fields) == {"tair", "rhz", "tdew", "vz", "tsurfobs"}   # PrecipitationForm is dropped
+    assert np.array_equal(src.fields["rhz"], [[90.0, M], [M, M]])
+    assert np.array_equal(src.fields["tdew"], [[M, M], [0.0, 0.5]])
+    stations[1]["time"][1] = "2024-01-10 02:00"
+    path.write_text(json.dumps(stations))
+    with pytest.raises(ValueError, match="own time axis"):
+        driver.read_json_source(str(path))
+
+    result = {"step": 120, "status": np.array([0, 3], np.int32)}
+    for k in driver.OUT_FIELDS:
+        result[k] = np.arange(6, dtype=float).reshape(2, 3)
+    out = tmp_path / "forecast.json"
+    driver.save_output(str(out), result, ids, lats, lons, dh.START, 30)
+    fc = json.loads(out.read_text())
+    assert len(fc) == 1 and fc[0]["statId"] == 101          # the rejected point is not written
+    assert fc[0]["time"] == ["2024-01-10T00:00", "2024-01-10T01:00", "2024-01-10T02:00"]
+    assert set(fc[0]) == {"statId", "lat", "lon", "time", "RoadTemperature", "Water", "Ice", "Snow", "Deposit"}
+
+
+def test_driver_host_helpers():
+    s = abi.default_settings(5761)
+    assert driver.output_rows(s) == (120, 49)          # roadrunner.cpp:290: 60 min / 30 s
+    s.outputStep = 7
+    assert driver.output_rows(s) == (14, 412)
+    cal = driver.calendar(dh.START, 3, 1800)
+    assert list(cal["hour"]) == [0, 0, 1] and list(cal["minute"]) == [0, 30, 0] and cal["year"][0] == 2024
+    a = np.zeros((4, 3))
+    with pytest.raises(ValueError):
+        driver.make_input([driver.RawSource(np.arange(2), {"tair": a})], 0, 0)      # wrong n_times
+    with pytest.raises(KeyError):
+        driver.make_input([driver.RawSource(np.arange(3), {"precphase": a})], 0, 0)
+    with pytest.raises(ValueError):
+        driver.make_input([driver.RawSource(np.arange(3), {"tair": a}),
+                           driver.RawSource(np.arange(3), {"tair": np.zeros((5, 3))})], 0, 0)
+    inp, keep = driver.make_input([driver.RawSource(np.arange(3), {"tair": a, "rhz": a})], 5, 9)
+    assert inp.n_points == 4 and inp.n_sources == 1 and inp.sources[0].n_times == 3
+    assert not inp.sources[0].tdew and inp.sources[0].rhz
+    l = driver._locals(3, None)
+    assert l[2].sky_view == 1.0 and l[2].couplingIndexI == -9999
