@@ -43,23 +43,37 @@ namespace rs {
 static __constant__ uint64_t c_gl_exp_tab[256] = {0};
 static __constant__ uint64_t c_gl_log_tab[256] = {0};
 
+/* Polynomial coefficients that are the ADDEND of a fused multiply-add whose multiplier is a
+ * constant too (fma(r, C3, C2)).  gfx950 is a GFX9-family target: a VOP3 instruction may
+ * read ONE scalar operand (SGPR or literal), so the second constant has to sit in VGPRs, and
+ * with loop-invariant code motion disabled (register budget) that was two v_mov_b32 per use,
+ * ~75 vector instructions per point-step.  From LDS the same value arrives by a broadcast
+ * ds_read_b64, which does not occupy the vector ALU. */
+enum { RS_K_EXP_SHIFT, RS_K_EXP_C2, RS_K_EXP_C4, RS_K_LOG_A1, RS_K_LOG_A3, RS_K_LOG_B1,
+       RS_K_LOG_B4, RS_K_LOG_B7, RS_K_COUNT };
+static __constant__ uint64_t c_gl_coef[RS_K_COUNT] = {
+    RS_GL_EXP_SHIFT, RS_GL_EXP_C2, RS_GL_EXP_C4, RS_GL_LOG_A1,
+    RS_GL_LOG_A3,    RS_GL_LOG_B1, RS_GL_LOG_B4, RS_GL_LOG_B7};
+
 /* LDS copies of the tables; filled by fill_math_tables() at kernel start. */
 struct MathTab {
   const uint64_t *expT; /* [128][2]  {tail, sbits}  */
   const double *logT;   /* [128][2]  {invc, logc}   */
+  const double *K;      /* [RS_K_COUNT] */
 };
 
-#define RS_MATH_LDS_DOUBLES 512
+#define RS_MATH_LDS_DOUBLES (512 + RS_K_COUNT)
 
 /* All threads of the workgroup call this (before any early return), then
  * __syncthreads().  lds must hold RS_MATH_LDS_DOUBLES 8-byte words. */
 __device__ __forceinline__ MathTab fill_math_tables(double *lds) {
   uint64_t *w = reinterpret_cast<uint64_t *>(lds);
   for (int i = threadIdx.x; i < RS_MATH_LDS_DOUBLES; i += blockDim.x)
-    w[i] = (i < 256) ? c_gl_exp_tab[i] : c_gl_log_tab[i - 256];
+    w[i] = (i < 256) ? c_gl_exp_tab[i] : (i < 512) ? c_gl_log_tab[i - 256] : c_gl_coef[i - 512];
   MathTab t;
   t.expT = w;
   t.logT = lds + 256;
+  t.K = lds + 512;
   return t;
 }
 
@@ -161,18 +175,19 @@ __device__ __forceinline__ double rs_exp(const MathTab &mt, double x) {
     return (x > 0.0) ? __builtin_inf() : 0.0;
   }
   /* x = ln2/N*k + r, k integer, |r| <= ln2/2N */
-  double kd = __builtin_fma(x, gl_d(RS_GL_EXP_INVLN2N), gl_d(RS_GL_EXP_SHIFT));
+  const double shift = mt.K[RS_K_EXP_SHIFT];
+  double kd = __builtin_fma(x, gl_d(RS_GL_EXP_INVLN2N), shift);
   const uint64_t ki = (uint64_t)__double_as_longlong(kd);
-  kd = kd - gl_d(RS_GL_EXP_SHIFT);
+  kd = kd - shift;
   double r = __builtin_fma(kd, gl_d(RS_GL_EXP_NEGLN2HIN), x);
   r = __builtin_fma(kd, gl_d(RS_GL_EXP_NEGLN2LON), r);
   const uint32_t idx = 2u * ((uint32_t)ki & 127u);
   const double tail = gl_d(mt.expT[idx]);
   const uint64_t sbits = mt.expT[idx + 1] + (ki << 45);
   const double r2 = r * r;
-  const double p23 = __builtin_fma(r, gl_d(RS_GL_EXP_C3), gl_d(RS_GL_EXP_C2));
+  const double p23 = __builtin_fma(r, gl_d(RS_GL_EXP_C3), mt.K[RS_K_EXP_C2]);
   const double t0 = r + tail;
-  const double p45 = __builtin_fma(r, gl_d(RS_GL_EXP_C5), gl_d(RS_GL_EXP_C4));
+  const double p45 = __builtin_fma(r, gl_d(RS_GL_EXP_C5), mt.K[RS_K_EXP_C4]);
   const double a = __builtin_fma(p23, r2, t0);
   const double r4 = r2 * r2;
   const double tmp = __builtin_fma(r4, p45, a);
@@ -191,10 +206,10 @@ __device__ __forceinline__ double rs_log(const MathTab &mt, double x) {
     /* 1 - 2^-4 <= x < 1 + 0x1.09p-4: polynomial in r = x - 1 with a double-double head */
     if (ix == 0x3ff0000000000000ull) return 0.0;
     const double r = x - 1.0;
-    const double p12 = __builtin_fma(r, gl_d(RS_GL_LOG_B2), gl_d(RS_GL_LOG_B1));
-    const double p45 = __builtin_fma(r, gl_d(RS_GL_LOG_B5), gl_d(RS_GL_LOG_B4));
+    const double p12 = __builtin_fma(r, gl_d(RS_GL_LOG_B2), mt.K[RS_K_LOG_B1]);
+    const double p45 = __builtin_fma(r, gl_d(RS_GL_LOG_B5), mt.K[RS_K_LOG_B4]);
     const double r2 = r * r;
-    const double p78 = __builtin_fma(r, gl_d(RS_GL_LOG_B8), gl_d(RS_GL_LOG_B7));
+    const double p78 = __builtin_fma(r, gl_d(RS_GL_LOG_B8), mt.K[RS_K_LOG_B7]);
     const double p123 = __builtin_fma(r2, gl_d(RS_GL_LOG_B3), p12);
     const double p456 = __builtin_fma(r2, gl_d(RS_GL_LOG_B6), p45);
     const double r3 = r * r2;
@@ -233,13 +248,13 @@ __device__ __forceinline__ double rs_log(const MathTab &mt, double x) {
   const double r = __builtin_fma(z, invc, -1.0);
   const double kd = (double)k;
   const double w = __builtin_fma(kd, gl_d(RS_GL_LOG_LN2HI), logc);
-  const double p12 = __builtin_fma(r, gl_d(RS_GL_LOG_A2), gl_d(RS_GL_LOG_A1));
+  const double p12 = __builtin_fma(r, gl_d(RS_GL_LOG_A2), mt.K[RS_K_LOG_A1]);
   const double hi = r + w;
   const double r2 = r * r;
   double lo = (w - hi) + r;
   lo = __builtin_fma(kd, gl_d(RS_GL_LOG_LN2LO), lo);
   const double r3 = r * r2;
-  const double p34 = __builtin_fma(r, gl_d(RS_GL_LOG_A4), gl_d(RS_GL_LOG_A3));
+  const double p34 = __builtin_fma(r, gl_d(RS_GL_LOG_A4), mt.K[RS_K_LOG_A3]);
   const double q = __builtin_fma(r2, gl_d(RS_GL_LOG_A0), lo);
   const double p = __builtin_fma(p34, r2, p12);
   const double y = __builtin_fma(r3, p, q);
