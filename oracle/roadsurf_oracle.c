@@ -180,6 +180,13 @@ static void CalcLE(Model *m, double TSurfAve, double TAmb, double Rhz, double Ai
   }
 }
 
+/* diagnostic (tools/bl_iterations.py): histogram of the trip count of the loop below */
+long oracle_bl_hist[64];
+int oracle_bl_hist_on = 0;
+/* optional per-call trace for ONE point at a time (single-threaded use) */
+unsigned char *oracle_bl_trace = 0;
+long oracle_bl_trace_pos = 0, oracle_bl_trace_cap = 0;
+
 /* src/BoundaryLayer.f90:3-109.  Returns the iteration count (known-answer tests). */
 static int CalcBLCondAndLE(Model *m) {
   const double ConvLim = R4(0.001);
@@ -215,6 +222,13 @@ static int CalcBLCondAndLE(Model *m) {
   RAero = calcRaero(m, PSIM, PSIH, VZ);
   CalcLE(m, TSurfAve, Tair, Rhz, AirDens, AirHCap, PsychC, RAero, WatDen);
   m->BLCond = BLCond;
+  if (oracle_bl_hist_on) {
+    const int jj = j > MaxIter ? MaxIter : j;
+#pragma omp atomic
+    oracle_bl_hist[jj]++;
+    if (oracle_bl_trace && oracle_bl_trace_pos < oracle_bl_trace_cap)
+      oracle_bl_trace[oracle_bl_trace_pos++] = (unsigned char)jj;
+  }
   return j > MaxIter ? MaxIter : j;
 }
 

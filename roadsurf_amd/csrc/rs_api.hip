@@ -228,9 +228,9 @@ int rs_hip_set_precision(RsPlan *pl, int32_t bits) {
 }
 
 int rs_hip_set_variant(RsPlan *pl, int32_t variant) {
-  if (!pl || variant < 0 || variant % 10 > 2 || variant / 10 > 4)
+  if (!pl || variant < 0 || variant % 10 > 3 || variant / 10 > 4)
     return set_err("rs_hip_set_variant: bad arguments");
-  if (variant % 10 == RS_VARIANT_REG && pl->c.NLayers != 15)
+  if ((variant % 10 == RS_VARIANT_REG || variant % 10 == RS_VARIANT_BT) && pl->c.NLayers != 15)
     return set_err("register-profile kernel is built for NLayers == 15 only (got %d)",
                    pl->c.NLayers);
   pl->variant = variant;

@@ -7,7 +7,7 @@
 #define RS_BLOCK 256
 #define RS_CONST_SLOTS 16 /* concurrent plans per device */
 
-enum { RS_VARIANT_AUTO = 0, RS_VARIANT_REG = 1, RS_VARIANT_LDS = 2 };
+enum { RS_VARIANT_AUTO = 0, RS_VARIANT_REG = 1, RS_VARIANT_LDS = 2, RS_VARIANT_BT = 3 };
 
 namespace rs {
 

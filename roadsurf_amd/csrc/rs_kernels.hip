@@ -256,6 +256,202 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
   }
 }
 
+/* ---- block-level compaction of the boundary-layer tail ------------------------------
+ * CalcBLCondAndLE iterates at least 5 times and then until |dBLCond| < 0.001
+ * (src/BoundaryLayer.f90:64-96).  On the synthetic workload 80 % of the point-steps stop at
+ * 5, the mean is 5.5, but the tail reaches 35 (tools/bl_iterations.py) - and a wavefront
+ * runs until its slowest lane is done: measured, the iterations beyond the fifth cost 26 %
+ * of the kernel with ~3 % of the lanes doing useful work in them.
+ * Here every lane does its 5 mandatory iterations; lanes that have not converged park their
+ * loop state in LDS, and after a workgroup barrier the parked items are handed out DENSELY
+ * to the first n lanes of one (rotating) wavefront, which finish them and leave the results
+ * in LDS for the owners.  The arithmetic per item is the same instruction sequence in the
+ * same order whichever lane executes it, so results are bit-identical.  Cost per
+ * workgroup-step: one tail instead of four, two barriers, ~20 LDS accesses. */
+struct BlTailShared {
+  double item[7][kBlock]; /* dT, den0, vkvz, avk, PSIM, PSIH, BLCond of a parked lane */
+  double res[3][kBlock];  /* PSIM, PSIH, BLCond when its loop has exited */
+  int32_t count[2];       /* parked items of the even / odd time index */
+};
+
+/* All threads of the workgroup call this once per time index (barriers inside); `active`
+ * lanes have a point to step, the others only take part as workers. */
+__device__ __forceinline__ Fluxes fluxes_block_tail(const RsConstants &c, const MathTab &mt,
+                                                    Scalars &s, bool active, double tair, double vz,
+                                                    double rhz, double prec_ts, double sw, double lw,
+                                                    int32_t phase, int32_t hour, BlTailShared &sh,
+                                                    int32_t k) {
+  Fluxes fx;
+  fx.blcond = fx.le = fx.evap = fx.rnet = fx.trffric = 0.0;
+  BlInv v;
+  BlVar x;
+  BlAux a;
+  v.dT = v.den0 = v.vkvz = v.avk = 0.0;
+  x.PSIM = x.PSIH = x.BLCond = 0.0;
+  a.AirDens = a.AirHCap = a.PsychC = a.WatDen = 0.0;
+  bool need = false;
+  if (active) {
+    fluxes_pre(c, mt, s, tair, vz, rhz, prec_ts, phase, hour, fx);
+    bl_setup(c, s.tsurf, tair, vz, v, x, a);
+    bool done = false;
+#pragma unroll
+    for (int j = 1; j <= 5; ++j) done = bl_iteration(c, mt, v, x, j);
+    need = !done && RS_BL_MAXIT > 5;
+  }
+  const int par = k & 1;
+  /* slots: one LDS atomic per wavefront */
+  const unsigned long long m = __ballot(need);
+  int slot = 0;
+  if (m) {
+    const unsigned wl = __lane_id();
+    const int pre = __popcll(m & ((1ull << wl) - 1ull));
+    int base = 0;
+    if (need && pre == 0) base = atomicAdd(&sh.count[par], __popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (need) {
+      slot = base + pre;
+      sh.item[0][slot] = v.dT;
+      sh.item[1][slot] = v.den0;
+      sh.item[2][slot] = v.vkvz;
+      sh.item[3][slot] = v.avk;
+      sh.item[4][slot] = x.PSIM;
+      sh.item[5][slot] = x.PSIH;
+      sh.item[6][slot] = x.BLCond;
+    }
+  }
+  __syncthreads();
+  const int n = sh.count[par];
+  if (threadIdx.x == 0) sh.count[par ^ 1] = 0; /* nobody touches it between these barriers */
+  /* the worker wavefront rotates over workgroups and time so that the four SIMDs of a CU
+   * share the tails (wave w of every resident workgroup sits on SIMD w) */
+  const int w = (int)((threadIdx.x - 64u * ((blockIdx.x + (unsigned)k) & 3u)) & (kBlock - 1));
+  if (w < n) {
+    BlInv wv;
+    BlVar wx;
+    wv.dT = sh.item[0][w];
+    wv.den0 = sh.item[1][w];
+    wv.vkvz = sh.item[2][w];
+    wv.avk = sh.item[3][w];
+    wx.PSIM = sh.item[4][w];
+    wx.PSIH = sh.item[5][w];
+    wx.BLCond = sh.item[6][w];
+    for (int j = 6; j <= RS_BL_MAXIT; ++j)
+      if (bl_iteration(c, mt, wv, wx, j)) break;
+    sh.res[0][w] = wx.PSIM;
+    sh.res[1][w] = wx.PSIH;
+    sh.res[2][w] = wx.BLCond;
+  }
+  __syncthreads();
+  if (need) {
+    x.PSIM = sh.res[0][slot];
+    x.PSIH = sh.res[1][slot];
+    x.BLCond = sh.res[2][slot];
+  }
+  if (active) {
+    fx.blcond = x.BLCond;
+    bl_finish(c, mt, a, x, s.tsurf, tair, vz, rhz, s.wat, fx.le, fx.evap);
+    fluxes_post(c, s, sw, lw, CouplingInputs(), fx);
+  }
+  return fx;
+}
+
+/* time_loop with the boundary-layer tail compacted over the workgroup.  Same statements as
+ * time_loop; what differs is that every thread of the workgroup stays in the loop (lanes
+ * without a point, or whose point has failed, are predicated off instead of leaving), because
+ * the barriers in fluxes_block_tail need all of them. */
+template <bool FULL, class Prof>
+__device__ __forceinline__ void time_loop_bt(const MathTab &mt, Prof &T, Scalars &s,
+                                             BlTailShared &sh, bool valid) {
+  KernArgs ka = kernargs();
+  const uint32_t lane = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * kBlock;
+  const int32_t nsteps = ka->nsteps, t0 = ka->t0;
+  double tbot = 0.0;
+  int32_t initlen = 0;
+  bool relax = false;
+  double tairR = 0, vzR = 0, rhR = 0;
+  Forcing nxt;
+  nxt.tair = nxt.tdew = nxt.vz = nxt.rhz = nxt.prec = nxt.sw = nxt.lw = 0.0;
+  nxt.tsurfobs = nxt.depth = R4(-9999.9);
+  nxt.phase = nxt.hour = 0;
+  if (valid) {
+    tbot = (ka->pp.tbottom + row0)[lane];
+    if (FULL) {
+      initlen = ka->pp.initlen ? (ka->pp.initlen + row0)[lane] : 0;
+      if (g_consts[ka->cslot].use_relaxation && ka->pp.tair_relax) {
+        /* setInputParam, src/InputOutput.f90:19-26: targets pass through REAL(4) */
+        tairR = (double)(float)(ka->pp.tair_relax + row0)[lane];
+        vzR = (double)(float)(ka->pp.vz_relax + row0)[lane];
+        rhR = (double)(float)(ka->pp.rh_relax + row0)[lane];
+        relax = !(tairR < R4(-100.0) || tairR > R4(100.0) || vzR < R4(0.0) || vzR > R4(100.0) ||
+                  rhR < R4(0.0) || rhR > 110);
+      }
+    }
+    nxt = load_forcing<FULL>(ka, row0, lane, 0);
+  }
+  for (int32_t k = 0; k < nsteps; ++k) {
+    asm volatile("" : "+s"(ka));
+    const RsConstants &c = g_consts[ka->cslot];
+    const int32_t i = t0 + k;
+    const Forcing f = nxt;
+    /* a failed point has left the loop in the reference: its outputs stay -9999.0 */
+    const bool active = valid && !s.failed;
+    double tair = f.tair, vz = f.vz, rhz = f.rhz;
+    double prec_ts = 0.0;
+    if (active) {
+      /* src/Initialization.f90:121-123: VZ(1) is raised to 0.4 in the input array */
+      if (i == 1 && vz < R4(0.4)) vz = R4(0.4);
+      prec_ts = rs_div(f.prec, 3600.0) * c.DTSecs; /* src/InputOutput.f90:111,186 */
+      if (i < c.SimLen) {
+        Forcing chk = f;
+        chk.vz = vz;
+        if (check_values(chk, s.tsurf, FULL && ka->f.tdew != nullptr)) s.failed = true;
+        if (FULL) {
+          /* SetCurrentValues obs forcing, src/InputOutput.f90:116-148 */
+          if ((i <= initlen || c.force_tsurf) && f.tsurfobs > R4(-100.0)) {
+            T.set(1, f.tsurfobs);
+            T.set(2, f.tsurfobs);
+            const double depth = (c.tsurfOutputDepth >= R4(0.0)) ? c.tsurfOutputDepth : f.depth;
+            s.tsurf = surface_temperature(c, T, tbot, depth);
+          }
+          /* RelaxationOperations, src/Relaxation.f90:10-47 */
+          if (relax) {
+            if (i == initlen) {
+              s.tair_end = tair;
+              s.vz_end = vz;
+              s.rh_end = rhz;
+            }
+            if (i > initlen) {
+              const double den = (double)(4.f * 3600.f);
+              const double e = rs_exp(mt, rs_div(-((c.DTSecs * i) - (c.DTSecs * initlen)), den));
+              tair = tair - (tairR - s.tair_end) * e;
+              vz = vz - (vzR - s.vz_end) * e;
+              rhz = rhz - (rhR - s.rh_end) * e;
+              if (rhz > R4(100.)) rhz = R4(100.0);
+            }
+          }
+        }
+      } else {
+        /* lastValues, src/InputOutput.f90:169-198 */
+        if (FULL) s.tsurf = surface_temperature(c, T, tbot, f.depth);
+      }
+      if (!FULL) { /* TmpNw(1:2) == Tmp(1:2) whenever observation forcing cannot act */
+        s.tnw1 = T.get(1);
+        s.tnw2 = T.get(2);
+      }
+    }
+    const Fluxes fx = fluxes_block_tail(c, mt, s, active, tair, vz, rhz, prec_ts, f.sw, f.lw,
+                                        f.phase, f.hour, sh, k);
+    if (valid && k + 1 < nsteps) nxt = load_forcing<FULL>(ka, row0, lane, k + 1);
+    if (active) {
+      model_step_ground(c, s, T, tbot, tair, fx, f.depth);
+      store_outputs(ka, i, row0, lane, s, true);
+    } else if (valid) {
+      store_outputs(ka, i, row0, lane, s, false);
+    }
+  }
+}
+
 /* ---- coupling: src/Coupling.f90 -------------------------------------------------
  * Per-point state machine that re-runs the point's coupling window with a scaled
  * short- or long-wave input until the simulated surface temperature at the end of
@@ -609,6 +805,31 @@ __global__ void __launch_bounds__(kBlock, WPE) step_kernel_reg(const StepArgs a)
   store_state<FULL>(a.state, a.np_pad, p, T, s);
 }
 
+/* Register profile + block-level tail compaction (the default for NLayers = 15). */
+template <int NL, bool FULL>
+__global__ void __launch_bounds__(kBlock, 4) step_kernel_bt(const StepArgs a) {
+  __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
+  __shared__ BlTailShared sh;
+  const MathTab mt = fill_math_tables(math_lds);
+  if (threadIdx.x < 2) sh.count[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool valid = p < a.npoints; /* no early exit: the time loop has workgroup barriers */
+  RegProfile<NL> T;
+  Scalars s;
+  if (valid) {
+    load_state<FULL>(a.state, a.np_pad, p, T, s);
+  } else {
+#pragma unroll
+    for (int j = 1; j <= NL; ++j) T.set(j, 0.0);
+    s.tnw1 = s.tnw2 = s.tsurf = s.wat = s.snow = s.ice = s.ice2 = s.dep = 0.0;
+    s.q2melt = s.t4melt = s.albedo = s.tair_end = s.vz_end = s.rh_end = 0.0;
+    s.verycold = s.failed = false;
+  }
+  time_loop_bt<FULL>(mt, T, s, sh, valid);
+  if (valid) store_state<FULL>(a.state, a.np_pad, p, T, s);
+}
+
 template <bool FULL, int WPE>
 __global__ void __launch_bounds__(kBlock, WPE) step_kernel_lds(const StepArgs a) {
   extern __shared__ double lds[]; /* [NLayers][kBlock] */
@@ -890,7 +1111,13 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
   int wpe = variant / 10;
   variant %= 10;
   if (variant == RS_VARIANT_AUTO) variant = (NL == 15) ? RS_VARIANT_REG : RS_VARIANT_LDS;
-  if (variant == RS_VARIANT_REG) {
+  if (variant == RS_VARIANT_BT) {
+    if (NL != 15) return hipErrorInvalidValue;
+    if (full)
+      hipLaunchKernelGGL((rs::step_kernel_bt<15, true>), g, b, 0, stream, a);
+    else
+      hipLaunchKernelGGL((rs::step_kernel_bt<15, false>), g, b, 0, stream, a);
+  } else if (variant == RS_VARIANT_REG) {
     if (NL != 15) return hipErrorInvalidValue;
     if (wpe == 0) wpe = 4;
 #define RS_REG(W)                                                                        \
