@@ -248,7 +248,8 @@ def main() -> None:
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
-                                  "per launch of 2.4e8 units)" if traffic else None,
+                                  "mean per launch, averaged over the launches of a pass like "
+                                  "avg_launch_ms)" if traffic else None,
                 "valu": valu,
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "launches": nlaunch,

@@ -294,8 +294,9 @@ __device__ __forceinline__ Fluxes fluxes_block_tail(const RsConstants &c, const 
     fluxes_pre(c, mt, s, tair, vz, rhz, prec_ts, phase, hour, fx);
     bl_setup(c, s.tsurf, tair, vz, v, x, a);
     bool done = false;
+    const double stab_num = bl_stab_num(c);
 #pragma unroll
-    for (int j = 1; j <= 5; ++j) done = bl_iteration(c, mt, v, x, j);
+    for (int j = 1; j <= 5; ++j) done = bl_iteration(c, mt, v, x, j, stab_num);
     need = !done && RS_BL_MAXIT > 5;
   }
   const int par = k & 1;
@@ -335,8 +336,9 @@ __device__ __forceinline__ Fluxes fluxes_block_tail(const RsConstants &c, const 
     wx.PSIM = sh.item[4][w];
     wx.PSIH = sh.item[5][w];
     wx.BLCond = sh.item[6][w];
+    const double stab_num = bl_stab_num(c);
     for (int j = 6; j <= RS_BL_MAXIT; ++j)
-      if (bl_iteration(c, mt, wv, wx, j)) break;
+      if (bl_iteration(c, mt, wv, wx, j, stab_num)) break;
     sh.res[0][w] = wx.PSIM;
     sh.res[1][w] = wx.PSIH;
     sh.res[2][w] = wx.BLCond;
