@@ -378,7 +378,8 @@ int rs_hip_set_precision(RsPlan *plan, int32_t bits);
 int rs_hip_division_mode(void);
 int64_t rs_hip_div_mismatch_count(RsPlan *plan);
 
-/* Kernel flavour: 0 auto (1 when NLayers == 15, else 2), 1 register profile, 2 LDS profile,
+/* Kernel flavour: 0 auto (1 for the LEAN feature set with NLayers == 15, else 2), 1 register
+ * profile, 2 LDS profile,
  * 3 register profile with the boundary-layer iteration tail compacted over the workgroup
  * (an experiment that executes 12 % fewer instructions and is slower: DESIGN.md 3.1).
  * All flavours return the same bits. */

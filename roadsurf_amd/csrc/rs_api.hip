@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -165,6 +166,12 @@ RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints, const RsConstants *c
   pl->np_pad = (npoints + RS_BLOCK - 1) / RS_BLOCK * RS_BLOCK;
   pl->c = *consts;
   pl->stream = (hipStream_t)stream;
+  if (const char *ev = getenv("ROADSURF_HIP_VARIANT")) { /* tuning: default flavour of new plans */
+    const int v = atoi(ev);
+    if (v >= 0 && v % 10 <= 3 && v / 10 <= 4 &&
+        !((v % 10 == RS_VARIANT_REG || v % 10 == RS_VARIANT_BT) && consts->NLayers != 15))
+      pl->variant = v;
+  }
   const size_t bytes = (size_t)RS_NSTATE * pl->np_pad * sizeof(double);
   if (hipMalloc(&pl->state, bytes) != hipSuccess ||
       hipMalloc(&pl->counter, sizeof(unsigned long long)) != hipSuccess) {
