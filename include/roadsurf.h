@@ -434,7 +434,7 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers,
  *   save_output          every (outputStep*60/DTSecs)-th index (roadrunner.cpp:285-315)
  * Out of scope: JSON/text parsing and writing (host work, roadsurf_amd/driver.py has a
  * reader/writer for the reference's schema).
- * Restriction: all points of one source share that source's raw time axis.
+ * A source's points either share one raw time axis or have one each (RsRawSource).
  * ---------------------------------------------------------------------- */
 #define RS_MAX_SOURCES 4
 
@@ -442,12 +442,18 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers,
  * [n_points][n_times] row-major (one contiguous series per point, as the reference's
  * InputData holds them); NULL = the variable is absent from this source (all missing,
  * -9999.9).  PrecipitationForm is not listed: the reference reads it but never hands it
- * on (JsonSource.cpp:323-373 does not copy PrecPhase). */
+ * on (JsonSource.cpp:323-373 does not copy PrecPhase).
+ * Time axis: either one axis shared by all points (times[n_times], lengths NULL: gridded NWP
+ * data), or one per point like the reference's per-station "time" arrays
+ * (times_per_point = 1: times[n_points][n_times], and lengths[n_points] gives how many leading
+ * entries of a point's row are real: rows are padded to the common width n_times). */
 typedef struct RsRawSource {
-  int32_t n_times;
+  int32_t n_times;          /* row width of every array below */
   int32_t is_observation;   /* DataHandler.cpp:65-66: counts for GetLatestObsIndex */
-  const int64_t *times;     /* [n_times] epoch seconds */
+  const int64_t *times;     /* epoch seconds, strictly increasing within a series */
   const double *tair, *rhz, *tdew, *vz, *prec, *lw_net, *lw, *sw, *sw_dir, *tsurfobs;
+  int32_t times_per_point;  /* 0 shared axis, 1 per-point axes */
+  const int32_t *lengths;   /* per-point series lengths (times_per_point = 1), or NULL = n_times */
 } RsRawSource;
 
 typedef struct RsDriverInput {

@@ -152,12 +152,15 @@ static int read_input_point(int nsrc, const RsRawSource *src, int64_t p, const I
     /* JsonSource.cpp:226-311 for this point */
     Series ip, raw;
     if (series_init(&ip, L)) return -1;
-    const int dataLen = src[s].n_times;
+    /* this point's series: its own "time" array or the source's shared one */
+    const int width = src[s].n_times;
+    const int dataLen = (src[s].times_per_point && src[s].lengths) ? src[s].lengths[p] : width;
+    const int64_t *rawtime = src[s].times_per_point ? src[s].times + (size_t)p * width : src[s].times;
     if (dataLen > 0) {
       if (series_init(&raw, dataLen)) return -1;
       for (int f = 0; f < NF; ++f) {
         const double *h = raw_field(&src[s], f);
-        if (h) memcpy(raw.v[f], h + (size_t)p * dataLen, sizeof(double) * (size_t)dataLen);
+        if (h) memcpy(raw.v[f], h + (size_t)p * width, sizeof(double) * (size_t)dataLen);
       }
       for (int i = 0; i < dataLen; ++i) { /* JsonSource.cpp:288-295 */
         if (raw.v[R_TDEW][i] < -100 && raw.v[R_RHZ][i] > -100 && raw.v[R_TAIR][i] > -100)
@@ -165,7 +168,7 @@ static int read_input_point(int nsrc, const RsRawSource *src, int64_t p, const I
         if (raw.v[R_RHZ][i] < -100 && raw.v[R_TDEW][i] > -100 && raw.v[R_TAIR][i] > -100)
           raw.v[R_RHZ][i] = oracle_calc_tdew_or_rh(raw.v[R_TAIR][i], raw.v[R_TDEW][i], -9999.9);
       }
-      interpolate(&raw, &ip, src[s].times, dataLen, simtime, L);
+      interpolate(&raw, &ip, rawtime, dataLen, simtime, L);
       series_free(&raw);
     }
     /* JsonSource::Impl::GetWeather, JsonSource.cpp:337-356 */

@@ -61,7 +61,11 @@ struct PlanStep {
 
 struct SrcDev {
   const double *fld[NFLD]; /* [n_times][np_pad], nullptr = variable absent */
-  const PlanStep *plan;    /* [SimLen] */
+  const PlanStep *plan;    /* [SimLen]; shared time axis only */
+  /* per-point time axes (RsRawSource.times_per_point): the walk runs per lane */
+  const int64_t *ptimes;   /* [n_times][np_pad] or nullptr */
+  const int32_t *plen;     /* [np_pad] series lengths */
+  int32_t *prp;            /* [np_pad] rawPos of the walk at the start of the current window */
   int32_t n_times;
   int32_t is_obs;
 };
@@ -72,6 +76,8 @@ struct SrcSet {
   int32_t simlen;
   int64_t np_pad;
   int64_t npoints;
+  int64_t sim0; /* simulation index i is at sim0 + i*dt seconds (JsonSource.cpp:199-205) */
+  int32_t dt;
 };
 
 /* examples/example1/src/InputData.cpp:5-26: every series starts out missing */
@@ -94,18 +100,94 @@ __device__ __forceinline__ bool source_value(const PlanStep &st, double a, doubl
   return v > thr;
 }
 
+/* ---- per-point time axes: JsonSource::interpolate's walk (JsonSource.cpp:57-85,113-114,171)
+ * evaluated per lane instead of once per source on the host.  State of the walk = rawPos. */
+constexpr int32_t PP_DEAD = 0x3fffffff; /* the while loop can never run (again) for this series */
+
+/* rawPos before the first simulation index (JsonSource.cpp:60-82) */
+__device__ __forceinline__ int32_t pp_initial(const SrcDev &sd, int64_t np_pad, int64_t p,
+                                              int64_t sim0) {
+  const int32_t len = sd.plen[p];
+  if (len <= 0) return PP_DEAD; /* JsonSource.cpp:233-237 */
+  if (sd.ptimes[p] < sim0) {
+    int32_t k = 0;
+    for (; k < len; ++k)
+      if (sd.ptimes[(int64_t)k * np_pad + p] >= sim0) break;
+    return k - 1;
+  }
+  return 0;
+}
+
+struct PpWalk {
+  int32_t rp, len, cached; /* cached: the rawPos tr/tr1 belong to, -1 none */
+  int64_t tr, tr1;
+};
+
+__device__ __forceinline__ void pp_begin(PpWalk &w, const SrcDev &sd, int64_t p, int32_t rp0) {
+  w.rp = rp0;
+  w.len = sd.plen[p];
+  w.cached = -1;
+  w.tr = w.tr1 = 0;
+}
+
+/* One pass of the reference's while loop for simulation time ts: what happens to this index. */
+__device__ __forceinline__ PlanStep pp_step(PpWalk &w, const SrcDev &sd, int64_t np_pad, int64_t p,
+                                            int64_t ts) {
+  PlanStep st;
+  st.kind = K_NONE;
+  st.rp = 0;
+  st.num = 0.0;
+  st.den = 1.0;
+  if (w.rp + 1 >= w.len) return st; /* `while (rawPos+1 < rawLen ...)` is over */
+  if (w.cached != w.rp) {
+    w.tr = sd.ptimes[(int64_t)w.rp * np_pad + p];
+    w.tr1 = sd.ptimes[(int64_t)(w.rp + 1) * np_pad + p];
+    w.cached = w.rp;
+  }
+  if (ts < w.tr) return st; /* simulation starts before the data: the walk has not begun */
+  if (ts == w.tr) {
+    st.kind = K_COPY;
+    st.rp = w.rp;
+  } else if (ts == w.tr1) {
+    /* rawPos++ and the loop condition is tested again for the same simulation index */
+    w.rp += 1;
+    if (w.rp + 1 >= w.len) {
+      w.rp = PP_DEAD;
+      return st;
+    }
+    w.tr = w.tr1;
+    w.tr1 = sd.ptimes[(int64_t)(w.rp + 1) * np_pad + p];
+    w.cached = w.rp;
+    st.kind = K_COPY;
+    st.rp = w.rp;
+  } else {
+    st.kind = K_INTERP;
+    st.rp = w.rp;
+    st.num = (double)(ts - w.tr);
+    st.den = (double)(w.tr1 - w.tr);
+  }
+  return st;
+}
+
 /* Sequential pass over simulation indices [i0, i1) of one variable of one point.
- * visit(i, merged value, bitmask of the sources that supplied a value). */
+ * visit(i, merged value, bitmask of the sources that supplied a value).
+ * rp0[s]: rawPos at i0 for sources with per-point time axes. */
 template <class Visit>
 __device__ __forceinline__ void walk_field(const SrcSet &S, int fld, int64_t p, int32_t i0,
-                                           int32_t i1, Visit &&visit) {
+                                           int32_t i1, const int32_t *rp0, Visit &&visit) {
   const double thr = threshold(fld);
   double a[RS_MAX_SOURCES], b[RS_MAX_SOURCES];
   int32_t cur[RS_MAX_SOURCES];
+  PpWalk pw[RS_MAX_SOURCES];
 #pragma unroll
   for (int s = 0; s < RS_MAX_SOURCES; ++s) {
     a[s] = b[s] = 0.0;
     cur[s] = -2;
+    pw[s].rp = PP_DEAD;
+    pw[s].len = 0;
+    pw[s].cached = -1;
+    pw[s].tr = pw[s].tr1 = 0;
+    if (s < S.nsrc && S.src[s].ptimes) pp_begin(pw[s], S.src[s], p, rp0[s]);
   }
   for (int32_t i = i0; i < i1; ++i) {
     double v = miss_r();
@@ -114,9 +196,15 @@ __device__ __forceinline__ void walk_field(const SrcSet &S, int fld, int64_t p, 
     for (int s = 0; s < RS_MAX_SOURCES; ++s) {
       if (s >= S.nsrc) continue;
       const double *x = S.src[s].fld[fld];
-      if (!x) continue;
-      const PlanStep st = S.src[s].plan[i]; /* uniform: scalar loads */
-      if (st.kind == K_NONE) continue;
+      PlanStep st;
+      if (S.src[s].ptimes) {
+        /* the walk advances whether or not this source has the variable */
+        st = pp_step(pw[s], S.src[s], S.np_pad, p, S.sim0 + (int64_t)i * S.dt);
+      } else {
+        if (!x) continue;
+        st = S.src[s].plan[i]; /* uniform: scalar loads */
+      }
+      if (!x || st.kind == K_NONE) continue;
       if (st.rp != cur[s]) {
         a[s] = x[(int64_t)st.rp * S.np_pad + p];
         b[s] = x[(int64_t)(st.rp + 1) * S.np_pad + p];
@@ -132,6 +220,13 @@ __device__ __forceinline__ void walk_field(const SrcSet &S, int fld, int64_t p, 
   }
 }
 
+/* rawPos at simulation index 0 of every per-point source */
+__device__ __forceinline__ void initial_positions(const SrcSet &S, int64_t p, int32_t *rp0) {
+#pragma unroll
+  for (int s = 0; s < RS_MAX_SOURCES; ++s)
+    rp0[s] = (s < S.nsrc && S.src[s].ptimes) ? pp_initial(S.src[s], S.np_pad, p, S.sim0) : 0;
+}
+
 /* Random access to the merged value (used for the relaxation targets). */
 __device__ __forceinline__ double merged_at(const SrcSet &S, int fld, int64_t p, int32_t i) {
   const double thr = threshold(fld);
@@ -139,7 +234,15 @@ __device__ __forceinline__ double merged_at(const SrcSet &S, int fld, int64_t p,
   for (int s = 0; s < S.nsrc; ++s) {
     const double *x = S.src[s].fld[fld];
     if (!x) continue;
-    const PlanStep st = S.src[s].plan[i];
+    PlanStep st;
+    if (S.src[s].ptimes) { /* replay the walk up to i */
+      PpWalk w;
+      pp_begin(w, S.src[s], p, pp_initial(S.src[s], S.np_pad, p, S.sim0));
+      st.kind = K_NONE;
+      for (int32_t k = 0; k <= i; ++k) st = pp_step(w, S.src[s], S.np_pad, p, S.sim0 + (int64_t)k * S.dt);
+    } else {
+      st = S.src[s].plan[i];
+    }
     if (st.kind == K_NONE) continue;
     const double a = x[(int64_t)st.rp * S.np_pad + p], b = x[(int64_t)(st.rp + 1) * S.np_pad + p];
     double vs;
@@ -164,6 +267,8 @@ __global__ void __launch_bounds__(RS_BLOCK) scan_raw_kernel(const ScanArgs A) {
   if (p >= A.S.npoints) return;
   const int y = blockIdx.y;
   const int L = A.S.simlen;
+  int32_t rp0[RS_MAX_SOURCES];
+  initial_positions(A.S, p, rp0);
   if (y < 6) {
     const int fld = (y == 0) ? R_TAIR : (y == 1) ? R_RHZ : (y == 2) ? R_PREC : (y == 3) ? R_SW
                   : (y == 4) ? R_LW : R_VZ;
@@ -171,7 +276,7 @@ __global__ void __launch_bounds__(RS_BLOCK) scan_raw_kernel(const ScanArgs A) {
     for (int s = 0; s < A.S.nsrc; ++s)
       if (A.S.src[s].is_obs) obsmask |= 1u << s;
     int32_t first = L, last = -1;
-    walk_field(A.S, fld, p, 0, L, [&](int32_t i, double v, uint32_t mask) {
+    walk_field(A.S, fld, p, 0, L, rp0, [&](int32_t i, double v, uint32_t mask) {
       if (first == L && is_missing(v)) first = i;
       /* JsonSource.cpp:412-416: `for i = SimLen..1: if tair[i-1] > -100 return i`, on the
        * source's OWN interpolated series; DataHandler.cpp:118-137 takes the max over the
@@ -184,7 +289,7 @@ __global__ void __launch_bounds__(RS_BLOCK) scan_raw_kernel(const ScanArgs A) {
     int32_t ci = -1;
     double ct = miss_r();
     /* roadrunner.cpp:256-261: last index whose TSurfObs is neither missing nor < -100 */
-    walk_field(A.S, R_OBS, p, 0, L, [&](int32_t i, double v, uint32_t) {
+    walk_field(A.S, R_OBS, p, 0, L, rp0, [&](int32_t i, double v, uint32_t) {
       if (!(is_missing(v) || v < -100)) {
         ci = i;
         ct = v;
@@ -287,7 +392,11 @@ __global__ void __launch_bounds__(RS_BLOCK) expand_raw_kernel(const ExpandRawArg
   }
   const int32_t i0 = A.i0;
   const int64_t stride = A.stride;
-  walk_field(A.S, fld, p, i0, i0 + A.nsteps, [&](int32_t i, double v, uint32_t) {
+  int32_t rp0[RS_MAX_SOURCES];
+#pragma unroll
+  for (int s = 0; s < RS_MAX_SOURCES; ++s)
+    rp0[s] = (s < A.S.nsrc && A.S.src[s].ptimes) ? A.S.src[s].prp[p] : 0;
+  walk_field(A.S, fld, p, i0, i0 + A.nsteps, rp0, [&](int32_t i, double v, uint32_t) {
     if (rejected) v = miss_r();
     if (i > clr_lo && i <= clr_hi) v = miss_r();
     out[(int64_t)(i - i0) * stride] = v;
@@ -305,6 +414,28 @@ __global__ void __launch_bounds__(RS_BLOCK) blank_rejected_kernel(double *out, i
   if (p >= npoints || status[p] == 0) return;
   for (int f = 0; f < 6; ++f)
     for (int32_t r = 0; r < nrows; ++r) out[((int64_t)f * nrows + r) * stride + p] = -9999.0;
+}
+
+/* Per-point walks: position at simulation index 0 ... */
+__global__ void __launch_bounds__(RS_BLOCK) pp_init_kernel(const SrcSet S) {
+  const int64_t p = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
+  if (p >= S.npoints) return;
+  for (int s = 0; s < S.nsrc; ++s)
+    if (S.src[s].ptimes) S.src[s].prp[p] = pp_initial(S.src[s], S.np_pad, p, S.sim0);
+}
+/* ... and moved past the window [i0, i0+nsteps) that has just been expanded. */
+__global__ void __launch_bounds__(RS_BLOCK) pp_advance_kernel(const SrcSet S, int32_t i0,
+                                                              int32_t nsteps) {
+  const int64_t p = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
+  if (p >= S.npoints) return;
+  for (int s = 0; s < S.nsrc; ++s) {
+    if (!S.src[s].ptimes) continue;
+    PpWalk w;
+    pp_begin(w, S.src[s], p, S.src[s].prp[p]);
+    for (int32_t i = i0; i < i0 + nsteps; ++i)
+      (void)pp_step(w, S.src[s], S.np_pad, p, S.sim0 + (int64_t)i * S.dt);
+    S.src[s].prp[p] = w.rp;
+  }
 }
 
 __global__ void __launch_bounds__(RS_BLOCK) fill_i32_kernel(int32_t *x, int64_t n, int32_t v) {
@@ -411,7 +542,16 @@ int prepare(const RsDriverInput *in, const InputSettings *st, Common &c) {
     const RsRawSource &rs = in->sources[s];
     if (rs.n_times < 0 || (rs.n_times > 0 && !rs.times))
       return fail_msg("rs_driver: source without a time axis", -1);
-    build_plan(rs.times, rs.n_times, c.simtime, c.plans[s]);
+    if (rs.times_per_point) {
+      if (rs.lengths)
+        for (int p = 0; p < c.n; ++p)
+          if (rs.lengths[p] < 0 || rs.lengths[p] > rs.n_times)
+            return fail_msg("rs_driver: lengths[p] outside 0..n_times", -1);
+      c.plans[s].assign(c.L, PlanStep{K_NONE, 0, 0.0, 1.0}); /* unused: the walk runs on the device */
+    } else {
+      if (rs.lengths) return fail_msg("rs_driver: lengths given without times_per_point", -1);
+      build_plan(rs.times, rs.n_times, c.simtime, c.plans[s]);
+    }
   }
   return 0;
 }
@@ -419,7 +559,9 @@ int prepare(const RsDriverInput *in, const InputSettings *st, Common &c) {
 /* Device copies of one tile's raw data + plans. */
 struct TileRaw {
   Dev plan[RS_MAX_SOURCES];
+  Dev ptimes[RS_MAX_SOURCES], plen[RS_MAX_SOURCES], prp[RS_MAX_SOURCES];
   Dev fld[RS_MAX_SOURCES][NFLD];
+  bool any_pp = false;
   Dev stage; /* [m][n_times] landing buffer for the H2D copy */
   SrcSet S{};
 };
@@ -430,6 +572,8 @@ int upload_tile(const RsDriverInput *in, const Common &c, int64_t p0, int m, int
   T.S.simlen = c.L;
   T.S.np_pad = mp;
   T.S.npoints = m;
+  T.S.sim0 = in->start_time;
+  T.S.dt = c.DT;
   int maxnt = 1;
   for (int s = 0; s < c.nsrc; ++s) maxnt = std::max(maxnt, in->sources[s].n_times);
   HOK(T.stage.alloc((size_t)m * maxnt * sizeof(double)));
@@ -438,10 +582,38 @@ int upload_tile(const RsDriverInput *in, const Common &c, int64_t p0, int m, int
     SrcDev &d = T.S.src[s];
     d.n_times = rs.n_times;
     d.is_obs = rs.is_observation;
-    HOK(T.plan[s].alloc((size_t)c.L * sizeof(PlanStep)));
-    HOK(hipMemcpyAsync(T.plan[s].p, c.plans[s].data(), (size_t)c.L * sizeof(PlanStep),
-                       hipMemcpyHostToDevice, stream));
-    d.plan = T.plan[s].as<PlanStep>();
+    d.plan = nullptr;
+    d.ptimes = nullptr;
+    d.plen = nullptr;
+    d.prp = nullptr;
+    if (rs.times_per_point && rs.n_times > 0) {
+      /* per-point axes: times [m][n_times] -> [n_times][mp], lengths, walk positions */
+      HOK(T.ptimes[s].alloc((size_t)rs.n_times * mp * sizeof(int64_t)));
+      HOK(hipMemcpyAsync(T.stage.p, rs.times + (size_t)p0 * rs.n_times,
+                         (size_t)m * rs.n_times * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+      HOK(transpose((const int64_t *)T.stage.p, T.ptimes[s].as<int64_t>(), m, rs.n_times, rs.n_times,
+                    mp, stream));
+      HOK(T.plen[s].alloc(mp * sizeof(int32_t)));
+      if (rs.lengths) {
+        HOK(hipMemsetAsync(T.plen[s].p, 0, mp * sizeof(int32_t), stream));
+        HOK(hipMemcpyAsync(T.plen[s].p, rs.lengths + p0, (size_t)m * sizeof(int32_t),
+                           hipMemcpyHostToDevice, stream));
+      } else {
+        hipLaunchKernelGGL(fill_i32_kernel, grid1(mp), dim3(RS_BLOCK), 0, stream,
+                           T.plen[s].as<int32_t>(), mp, (int32_t)rs.n_times);
+        HOK(hipGetLastError());
+      }
+      HOK(T.prp[s].alloc(mp * sizeof(int32_t)));
+      d.ptimes = T.ptimes[s].as<int64_t>();
+      d.plen = T.plen[s].as<int32_t>();
+      d.prp = T.prp[s].as<int32_t>();
+      T.any_pp = true;
+    } else {
+      HOK(T.plan[s].alloc((size_t)c.L * sizeof(PlanStep)));
+      HOK(hipMemcpyAsync(T.plan[s].p, c.plans[s].data(), (size_t)c.L * sizeof(PlanStep),
+                         hipMemcpyHostToDevice, stream));
+      d.plan = T.plan[s].as<PlanStep>();
+    }
     for (int f = 0; f < NFLD; ++f) {
       const double *h = raw_field(rs, f);
       d.fld[f] = nullptr;
@@ -467,6 +639,10 @@ int upload_tile(const RsDriverInput *in, const Common &c, int64_t p0, int m, int
       HOK(rs_launch_humidity_fill(d.fld[R_TAIR], const_cast<double *>(d.fld[R_TDEW]),
                                   const_cast<double *>(d.fld[R_RHZ]), (int64_t)rs.n_times * mp,
                                   stream));
+  }
+  if (T.any_pp) {
+    hipLaunchKernelGGL(pp_init_kernel, grid1(mp), dim3(RS_BLOCK), 0, stream, T.S);
+    HOK(hipGetLastError());
   }
   return 0;
 }
@@ -901,6 +1077,11 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputP
       hipLaunchKernelGGL(expand_raw_kernel, dim3((unsigned)(mp / RS_BLOCK), NFLD), dim3(RS_BLOCK), 0,
                          stream, ea);
       HOK(hipGetLastError());
+      if (T.any_pp && t0 + len <= L) { /* per-point walks: move to the start of the next window */
+        hipLaunchKernelGGL(pp_advance_kernel, grid1(mp), dim3(RS_BLOCK), 0, stream, T.S,
+                           (int32_t)(t0 - 1), (int32_t)len);
+        HOK(hipGetLastError());
+      }
       RsForcing fo;
       std::memset(&fo, 0, sizeof(fo));
       fo.tair = ea.out[R_TAIR]; fo.tdew = ea.out[R_TDEW]; fo.vz = ea.out[R_VZ];

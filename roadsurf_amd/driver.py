@@ -42,7 +42,7 @@ c_int64_p = C.POINTER(C.c_int64)
 class RsRawSource(C.Structure):
     _fields_ = [("n_times", C.c_int32), ("is_observation", C.c_int32), ("times", c_int64_p)] + [
         (n, abi.c_double_p) for n in RAW_FIELDS
-    ]
+    ] + [("times_per_point", C.c_int32), ("lengths", abi.c_int32_p)]
 
 
 class RsDriverInput(C.Structure):
@@ -60,11 +60,14 @@ class RsDriverOutput(C.Structure):
 
 @dataclasses.dataclass
 class RawSource:
-    """One data source: ``times`` [n_times] epoch seconds shared by all points, ``fields``
-    name -> [n_points][n_times] float64 (absent name = variable not in the source)."""
+    """One data source: ``fields`` name -> [n_points][n_times] float64 (absent name = variable
+    not in the source) and ``times`` epoch seconds, either [n_times] shared by all points or
+    [n_points][n_times] with one axis per point; ``lengths`` [n_points] then says how many
+    leading entries of each row are real (rows are padded to a common width)."""
     times: np.ndarray
     fields: dict
     is_observation: bool = False
+    lengths: np.ndarray | None = None
 
 
 def calendar(start_time: int, simlen: int, dtsecs: int, utc: bool = True) -> dict:
@@ -97,15 +100,30 @@ def make_input(sources, start_time: int, forecast_time: int, cal: dict | None = 
     for k, s in enumerate(sources):
         t = np.ascontiguousarray(s.times, np.int64)
         keep.append(t)
-        arr[k].n_times = t.shape[0]
+        width = t.shape[-1]
+        arr[k].n_times = width
         arr[k].is_observation = 1 if s.is_observation else 0
         arr[k].times = t.ctypes.data_as(c_int64_p)
+        arr[k].times_per_point = 1 if t.ndim == 2 else 0
+        if t.ndim == 2:
+            if n_points is None:
+                n_points = t.shape[0]
+            elif t.shape[0] != n_points:
+                raise ValueError("all sources must hold the same points")
+            if s.lengths is not None:
+                ln = np.ascontiguousarray(s.lengths, np.int32)
+                if ln.shape != (t.shape[0],) or ln.min() < 0 or ln.max() > width:
+                    raise ValueError("lengths: [n_points] values in 0..n_times")
+                keep.append(ln)
+                arr[k].lengths = ln.ctypes.data_as(abi.c_int32_p)
+        elif s.lengths is not None:
+            raise ValueError("lengths needs per-point time axes")
         for name, a in s.fields.items():
             if name not in RAW_FIELDS:
                 raise KeyError(name)
             a = np.ascontiguousarray(a, np.float64)
-            if a.ndim != 2 or a.shape[1] != t.shape[0]:
-                raise ValueError(f"{name}: expected [n_points][{t.shape[0]}], got {a.shape}")
+            if a.ndim != 2 or a.shape[1] != width:
+                raise ValueError(f"{name}: expected [n_points][{width}], got {a.shape}")
             if n_points is None:
                 n_points = a.shape[0]
             elif a.shape[0] != n_points:

@@ -96,3 +96,30 @@ def scenario(n, hours=12, seed=7, obs_hours=6, gaps=True):
         fc[names[j % 5]][p, 3 + j % 4] = -9999.9
     src = [driver.RawSource(fc_t, fc, False), driver.RawSource(ob_t, ob, True)]
     return src, L, START, START + obs_hours * 3600
+
+
+def ragged(src: driver.RawSource, seed=3, drop=0.25, pad_value=-9999.9):
+    """Per-point time axes from a shared-axis source: every point loses a random subset of its
+    time stamps (the station did not report then), rows are compacted and padded to a common
+    width, like the per-station "time" arrays of the reference's JSON input."""
+    rs = np.random.RandomState(seed)
+    t = np.asarray(src.times, np.int64)
+    n = next(iter(src.fields.values())).shape[0]
+    nt = t.shape[0]
+    keep = rs.rand(n, nt) >= drop
+    keep[:, 0] |= rs.rand(n) < 0.7          # most series keep their first stamp
+    keep[n // 3] = True                      # one complete series
+    keep[n // 2] = False                     # one empty series
+    if n > 5:
+        keep[5] = False
+        keep[5, nt // 2] = True             # one series with a single stamp
+    lengths = keep.sum(axis=1).astype(np.int32)
+    width = int(max(1, lengths.max()))
+    times = np.full((n, width), np.iinfo(np.int64).min, np.int64)
+    fields = {k: np.full((n, width), pad_value) for k in src.fields}
+    for p in range(n):
+        idx = np.nonzero(keep[p])[0]
+        times[p, :len(idx)] = t[idx]
+        for k, a in src.fields.items():
+            fields[k][p, :len(idx)] = a[p, idx]
+    return driver.RawSource(times, fields, src.is_observation, lengths)

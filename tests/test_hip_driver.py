@@ -147,3 +147,46 @@ def test_argument_errors_are_reported():
     s.NLayers = 99
     with pytest.raises(RuntimeError, match="bad settings"):
         driver.run(src, s, abi.default_parameters(), t0, tf)
+
+
+def test_per_point_time_axes_match_checker():
+    """Observation series with their own time stamps per point (ragged, padded rows)."""
+    n = 300
+    src, L, t0, tf = dh.scenario(n, hours=12, seed=31)
+    pp = [src[0], dh.ragged(src[1], seed=4)]
+    assert pp[1].times.ndim == 2 and pp[1].lengths.min() == 0 and pp[1].lengths.max() > 10
+    for kw in (dict(use_relaxation=1), dict(use_relaxation=1, use_coupling=1, coupling_minutes=60)):
+        s = _settings(L, **kw)
+        g = driver.read_input(pp, s, t0, tf)
+        o = dh.oracle_read_input(pp, s, t0, tf)
+        _compare_read_input(g, o, n)
+    # dropping stamps changes what read_input returns (gaps are bridged instead of staying gaps)
+    shared = dh.oracle_read_input(src, s, t0, tf)
+    assert not np.array_equal(shared["merged"]["tsurfobs"], o["merged"]["tsurfobs"])
+    # both sources per point, forecast too; simulation chunked so that the walks are carried on
+    both = [dh.ragged(src[0], seed=9, drop=0.1), pp[1]]
+    s = _settings(L, use_relaxation=1, outputStep=30)
+    p = abi.default_parameters()
+    o = dh.oracle_run(_kind(False), both, s, p, t0, tf)
+    g = driver.run(both, s, p, t0, tf)
+    assert np.array_equal(g["status"], o["status"]) and (o["status"] == 0).sum() > n // 4
+    assert np.array_equal(g["missing_index"], o["missing_index"])
+    for k in driver.OUT_FIELDS:
+        assert _same_bits(g[k], o[k]), k
+
+
+def test_identical_per_point_axes_equal_the_shared_axis(monkeypatch):
+    n = 200
+    src, L, t0, tf = dh.scenario(n, hours=6, seed=8, obs_hours=3)
+    tiled = [driver.RawSource(np.tile(x.times, (n, 1)), x.fields, x.is_observation) for x in src]
+    s = _settings(L, use_relaxation=1, use_coupling=1, coupling_minutes=30)
+    p = abi.default_parameters()
+    monkeypatch.setenv("ROADSURF_HIP_TILE_POINTS", "128")
+    a = driver.run(src, s, p, t0, tf)
+    b = driver.run(tiled, s, p, t0, tf)
+    for k in driver.OUT_FIELDS:
+        assert _same_bits(a[k], b[k]), k
+    assert np.array_equal(a["status"], b["status"])
+    for q in range(n):
+        for f in LP_FIELDS:
+            assert getattr(a["local"][q], f) == getattr(b["local"][q], f)
