@@ -233,13 +233,14 @@ def run(sources, settings: abi.InputSettings, params: abi.InputParameters, start
 def read_json_source(path: str, is_observation: bool = False, utc: bool = True):
     """Parse one input file of the reference's JSON schema (JsonSource.cpp:206-286): a list of
     stations ``{"statId", "lat", "lon", "time": ["%Y-%m-%d %H:%M", ...], "<variable>": [...]}``.
-    Returns (RawSource, station ids, lats, lons).  All stations must share one time axis
-    (the device path's restriction); values absent or null become -9999.9."""
+    Returns (RawSource, station ids, lats, lons).  If all stations carry the same time stamps
+    the source gets one shared axis, otherwise per-point axes (padded rows + lengths); values
+    absent or null become -9999.9."""
     import calendar as _cal
 
     with open(path) as fh:
         stations = json.load(fh)
-    ids, lats, lons, times = [], [], [], None
+    ids, lats, lons, axes = [], [], [], []
     cols = {v: [] for v in JSON_VARIABLES.values()}
     present = set()
     for st in stations:
@@ -247,12 +248,7 @@ def read_json_source(path: str, is_observation: bool = False, utc: bool = True):
         for s in st.get("time", []):
             tm = _time.strptime(s, "%Y-%m-%d %H:%M")
             tt.append(_cal.timegm(tm) if utc else int(_time.mktime(tm)))
-        tt = np.asarray(tt, np.int64)
-        if times is None:
-            times = tt
-        elif not np.array_equal(times, tt):
-            raise ValueError(f"{path}: station {st.get('statId')} has its own time axis; "
-                             "split the file into sources with one shared axis each")
+        axes.append(np.asarray(tt, np.int64))
         ids.append(int(st["statId"]))
         lats.append(float(st["lat"]))
         lons.append(float(st["lon"]))
@@ -263,8 +259,21 @@ def read_json_source(path: str, is_observation: bool = False, utc: bool = True):
             else:
                 present.add(name)
                 cols[name].append(np.asarray([-9999.9 if x is None else float(x) for x in v]))
-    fields = {k: np.stack(v) for k, v in cols.items() if k in present}
-    return RawSource(times, fields, is_observation), ids, np.asarray(lats), np.asarray(lons)
+    shared = all(np.array_equal(axes[0], a) for a in axes[1:])
+    if shared:
+        fields = {k: np.stack(v) for k, v in cols.items() if k in present}
+        src = RawSource(axes[0], fields, is_observation)
+    else:
+        lengths = np.asarray([len(a) for a in axes], np.int32)
+        width = int(max(1, lengths.max()))
+        times = np.full((len(axes), width), np.iinfo(np.int64).min, np.int64)
+        fields = {k: np.full((len(axes), width), -9999.9) for k in cols if k in present}
+        for p, a in enumerate(axes):
+            times[p, :len(a)] = a
+            for k in fields:
+                fields[k][p, :len(a)] = cols[k][p]
+        src = RawSource(times, fields, is_observation, lengths)
+    return src, ids, np.asarray(lats), np.asarray(lons)
 
 
 def save_output(path: str, result: dict, ids, lats, lons, start_time: int, dtsecs: int) -> None:

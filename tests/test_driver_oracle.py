@@ -175,10 +175,18 @@ def test_json_reader_and_writer_follow_the_reference_schema(tmp_path):
     assert set(src.fields) == {"tair", "rhz", "tdew", "vz", "tsurfobs"}   # PrecipitationForm is dropped
     assert np.array_equal(src.fields["rhz"], [[90.0, M], [M, M]])
     assert np.array_equal(src.fields["tdew"], [[M, M], [0.0, 0.5]])
-    stations[1]["time"][1] = "2024-01-10 02:00"
+    # stations with their own time stamps: per-point axes, padded rows + lengths
+    stations[1]["time"] = ["2024-01-10 00:00", "2024-01-10 02:00", "2024-01-10 03:00"]
+    stations[1]["Temperature 2m"] = [1.0, 1.5, 2.0]
+    stations[1]["DewPoint"] = [0.0, 0.5, 0.7]
+    stations[1]["WindSpeed"] = [5.0, 6.0, 7.0]
     path.write_text(json.dumps(stations))
-    with pytest.raises(ValueError, match="own time axis"):
-        driver.read_json_source(str(path))
+    pp, _, _, _ = driver.read_json_source(str(path))
+    assert pp.times.shape == (2, 3) and list(pp.lengths) == [2, 3]
+    assert list(pp.times[0, :2]) == [dh.START, dh.START + 3600] and pp.times[1, 2] == dh.START + 10800
+    assert np.array_equal(pp.fields["tair"], [[-3.0, -2.5, M], [1.0, 1.5, 2.0]])
+    inp, keep = driver.make_input([pp], 0, 0)
+    assert inp.sources[0].times_per_point == 1 and inp.sources[0].lengths[1] == 3
 
     result = {"step": 120, "status": np.array([0, 3], np.int32)}
     for k in driver.OUT_FIELDS:
