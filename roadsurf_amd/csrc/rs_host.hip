@@ -140,126 +140,204 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
   }
 
   [[maybe_unused]] const int nthreads = rsu::host_threads(omp_get_num_procs());
-  int rc = 0;
-  for (int64_t p0 = 0; p0 < n && rc == 0; p0 += P) {
-    const int m = (int)std::min<int64_t>(P, n - p0);
-    RsPlan *plan = rs_hip_plan_create(device, m, consts, stream);
-    if (!plan) {
-      rc = -11; /* rs_last_error() is set */
-      break;
-    }
-    const int64_t mp = rs_hip_plan_npoints_padded(plan);
-    /* per-point parameters */
-    for (int p = 0; p < m; ++p) {
-      pp64[p] = tbottom[p0 + p];
-      pp64[(size_t)Ppad + p] = localParam[p0 + p].tair_relax;
-      pp64[(size_t)2 * Ppad + p] = localParam[p0 + p].VZ_relax;
-      pp64[(size_t)3 * Ppad + p] = localParam[p0 + p].RH_relax;
-      pp64[(size_t)4 * Ppad + p] = localParam[p0 + p].couplingTsurf;
-      pp64[(size_t)5 * Ppad + p] = localParam[p0 + p].sky_view;
-      if (skyview) {
-        pp64[(size_t)6 * Ppad + p] = extras->sin_lat[p0 + p];
-        pp64[(size_t)7 * Ppad + p] = extras->cos_lat[p0 + p];
-        pp64[(size_t)8 * Ppad + p] = extras->lon_rad[p0 + p];
-        std::memcpy((double *)h_hz.p + (size_t)p * 360, inPointers[p0 + p].c_local_horizons,
-                    360 * sizeof(double));
-      }
-      pp32[p] = localParam[p0 + p].InitLenI;
-      pp32[(size_t)Ppad + p] = localParam[p0 + p].couplingIndexI;
-    }
-    HOK(hipMemcpyAsync(d_pp64.p, pp64.data(), pp64.size() * sizeof(double),
-                       hipMemcpyHostToDevice, stream));
-    HOK(hipMemcpyAsync(d_pp32.p, pp32.data(), pp32.size() * sizeof(int32_t),
-                       hipMemcpyHostToDevice, stream));
-    RsPointParams pp;
-    pp.tbottom = (double *)d_pp64.p;
-    pp.tair_relax = (double *)d_pp64.p + Ppad;
-    pp.vz_relax = (double *)d_pp64.p + 2 * (size_t)Ppad;
-    pp.rh_relax = (double *)d_pp64.p + 3 * (size_t)Ppad;
-    pp.initlen = (int32_t *)d_pp32.p;
-    pp.coupling_tsurf = coupled ? (double *)d_pp64.p + 4 * (size_t)Ppad : nullptr;
-    pp.coupling_index = coupled ? (int32_t *)d_pp32.p + Ppad : nullptr;
-    pp.sky_view = pp.sin_lat = pp.cos_lat = pp.lon_rad = pp.horizons = nullptr;
-    pp.albedo_surroundings = 0.0;
-    if (skyview) {
-      pp.sky_view = (double *)d_pp64.p + 5 * (size_t)Ppad;
-      pp.sin_lat = (double *)d_pp64.p + 6 * (size_t)Ppad;
-      pp.cos_lat = (double *)d_pp64.p + 7 * (size_t)Ppad;
-      pp.lon_rad = (double *)d_pp64.p + 8 * (size_t)Ppad;
-      pp.albedo_surroundings = extras->albedo_surroundings;
-      /* horizon table [point][360] -> [360][point] */
-      HOK(hipMemcpyAsync(d_hz_pt.p, h_hz.p, (size_t)m * 360 * sizeof(double), hipMemcpyHostToDevice,
-                         stream));
-      HOK(transpose((const double *)d_hz_pt.p, (double *)d_hz.p, m, 360, 360, mp, stream));
-      pp.horizons = (double *)d_hz.p;
-    }
 
+  /* ---- work items: (tile of points) x (chunk of time), processed as a two-stage pipeline.
+   * While the GPU works on item k (H2D, transposes, kernels, D2H on `stream`), the host
+   * scatters the outputs of item k-1 to the caller's rows and gathers the inputs of item
+   * k+1 into the other pinned staging set. */
+  struct Item {
+    int64_t p0;
+    int m, t0, len;
+    bool first, last; /* of its tile */
+  };
+  std::vector<Item> items;
+  for (int64_t p0 = 0; p0 < n; p0 += P)
     for (int t0 = 1; t0 <= L; t0 += TC) {
       const int len = std::min(TC, L - t0 + 1);
-      /* gather rows into pinned staging [field][p][len] */
-      double *hin = (double *)h_in.p;
-      int32_t *hi = (int32_t *)h_i32.p;
-#pragma omp parallel for schedule(static) num_threads(nthreads)
-      for (int p = 0; p < m; ++p) {
-        const InputPointers &ip = inPointers[p0 + p];
-        for (int f = 0; f < nf64; ++f)
-          std::memcpy(hin + ((size_t)f * m + p) * len, in_f64(ip, f) + (t0 - 1),
-                      (size_t)len * sizeof(double));
-        std::memcpy(hi + (size_t)p * len, ip.c_PrecPhase + (t0 - 1), (size_t)len * sizeof(int32_t));
-        std::memcpy(hi + ((size_t)m + p) * len, ip.c_hour + (t0 - 1), (size_t)len * sizeof(int32_t));
-      }
-      HOK(hipMemcpyAsync(d_pt.p, hin, (size_t)nf64 * m * len * sizeof(double),
-                         hipMemcpyHostToDevice, stream));
-      HOK(hipMemcpyAsync(d_i32pt.p, hi, (size_t)2 * m * len * sizeof(int32_t),
-                         hipMemcpyHostToDevice, stream));
-      for (int f = 0; f < nf64; ++f)
-        HOK(transpose((const double *)d_pt.p + (size_t)f * m * len,
-                      (double *)d_tp.p + (size_t)f * mp * TC, m, len, len, mp, stream));
-      for (int f = 0; f < 2; ++f)
-        HOK(transpose((const int32_t *)d_i32pt.p + (size_t)f * m * len,
-                      (int32_t *)d_i32tp.p + (size_t)f * mp * TC, m, len, len, mp, stream));
-      RsForcing fo;
-      double *b = (double *)d_tp.p;
-      const size_t fs = (size_t)mp * TC;
-      fo.tair = b + F_TAIR * fs; fo.tdew = b + F_TDEW * fs; fo.vz = b + F_VZ * fs;
-      fo.rhz = b + F_RHZ * fs; fo.prec = b + F_PREC * fs; fo.sw = b + F_SW * fs;
-      fo.lw = b + F_LW * fs; fo.tsurfobs = b + F_OBS * fs; fo.depth = b + F_DEPTH * fs;
-      fo.precphase = (int32_t *)d_i32tp.p;
-      fo.hour = (int32_t *)d_i32tp.p + fs;
-      fo.t_stride = mp;
-      fo.hour_pstride = 1;
-      fo.sw_dir = fo.lw_net = fo.sun = nullptr;
-      if (skyview) {
-        fo.sw_dir = b + F_SWDIR * fs;
-        fo.lw_net = b + F_LWNET * fs;
-        fo.sun = (double *)d_sun.p + (size_t)(t0 - 1) * 4;
-        /* the time axis is shared (checked by the Fortran caller): hour as a shared axis */
-        fo.hour = (int32_t *)d_i32pt.p + (size_t)m * len; /* point 0's row of the [p][t] copy */
-        fo.hour_pstride = 0;
-      }
-      RsOutputs oo;
-      double *ob = (double *)d_out_tp.p;
-      oo.tsurf = ob; oo.snow = ob + fs; oo.water = ob + 2 * fs; oo.ice = ob + 3 * fs;
-      oo.deposit = ob + 4 * fs; oo.ice2 = ob + 5 * fs;
-      oo.t_stride = mp;
-      oo.decimate = 1;
-      oo.row0 = t0 - 1;
-      if (t0 == 1 && rs_hip_init_state(plan, &fo, &pp) != 0) { rc = -12; break; }
-      if (rs_hip_step(plan, &fo, &oo, &pp, t0, len) != 0) { rc = -13; break; }
-      for (int f = 0; f < 6; ++f)
-        HOK(transpose((const double *)d_out_tp.p + (size_t)f * fs,
-                      (double *)d_out_pt.p + (size_t)f * m * len, len, m, mp, len, stream));
-      HOK(hipMemcpyAsync(h_out.p, d_out_pt.p, (size_t)6 * m * len * sizeof(double),
-                         hipMemcpyDeviceToHost, stream));
-      HOK(hipStreamSynchronize(stream));
-      const double *hout = (const double *)h_out.p;
-#pragma omp parallel for schedule(static) num_threads(nthreads)
-      for (int p = 0; p < m; ++p)
-        for (int f = 0; f < 6; ++f)
-          std::memcpy(out_f64(outPointers[p0 + p], f) + (t0 - 1), hout + ((size_t)f * m + p) * len,
-                      (size_t)len * sizeof(double));
+      items.push_back(Item{p0, (int)std::min<int64_t>(P, n - p0), t0, len, t0 == 1, t0 + len > L});
     }
-    rs_hip_plan_destroy(plan);
+  Pinned h_in2, h_out2, h_i322;
+  HOK(h_in2.alloc(in_elems * nf64 * sizeof(double)));
+  HOK(h_out2.alloc(in_elems * 6 * sizeof(double)));
+  HOK(h_i322.alloc(in_elems * 2 * sizeof(int32_t)));
+  double *hin_b[2] = {(double *)h_in.p, (double *)h_in2.p};
+  double *hout_b[2] = {(double *)h_out.p, (double *)h_out2.p};
+  int32_t *hi_b[2] = {(int32_t *)h_i32.p, (int32_t *)h_i322.p};
+  hipEvent_t done[2];
+  HOK(hipEventCreateWithFlags(&done[0], hipEventDisableTiming));
+  HOK(hipEventCreateWithFlags(&done[1], hipEventDisableTiming));
+  struct EventGuard {
+    hipEvent_t *e;
+    ~EventGuard() {
+      (void)hipEventDestroy(e[0]);
+      (void)hipEventDestroy(e[1]);
+    }
+  } event_guard{done};
+
+  auto gather = [&](const Item &it, int buf) {
+    double *hin = hin_b[buf];
+    int32_t *hi = hi_b[buf];
+    const int m = it.m, len = it.len, t0 = it.t0;
+    const int64_t p0 = it.p0;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int p = 0; p < m; ++p) {
+      const InputPointers &ip = inPointers[p0 + p];
+      for (int f = 0; f < nf64; ++f)
+        std::memcpy(hin + ((size_t)f * m + p) * len, in_f64(ip, f) + (t0 - 1),
+                    (size_t)len * sizeof(double));
+      std::memcpy(hi + (size_t)p * len, ip.c_PrecPhase + (t0 - 1), (size_t)len * sizeof(int32_t));
+      std::memcpy(hi + ((size_t)m + p) * len, ip.c_hour + (t0 - 1), (size_t)len * sizeof(int32_t));
+    }
+  };
+  auto scatter = [&](const Item &it, int buf) {
+    const double *hout = hout_b[buf];
+    const int m = it.m, len = it.len, t0 = it.t0;
+    const int64_t p0 = it.p0;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int p = 0; p < m; ++p)
+      for (int f = 0; f < 6; ++f)
+        std::memcpy(out_f64(outPointers[p0 + p], f) + (t0 - 1), hout + ((size_t)f * m + p) * len,
+                    (size_t)len * sizeof(double));
+  };
+
+  RsPlan *plan = nullptr, *retired = nullptr; /* retired: its last item is still in flight */
+  struct PlanGuard {
+    RsPlan **a, **b;
+    ~PlanGuard() {
+      if (*a) rs_hip_plan_destroy(*a);
+      if (*b) rs_hip_plan_destroy(*b);
+    }
+  } plan_guard{&plan, &retired};
+  RsPointParams pp;
+  std::memset(&pp, 0, sizeof(pp));
+  int64_t mp = 0;
+  int rc = 0;
+
+  /* everything the GPU does for one item, enqueued on `stream` */
+  auto enqueue = [&](const Item &it, int buf) -> int {
+    const int m = it.m, len = it.len, t0 = it.t0;
+    const int64_t p0 = it.p0;
+    if (it.first) {
+      plan = rs_hip_plan_create(device, m, consts, stream);
+      if (!plan) return -11; /* rs_last_error() is set */
+      mp = rs_hip_plan_npoints_padded(plan);
+      for (int p = 0; p < m; ++p) {
+        pp64[p] = tbottom[p0 + p];
+        pp64[(size_t)Ppad + p] = localParam[p0 + p].tair_relax;
+        pp64[(size_t)2 * Ppad + p] = localParam[p0 + p].VZ_relax;
+        pp64[(size_t)3 * Ppad + p] = localParam[p0 + p].RH_relax;
+        pp64[(size_t)4 * Ppad + p] = localParam[p0 + p].couplingTsurf;
+        pp64[(size_t)5 * Ppad + p] = localParam[p0 + p].sky_view;
+        if (skyview) {
+          pp64[(size_t)6 * Ppad + p] = extras->sin_lat[p0 + p];
+          pp64[(size_t)7 * Ppad + p] = extras->cos_lat[p0 + p];
+          pp64[(size_t)8 * Ppad + p] = extras->lon_rad[p0 + p];
+          std::memcpy((double *)h_hz.p + (size_t)p * 360, inPointers[p0 + p].c_local_horizons,
+                      360 * sizeof(double));
+        }
+        pp32[p] = localParam[p0 + p].InitLenI;
+        pp32[(size_t)Ppad + p] = localParam[p0 + p].couplingIndexI;
+      }
+      HOK(hipMemcpyAsync(d_pp64.p, pp64.data(), pp64.size() * sizeof(double),
+                         hipMemcpyHostToDevice, stream));
+      HOK(hipMemcpyAsync(d_pp32.p, pp32.data(), pp32.size() * sizeof(int32_t),
+                         hipMemcpyHostToDevice, stream));
+      pp.tbottom = (double *)d_pp64.p;
+      pp.tair_relax = (double *)d_pp64.p + Ppad;
+      pp.vz_relax = (double *)d_pp64.p + 2 * (size_t)Ppad;
+      pp.rh_relax = (double *)d_pp64.p + 3 * (size_t)Ppad;
+      pp.initlen = (int32_t *)d_pp32.p;
+      pp.coupling_tsurf = coupled ? (double *)d_pp64.p + 4 * (size_t)Ppad : nullptr;
+      pp.coupling_index = coupled ? (int32_t *)d_pp32.p + Ppad : nullptr;
+      pp.sky_view = pp.sin_lat = pp.cos_lat = pp.lon_rad = pp.horizons = nullptr;
+      pp.albedo_surroundings = 0.0;
+      if (skyview) {
+        pp.sky_view = (double *)d_pp64.p + 5 * (size_t)Ppad;
+        pp.sin_lat = (double *)d_pp64.p + 6 * (size_t)Ppad;
+        pp.cos_lat = (double *)d_pp64.p + 7 * (size_t)Ppad;
+        pp.lon_rad = (double *)d_pp64.p + 8 * (size_t)Ppad;
+        pp.albedo_surroundings = extras->albedo_surroundings;
+        /* horizon table [point][360] -> [360][point] */
+        HOK(hipMemcpyAsync(d_hz_pt.p, h_hz.p, (size_t)m * 360 * sizeof(double), hipMemcpyHostToDevice,
+                           stream));
+        HOK(transpose((const double *)d_hz_pt.p, (double *)d_hz.p, m, 360, 360, mp, stream));
+        pp.horizons = (double *)d_hz.p;
+        /* h_hz is reused by the next tile: its copy must have left the host first */
+        HOK(hipStreamSynchronize(stream));
+      }
+    }
+    HOK(hipMemcpyAsync(d_pt.p, hin_b[buf], (size_t)nf64 * m * len * sizeof(double),
+                       hipMemcpyHostToDevice, stream));
+    HOK(hipMemcpyAsync(d_i32pt.p, hi_b[buf], (size_t)2 * m * len * sizeof(int32_t),
+                       hipMemcpyHostToDevice, stream));
+    for (int f = 0; f < nf64; ++f)
+      HOK(transpose((const double *)d_pt.p + (size_t)f * m * len,
+                    (double *)d_tp.p + (size_t)f * mp * TC, m, len, len, mp, stream));
+    for (int f = 0; f < 2; ++f)
+      HOK(transpose((const int32_t *)d_i32pt.p + (size_t)f * m * len,
+                    (int32_t *)d_i32tp.p + (size_t)f * mp * TC, m, len, len, mp, stream));
+    RsForcing fo;
+    double *b = (double *)d_tp.p;
+    const size_t fs = (size_t)mp * TC;
+    fo.tair = b + F_TAIR * fs; fo.tdew = b + F_TDEW * fs; fo.vz = b + F_VZ * fs;
+    fo.rhz = b + F_RHZ * fs; fo.prec = b + F_PREC * fs; fo.sw = b + F_SW * fs;
+    fo.lw = b + F_LW * fs; fo.tsurfobs = b + F_OBS * fs; fo.depth = b + F_DEPTH * fs;
+    fo.precphase = (int32_t *)d_i32tp.p;
+    fo.hour = (int32_t *)d_i32tp.p + fs;
+    fo.t_stride = mp;
+    fo.hour_pstride = 1;
+    fo.sw_dir = fo.lw_net = fo.sun = nullptr;
+    if (skyview) {
+      fo.sw_dir = b + F_SWDIR * fs;
+      fo.lw_net = b + F_LWNET * fs;
+      fo.sun = (double *)d_sun.p + (size_t)(t0 - 1) * 4;
+      /* the time axis is shared (checked by the Fortran caller): hour as a shared axis */
+      fo.hour = (int32_t *)d_i32pt.p + (size_t)m * len; /* point 0's row of the [p][t] copy */
+      fo.hour_pstride = 0;
+    }
+    RsOutputs oo;
+    double *ob = (double *)d_out_tp.p;
+    oo.tsurf = ob; oo.snow = ob + fs; oo.water = ob + 2 * fs; oo.ice = ob + 3 * fs;
+    oo.deposit = ob + 4 * fs; oo.ice2 = ob + 5 * fs;
+    oo.t_stride = mp;
+    oo.decimate = 1;
+    oo.row0 = t0 - 1;
+    if (t0 == 1 && rs_hip_init_state(plan, &fo, &pp) != 0) return -12;
+    if (rs_hip_step(plan, &fo, &oo, &pp, t0, len) != 0) return -13;
+    for (int f = 0; f < 6; ++f)
+      HOK(transpose((const double *)d_out_tp.p + (size_t)f * fs,
+                    (double *)d_out_pt.p + (size_t)f * m * len, len, m, mp, len, stream));
+    HOK(hipMemcpyAsync(hout_b[buf], d_out_pt.p, (size_t)6 * m * len * sizeof(double),
+                       hipMemcpyDeviceToHost, stream));
+    HOK(hipEventRecord(done[buf], stream));
+    return 0;
+  };
+
+  const int N = (int)items.size();
+  gather(items[0], 0);
+  for (int k = 0; k < N && rc == 0; ++k) {
+    const int buf = k & 1;
+    rc = enqueue(items[k], buf);
+    if (rc != 0) break;
+    if (k >= 1) { /* item k-1 used the other staging set */
+      HOK(hipEventSynchronize(done[buf ^ 1]));
+      if (retired) {
+        rs_hip_plan_destroy(retired);
+        retired = nullptr;
+      }
+      scatter(items[k - 1], buf ^ 1);
+    }
+    if (items[k].last) { /* the next item starts a new tile with a new plan */
+      retired = plan;
+      plan = nullptr;
+    }
+    if (k + 1 < N) gather(items[k + 1], buf ^ 1);
+  }
+  if (rc == 0) {
+    HOK(hipEventSynchronize(done[(N - 1) & 1]));
+    scatter(items[N - 1], (N - 1) & 1);
+  } else {
+    (void)hipStreamSynchronize(stream);
   }
   (void)hipStreamDestroy(stream);
   return rc;
