@@ -59,7 +59,8 @@ for c0 in range(0, L - CH, CH):
     tot += wave_cost(cur[order]); nchunks += 1
 print("sorted globally by the chunk's own total (bound)       : %.3f" % (tot / nchunks))
 
-np.save("/tmp/bl_trace.npy", t)
+os.makedirs(os.path.join(os.path.dirname(__file__), "..", "gpurun_out"), exist_ok=True)
+np.save(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "bl_trace.npy"), t)
 for CH in (60, 120, 240, 480):
     for hist in (1, 2):
         tot = 0.0; nchunks = 0
