@@ -647,10 +647,14 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Pr
   }
 
   int32_t i = t0;
+  int32_t written_hi = t0 - 1; /* highest index this launch has saved an output for */
   bool stale_all = false; /* first step after a restore: TmpNw is the pre-restore profile */
   while (i < tend) {
-    if (s.failed) { /* the reference's loop has exited: remaining outputs stay -9999.0 */
-      store_outputs(ka, i, p, 0u, s, false);
+    if (s.failed) {
+      /* the reference's loop has exited: outputs it never saved stay -9999.0 - but a point
+       * that fails in the middle of a coupling replay keeps, beyond the failure, what the
+       * EARLIER passes saved there (src/InputOutput.f90:151-165 only ever overwrites) */
+      if (i > written_hi) store_outputs(ka, i, p, 0u, s, false);
       ++i;
       continue;
     }
@@ -783,6 +787,7 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Pr
       model_step_ground(c, s, T, tbot, tair, fx, f.depth, cp);
     }
     store_outputs(ka, i, p, 0u, s, true);
+    if (i > written_hi) written_hi = i;
     /* CheckEndCoupling + CouplingOperations2, src/Coupling.f90:98-141 */
     if (i < c.SimLen && q.on && i == q.ce && !q.failed) {
       if (q.iter == 0) q.tend1 = s.tsurf;

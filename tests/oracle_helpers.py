@@ -159,7 +159,7 @@ def point_pointers(f: dict, p: int, out: dict | None = None):
                       ("c_LW_net", "lw_net"), ("c_TSurfObs", "tsurfobs"), ("c_Depth", "depth")):
         setattr(ip, name, f[key][p].ctypes.data_as(abi.c_double_p))
     ip.c_PrecPhase = f["precphase"][p].ctypes.data_as(abi.c_int32_p)
-    hz = np.zeros(360)
+    hz = f["local_horizons"][p] if f.get("local_horizons") is not None else np.zeros(360)
     ip.c_local_horizons = hz.ctypes.data_as(abi.c_double_p)
     for name in I32_AXIS:
         setattr(ip, "c_" + name, f[name].ctypes.data_as(abi.c_int32_p))
