@@ -190,3 +190,58 @@ def test_identical_per_point_axes_equal_the_shared_axis(monkeypatch):
     for q in range(n):
         for f in LP_FIELDS:
             assert getattr(a["local"][q], f) == getattr(b["local"][q], f)
+
+
+def _random_case(seed):
+    rs = np.random.RandomState(500 + seed)
+    n = int(rs.choice([70, 257, 400]))
+    hours = int(rs.choice([4, 6, 12]))
+    obs_hours = int(rs.randint(2, hours))
+    src, L, t0, tf = dh.scenario(n, hours=hours, seed=40 + seed, obs_hours=obs_hours, gaps=bool(rs.rand() < 0.8))
+    if rs.rand() < 0.5:      # a third source: radiation from another model, every 3 hours
+        fc = src[0]
+        idx = np.arange(0, len(fc.times), 3)
+        rad = driver.RawSource(fc.times[idx], {k: np.ascontiguousarray(fc.fields[k][:, idx] * 1.05)
+                                               for k in ("sw", "lw")}, False)
+        src = [fc, rad, src[1]]
+    if rs.rand() < 0.5:
+        src[-1] = dh.ragged(src[-1], seed=seed, drop=float(rs.uniform(0.05, 0.4)))
+    if rs.rand() < 0.3:
+        src[0] = dh.ragged(src[0], seed=seed + 1, drop=0.08)
+    kw = dict(use_relaxation=int(rs.rand() < 0.7), use_coupling=int(rs.rand() < 0.5),
+              coupling_minutes=int(rs.choice([30, 60, 120])), outputStep=int(rs.choice([10, 20, 60])),
+              NLayers=int(rs.choice([7, 15, 15, 22])),
+              tsurfOutputDepth=float(rs.choice([-9999.9, -9999.9, 0.0, 0.03])))
+    s = _settings(L, **kw)
+    local, hz = None, None
+    if rs.rand() < 0.4:
+        local = []
+        for i in range(n):
+            lp = abi.default_local()
+            lp.lat, lp.lon = 60.0 + rs.uniform(0, 8), 21.0 + rs.uniform(0, 8)
+            lp.sky_view = float(rs.uniform(0.3, 1.0)) if rs.rand() < 0.7 else 1.0
+            local.append(lp)
+        hz = rs.uniform(0, 25, (n, 360)) if rs.rand() < 0.7 else None
+    tile = int(rs.choice([64, 200, 4096]))
+    chunk = int(rs.choice([50, 97, 256]))
+    return src, s, t0, tf, local, hz, tile, chunk
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_driver_case_matches_checker(seed, monkeypatch):
+    src, s, t0, tf, local, hz, tile, chunk = _random_case(seed)
+    monkeypatch.setenv("ROADSURF_HIP_TILE_POINTS", str(tile))
+    monkeypatch.setenv("ROADSURF_HIP_CHUNK_STEPS", str(chunk))
+    p = abi.default_parameters()
+    g = driver.run(src, s, p, t0, tf, local=local, horizons=hz)
+    o = dh.oracle_run("port", src, s, p, t0, tf, local=local, horizons=hz)
+    desc = (f"n{len(g['status'])} L{s.SimLen} src{len(src)} pp{[x.times.ndim == 2 for x in src]} relax{s.use_relaxation} "
+            f"cpl{s.use_coupling}/{s.coupling_minutes} out{s.outputStep} NL{s.NLayers} depth{s.tsurfOutputDepth:g} "
+            f"sky{local is not None} hz{hz is not None} tile{tile} chunk{chunk}")
+    assert np.array_equal(g["status"], o["status"]), desc
+    assert np.array_equal(g["missing_index"], o["missing_index"]), desc
+    for k in driver.OUT_FIELDS:
+        assert _same_bits(g[k], o[k]), (desc, k, int((g[k] != o[k]).sum()))
+    for q in range(len(g["status"])):
+        for f in LP_FIELDS:
+            assert getattr(g["local"][q], f) == getattr(o["local"][q], f), (desc, q, f)

@@ -83,3 +83,15 @@ def test_random_configuration_is_bit_identical(seed):
         bad = int((out[k] != ora[k]).sum())
         assert bad == 0, (desc, k, bad, float(np.nanmax(np.abs(out[k] - ora[k]))))
     assert (ora["tsurf"] > -100).mean() > 0.9, desc
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 32])
+@pytest.mark.parametrize("seed", [1, 4, 9])
+def test_kernel_flavours_agree_on_random_configurations(seed, variant, monkeypatch):
+    """The same draws with every kernel flavour forced (ROADSURF_HIP_VARIANT): register profile,
+    LDS profile at 4 and 3 waves/SIMD, workgroup tail compaction."""
+    f, s, p, ls = _draw(seed)
+    if s.NLayers != 15 and variant in (1, 3):
+        pytest.skip("register flavours are built for NLayers = 15")
+    monkeypatch.setenv("ROADSURF_HIP_VARIANT", str(variant))
+    test_random_configuration_is_bit_identical(seed)
