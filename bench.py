@@ -104,6 +104,9 @@ def main() -> None:
     ap.add_argument("--f32", action="store_true",
                     help="BASELINE config 5 flavour: fp32 state/forcing/outputs/arithmetic "
                          "(tolerance-gated, not the parity path); default is fp64")
+    ap.add_argument("--cluster", type=int, default=1,
+                    help="1: re-sort the plan's slots by boundary-layer passes after every launch "
+                         "(rs_hip_recluster; windows are generated in slot order), 0: natural order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16384)
     args = ap.parse_args()
@@ -160,9 +163,30 @@ def main() -> None:
     ev_filled = [torch.cuda.Event() for _ in range(nbuf)]    # window b holds fresh forcing
     ev_consumed = [torch.cuda.Event() for _ in range(nbuf)]  # step kernel is done with window b
 
+    cluster = bool(args.cluster) and not args.f32 and not overlap
+    kbuf = torch.empty((chunk // spk + 3, 9, npad), dtype=torch.float64, device=dev) if cluster else None
+
+    def clustered_pass():
+        """Like the plain pass, with the plan's slots re-sorted after every launch: the knots
+        of each window are generated in the current slot order, so the window is born coalesced
+        in that order; the re-sort (hipCUB radix sort + state permutation) is inside the timing."""
+        plan.synth_knots_range(spec, kbuf, 0, 2, ordered=True)
+        plan.expand_range(spec, kbuf, 0, 2, win0, 1, 1)
+        plan.init_state(win0, pp)
+        for t0 in starts:
+            ns = min(chunk, simlen - t0 + 1)
+            k0 = (t0 - 1) // spk
+            nk = (t0 + ns - 2) // spk + 1 - k0 + 1
+            plan.synth_knots_range(spec, kbuf, k0, nk, ordered=True)
+            plan.expand_range(spec, kbuf, k0, nk, wins[0], t0, ns)
+            plan.step(wins[0], out, pp, t0, ns, out_row0=t0 - 1)
+            plan.recluster()
+
     def one_pass():
         """init -> per window: expand (HBM-bound, side stream) || step (VALU-bound, main stream).
         Double-buffered: expansion of window c+1 overlaps stepping of window c."""
+        if cluster:
+            return clustered_pass()
         plan.expand(spec, knots, win0, 1, 1)
         plan.init_state(win0, pp)
         if not overlap:
@@ -234,7 +258,7 @@ def main() -> None:
                 "points_per_gpu": n,
                 "simlen": simlen,
                 "chunk_steps": chunk,
-                "overlap_expand_with_step": overlap,
+                "overlap_expand_with_step": overlap, "recluster_after_every_launch": cluster,
                 "kernel_variant": args.variant,
                 "parallelism": f"points sharded over {world} GPU(s), no collectives",
                 "failed_points": int(nfail),

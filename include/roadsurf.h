@@ -334,6 +334,8 @@ typedef struct RsSynthSpec {
   int64_t point_offset;   /* global id of local point 0 (multi-GPU shards) */
   int32_t steps_per_knot; /* 3600/DTSecs = 120 */
   int32_t start_hour;     /* hour of day at absolute index 1 */
+  const int32_t *order;   /* NULL, or rs_hip_plan_order(): knot column p then belongs to local
+                             point order[p] (plan-order windows, see rs_hip_recluster) */
 } RsSynthSpec;
 
 /* Number of doubles per point and knot in a knot buffer. */
@@ -384,6 +386,24 @@ int64_t rs_hip_div_mismatch_count(RsPlan *plan);
  * (an experiment that executes 12 % fewer instructions and is slower: DESIGN.md 3.1).
  * All flavours return the same bits. */
 int rs_hip_set_variant(RsPlan *plan, int32_t variant);
+
+/* ---- plan order: load balancing by regime ----------------------------------------------
+ * The boundary-layer fixed point (src/BoundaryLayer.f90:64-96) stops after its 5 mandatory passes
+ * for most point-steps but needs up to ~35 for some, and a wavefront runs until its slowest lane
+ * is done: with independent points in arbitrary order a wave averages 13.9 passes where a lane
+ * averages 5.5.  Slow convergence is a property of the weather regime and persists for hours.
+ * rs_hip_recluster sorts the plan's SLOTS by the extra passes each point needed during the last
+ * launch and moves the carried state accordingly, so that slow points share wavefronts.  From
+ * then on everything indexed by "point" in this API - forcing and output windows, RsPointParams
+ * arrays - is indexed by SLOT: slot s holds local point rs_hip_plan_order(plan)[s].  Producers
+ * generate their windows in that order (the synthetic generator takes the order in RsSynthSpec;
+ * raw series are 130x smaller than the windows, so gathering them is cheap) and consumers map
+ * the outputs back with the same array.  Points do not interact: the order changes no value.
+ *   rs_hip_plan_order   device pointer to order[npoints_padded] (identity until the first
+ *                       recluster; allocated by the first call), valid until the next recluster
+ *   rs_hip_recluster    asynchronous on the plan's stream; the order changes for the NEXT launch */
+const int32_t *rs_hip_plan_order(RsPlan *plan);
+int rs_hip_recluster(RsPlan *plan);
 
 /* Device timing of the step kernel with HIP events recorded on the plan's
  * stream around every rs_hip_step launch since the last reset.  Returns the

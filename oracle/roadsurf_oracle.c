@@ -203,6 +203,7 @@ static int CalcBLCondAndLE(Model *m) {
   const double PsychC = R4(0.1) * (R4(0.00063) * TaK + R4(0.47496));
   const double WatDen = R4(-0.0050) * TSurfAve * TSurfAve + R4(0.0079) * TSurfAve + R4(1000.0028);
 
+  int n_unstable = 0;
   for (j = 1; j <= MaxIter; ++j) {
     BLCond_Old = BLCond;
     UStar = m->VK * VZ / (m->logUstar + PSIM);
@@ -216,6 +217,7 @@ static int CalcBLCondAndLE(Model *m) {
     } else {
       PSIH = R4(-2.0) * log((R4(1.0) + sqrt(R4(1.0) - R4(16.0) * Stab)) / R4(2.0));
       PSIM = R4(0.6) * PSIH;
+      n_unstable++;
     }
     if ((fabs(BLCond - BLCond_Old) < ConvLim) && (j >= 5)) break;
   }
@@ -226,8 +228,10 @@ static int CalcBLCondAndLE(Model *m) {
     const int jj = j > MaxIter ? MaxIter : j;
 #pragma omp atomic
     oracle_bl_hist[jj]++;
-    if (oracle_bl_trace && oracle_bl_trace_pos < oracle_bl_trace_cap)
+    if (oracle_bl_trace && oracle_bl_trace_pos + 1 < oracle_bl_trace_cap) {
       oracle_bl_trace[oracle_bl_trace_pos++] = (unsigned char)jj;
+      oracle_bl_trace[oracle_bl_trace_pos++] = (unsigned char)n_unstable; /* passes through the log/sqrt branch */
+    }
   }
   return j > MaxIter ? MaxIter : j;
 }

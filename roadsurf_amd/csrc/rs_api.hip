@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "../../include/roadsurf.h"
@@ -47,6 +48,12 @@ struct RsPlan {
   hipStream_t stream = nullptr;
   double *state = nullptr;
   unsigned long long *counter = nullptr;
+  /* plan order (rs_hip_recluster): slot -> local point, second state block and sort scratch */
+  int32_t *order = nullptr, *order_alt = nullptr;
+  double *state_alt = nullptr;
+  void *sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  uint32_t *sort_keys = nullptr; /* [4][np_pad]: keys in/out, slots in/out */
   int variant = RS_VARIANT_AUTO;
   int cslot = -1;
   bool f32 = false; /* single-precision flavour: windows and state hold floats */
@@ -217,7 +224,51 @@ void rs_hip_plan_destroy(RsPlan *pl) {
   }
   (void)hipFree(pl->state);
   (void)hipFree(pl->counter);
+  if (pl->order) (void)hipFree(pl->order);
+  if (pl->order_alt) (void)hipFree(pl->order_alt);
+  if (pl->state_alt) (void)hipFree(pl->state_alt);
+  if (pl->sort_tmp) (void)hipFree(pl->sort_tmp);
+  if (pl->sort_keys) (void)hipFree(pl->sort_keys);
   delete pl;
+}
+
+const int32_t *rs_hip_plan_order(RsPlan *pl) {
+  if (!pl) {
+    set_err("rs_hip_plan_order: null plan");
+    return nullptr;
+  }
+  if (!pl->order) {
+    if (hipSetDevice(pl->device) != hipSuccess ||
+        hipMalloc(&pl->order, pl->np_pad * sizeof(int32_t)) != hipSuccess ||
+        rs_cluster_identity(pl->order, pl->np_pad, pl->stream) != hipSuccess) {
+      set_err("rs_hip_plan_order: allocation failed");
+      return nullptr;
+    }
+  }
+  return pl->order;
+}
+
+int rs_hip_recluster(RsPlan *pl) {
+  if (!pl) return set_err("rs_hip_recluster: null plan");
+  if (pl->f32) return set_err("rs_hip_recluster: fp64 plans only");
+  if (!rs_hip_plan_order(pl)) return -1;
+  HIP_OK(hipSetDevice(pl->device));
+  const size_t state_bytes = (size_t)RS_NSTATE * pl->np_pad * sizeof(double);
+  if (!pl->state_alt) {
+    HIP_OK(hipMalloc(&pl->state_alt, state_bytes));
+    HIP_OK(hipMalloc(&pl->order_alt, pl->np_pad * sizeof(int32_t)));
+    HIP_OK(hipMalloc(&pl->sort_keys, (size_t)4 * pl->np_pad * sizeof(uint32_t)));
+    pl->sort_tmp_bytes = rs_cluster_scratch_bytes(pl->npoints);
+    HIP_OK(hipMalloc(&pl->sort_tmp, pl->sort_tmp_bytes ? pl->sort_tmp_bytes : 8));
+  }
+  HIP_OK(rs_cluster_sort(pl->state, pl->np_pad, pl->npoints, pl->sort_keys, pl->sort_tmp,
+                         pl->sort_tmp_bytes, pl->stream));
+  HIP_OK(rs_cluster_apply(pl->state, pl->state_alt, pl->order, pl->order_alt,
+                          pl->sort_keys + 3 * pl->np_pad, pl->np_pad, pl->npoints, pl->c.NLayers,
+                          pl->c.use_coupling != 0, pl->stream));
+  std::swap(pl->state, pl->state_alt);
+  std::swap(pl->order, pl->order_alt);
+  return 0;
 }
 
 int64_t rs_hip_plan_npoints(const RsPlan *pl) { return pl ? pl->npoints : 0; }

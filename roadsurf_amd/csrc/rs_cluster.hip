@@ -1,0 +1,93 @@
+/*
+ * rs_cluster.hip — plan order (include/roadsurf.h, rs_hip_recluster): sort the slots of a plan
+ * by the boundary-layer passes their points needed during the last launch and move the carried
+ * state along.  Device-wide radix sort from hipCUB; everything else is streaming copies.
+ */
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "rs_kernels.h"
+#include "rs_state.h"
+
+namespace {
+
+constexpr int KEY_BITS = 21; /* rs_kernels.hip, bl_score_key: 19 bits of passes + regime + cover */
+
+__global__ void __launch_bounds__(RS_BLOCK) keys_kernel(const double *__restrict__ state,
+                                                        int64_t np_pad, int64_t npoints,
+                                                        uint32_t *keys, uint32_t *slots) {
+  const int64_t s = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
+  if (s >= npoints) return;
+  double v = state[(int64_t)RS_ST_BLSCORE * np_pad + s];
+  if (!(v >= 0.0)) v = 0.0;
+  const double top = (double)((1u << KEY_BITS) - 1u);
+  keys[s] = (uint32_t)(v > top ? top : v);
+  slots[s] = (uint32_t)s;
+}
+
+/* dst[row][s] = src[row][perm[s]] for the carried state, order_dst[s] = order_src[perm[s]];
+ * slots beyond npoints (padding) stay where they are */
+__global__ void __launch_bounds__(RS_BLOCK) apply_kernel(const double *__restrict__ src,
+                                                         double *__restrict__ dst,
+                                                         const int32_t *__restrict__ order_src,
+                                                         int32_t *__restrict__ order_dst,
+                                                         const uint32_t *__restrict__ perm,
+                                                         int64_t np_pad, int64_t npoints,
+                                                         int32_t nlayers) {
+  const int64_t s = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
+  if (s >= np_pad) return;
+  const int64_t from = (s < npoints) ? (int64_t)perm[s] : s;
+  if (blockIdx.y == 0) order_dst[s] = order_src[from];
+  /* rows in use: the profile Tmp(1..NLayers), then everything from TmpNw(1) on */
+  const int64_t row = ((int)blockIdx.y < nlayers) ? blockIdx.y
+                                                  : (int64_t)RS_MAX_LAYERS + (blockIdx.y - nlayers);
+  dst[row * np_pad + s] = src[row * np_pad + from];
+}
+
+__global__ void __launch_bounds__(RS_BLOCK) iota_kernel(int32_t *x, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
+  if (i < n) x[i] = (int32_t)i;
+}
+
+inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + RS_BLOCK - 1) / RS_BLOCK)); }
+
+}  // namespace
+
+hipError_t rs_cluster_identity(int32_t *order, int64_t np_pad, hipStream_t stream) {
+  hipLaunchKernelGGL(iota_kernel, grid1(np_pad), dim3(RS_BLOCK), 0, stream, order, np_pad);
+  return hipGetLastError();
+}
+
+size_t rs_cluster_scratch_bytes(int64_t npoints) {
+  size_t bytes = 0;
+  uint32_t *k = nullptr;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k, k, k, k, (int)npoints, 0, KEY_BITS);
+  return bytes;
+}
+
+/* scratch: [4][np_pad] uint32 (keys in/out, slots in/out) + `tmp` for hipCUB.
+ * Leaves the permutation (new slot -> old slot) in scratch + 3*np_pad. */
+hipError_t rs_cluster_sort(const double *state, int64_t np_pad, int64_t npoints, uint32_t *scratch,
+                           void *tmp, size_t tmp_bytes, hipStream_t stream) {
+  uint32_t *kin = scratch, *kout = scratch + np_pad, *sin = scratch + 2 * np_pad,
+           *sout = scratch + 3 * np_pad;
+  hipLaunchKernelGGL(keys_kernel, grid1(npoints), dim3(RS_BLOCK), 0, stream, state, np_pad, npoints,
+                     kin, sin);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  /* stable: points with equal scores keep their relative order */
+  return hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, kin, kout, sin, sout, (int)npoints, 0,
+                                            KEY_BITS, stream);
+}
+
+/* nlayers: NLayers of the plan; coupled: also move the coupling block (saved state etc.) */
+hipError_t rs_cluster_apply(const double *state_src, double *state_dst, const int32_t *order_src,
+                            int32_t *order_dst, const uint32_t *perm, int64_t np_pad,
+                            int64_t npoints, int nlayers, bool coupled, hipStream_t stream) {
+  dim3 g = grid1(np_pad);
+  const int last = coupled ? RS_NSTATE - 1 : RS_ST_BLSCORE;
+  g.y = (unsigned)(nlayers + (last - RS_MAX_LAYERS + 1));
+  hipLaunchKernelGGL(apply_kernel, g, dim3(RS_BLOCK), 0, stream, state_src, state_dst, order_src,
+                     order_dst, perm, np_pad, npoints, (int32_t)nlayers);
+  return hipGetLastError();
+}

@@ -26,6 +26,11 @@
 #include "rs_synth.h"
 #include "rs_kernels.h"
 
+#ifndef RS_REGIME_WINDOW
+#define RS_REGIME_WINDOW 30 /* indices at the end of a launch that define a point's regime
+                               (rs_hip_recluster; 8 ... 90 measured equal) */
+#endif
+
 namespace rs {
 
 constexpr int kBlock = RS_BLOCK;
@@ -169,7 +174,7 @@ __device__ __forceinline__ void store_outputs(KernArgs ka, int32_t i, int64_t ro
 /* The time loop of runsimulation (examples/example1/src/Simulation.f90:57-115)
  * for one point over absolute indices [t0, t0+nsteps). */
 template <bool FULL, class Prof>
-__device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s) {
+__device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s, int32_t &score) {
   KernArgs ka = kernargs();
   const uint32_t lane = threadIdx.x;
   const int64_t row0 = (int64_t)blockIdx.x * kBlock; /* first point of this workgroup */
@@ -247,6 +252,10 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
     }
     const Fluxes fx =
         model_step_fluxes(c, mt, s, tair, vz, rhz, prec_ts, f.sw, f.lw, f.phase, f.hour);
+    /* scheduling hint (bl_score_key): extra passes of this launch; bit 30 = the point was in
+     * the unstable regime at some index of the launch's last 30 */
+    score += (fx.trips & 63) - 5;
+    if ((fx.trips & 64) && k >= nsteps - RS_REGIME_WINDOW) score |= 1 << 30;
     /* next index's forcing: issued here, half a step before its first use, so the
      * HBM latency hides under the ground/storage half without holding 14 VGPRs
      * across the boundary-layer iteration */
@@ -283,6 +292,7 @@ __device__ __forceinline__ Fluxes fluxes_block_tail(const RsConstants &c, const 
                                                     int32_t k) {
   Fluxes fx;
   fx.blcond = fx.le = fx.evap = fx.rnet = fx.trffric = 0.0;
+  fx.trips = 5;
   BlInv v;
   BlVar x;
   BlAux a;
@@ -798,6 +808,18 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Pr
   }
 }
 
+/* RS_ST_BLSCORE from the loop's counter: bits 0-18 extra passes (saturating), bit 19 regime.
+ * Sorting ascending puts the stable-regime points first (their waves never enter the log/sqrt
+ * branch), then the others by the passes they needed (tools/bl_persistence.py). */
+__device__ __forceinline__ double bl_score_key(int32_t score, const Scalars &s) {
+  const int32_t extra = score & 0x3fffffff;
+  const int32_t lo = extra > 0x7ffff ? 0x7ffff : extra;
+  /* bit 20: something lies on the road (the storage and melting branches are skipped by a
+   * wavefront whose lanes are all bare) */
+  const int32_t covered = (s.wat > 0.0 || s.snow > 0.0 || s.ice > 0.0 || s.ice2 > 0.0 || s.dep > 0.0) ? 1 : 0;
+  return (double)(lo | (covered << 19) | (((score >> 30) & 1) << 20));
+}
+
 template <int NL, bool FULL, int WPE>
 __global__ void __launch_bounds__(kBlock, WPE) step_kernel_reg(const StepArgs a) {
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
@@ -807,9 +829,11 @@ __global__ void __launch_bounds__(kBlock, WPE) step_kernel_reg(const StepArgs a)
   if (p >= a.npoints) return;
   RegProfile<NL> T;
   Scalars s;
+  int32_t score = 0;
   load_state<FULL>(a.state, a.np_pad, p, T, s);
-  time_loop<FULL>(mt, T, s);
+  time_loop<FULL>(mt, T, s, score);
   store_state<FULL>(a.state, a.np_pad, p, T, s);
+  a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
 }
 
 /* Register profile + block-level tail compaction (the default for NLayers = 15). */
@@ -847,9 +871,11 @@ __global__ void __launch_bounds__(kBlock, WPE) step_kernel_lds(const StepArgs a)
   if (p >= a.npoints) return; /* no barriers below: each lane owns its column */
   LdsProfile T{lds + threadIdx.x, g_consts[a.cslot].NLayers};
   Scalars s;
+  int32_t score = 0;
   load_state<FULL>(a.state, a.np_pad, p, T, s);
-  time_loop<FULL>(mt, T, s);
+  time_loop<FULL>(mt, T, s, score);
   store_state<FULL>(a.state, a.np_pad, p, T, s);
+  a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
 }
 
 /* Coupled variant: LDS profile (any NLayers), FULL feature set + coupling. */
@@ -931,6 +957,7 @@ __global__ void __launch_bounds__(kBlock) init_kernel(const InitArgs a) {
   st[(int64_t)RS_ST_TAIR_END * np + p] = R4(-99.9); /* src/Initialization.f90:377-379 */
   st[(int64_t)RS_ST_VZ_END * np + p] = R4(-99.9);
   st[(int64_t)RS_ST_RH_END * np + p] = R4(-99.9);
+  st[(int64_t)RS_ST_BLSCORE * np + p] = 0.0;
   /* initCoupling, src/Coupling.f90:144-169 */
   st[(int64_t)RS_ST_CPL_ITER * np + p] = 0.0;
   st[(int64_t)RS_ST_CPL_FLAGS * np + p] = 0.0;
@@ -953,7 +980,9 @@ __global__ void __launch_bounds__(kBlock) synth_knots_kernel(const KnotArgs a) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= a.npoints) return;
   const int32_t k = a.k0 + blockIdx.y;
-  const RsSynthKnot q = rs_sy_knot(a.spec.seed, a.spec.point_offset + p, k, a.spec.start_hour);
+  /* with a plan order (rs_hip_plan_order) slot p holds point order[p] */
+  const int64_t gid = a.spec.point_offset + (a.spec.order ? (int64_t)a.spec.order[p] : p);
+  const RsSynthKnot q = rs_sy_knot(a.spec.seed, gid, k, a.spec.start_hour);
   double *base = a.knots + ((int64_t)blockIdx.y * RS_KNOT_FIELDS) * a.np_pad + p;
   base[0 * a.np_pad] = q.tair;
   base[1 * a.np_pad] = q.tdew;

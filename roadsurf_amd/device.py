@@ -205,6 +205,38 @@ class Plan:
                                             0, nknots), "rs_hip_synth_knots")
         return spec, knots
 
+    # -- plan order (rs_hip_recluster) ---------------------------------------------
+    def order(self) -> torch.Tensor:
+        """Zero-copy view of the plan's slot -> local point array (int32 [np_pad]).  Valid until
+        the next recluster(): clone it to keep the order a window was produced in."""
+        ptr = self.L.rs_hip_plan_order(self._h)
+        if not ptr:
+            raise RuntimeError("rs_hip_plan_order failed: " + lib.last_error())
+
+        class _View:
+            __cuda_array_interface__ = {"shape": (self.np_pad,), "typestr": "<i4",
+                                        "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(_View(), device=self.device)
+
+    def recluster(self) -> None:
+        """Sort the slots by the boundary-layer passes of the last launch; later windows,
+        per-point parameters and outputs are in the new slot order."""
+        lib.check(self.L.rs_hip_recluster(self._h), "rs_hip_recluster")
+
+    def synth_knots_range(self, spec, knots: torch.Tensor, k0: int, nknots: int, ordered: bool):
+        """Knots k0..k0+nknots-1 into the first rows of ``knots``; with ``ordered`` column p
+        belongs to point order()[p]."""
+        spec.order = self.L.rs_hip_plan_order(self._h) if ordered else None
+        lib.check(self.L.rs_hip_synth_knots(self._h, C.byref(spec), C.c_void_p(knots.data_ptr()),
+                                            k0, nknots), "rs_hip_synth_knots")
+
+    def expand_range(self, spec, knots: torch.Tensor, k0: int, nknots: int, window: ForcingWindow,
+                     t0: int, nsteps: int) -> None:
+        f = window.struct(0)
+        lib.check(self.L.rs_hip_expand_forcing(self._h, C.byref(spec), C.c_void_p(knots.data_ptr()),
+                                               k0, nknots, C.byref(f), t0, nsteps),
+                  "rs_hip_expand_forcing")
+
     def expand(self, spec, knots, window: ForcingWindow, t0: int, nsteps: int,
                stream: torch.cuda.Stream | None = None) -> None:
         f = window.struct(0)

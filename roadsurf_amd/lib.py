@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("ROADSURF_HIP_LIB") or os.path.join(_HERE, "lib", "lib
 
 RS_MAX_LAYERS = abi.RS_MAX_LAYERS
 RS_KNOT_FIELDS = 9
-RS_NSTATE = RS_MAX_LAYERS + 16 + 20 + RS_MAX_LAYERS
+RS_NSTATE = RS_MAX_LAYERS + 17 + 20 + RS_MAX_LAYERS
 
 _tbl = C.c_double * (RS_MAX_LAYERS + 2)
 
@@ -76,7 +76,7 @@ class RsHostExtras(C.Structure):
 
 class RsSynthSpec(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("point_offset", C.c_int64),
-                ("steps_per_knot", C.c_int32), ("start_hour", C.c_int32)]
+                ("steps_per_knot", C.c_int32), ("start_hour", C.c_int32), ("order", C.c_void_p)]
 
 
 #: every symbol ``include/roadsurf.h`` declares
@@ -88,7 +88,7 @@ EXPORTS = (
     "rs_hip_plan_npoints", "rs_hip_plan_npoints_padded", "rs_hip_plan_state_bytes",
     "rs_hip_init_state", "rs_hip_step", "rs_hip_state_download", "rs_hip_state_upload",
     "rs_hip_failed_count", "rs_hip_sync", "rs_hip_synth_knots", "rs_hip_expand_forcing", "rs_hip_expand_forcing_on",
-    "rs_hip_set_variant", "rs_hip_set_precision", "rs_hip_test_math", "rs_hip_division_mode", "rs_hip_div_mismatch_count", "rs_hip_timing_reset", "rs_hip_timing_step_ms",
+    "rs_hip_plan_order", "rs_hip_recluster", "rs_hip_set_variant", "rs_hip_set_precision", "rs_hip_test_math", "rs_hip_division_mode", "rs_hip_div_mismatch_count", "rs_hip_timing_reset", "rs_hip_timing_step_ms",
     "rs_host_run_batch", "rs_driver_run", "rs_driver_expand", "rs_driver_release_cache", "rs_abi_version", "rs_abi_sizeof", "rs_fortran_sizeof",
 )
 
@@ -156,6 +156,9 @@ def load() -> C.CDLL:
                                         C.c_int32, P(RsForcing), C.c_int32, C.c_int32]
     L.rs_hip_expand_forcing_on.argtypes = [C.c_void_p, P(RsSynthSpec), C.c_void_p, C.c_int32,
                                            C.c_int32, P(RsForcing), C.c_int32, C.c_int32, C.c_void_p]
+    L.rs_hip_plan_order.argtypes = [C.c_void_p]
+    L.rs_hip_plan_order.restype = C.c_void_p
+    L.rs_hip_recluster.argtypes = [C.c_void_p]
     L.rs_hip_set_variant.argtypes = [C.c_void_p, C.c_int32]
     L.rs_hip_set_precision.argtypes = [C.c_void_p, C.c_int32]
     L.rs_hip_div_mismatch_count.argtypes = [C.c_void_p]

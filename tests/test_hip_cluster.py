@@ -1,0 +1,82 @@
+"""GPU: plan order (rs_hip_recluster).  Re-sorting the slots of a plan between launches and
+generating the windows in slot order must not change any value: outputs mapped back through
+the order array are bit-identical to the checker's natural-order run."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_helpers as oh
+from roadsurf_amd import abi, device
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reclustered_run_is_bit_identical_and_really_reorders():
+    n, L, chunk, seed, spk = 3000, 1441, 120, 424242, 120
+    s = abi.default_settings(L); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
+    f = oh.synth_forcing(n, L, seed=seed)
+    ora, _, _ = oh.run_oracle("port", f, s, p, l)
+
+    plan = device.Plan(n, s, p, 0)
+    dev, npad = plan.device, plan.np_pad
+    spec, _ = plan.synth_knots(seed, 2, steps_per_knot=spk)
+    kbuf = torch.empty((chunk // spk + 3, 9, npad), dtype=torch.float64, device=dev)
+    win = device.ForcingWindow.empty(chunk, npad, dev, optional=())
+    win0 = device.ForcingWindow.empty(1, npad, dev, optional=("tsurfobs",))
+    out = device.OutputWindow.empty(chunk, npad, dev)
+    pp = plan.point_params(plan.uniform_tbottom(2024, 1, 10))
+    res = {k: np.full((n, L), np.nan) for k in oh.F64_OUT}
+    names = dict(tsurf="tsurf", snow="snow", water="water", ice="ice", deposit="deposit", ice2="ice2")
+
+    order0 = plan.order().clone()
+    assert torch.equal(order0[:n].cpu(), torch.arange(n, dtype=torch.int32))
+    plan.synth_knots_range(spec, kbuf, 0, 2, ordered=True)
+    plan.expand_range(spec, kbuf, 0, 2, win0, 1, 1)
+    plan.init_state(win0, pp)
+    moved = 0
+    for t0 in range(1, L + 1, chunk):
+        ns = min(chunk, L - t0 + 1)
+        k0 = (t0 - 1) // spk
+        nk = (t0 + ns - 2) // spk + 1 - k0 + 1
+        order = plan.order().clone()          # the order this window is produced and stepped in
+        plan.synth_knots_range(spec, kbuf, k0, nk, ordered=True)
+        plan.expand_range(spec, kbuf, k0, nk, win, t0, ns)
+        plan.step(win, out, pp, t0, ns, out_row0=t0 - 1)
+        plan.sync()
+        idx = order[:n].cpu().numpy()
+        assert sorted(idx.tolist()) == list(range(n))          # a permutation of the points
+        moved += int((idx != np.arange(n)).sum())
+        for k, attr in names.items():
+            rows = out.tensors[attr][:ns, :n].cpu().numpy()    # [t][slot]
+            res[k][idx, t0 - 1:t0 - 1 + ns] = rows.T
+        plan.recluster()
+    assert moved > n          # the order did change along the way
+    for k in oh.F64_OUT:
+        assert np.array_equal(res[k], ora[k]), (k, int((res[k] != ora[k]).sum()))
+    plan.close()
+
+
+def test_recluster_sorts_by_the_score_slot():
+    from roadsurf_amd import lib
+    n = 1000
+    s = abi.default_settings(10); p = abi.default_parameters()
+    plan = device.Plan(n, s, p, 0)
+    st = plan.state()
+    rs = np.random.RandomState(0)
+    score = rs.randint(0, 500, n).astype(np.float64)
+    nst = st.shape[0]
+    slot = lib.RS_MAX_LAYERS + 16          # RS_ST_BLSCORE
+    st[:] = 0
+    st[slot, :n] = torch.from_numpy(score)
+    st[0, :n] = torch.arange(n, dtype=torch.float64) * 10   # a model-state row travels with its point
+    plan.load_state(st)
+    plan.order()
+    plan.recluster()
+    plan.sync()
+    st2 = plan.state()
+    order = plan.order()[:n].cpu().numpy()
+    assert np.array_equal(st2[slot, :n].numpy(), np.sort(score, kind="stable"))
+    assert np.array_equal(order, np.argsort(score, kind="stable"))
+    assert np.array_equal(st2[0, :n].numpy(), order * 10.0)
+    assert nst == st2.shape[0]
+    plan.close()

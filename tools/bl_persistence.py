@@ -13,7 +13,7 @@ lib = oh.load("port")
 C.c_int.in_dll(lib, "oracle_bl_hist_on").value = 1
 f = oh.synth_forcing(n, L, seed=20240110)
 s = abi.default_settings(L); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
-trace = np.zeros((n, L + 8), np.uint8)
+trace = np.zeros((n, 2 * (L + 8)), np.uint8)
 out = {k: np.empty((1, L)) for k in oh.F64_OUT}
 lib.runsimulation.argtypes = [C.POINTER(abi.OutputPointers), C.POINTER(abi.InputPointers),
                               C.POINTER(abi.InputSettings), C.POINTER(abi.InputParameters),
@@ -24,12 +24,16 @@ for q in range(n):
     ip, op, keep = oh.point_pointers(f, q)
     C.c_void_p.in_dll(lib, "oracle_bl_trace").value = trace[q].ctypes.data
     C.c_long.in_dll(lib, "oracle_bl_trace_pos").value = 0
-    C.c_long.in_dll(lib, "oracle_bl_trace_cap").value = L + 8
+    C.c_long.in_dll(lib, "oracle_bl_trace_cap").value = 2 * (L + 8)
     lib.runsimulation(C.byref(op), C.byref(ip), C.byref(s), C.byref(p), C.byref(l))
     cnt[q] = C.c_long.in_dll(lib, "oracle_bl_trace_pos").value
 print("calls per point", cnt.min(), cnt.max())
+cnt //= 2                   # two bytes per call: passes, passes through the unstable branch
 off = int(cnt.min()) - L   # calls before the time loop (initialisation)
-t = trace[:, off:off + L].astype(np.int32)          # [point][step]
+t = trace[:, 2 * off:2 * (off + L):2].astype(np.int32)          # [point][step]
+u = trace[:, 2 * off + 1:2 * (off + L) + 1:2].astype(np.int32)  # unstable passes of the step
+np.save(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "bl_unstable.npy"), u)
+print("share of point-steps with no unstable pass: %.3f" % (u == 0).mean())
 extra = t - 5
 print("mean trip %.3f" % t.mean())
 
