@@ -80,3 +80,68 @@ def test_recluster_sorts_by_the_score_slot():
     assert np.array_equal(st2[0, :n].numpy(), order * 10.0)
     assert nst == st2.shape[0]
     plan.close()
+
+
+def test_full_feature_run_in_plan_order_with_per_point_parameters():
+    """The documented contract for callers: after a recluster, windows AND per-point parameter
+    arrays are indexed by slot.  Relaxation + observation forcing + Tdew check (FULL kernel),
+    windows gathered through the order on the device, recluster after every chunk."""
+    n, L, chunk = 1500, 1441, 97
+    rs = np.random.RandomState(12)
+    s = abi.default_settings(L); s.use_relaxation = 1
+    p = abi.default_parameters()
+    f = oh.synth_forcing(n, L, seed=99)
+    base_l = abi.default_local(); base_l.InitLenI = 1
+    base, _, _ = oh.run_oracle("port", f, abi.default_settings(L), p, base_l)
+    f["tsurfobs"] = np.ascontiguousarray(base["tsurf"] + rs.uniform(-1, 1, (n, 1)))
+    ls = []
+    for i in range(n):
+        li = abi.default_local()
+        li.InitLenI = int(rs.randint(2, L // 2))
+        li.tair_relax = float(f["tair"][i, li.InitLenI] + rs.uniform(-3, 3))
+        li.VZ_relax = float(rs.uniform(0.5, 9)); li.RH_relax = float(rs.uniform(40, 100))
+        ls.append(li)
+    ora, _, _ = oh.run_oracle("port", f, s, p, ls)
+
+    plan = device.Plan(n, s, p, 0)
+    dev, npad = plan.device, plan.np_pad
+
+    def dev_rows(a, dtype):      # host [n][L] -> device [L][npad] in NATURAL order
+        t = torch.zeros((L, npad), dtype=dtype, device=dev)
+        t[:, :n] = torch.from_numpy(np.ascontiguousarray(a)).to(dev).T
+        return t
+    nat = {k: dev_rows(f[k], torch.float64) for k in ("tair", "tdew", "vz", "rhz", "prec", "sw", "lw", "tsurfobs")}
+    nat["precphase"] = dev_rows(f["precphase"], torch.int32)
+    hour = torch.from_numpy(np.ascontiguousarray(f["hour"])).to(dev)
+
+    def vec(vals, dtype):
+        t = torch.zeros((npad,), dtype=dtype, device=dev)
+        t[:n] = torch.tensor(vals, dtype=dtype)
+        return t
+    pnat = dict(initlen=vec([l.InitLenI for l in ls], torch.int32),
+                tair=vec([l.tair_relax for l in ls], torch.float64),
+                vz=vec([l.VZ_relax for l in ls], torch.float64),
+                rh=vec([l.RH_relax for l in ls], torch.float64))
+    tbot = plan.uniform_tbottom(int(f["year"][0]), int(f["month"][0]), int(f["day"][0]))
+    out = device.OutputWindow.empty(chunk, npad, dev)
+    res = {k: np.full((n, L), np.nan) for k in oh.F64_OUT}
+    for t0 in range(1, L + 1, chunk):
+        ns = min(chunk, L - t0 + 1)
+        order = plan.order().clone().long()
+        tens = {k: v[t0 - 1:t0 - 1 + ns].index_select(1, order).contiguous() for k, v in nat.items()}
+        tens["hour"] = hour[t0 - 1:t0 - 1 + ns].contiguous()
+        tens["depth"] = None
+        win = device.ForcingWindow(ns, npad, tens)
+        pp = plan.point_params(tbot, pnat["initlen"][order].contiguous(), pnat["tair"][order].contiguous(),
+                               pnat["vz"][order].contiguous(), pnat["rh"][order].contiguous())
+        if t0 == 1:
+            plan.init_state(win, pp)
+        plan.step(win, out, pp, t0, ns, out_row0=t0 - 1)
+        plan.sync()
+        idx = order[:n].cpu().numpy()
+        for k in oh.F64_OUT:
+            res[k][idx, t0 - 1:t0 - 1 + ns] = out.tensors[k][:ns, :n].cpu().numpy().T
+        plan.recluster()
+    for k in oh.F64_OUT:
+        assert np.array_equal(res[k], ora[k]), (k, int((res[k] != ora[k]).sum()))
+    plan.close()
