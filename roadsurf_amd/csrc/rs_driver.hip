@@ -371,14 +371,19 @@ struct ExpandRawArgs {
   int32_t cplLen;
   int32_t i0, nsteps; /* 0-based first simulation index of the window */
   int64_t stride;
+  const int32_t *order; /* plan order (rs_hip_recluster): window column s holds point order[s];
+                           nullptr = natural order */
 };
 
 __global__ void __launch_bounds__(RS_BLOCK) expand_raw_kernel(const ExpandRawArgs A) {
-  const int64_t p = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
+  const int64_t slot = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
   const int fld = blockIdx.y;
   double *out = A.out[fld];
-  if (p >= A.S.npoints || !out) return;
-  out += p;
+  if (slot >= A.S.npoints || !out) return;
+  out += slot;
+  /* everything per point (raw columns, walk positions, decisions) is read at the point's own
+   * index: the raw series are ~100x smaller than the window, gathering them is cheap */
+  const int64_t p = A.order ? (int64_t)A.order[slot] : slot;
   /* a point read_input rejects is not simulated by the reference (roadrunner.cpp:393): a
    * missing air temperature makes CheckValues stop its lane at the first index (its output
    * rows are blanked afterwards, blank_rejected_kernel) */
@@ -436,6 +441,34 @@ __global__ void __launch_bounds__(RS_BLOCK) pp_advance_kernel(const SrcSet S, in
       (void)pp_step(w, S.src[s], S.np_pad, p, S.sim0 + (int64_t)i * S.dt);
     S.src[s].prp[p] = w.rp;
   }
+}
+
+/* per-point parameters into slot order */
+__global__ void __launch_bounds__(RS_BLOCK) gather_params_kernel(
+    const int32_t *__restrict__ order, int64_t npoints, const int32_t *initlen_p, int32_t *initlen_s,
+    const double *tair_p, double *tair_s, const double *vz_p, double *vz_s, const double *rh_p,
+    double *rh_s) {
+  const int64_t s = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
+  if (s >= npoints) return;
+  const int64_t p = order[s];
+  initlen_s[s] = initlen_p[p];
+  tair_s[s] = tair_p[p];
+  vz_s[s] = vz_p[p];
+  rh_s[s] = rh_p[p];
+}
+
+/* output rows of one launch, written in slot order, into the natural-order result */
+__global__ void __launch_bounds__(RS_BLOCK) unpermute_rows_kernel(
+    const int32_t *__restrict__ order, int64_t npoints, const double *__restrict__ chunk_out,
+    int64_t chunk_rows, double *final_out, int64_t final_rows, int64_t row0, int32_t nrows,
+    int64_t stride) {
+  const int64_t s = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
+  if (s >= npoints) return;
+  const int64_t p = order[s];
+  const int f = blockIdx.y;
+  for (int32_t r = 0; r < nrows; ++r)
+    final_out[((int64_t)f * final_rows + row0 + r) * stride + p] =
+        chunk_out[((int64_t)f * chunk_rows + r) * stride + s];
 }
 
 __global__ void __launch_bounds__(RS_BLOCK) fill_i32_kernel(int32_t *x, int64_t n, int32_t v) {
@@ -879,6 +912,7 @@ int rs_driver_expand(const RsDriverInput *in, const InputSettings *st, LocalPara
     ea.S = T.S;
     for (int f = 0; f < NFLD; ++f) ea.out[f] = win.as<double>() + (size_t)f * c.L * mp;
     ea.status = nullptr; /* the test hook shows what read_input returns, rejected or not */
+    ea.order = nullptr;
     ea.cpl_hi = st->use_coupling == 1 ? D.cpl_hi.as<int32_t>() : nullptr;
     ea.cplLen = c.cplLen;
     ea.i0 = 0;
@@ -1060,6 +1094,7 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputP
     ea.cpl_hi = coupled ? D.cpl_hi.as<int32_t>() : nullptr;
     ea.cplLen = c.cplLen;
     ea.stride = mp;
+    ea.order = nullptr;
 
     RsOutputs oo;
     double *ob = d_out.as<double>();
@@ -1069,6 +1104,40 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputP
     oo.decimate = step;
     oo.row0 = 0;
 
+    /* Plan order (rs_hip_recluster): with more than one launch per tile the slots
+     * are re-sorted by regime after every launch; windows and per-point parameters are then
+     * produced in slot order and each launch's output rows are mapped back.  Not for the
+     * general kernel (coupling, sky view), which leaves no sort key. */
+    const char *ec = getenv("ROADSURF_HIP_CLUSTER");
+    const bool cluster = !coupled && !skyview && TC < L && !(ec && atoi(ec) == 0);
+    const int rows_c = TC / step + 2; /* output rows one launch can produce */
+    Dev d_outc, d_pp_s;
+    RsOutputs oc = oo;
+    RsPointParams pps = pp;
+    if (cluster) {
+      HOK(d_outc.alloc((size_t)6 * rows_c * mp * sizeof(double)));
+      double *cb = d_outc.as<double>();
+      const size_t cs = (size_t)rows_c * mp;
+      oc.tsurf = cb; oc.snow = cb + cs; oc.water = cb + 2 * cs; oc.ice = cb + 3 * cs;
+      oc.deposit = cb + 4 * cs; oc.ice2 = cb + 5 * cs;
+      HOK(d_pp_s.alloc((size_t)mp * (sizeof(int32_t) + 3 * sizeof(double))));
+      double *pd = d_pp_s.as<double>();
+      pps.tair_relax = st->use_relaxation == 1 ? pd : nullptr;
+      pps.vz_relax = st->use_relaxation == 1 ? pd + mp : nullptr;
+      pps.rh_relax = st->use_relaxation == 1 ? pd + 2 * mp : nullptr;
+      pps.initlen = reinterpret_cast<int32_t *>(pd + 3 * mp);
+      HOK(hipMemsetAsync(d_pp_s.p, 0, (size_t)mp * (sizeof(int32_t) + 3 * sizeof(double)), stream));
+    }
+
+    if (cluster) {
+      ea.order = rs_hip_plan_order(pg.p); /* identity until the first recluster */
+      if (!ea.order) return -14;
+      hipLaunchKernelGGL(gather_params_kernel, grid1(m), dim3(RS_BLOCK), 0, stream, ea.order, (int64_t)m,
+                         pp.initlen, const_cast<int32_t *>(pps.initlen), D.tair_relax.as<double>(),
+                         d_pp_s.as<double>(), D.vz_relax.as<double>(), d_pp_s.as<double>() + mp,
+                         D.rh_relax.as<double>(), d_pp_s.as<double>() + 2 * mp);
+      HOK(hipGetLastError());
+    }
     pt.lap(3);
     for (int t0 = 1; t0 <= L; t0 += TC) {
       const int len = std::min(TC, L - t0 + 1);
@@ -1097,8 +1166,34 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputP
         fo.lw_net = ea.out[R_LWNET];
         fo.sun = d_sun.as<double>() + (size_t)(t0 - 1) * 4;
       }
-      if (t0 == 1 && rs_hip_init_state(pg.p, &fo, &pp) != 0) return -12;
-      if (rs_hip_step(pg.p, &fo, &oo, &pp, t0, len) != 0) return -13;
+      if (!cluster) {
+        if (t0 == 1 && rs_hip_init_state(pg.p, &fo, &pp) != 0) return -12;
+        if (rs_hip_step(pg.p, &fo, &oo, &pp, t0, len) != 0) return -13;
+        continue;
+      }
+      /* this launch's rows go to the launch buffer in slot order, then home */
+      const int64_t r_first = ((int64_t)t0 - 1 + step - 1) / step;
+      const int64_t r_last = ((int64_t)t0 + len - 2) / step;
+      oc.row0 = r_first;
+      if (t0 == 1 && rs_hip_init_state(pg.p, &fo, &pps) != 0) return -12;
+      if (rs_hip_step(pg.p, &fo, &oc, &pps, t0, len) != 0) return -13;
+      if (r_last >= r_first) {
+        hipLaunchKernelGGL(unpermute_rows_kernel, dim3((unsigned)(mp / RS_BLOCK), 6), dim3(RS_BLOCK), 0,
+                           stream, ea.order, (int64_t)m, (const double *)d_outc.as<double>(),
+                           (int64_t)rows_c, ob, (int64_t)n_out, r_first, (int32_t)(r_last - r_first + 1),
+                           (int64_t)mp);
+        HOK(hipGetLastError());
+      }
+      if (t0 + len <= L) {
+        if (rs_hip_recluster(pg.p) != 0) return -14;
+        ea.order = rs_hip_plan_order(pg.p);
+        hipLaunchKernelGGL(gather_params_kernel, grid1(m), dim3(RS_BLOCK), 0, stream, ea.order,
+                           (int64_t)m, pp.initlen, const_cast<int32_t *>(pps.initlen),
+                           D.tair_relax.as<double>(), d_pp_s.as<double>(), D.vz_relax.as<double>(),
+                           d_pp_s.as<double>() + mp, D.rh_relax.as<double>(),
+                           d_pp_s.as<double>() + 2 * mp);
+        HOK(hipGetLastError());
+      }
     }
     pt.lap(4);
     hipLaunchKernelGGL(blank_rejected_kernel, grid1(m), dim3(RS_BLOCK), 0, stream, ob, (int64_t)mp,
@@ -1114,6 +1209,8 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputP
     HOK(hipStreamSynchronize(stream));
     pt.lap(5);
     d_phase.release();
+    d_outc.release();
+    d_pp_s.release();
     d_out.release();
     d_outpt.release();
     pt.lap(7);
