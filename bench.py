@@ -163,7 +163,7 @@ def main() -> None:
     ev_filled = [torch.cuda.Event() for _ in range(nbuf)]    # window b holds fresh forcing
     ev_consumed = [torch.cuda.Event() for _ in range(nbuf)]  # step kernel is done with window b
 
-    cluster = bool(args.cluster) and not args.f32 and not overlap
+    cluster = bool(args.cluster) and not overlap
     kbuf = torch.empty((chunk // spk + 3, 9, npad), dtype=torch.float64, device=dev) if cluster else None
 
     def clustered_pass():

@@ -250,7 +250,6 @@ const int32_t *rs_hip_plan_order(RsPlan *pl) {
 
 int rs_hip_recluster(RsPlan *pl) {
   if (!pl) return set_err("rs_hip_recluster: null plan");
-  if (pl->f32) return set_err("rs_hip_recluster: fp64 plans only");
   if (!rs_hip_plan_order(pl)) return -1;
   HIP_OK(hipSetDevice(pl->device));
   const size_t state_bytes = (size_t)RS_NSTATE * pl->np_pad * sizeof(double);
@@ -261,9 +260,9 @@ int rs_hip_recluster(RsPlan *pl) {
     pl->sort_tmp_bytes = rs_cluster_scratch_bytes(pl->npoints);
     HIP_OK(hipMalloc(&pl->sort_tmp, pl->sort_tmp_bytes ? pl->sort_tmp_bytes : 8));
   }
-  HIP_OK(rs_cluster_sort(pl->state, pl->np_pad, pl->npoints, pl->sort_keys, pl->sort_tmp,
+  HIP_OK(rs_cluster_sort(pl->state, pl->f32, pl->np_pad, pl->npoints, pl->sort_keys, pl->sort_tmp,
                          pl->sort_tmp_bytes, pl->stream));
-  HIP_OK(rs_cluster_apply(pl->state, pl->state_alt, pl->order, pl->order_alt,
+  HIP_OK(rs_cluster_apply(pl->state, pl->state_alt, pl->f32, pl->order, pl->order_alt,
                           pl->sort_keys + 3 * pl->np_pad, pl->np_pad, pl->npoints, pl->c.NLayers,
                           pl->c.use_coupling != 0, pl->stream));
   std::swap(pl->state, pl->state_alt);

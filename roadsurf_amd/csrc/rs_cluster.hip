@@ -13,12 +13,13 @@ namespace {
 
 constexpr int KEY_BITS = 21; /* rs_kernels.hip, bl_score_key: 19 bits of passes + regime + cover */
 
-__global__ void __launch_bounds__(RS_BLOCK) keys_kernel(const double *__restrict__ state,
+template <typename T> /* element type of the state block: double, or float for fp32 plans */
+__global__ void __launch_bounds__(RS_BLOCK) keys_kernel(const T *__restrict__ state,
                                                         int64_t np_pad, int64_t npoints,
                                                         uint32_t *keys, uint32_t *slots) {
   const int64_t s = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
   if (s >= npoints) return;
-  double v = state[(int64_t)RS_ST_BLSCORE * np_pad + s];
+  double v = (double)state[(int64_t)RS_ST_BLSCORE * np_pad + s];
   if (!(v >= 0.0)) v = 0.0;
   const double top = (double)((1u << KEY_BITS) - 1u);
   keys[s] = (uint32_t)(v > top ? top : v);
@@ -27,8 +28,9 @@ __global__ void __launch_bounds__(RS_BLOCK) keys_kernel(const double *__restrict
 
 /* dst[row][s] = src[row][perm[s]] for the carried state, order_dst[s] = order_src[perm[s]];
  * slots beyond npoints (padding) stay where they are */
-__global__ void __launch_bounds__(RS_BLOCK) apply_kernel(const double *__restrict__ src,
-                                                         double *__restrict__ dst,
+template <typename T>
+__global__ void __launch_bounds__(RS_BLOCK) apply_kernel(const T *__restrict__ src,
+                                                         T *__restrict__ dst,
                                                          const int32_t *__restrict__ order_src,
                                                          int32_t *__restrict__ order_dst,
                                                          const uint32_t *__restrict__ perm,
@@ -67,12 +69,16 @@ size_t rs_cluster_scratch_bytes(int64_t npoints) {
 
 /* scratch: [4][np_pad] uint32 (keys in/out, slots in/out) + `tmp` for hipCUB.
  * Leaves the permutation (new slot -> old slot) in scratch + 3*np_pad. */
-hipError_t rs_cluster_sort(const double *state, int64_t np_pad, int64_t npoints, uint32_t *scratch,
-                           void *tmp, size_t tmp_bytes, hipStream_t stream) {
+hipError_t rs_cluster_sort(const double *state, bool f32, int64_t np_pad, int64_t npoints,
+                           uint32_t *scratch, void *tmp, size_t tmp_bytes, hipStream_t stream) {
   uint32_t *kin = scratch, *kout = scratch + np_pad, *sin = scratch + 2 * np_pad,
            *sout = scratch + 3 * np_pad;
-  hipLaunchKernelGGL(keys_kernel, grid1(npoints), dim3(RS_BLOCK), 0, stream, state, np_pad, npoints,
-                     kin, sin);
+  if (f32)
+    hipLaunchKernelGGL(keys_kernel<float>, grid1(npoints), dim3(RS_BLOCK), 0, stream,
+                       reinterpret_cast<const float *>(state), np_pad, npoints, kin, sin);
+  else
+    hipLaunchKernelGGL(keys_kernel<double>, grid1(npoints), dim3(RS_BLOCK), 0, stream, state, np_pad,
+                       npoints, kin, sin);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   /* stable: points with equal scores keep their relative order */
@@ -81,13 +87,19 @@ hipError_t rs_cluster_sort(const double *state, int64_t np_pad, int64_t npoints,
 }
 
 /* nlayers: NLayers of the plan; coupled: also move the coupling block (saved state etc.) */
-hipError_t rs_cluster_apply(const double *state_src, double *state_dst, const int32_t *order_src,
-                            int32_t *order_dst, const uint32_t *perm, int64_t np_pad,
-                            int64_t npoints, int nlayers, bool coupled, hipStream_t stream) {
+hipError_t rs_cluster_apply(const double *state_src, double *state_dst, bool f32,
+                            const int32_t *order_src, int32_t *order_dst, const uint32_t *perm,
+                            int64_t np_pad, int64_t npoints, int nlayers, bool coupled,
+                            hipStream_t stream) {
   dim3 g = grid1(np_pad);
   const int last = coupled ? RS_NSTATE - 1 : RS_ST_BLSCORE;
   g.y = (unsigned)(nlayers + (last - RS_MAX_LAYERS + 1));
-  hipLaunchKernelGGL(apply_kernel, g, dim3(RS_BLOCK), 0, stream, state_src, state_dst, order_src,
-                     order_dst, perm, np_pad, npoints, (int32_t)nlayers);
+  if (f32)
+    hipLaunchKernelGGL(apply_kernel<float>, g, dim3(RS_BLOCK), 0, stream,
+                       reinterpret_cast<const float *>(state_src), reinterpret_cast<float *>(state_dst),
+                       order_src, order_dst, perm, np_pad, npoints, (int32_t)nlayers);
+  else
+    hipLaunchKernelGGL(apply_kernel<double>, g, dim3(RS_BLOCK), 0, stream, state_src, state_dst,
+                       order_src, order_dst, perm, np_pad, npoints, (int32_t)nlayers);
   return hipGetLastError();
 }

@@ -64,11 +64,12 @@ hipError_t rs_launch_count_failed(const double *st, int64_t np_pad, int64_t npoi
 /* plan order (rs_cluster.hip) */
 hipError_t rs_cluster_identity(int32_t *order, int64_t np_pad, hipStream_t stream);
 size_t rs_cluster_scratch_bytes(int64_t npoints);
-hipError_t rs_cluster_sort(const double *state, int64_t np_pad, int64_t npoints, uint32_t *scratch,
-                           void *tmp, size_t tmp_bytes, hipStream_t stream);
-hipError_t rs_cluster_apply(const double *state_src, double *state_dst, const int32_t *order_src,
-                            int32_t *order_dst, const uint32_t *perm, int64_t np_pad,
-                            int64_t npoints, int nlayers, bool coupled, hipStream_t stream);
+hipError_t rs_cluster_sort(const double *state, bool f32, int64_t np_pad, int64_t npoints,
+                           uint32_t *scratch, void *tmp, size_t tmp_bytes, hipStream_t stream);
+hipError_t rs_cluster_apply(const double *state_src, double *state_dst, bool f32,
+                            const int32_t *order_src, int32_t *order_dst, const uint32_t *perm,
+                            int64_t np_pad, int64_t npoints, int nlayers, bool coupled,
+                            hipStream_t stream);
 
 /* fp32 flavour (rs_kernels_f32.hip) */
 hipError_t rs32_upload_constants(int slot, const RsConstants *c, hipStream_t stream);

@@ -75,7 +75,8 @@ __device__ __forceinline__ void run(const rs::StepArgs &a, Prof &T) {
   s.tair_end = s.vz_end = s.rh_end = 0.f;
   const float tbot = (float)(ka->pp.tbottom + row0)[lane];
   const int32_t nsteps = ka->nsteps, t0 = ka->t0;
-  rs::MathTab mt{nullptr, nullptr}; /* fp32 exp/log take no tables */
+  rs::MathTab mt{nullptr, nullptr, nullptr}; /* fp32 exp/log take no tables */
+  int32_t score = 0, regime = 0;
 
   for (int32_t k = 0; k < nsteps; ++k) {
     asm volatile("" : "+s"(ka));
@@ -112,6 +113,9 @@ __device__ __forceinline__ void run(const rs::StepArgs &a, Prof &T) {
     s.tnw2 = T.get(2);
     const Fluxes fx = model_step_fluxes(c, mt, s, f.tair, f.vz, f.rhz, prec_ts, f.sw, f.lw, f.phase,
                                         f.hour);
+    /* sort key of rs_hip_recluster, as in the fp64 kernels (rs_kernels.hip, bl_score_key) */
+    score += (fx.trips & 63) - 5;
+    if ((fx.trips & 64) && k >= nsteps - 30) regime = 1;
     model_step_ground(c, s, T, tbot, f.tair, fx, f.depth);
     if (write) {
       F32OUT(tsurf) = s.tsurf; F32OUT(snow) = s.snow; F32OUT(water) = s.wat;
@@ -126,6 +130,11 @@ __device__ __forceinline__ void run(const rs::StepArgs &a, Prof &T) {
   st[(int64_t)RS_ST_T4MELT * np + p] = s.t4melt; st[(int64_t)RS_ST_ALBEDO * np + p] = s.albedo;
   st[(int64_t)RS_ST_VERYCOLD * np + p] = s.verycold ? 1.f : 0.f;
   st[(int64_t)RS_ST_FAILED * np + p] = s.failed ? 1.f : 0.f;
+  {
+    const int32_t lo = score > 0x7ffff ? 0x7ffff : (score < 0 ? 0 : score);
+    const int32_t covered = (s.wat > 0.f || s.snow > 0.f || s.ice > 0.f || s.ice2 > 0.f || s.dep > 0.f) ? 1 : 0;
+    st[(int64_t)RS_ST_BLSCORE * np + p] = (float)(lo | (covered << 19) | (regime << 20));
+  }
 }
 
 __global__ void __launch_bounds__(kBlock, 4) step_kernel_f32_reg15(const rs::StepArgs a) {
@@ -164,6 +173,7 @@ __global__ void __launch_bounds__(kBlock) init_kernel_f32(const rs::InitArgs a) 
   st[(int64_t)RS_ST_DEP * np + p] = 0.f; st[(int64_t)RS_ST_Q2MELT * np + p] = 0.f;
   st[(int64_t)RS_ST_T4MELT * np + p] = c.T4Melt0; st[(int64_t)RS_ST_ALBEDO * np + p] = c.Albedo0;
   st[(int64_t)RS_ST_VERYCOLD * np + p] = 0.f; st[(int64_t)RS_ST_FAILED * np + p] = 0.f;
+  st[(int64_t)RS_ST_BLSCORE * np + p] = 0.f;
 }
 
 /* fp32 twin of expand_kernel: same knots (fp64), rounded once at the end. */

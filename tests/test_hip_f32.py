@@ -51,3 +51,13 @@ def test_fp32_rejects_non_lean_features():
     with pytest.raises(RuntimeError, match="LEAN feature set"):
         plan.step(win, out, pp, 1, 10)
     plan.close()
+
+
+def test_fp32_plan_order_changes_no_value():
+    """rs_hip_recluster on an fp32 plan: the re-sorted run equals the natural-order run bit for bit."""
+    from f32_experiment import run_f32
+    n, L, seed = 2000, 1441, 7
+    a = run_f32(n, L, seed, chunk=120)
+    b = run_f32(n, L, seed, chunk=120, cluster=True)
+    for k in ("tsurf", "snow", "water", "ice", "deposit", "ice2"):
+        assert np.array_equal(a[k], b[k]), k
