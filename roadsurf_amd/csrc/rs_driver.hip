@@ -172,7 +172,7 @@ __device__ __forceinline__ PlanStep pp_step(PpWalk &w, const SrcDev &sd, int64_t
 /* Sequential pass over simulation indices [i0, i1) of one variable of one point.
  * visit(i, merged value, bitmask of the sources that supplied a value).
  * rp0[s]: rawPos at i0 for sources with per-point time axes. */
-template <class Visit>
+template <bool PP, class Visit> /* PP: some source has per-point time axes */
 __device__ __forceinline__ void walk_field(const SrcSet &S, int fld, int64_t p, int32_t i0,
                                            int32_t i1, const int32_t *rp0, Visit &&visit) {
   const double thr = threshold(fld);
@@ -187,7 +187,7 @@ __device__ __forceinline__ void walk_field(const SrcSet &S, int fld, int64_t p, 
     pw[s].len = 0;
     pw[s].cached = -1;
     pw[s].tr = pw[s].tr1 = 0;
-    if (s < S.nsrc && S.src[s].ptimes) pp_begin(pw[s], S.src[s], p, rp0[s]);
+    if (PP && s < S.nsrc && S.src[s].ptimes) pp_begin(pw[s], S.src[s], p, rp0[s]);
   }
   for (int32_t i = i0; i < i1; ++i) {
     double v = miss_r();
@@ -197,7 +197,7 @@ __device__ __forceinline__ void walk_field(const SrcSet &S, int fld, int64_t p, 
       if (s >= S.nsrc) continue;
       const double *x = S.src[s].fld[fld];
       PlanStep st;
-      if (S.src[s].ptimes) {
+      if (PP && S.src[s].ptimes) {
         /* the walk advances whether or not this source has the variable */
         st = pp_step(pw[s], S.src[s], S.np_pad, p, S.sim0 + (int64_t)i * S.dt);
       } else {
@@ -262,13 +262,14 @@ struct ScanArgs {
   double *cpl_t;          /* [np_pad] that observation */
 };
 
+template <bool PP>
 __global__ void __launch_bounds__(RS_BLOCK) scan_raw_kernel(const ScanArgs A) {
   const int64_t p = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
   if (p >= A.S.npoints) return;
   const int y = blockIdx.y;
   const int L = A.S.simlen;
-  int32_t rp0[RS_MAX_SOURCES];
-  initial_positions(A.S, p, rp0);
+  int32_t rp0[RS_MAX_SOURCES] = {0, 0, 0, 0};
+  if (PP) initial_positions(A.S, p, rp0);
   if (y < 6) {
     const int fld = (y == 0) ? R_TAIR : (y == 1) ? R_RHZ : (y == 2) ? R_PREC : (y == 3) ? R_SW
                   : (y == 4) ? R_LW : R_VZ;
@@ -276,7 +277,7 @@ __global__ void __launch_bounds__(RS_BLOCK) scan_raw_kernel(const ScanArgs A) {
     for (int s = 0; s < A.S.nsrc; ++s)
       if (A.S.src[s].is_obs) obsmask |= 1u << s;
     int32_t first = L, last = -1;
-    walk_field(A.S, fld, p, 0, L, rp0, [&](int32_t i, double v, uint32_t mask) {
+    walk_field<PP>(A.S, fld, p, 0, L, rp0, [&](int32_t i, double v, uint32_t mask) {
       if (first == L && is_missing(v)) first = i;
       /* JsonSource.cpp:412-416: `for i = SimLen..1: if tair[i-1] > -100 return i`, on the
        * source's OWN interpolated series; DataHandler.cpp:118-137 takes the max over the
@@ -289,7 +290,7 @@ __global__ void __launch_bounds__(RS_BLOCK) scan_raw_kernel(const ScanArgs A) {
     int32_t ci = -1;
     double ct = miss_r();
     /* roadrunner.cpp:256-261: last index whose TSurfObs is neither missing nor < -100 */
-    walk_field(A.S, R_OBS, p, 0, L, rp0, [&](int32_t i, double v, uint32_t) {
+    walk_field<PP>(A.S, R_OBS, p, 0, L, rp0, [&](int32_t i, double v, uint32_t) {
       if (!(is_missing(v) || v < -100)) {
         ci = i;
         ct = v;
@@ -375,6 +376,7 @@ struct ExpandRawArgs {
                            nullptr = natural order */
 };
 
+template <bool PP>
 __global__ void __launch_bounds__(RS_BLOCK) expand_raw_kernel(const ExpandRawArgs A) {
   const int64_t slot = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
   const int fld = blockIdx.y;
@@ -400,8 +402,8 @@ __global__ void __launch_bounds__(RS_BLOCK) expand_raw_kernel(const ExpandRawArg
   int32_t rp0[RS_MAX_SOURCES];
 #pragma unroll
   for (int s = 0; s < RS_MAX_SOURCES; ++s)
-    rp0[s] = (s < A.S.nsrc && A.S.src[s].ptimes) ? A.S.src[s].prp[p] : 0;
-  walk_field(A.S, fld, p, i0, i0 + A.nsteps, rp0, [&](int32_t i, double v, uint32_t) {
+    rp0[s] = (PP && s < A.S.nsrc && A.S.src[s].ptimes) ? A.S.src[s].prp[p] : 0;
+  walk_field<PP>(A.S, fld, p, i0, i0 + A.nsteps, rp0, [&](int32_t i, double v, uint32_t) {
     if (rejected) v = miss_r();
     if (i > clr_lo && i <= clr_hi) v = miss_r();
     out[(int64_t)(i - i0) * stride] = v;
@@ -478,6 +480,14 @@ __global__ void __launch_bounds__(RS_BLOCK) fill_i32_kernel(int32_t *x, int64_t 
 __global__ void __launch_bounds__(RS_BLOCK) fill_f64_kernel(double *x, int64_t n, double v) {
   const int64_t i = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
   if (i < n) x[i] = v;
+}
+
+void launch_expand_raw(bool any_pp, int64_t mp, const ExpandRawArgs &ea, hipStream_t stream) {
+  const dim3 g((unsigned)(mp / RS_BLOCK), NFLD), b(RS_BLOCK);
+  if (any_pp)
+    hipLaunchKernelGGL(expand_raw_kernel<true>, g, b, 0, stream, ea);
+  else
+    hipLaunchKernelGGL(expand_raw_kernel<false>, g, b, 0, stream, ea);
 }
 
 inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + RS_BLOCK - 1) / RS_BLOCK)); }
@@ -703,8 +713,12 @@ int decide_tile(const Common &c, const InputSettings *st, const TileRaw &T, Tile
   sa.last_obs = D.last_obs.as<int32_t>();
   sa.cpl_i = D.cpl_i.as<int32_t>();
   sa.cpl_t = D.cpl_t.as<double>();
-  hipLaunchKernelGGL(scan_raw_kernel, dim3((unsigned)(mp / RS_BLOCK), 7), dim3(RS_BLOCK), 0, stream,
-                     sa);
+  if (T.any_pp)
+    hipLaunchKernelGGL(scan_raw_kernel<true>, dim3((unsigned)(mp / RS_BLOCK), 7), dim3(RS_BLOCK), 0,
+                       stream, sa);
+  else
+    hipLaunchKernelGGL(scan_raw_kernel<false>, dim3((unsigned)(mp / RS_BLOCK), 7), dim3(RS_BLOCK), 0,
+                       stream, sa);
   HOK(hipGetLastError());
   FinalArgs fa;
   fa.S = T.S;
@@ -918,8 +932,7 @@ int rs_driver_expand(const RsDriverInput *in, const InputSettings *st, LocalPara
     ea.i0 = 0;
     ea.nsteps = c.L;
     ea.stride = mp;
-    hipLaunchKernelGGL(expand_raw_kernel, dim3((unsigned)(mp / RS_BLOCK), NFLD), dim3(RS_BLOCK), 0,
-                       sg.s, ea);
+    launch_expand_raw(T.any_pp, mp, ea, sg.s);
     HOK(hipGetLastError());
     for (int f = 0; f < NFLD; ++f) {
       HOK(transpose((const double *)ea.out[f], pt.as<double>(), c.L, m, mp, c.L, sg.s));
@@ -1143,8 +1156,7 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputP
       const int len = std::min(TC, L - t0 + 1);
       ea.i0 = t0 - 1;
       ea.nsteps = len;
-      hipLaunchKernelGGL(expand_raw_kernel, dim3((unsigned)(mp / RS_BLOCK), NFLD), dim3(RS_BLOCK), 0,
-                         stream, ea);
+      launch_expand_raw(T.any_pp, mp, ea, stream);
       HOK(hipGetLastError());
       if (T.any_pp && t0 + len <= L) { /* per-point walks: move to the start of the next window */
         hipLaunchKernelGGL(pp_advance_kernel, grid1(mp), dim3(RS_BLOCK), 0, stream, T.S,
