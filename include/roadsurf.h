@@ -383,8 +383,8 @@ int64_t rs_hip_div_mismatch_count(RsPlan *plan);
 /* Kernel flavour: 0 auto (1 for the LEAN feature set with NLayers == 15, else 2), 1 register
  * profile, 2 LDS profile,
  * 3 register profile with the boundary-layer iteration tail compacted over the workgroup
- * (an experiment that executes 12 % fewer instructions and is slower; it leaves no
- * sort key for rs_hip_recluster).  All flavours return the same bits. */
+ * (an experiment that executes 12 % fewer instructions and is slower, with or without plan
+ * order: DESIGN.md 6).  All flavours return the same bits. */
 int rs_hip_set_variant(RsPlan *plan, int32_t variant);
 
 /* ---- plan order: load balancing by regime ----------------------------------------------

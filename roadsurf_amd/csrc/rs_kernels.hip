@@ -280,6 +280,7 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
 struct BlTailShared {
   double item[7][kBlock]; /* dT, den0, vkvz, avk, PSIM, PSIH, BLCond of a parked lane */
   double res[3][kBlock];  /* PSIM, PSIH, BLCond when its loop has exited */
+  int32_t trips[kBlock];  /* passes it took */
   int32_t count[2];       /* parked items of the even / odd time index */
 };
 
@@ -299,14 +300,15 @@ __device__ __forceinline__ Fluxes fluxes_block_tail(const RsConstants &c, const 
   v.dT = v.den0 = v.vkvz = v.avk = 0.0;
   x.PSIM = x.PSIH = x.BLCond = 0.0;
   a.AirDens = a.AirHCap = a.PsychC = a.WatDen = 0.0;
-  bool need = false;
+  bool need = false, unstable = false;
+  int32_t passes = 5;
   if (active) {
     fluxes_pre(c, mt, s, tair, vz, rhz, prec_ts, phase, hour, fx);
     bl_setup(c, s.tsurf, tair, vz, v, x, a);
     bool done = false;
     const double stab_num = bl_stab_num(c);
 #pragma unroll
-    for (int j = 1; j <= 5; ++j) done = bl_iteration(c, mt, v, x, j, stab_num);
+    for (int j = 1; j <= 5; ++j) done = bl_iteration(c, mt, v, x, j, stab_num, &unstable);
     need = !done && RS_BL_MAXIT > 5;
   }
   const int par = k & 1;
@@ -347,19 +349,24 @@ __device__ __forceinline__ Fluxes fluxes_block_tail(const RsConstants &c, const 
     wx.PSIH = sh.item[5][w];
     wx.BLCond = sh.item[6][w];
     const double stab_num = bl_stab_num(c);
-    for (int j = 6; j <= RS_BL_MAXIT; ++j)
+    int j = 6;
+    for (; j <= RS_BL_MAXIT; ++j)
       if (bl_iteration(c, mt, wv, wx, j, stab_num)) break;
     sh.res[0][w] = wx.PSIM;
     sh.res[1][w] = wx.PSIH;
     sh.res[2][w] = wx.BLCond;
+    sh.trips[w] = j;
   }
   __syncthreads();
   if (need) {
     x.PSIM = sh.res[0][slot];
     x.PSIH = sh.res[1][slot];
     x.BLCond = sh.res[2][slot];
+    passes = sh.trips[slot];
+    unstable = true; /* a parked loop is in the unstable regime for all practical purposes */
   }
   if (active) {
+    fx.trips = passes + (unstable ? 64 : 0);
     fx.blcond = x.BLCond;
     bl_finish(c, mt, a, x, s.tsurf, tair, vz, rhz, s.wat, fx.le, fx.evap);
     fluxes_post(c, s, sw, lw, CouplingInputs(), fx);
@@ -373,7 +380,7 @@ __device__ __forceinline__ Fluxes fluxes_block_tail(const RsConstants &c, const 
  * the barriers in fluxes_block_tail need all of them. */
 template <bool FULL, class Prof>
 __device__ __forceinline__ void time_loop_bt(const MathTab &mt, Prof &T, Scalars &s,
-                                             BlTailShared &sh, bool valid) {
+                                             BlTailShared &sh, bool valid, int32_t &score) {
   KernArgs ka = kernargs();
   const uint32_t lane = threadIdx.x;
   const int64_t row0 = (int64_t)blockIdx.x * kBlock;
@@ -456,6 +463,8 @@ __device__ __forceinline__ void time_loop_bt(const MathTab &mt, Prof &T, Scalars
                                         f.phase, f.hour, sh, k);
     if (valid && k + 1 < nsteps) nxt = load_forcing<FULL>(ka, row0, lane, k + 1);
     if (active) {
+      score += (fx.trips & 63) - 5;
+      if ((fx.trips & 64) && k >= nsteps - RS_REGIME_WINDOW) score |= 1 << 30;
       model_step_ground(c, s, T, tbot, tair, fx, f.depth);
       store_outputs(ka, i, row0, lane, s, true);
     } else if (valid) {
@@ -857,8 +866,12 @@ __global__ void __launch_bounds__(kBlock, 4) step_kernel_bt(const StepArgs a) {
     s.q2melt = s.t4melt = s.albedo = s.tair_end = s.vz_end = s.rh_end = 0.0;
     s.verycold = s.failed = false;
   }
-  time_loop_bt<FULL>(mt, T, s, sh, valid);
-  if (valid) store_state<FULL>(a.state, a.np_pad, p, T, s);
+  int32_t score = 0;
+  time_loop_bt<FULL>(mt, T, s, sh, valid, score);
+  if (valid) {
+    store_state<FULL>(a.state, a.np_pad, p, T, s);
+    a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
+  }
 }
 
 template <bool FULL, int WPE>
