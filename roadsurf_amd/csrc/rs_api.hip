@@ -395,6 +395,8 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
       return set_err("rs_hip_step: the fp32 flavour supports the LEAN feature set only (no Tdew, "
                      "observation forcing, depth, relaxation, coupling, sky view)");
     HIP_OK(rs32_launch_step(a, pl->c.NLayers, pl->variant, pl->stream));
+  } else if (skyview && !pl->c.use_coupling) {
+    HIP_OK(rs_launch_step_sky(a, pl->c.NLayers, pl->stream)); /* lock-step FULL + sky view */
   } else if (coupled || skyview) {
     if (!pp->coupling_index && pl->c.use_coupling)
       return set_err("rs_hip_step: use_coupling is set: pass coupling_index/coupling_tsurf");

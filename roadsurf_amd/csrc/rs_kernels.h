@@ -55,6 +55,7 @@ hipError_t rs_upload_constants(int slot, const RsConstants *c, hipStream_t strea
 hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
                           hipStream_t stream);
 hipError_t rs_launch_step_coupled(const rs::StepArgs &a, int NL, hipStream_t stream);
+hipError_t rs_launch_step_sky(const rs::StepArgs &a, int NL, hipStream_t stream);
 hipError_t rs_launch_init(const rs::InitArgs &a, hipStream_t stream);
 hipError_t rs_launch_knots(const rs::KnotArgs &a, int32_t nknots, hipStream_t stream);
 hipError_t rs_launch_expand(const rs::ExpandArgs &a, int32_t nintervals, hipStream_t stream);

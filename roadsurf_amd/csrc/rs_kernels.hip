@@ -173,13 +173,27 @@ __device__ __forceinline__ void store_outputs(KernArgs ka, int32_t i, int64_t ro
 
 /* The time loop of runsimulation (examples/example1/src/Simulation.f90:57-115)
  * for one point over absolute indices [t0, t0+nsteps). */
-template <bool FULL, class Prof>
+/* SKY: sky view / local horizons (src/ModRadiation.f90, examples/example1/src/Simulation.f90:
+ * 151-162) in the lock-step loop; with coupling the general kernel below does it. */
+template <bool FULL, class Prof, bool SKY = false>
 __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s, int32_t &score) {
+  static_assert(FULL || !SKY, "sky view belongs to the FULL feature set");
   KernArgs ka = kernargs();
   const uint32_t lane = threadIdx.x;
   const int64_t row0 = (int64_t)blockIdx.x * kBlock; /* first point of this workgroup */
   const int32_t nsteps = ka->nsteps, t0 = ka->t0;
   const double tbot = (ka->pp.tbottom + row0)[lane];
+  double skyv = R4(1.0), sinlat = 0, coslat = 0, lonrad = 0;
+  bool sky_on = false;
+  if (SKY) {
+    skyv = (ka->pp.sky_view + row0)[lane];
+    sky_on = (skyv < R4(1.0) && skyv > R4(-0.01));
+    if (sky_on) {
+      sinlat = (ka->pp.sin_lat + row0)[lane];
+      coslat = (ka->pp.cos_lat + row0)[lane];
+      lonrad = (ka->pp.lon_rad + row0)[lane];
+    }
+  }
   int32_t initlen = 0;
   bool relax = false;
   double tairR = 0, vzR = 0, rhR = 0;
@@ -212,10 +226,22 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
     if (i == 1 && vz < R4(0.4)) vz = R4(0.4);
     const double prec_ts = rs_div(f.prec, 3600.0) * c.DTSecs; /* src/InputOutput.f90:111,186 */
 
+    double sw_dir = 0.0, lw_net = 0.0;
+    if (SKY) {
+      const int64_t row = (int64_t)k * ka->f.t_stride + row0;
+      sw_dir = (ka->f.sw_dir + row)[lane];
+      lw_net = (ka->f.lw_net + row)[lane];
+    }
     if (i < c.SimLen) {
       Forcing chk = f;
       chk.vz = vz;
       if (check_values(chk, s.tsurf, FULL && ka->f.tdew != nullptr)) s.failed = true;
+      if (SKY) {
+        if (sky_on && (sw_dir < R4(-0.1) || sw_dir > R4(4000.0) || lw_net < R4(-1000.0) ||
+                       lw_net > R4(1000.0)))
+          s.failed = true;                      /* src/InputOutput.f90:68-74 */
+        if (sw_dir > f.sw) sw_dir = f.sw;       /* :75-77 */
+      }
       if (FULL) {
         /* SetCurrentValues obs forcing, src/InputOutput.f90:116-148 */
         if ((i <= initlen || c.force_tsurf) && f.tsurfobs > R4(-100.0)) {
@@ -250,8 +276,18 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
       s.tnw1 = T.get(1);
       s.tnw2 = T.get(2);
     }
+    double sw_in = f.sw, lw_in = f.lw;
+    if (SKY && sky_on) {
+      /* the reference runs this between PrecipitationToStorage and BalanceModelOneStep
+       * (Simulation.f90:151-162); the two do not share data, so the order is free */
+      if (!sky_view_radiation(ka->f.sun + (int64_t)k * 4, sinlat, coslat, lonrad, skyv,
+                              ka->pp.albedo_surroundings,
+                              ka->pp.horizons ? ka->pp.horizons + row0 + lane : nullptr, ka->np_pad,
+                              sw_in, sw_dir, lw_in, lw_net))
+        s.failed = true; /* the reference would `stop` the process here */
+    }
     const Fluxes fx =
-        model_step_fluxes(c, mt, s, tair, vz, rhz, prec_ts, f.sw, f.lw, f.phase, f.hour);
+        model_step_fluxes(c, mt, s, tair, vz, rhz, prec_ts, sw_in, lw_in, f.phase, f.hour);
     /* scheduling hint (bl_score_key): extra passes of this launch; bit 30 = the point was in
      * the unstable regime at some index of the launch's last 30 */
     score += (fx.trips & 63) - 5;
@@ -891,6 +927,23 @@ __global__ void __launch_bounds__(kBlock, WPE) step_kernel_lds(const StepArgs a)
   a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
 }
 
+/* FULL feature set + sky view in lock step, LDS profile (any NLayers). */
+__global__ void __launch_bounds__(kBlock, 3) step_kernel_sky(const StepArgs a) {
+  extern __shared__ double lds[]; /* [NLayers][kBlock] */
+  __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
+  const MathTab mt = fill_math_tables(math_lds);
+  __syncthreads();
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= a.npoints) return;
+  LdsProfile T{lds + threadIdx.x, g_consts[a.cslot].NLayers};
+  Scalars s;
+  int32_t score = 0;
+  load_state<true>(a.state, a.np_pad, p, T, s);
+  time_loop<true, LdsProfile, true>(mt, T, s, score);
+  store_state<true>(a.state, a.np_pad, p, T, s);
+  a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
+}
+
 /* Coupled variant: LDS profile (any NLayers), FULL feature set + coupling. */
 __global__ void __launch_bounds__(kBlock, 2) step_kernel_coupled(const StepArgs a) {
   extern __shared__ double lds[]; /* [2][NLayers][kBlock]: profile, stale TmpNw */
@@ -1145,6 +1198,12 @@ hipError_t rs_upload_constants(int slot, const RsConstants *c, hipStream_t strea
   if (e != hipSuccess) return e;
   return hipMemcpyToSymbolAsync(HIP_SYMBOL(rs::g_consts), c, sizeof(RsConstants),
                                 (size_t)slot * sizeof(RsConstants), hipMemcpyHostToDevice, stream);
+}
+
+hipError_t rs_launch_step_sky(const rs::StepArgs &a, int NL, hipStream_t stream) {
+  const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
+  hipLaunchKernelGGL(rs::step_kernel_sky, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
+  return hipGetLastError();
 }
 
 hipError_t rs_launch_step_coupled(const rs::StepArgs &a, int NL, hipStream_t stream) {
