@@ -22,7 +22,9 @@ __global__ void __launch_bounds__(RS_BLOCK) keys_kernel(const T *__restrict__ st
   double v = (double)state[(int64_t)RS_ST_BLSCORE * np_pad + s];
   if (!(v >= 0.0)) v = 0.0;
   const double top = (double)((1u << KEY_BITS) - 1u);
-  keys[s] = (uint32_t)(v > top ? top : v);
+  /* descending: the expensive points get the low slots, so their workgroups are dispatched
+   * first and the cheap ones fill the end of the grid (longest job first) */
+  keys[s] = (uint32_t)top - (uint32_t)(v > top ? top : v);
   slots[s] = (uint32_t)s;
 }
 

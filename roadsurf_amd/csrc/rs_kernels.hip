@@ -854,8 +854,9 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Pr
 }
 
 /* RS_ST_BLSCORE from the loop's counter: bits 0-18 extra passes (saturating), bit 19 regime.
- * Sorting ascending puts the stable-regime points first (their waves never enter the log/sqrt
- * branch), then the others by the passes they needed (tools/bl_persistence.py). */
+ * Sorted (descending: expensive first, rs_cluster.hip) the unstable-regime points come first,
+ * by the passes they needed, then the stable-regime points, whose waves never enter the log/sqrt
+ * branch (tools/bl_persistence.py). */
 __device__ __forceinline__ double bl_score_key(int32_t score, const Scalars &s) {
   const int32_t extra = score & 0x3fffffff;
   const int32_t lo = extra > 0x7ffff ? 0x7ffff : extra;

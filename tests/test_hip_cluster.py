@@ -75,8 +75,10 @@ def test_recluster_sorts_by_the_score_slot():
     plan.sync()
     st2 = plan.state()
     order = plan.order()[:n].cpu().numpy()
-    assert np.array_equal(st2[slot, :n].numpy(), np.sort(score, kind="stable"))
-    assert np.array_equal(order, np.argsort(score, kind="stable"))
+    # descending (the expensive points get the low slots: their workgroups start first), stable
+    want = np.argsort(-score, kind="stable")
+    assert np.array_equal(st2[slot, :n].numpy(), score[want])
+    assert np.array_equal(order, want)
     assert np.array_equal(st2[0, :n].numpy(), order * 10.0)
     assert nst == st2.shape[0]
     plan.close()
