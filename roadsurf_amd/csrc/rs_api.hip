@@ -37,9 +37,10 @@ static int set_err(const char *fmt, ...) {
       return set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
-static bool g_slot_used[64][RS_CONST_SLOTS];
-static std::mutex g_slot_mutex; /* runsimulation is called concurrently from driver threads
-                                    (examples/example1/src/roadrunner.cpp:490-497) */
+/* exp/log tables are per-device globals, uploaded once per device; plans are created
+ * concurrently from driver threads (examples/example1/src/roadrunner.cpp:490-497) */
+static bool g_tables_up[64];
+static std::mutex g_tables_mutex;
 
 struct RsPlan {
   int device = 0;
@@ -55,7 +56,9 @@ struct RsPlan {
   size_t sort_tmp_bytes = 0;
   uint32_t *sort_keys = nullptr; /* [4][np_pad]: keys in/out, slots in/out */
   int variant = RS_VARIANT_AUTO;
-  int cslot = -1;
+  /* the plan's constants on the device (no table of slots: any number of plans may be alive) */
+  void *consts_dev = nullptr;   /* RsConstants */
+  void *consts32_dev = nullptr; /* RsConstantsF, allocated by rs_hip_set_precision(32) */
   bool f32 = false; /* single-precision flavour: windows and state hold floats */
   std::vector<hipEvent_t> ev; /* start/stop pairs */
   size_t ev_used = 0;
@@ -188,23 +191,20 @@ RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints, const RsConstants *c
     return nullptr;
   }
   (void)hipMemsetAsync(pl->state, 0, bytes, pl->stream);
-  /* claim a slot of the per-device __constant__ table */
-  {
-    std::lock_guard<std::mutex> lock(g_slot_mutex);
-    for (int sidx = 0; sidx < RS_CONST_SLOTS; ++sidx)
-      if (!g_slot_used[device][sidx]) {
-        g_slot_used[device][sidx] = true;
-        pl->cslot = sidx;
-        break;
-      }
-  }
-  if (pl->cslot < 0 || rs_upload_constants(pl->cslot, &pl->c, pl->stream) != hipSuccess) {
-    set_err("rs_hip_plan_create: no free constant slot (max %d plans per device) or upload failed",
-            RS_CONST_SLOTS);
-    if (pl->cslot >= 0) {
-      std::lock_guard<std::mutex> lock(g_slot_mutex);
-      g_slot_used[device][pl->cslot] = false;
+  hipError_t ce = hipMalloc(&pl->consts_dev, sizeof(RsConstants));
+  if (ce == hipSuccess)
+    ce = hipMemcpyAsync(pl->consts_dev, &pl->c, sizeof(RsConstants), hipMemcpyHostToDevice, pl->stream);
+  if (ce == hipSuccess) {
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
+    if (!g_tables_up[device]) {
+      ce = rs_upload_math_tables(pl->stream);
+      if (ce == hipSuccess) ce = hipStreamSynchronize(pl->stream);
+      if (ce == hipSuccess) g_tables_up[device] = true;
     }
+  }
+  if (ce != hipSuccess) {
+    set_err("rs_hip_plan_create: upload of the constants failed: %s", hipGetErrorString(ce));
+    if (pl->consts_dev) (void)hipFree(pl->consts_dev);
     (void)hipFree(pl->state);
     (void)hipFree(pl->counter);
     delete pl;
@@ -218,10 +218,8 @@ void rs_hip_plan_destroy(RsPlan *pl) {
   (void)hipSetDevice(pl->device);
   (void)hipStreamSynchronize(pl->stream);
   for (hipEvent_t e : pl->ev) (void)hipEventDestroy(e);
-  if (pl->cslot >= 0) {
-    std::lock_guard<std::mutex> lock(g_slot_mutex);
-    g_slot_used[pl->device][pl->cslot] = false;
-  }
+  if (pl->consts_dev) (void)hipFree(pl->consts_dev);
+  if (pl->consts32_dev) (void)hipFree(pl->consts32_dev);
   (void)hipFree(pl->state);
   (void)hipFree(pl->counter);
   if (pl->order) (void)hipFree(pl->order);
@@ -279,7 +277,10 @@ size_t rs_hip_plan_state_bytes(const RsPlan *pl) {
 int rs_hip_set_precision(RsPlan *pl, int32_t bits) {
   if (!pl || (bits != 32 && bits != 64)) return set_err("rs_hip_set_precision: bits must be 32 or 64");
   HIP_OK(hipSetDevice(pl->device));
-  if (bits == 32) HIP_OK(rs32_upload_constants(pl->cslot, &pl->c, pl->stream));
+  if (bits == 32) {
+    if (!pl->consts32_dev) HIP_OK(hipMalloc(&pl->consts32_dev, rs32_constants_bytes()));
+    HIP_OK(rs32_upload_constants(pl->consts32_dev, &pl->c, pl->stream));
+  }
   pl->f32 = (bits == 32);
   return 0;
 }
@@ -310,7 +311,7 @@ int rs_hip_init_state(RsPlan *pl, const RsForcing *f, const RsPointParams *pp) {
   if (!pp || !pp->tbottom) return set_err("rs_hip_init_state: tbottom is required");
   HIP_OK(hipSetDevice(pl->device));
   rs::InitArgs a;
-  a.cslot = pl->cslot;
+  a.consts = pl->f32 ? pl->consts32_dev : pl->consts_dev;
   a.f = *f;
   a.pp = *pp;
   a.state = pl->state;
@@ -366,8 +367,15 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
       return set_err("rs_hip_step: with coupling the window must be the whole series "
                      "(t0 = 1, nsteps = SimLen = %d): coupling windows are replayed", pl->c.SimLen);
   }
+  /* every argument / feature check comes before the event pool is touched: a start event
+   * without its stop event would poison rs_hip_timing_step_ms */
+  if (pl->c.use_coupling && !pp->coupling_index)
+    return set_err("rs_hip_step: use_coupling is set: pass coupling_index/coupling_tsurf");
+  if (pl->f32 && (full || coupled || skyview))
+    return set_err("rs_hip_step: the fp32 flavour supports the LEAN feature set only (no Tdew, "
+                   "observation forcing, depth, relaxation, coupling, sky view)");
   rs::StepArgs a;
-  a.cslot = pl->cslot;
+  a.consts = pl->f32 ? pl->consts32_dev : pl->consts_dev;
   a.f = *f;
   a.o = *o;
   a.pp = *pp;
@@ -381,30 +389,32 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
     if (pl->ev_used + 2 > pl->ev.size()) {
       hipEvent_t x, y;
       HIP_OK(hipEventCreate(&x));
-      HIP_OK(hipEventCreate(&y));
+      if (hipEventCreate(&y) != hipSuccess) {
+        (void)hipEventDestroy(x);
+        return set_err("rs_hip_step: hipEventCreate failed");
+      }
       pl->ev.push_back(x);
       pl->ev.push_back(y);
     }
     e0 = pl->ev[pl->ev_used];
     e1 = pl->ev[pl->ev_used + 1];
-    pl->ev_used += 2;
     HIP_OK(hipEventRecord(e0, pl->stream));
   }
-  if (pl->f32) {
-    if (full || coupled || skyview)
-      return set_err("rs_hip_step: the fp32 flavour supports the LEAN feature set only (no Tdew, "
-                     "observation forcing, depth, relaxation, coupling, sky view)");
-    HIP_OK(rs32_launch_step(a, pl->c.NLayers, pl->variant, pl->stream));
-  } else if (skyview && !pl->c.use_coupling) {
-    HIP_OK(rs_launch_step_sky(a, pl->c.NLayers, pl->stream)); /* lock-step FULL + sky view */
-  } else if (coupled || skyview) {
-    if (!pp->coupling_index && pl->c.use_coupling)
-      return set_err("rs_hip_step: use_coupling is set: pass coupling_index/coupling_tsurf");
-    HIP_OK(rs_launch_step_coupled(a, pl->c.NLayers, pl->stream));
-  }
+  hipError_t le;
+  if (pl->f32)
+    le = rs32_launch_step(a, pl->c.NLayers, pl->variant, pl->stream);
+  else if (skyview && !coupled)
+    le = rs_launch_step_sky(a, pl->c.NLayers, pl->stream); /* lock-step FULL + sky view */
+  else if (coupled)
+    le = rs_launch_step_coupled(a, pl->c.NLayers, pl->stream);
   else
-    HIP_OK(rs_launch_step(a, pl->c.NLayers, full, pl->variant, pl->stream));
-  if (pl->timing) HIP_OK(hipEventRecord(e1, pl->stream));
+    le = rs_launch_step(a, pl->c.NLayers, full, pl->variant, pl->stream);
+  if (le != hipSuccess) /* the pair stays unused: ev_used has not advanced */
+    return set_err("rs_hip_step: kernel launch failed: %s", hipGetErrorString(le));
+  if (pl->timing) {
+    HIP_OK(hipEventRecord(e1, pl->stream));
+    pl->ev_used += 2;
+  }
   return 0;
 }
 

@@ -834,6 +834,7 @@ struct WindowCache {
 struct WindowLease {
   void *p = nullptr;
   bool cached = false;
+  hipStream_t stream = nullptr; /* the stream whose kernels use the block */
   ~WindowLease() { release(); }
   hipError_t acquire(size_t bytes, int device) {
     std::lock_guard<std::mutex> lk(g_wincache.m);
@@ -863,6 +864,10 @@ struct WindowLease {
   }
   void release() {
     if (!p) return;
+    /* error returns leave kernels in flight on the call's stream: nobody else may get the
+     * block before they have drained (the lease is declared after the stream guard, so the
+     * stream is still alive here) */
+    if (stream) (void)hipStreamSynchronize(stream);
     if (cached) {
       std::lock_guard<std::mutex> lk(g_wincache.m);
       g_wincache.busy = false;
@@ -1017,6 +1022,7 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputP
   PhaseTimer pt(stream);
   pt.lap(0);
   WindowLease win;
+  win.stream = stream;
   {
     const int64_t Ppad = ((int64_t)P + RS_BLOCK - 1) / RS_BLOCK * RS_BLOCK;
     const int nwin = skyview ? NFLD : NFLD - 2;

@@ -108,8 +108,19 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
     return -9;
   }
   HOK(hipSetDevice(device));
-  hipStream_t stream;
-  HOK(hipStreamCreate(&stream));
+  /* declared before every buffer, so destroyed after them: error returns below leave work in
+   * flight, and the stream must outlive it (buffers are released by hipFree, which waits) */
+  struct StreamGuard {
+    hipStream_t s = nullptr;
+    ~StreamGuard() {
+      if (s) {
+        (void)hipStreamSynchronize(s);
+        (void)hipStreamDestroy(s);
+      }
+    }
+  } stream_guard;
+  HOK(hipStreamCreate(&stream_guard.s));
+  hipStream_t stream = stream_guard.s;
 
   const size_t in_elems = (size_t)P * TC, tp_elems = (size_t)Ppad * TC;
   Pinned h_in, h_out, h_i32;
@@ -336,10 +347,7 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
   if (rc == 0) {
     HOK(hipEventSynchronize(done[(N - 1) & 1]));
     scatter(items[N - 1], (N - 1) & 1);
-  } else {
-    (void)hipStreamSynchronize(stream);
   }
-  (void)hipStreamDestroy(stream);
   return rc;
 }
 

@@ -5,14 +5,14 @@
 #include "rs_synth.h"
 
 #define RS_BLOCK 256
-#define RS_CONST_SLOTS 16 /* concurrent plans per device */
 
 enum { RS_VARIANT_AUTO = 0, RS_VARIANT_REG = 1, RS_VARIANT_LDS = 2, RS_VARIANT_BT = 3 };
 
 namespace rs {
 
 struct StepArgs {
-  int32_t cslot; /* index into the __constant__ table */
+  const void *consts; /* the plan's constants in HBM: RsConstants (fp64 kernels) or RsConstantsF
+                         (fp32 kernels); read through the scalar cache (address space 4) */
   RsForcing f;
   RsOutputs o;
   RsPointParams pp;
@@ -22,7 +22,7 @@ struct StepArgs {
 };
 
 struct InitArgs {
-  int32_t cslot;
+  const void *consts;
   RsForcing f;
   RsPointParams pp;
   double *state;
@@ -51,7 +51,8 @@ hipError_t rs_launch_math_test(int fn, int64_t n, const double *x, double *y, hi
 /* raw-series Tdew<->RH completion (needs the math tables: create a plan first) */
 hipError_t rs_launch_humidity_fill(const double *tair, double *tdew, double *rhz, int64_t n,
                                    hipStream_t stream);
-hipError_t rs_upload_constants(int slot, const RsConstants *c, hipStream_t stream);
+/* exp/log tables of the device (same for every plan) */
+hipError_t rs_upload_math_tables(hipStream_t stream);
 hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
                           hipStream_t stream);
 hipError_t rs_launch_step_coupled(const rs::StepArgs &a, int NL, hipStream_t stream);
@@ -73,7 +74,9 @@ hipError_t rs_cluster_apply(const double *state_src, double *state_dst, bool f32
                             hipStream_t stream);
 
 /* fp32 flavour (rs_kernels_f32.hip) */
-hipError_t rs32_upload_constants(int slot, const RsConstants *c, hipStream_t stream);
+/* single-precision mirror of the constants: fills *dst (device, rs32_constants_bytes() bytes) */
+size_t rs32_constants_bytes(void);
+hipError_t rs32_upload_constants(void *dst, const RsConstants *c, hipStream_t stream);
 hipError_t rs32_launch_step(const rs::StepArgs &a, int NL, int variant, hipStream_t stream);
 hipError_t rs32_launch_init(const rs::InitArgs &a, hipStream_t stream);
 hipError_t rs32_launch_expand(const rs::ExpandArgs &a, int32_t nintervals, hipStream_t stream);

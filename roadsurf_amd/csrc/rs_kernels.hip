@@ -35,13 +35,20 @@ namespace rs {
 
 constexpr int kBlock = RS_BLOCK;
 
-/* Model constants live in constant memory (address space 4): every access is a
- * scalar load through the scalar cache.  The time loop re-derives the slot
- * index through an empty asm every iteration so that the compiler cannot hoist
- * ~220 uniform doubles (= 440 SGPRs, against 102 available) out of the loop and
- * then spill them into VGPR lanes; loaded at the point of use they cost one
- * s_load each and no live range. */
-__constant__ RsConstants g_consts[RS_CONST_SLOTS];
+/* Model constants: one RsConstants block per plan in HBM, reached through a pointer in the
+ * kernel arguments and read as constant memory (address space 4): every access is a scalar
+ * load through the scalar cache.  (A per-plan block, not a __constant__ table: the reference
+ * driver calls runsimulation from as many threads as it likes,
+ * examples/example1/src/roadrunner.cpp:490-497, so the number of live plans is unbounded.)
+ * The time loop re-derives the pointer through an empty asm every iteration so that the
+ * compiler cannot hoist ~220 uniform doubles (= 440 SGPRs, against 102 available) out of the
+ * loop and then spill them into VGPR lanes; loaded at the point of use they cost one s_load
+ * each and no live range. */
+typedef RsConstants __attribute__((address_space(4))) ConstsAS;
+template <class Args>
+__device__ __forceinline__ const ConstsAS &consts_of(Args a) {
+  return *(const ConstsAS *)a->consts;
+}
 
 template <int NL>
 struct RegProfile {
@@ -199,7 +206,7 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
   double tairR = 0, vzR = 0, rhR = 0;
   if (FULL) {
     initlen = ka->pp.initlen ? (ka->pp.initlen + row0)[lane] : 0;
-    if (g_consts[ka->cslot].use_relaxation && ka->pp.tair_relax) {
+    if (consts_of(ka).use_relaxation && ka->pp.tair_relax) {
       /* setInputParam, src/InputOutput.f90:19-26: targets pass through REAL(4) */
       tairR = (double)(float)(ka->pp.tair_relax + row0)[lane];
       vzR = (double)(float)(ka->pp.vz_relax + row0)[lane];
@@ -212,7 +219,7 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
   Forcing nxt = load_forcing<FULL>(ka, row0, lane, 0);
   for (int32_t k = 0; k < nsteps; ++k) {
     asm volatile("" : "+s"(ka));
-    const RsConstants &c = g_consts[ka->cslot];
+    const ConstsAS &c = consts_of(ka);
     const int32_t i = t0 + k;
     const Forcing f = nxt;
 
@@ -288,8 +295,8 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
     }
     const Fluxes fx =
         model_step_fluxes(c, mt, s, tair, vz, rhz, prec_ts, sw_in, lw_in, f.phase, f.hour);
-    /* scheduling hint (bl_score_key): extra passes of this launch; bit 30 = the point was in
-     * the unstable regime at some index of the launch's last 30 */
+    /* scheduling hint (bl_score_key): extra passes of this launch; bit 30 of the counter = the
+     * point was in the unstable regime at some index of the launch's last RS_REGIME_WINDOW */
     score += (fx.trips & 63) - 5;
     if ((fx.trips & 64) && k >= nsteps - RS_REGIME_WINDOW) score |= 1 << 30;
     /* next index's forcing: issued here, half a step before its first use, so the
@@ -322,7 +329,7 @@ struct BlTailShared {
 
 /* All threads of the workgroup call this once per time index (barriers inside); `active`
  * lanes have a point to step, the others only take part as workers. */
-__device__ __forceinline__ Fluxes fluxes_block_tail(const RsConstants &c, const MathTab &mt,
+__device__ __forceinline__ Fluxes fluxes_block_tail(const ConstsAS &c, const MathTab &mt,
                                                     Scalars &s, bool active, double tair, double vz,
                                                     double rhz, double prec_ts, double sw, double lw,
                                                     int32_t phase, int32_t hour, BlTailShared &sh,
@@ -433,7 +440,7 @@ __device__ __forceinline__ void time_loop_bt(const MathTab &mt, Prof &T, Scalars
     tbot = (ka->pp.tbottom + row0)[lane];
     if (FULL) {
       initlen = ka->pp.initlen ? (ka->pp.initlen + row0)[lane] : 0;
-      if (g_consts[ka->cslot].use_relaxation && ka->pp.tair_relax) {
+      if (consts_of(ka).use_relaxation && ka->pp.tair_relax) {
         /* setInputParam, src/InputOutput.f90:19-26: targets pass through REAL(4) */
         tairR = (double)(float)(ka->pp.tair_relax + row0)[lane];
         vzR = (double)(float)(ka->pp.vz_relax + row0)[lane];
@@ -446,7 +453,7 @@ __device__ __forceinline__ void time_loop_bt(const MathTab &mt, Prof &T, Scalars
   }
   for (int32_t k = 0; k < nsteps; ++k) {
     asm volatile("" : "+s"(ka));
-    const RsConstants &c = g_consts[ka->cslot];
+    const ConstsAS &c = consts_of(ka);
     const int32_t i = t0 + k;
     const Forcing f = nxt;
     /* a failed point has left the loop in the reference: its outputs stay -9999.0 */
@@ -664,7 +671,7 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Pr
   KernArgs ka = kernargs();
   const uint32_t lane = threadIdx.x;
   const int64_t row0 = (int64_t)blockIdx.x * kBlock;
-  const RsConstants &c = g_consts[ka->cslot];
+  const ConstsAS &c = consts_of(ka);
   const int N = T.nlayers();
   const int32_t t0 = ka->t0, tend = ka->t0 + ka->nsteps;
   const double tbot = ka->pp.tbottom[p];
@@ -853,7 +860,8 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Pr
   }
 }
 
-/* RS_ST_BLSCORE from the loop's counter: bits 0-18 extra passes (saturating), bit 19 regime.
+/* RS_ST_BLSCORE from the loop's counter: bits 0-18 extra passes (saturating), bit 19 cover,
+ * bit 20 regime (the counter itself carries the regime flag in bit 30).
  * Sorted (descending: expensive first, rs_cluster.hip) the unstable-regime points come first,
  * by the passes they needed, then the stable-regime points, whose waves never enter the log/sqrt
  * branch (tools/bl_persistence.py). */
@@ -919,7 +927,7 @@ __global__ void __launch_bounds__(kBlock, WPE) step_kernel_lds(const StepArgs a)
   __syncthreads();
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= a.npoints) return; /* no barriers below: each lane owns its column */
-  LdsProfile T{lds + threadIdx.x, g_consts[a.cslot].NLayers};
+  LdsProfile T{lds + threadIdx.x, consts_of(&a).NLayers};
   Scalars s;
   int32_t score = 0;
   load_state<FULL>(a.state, a.np_pad, p, T, s);
@@ -936,7 +944,7 @@ __global__ void __launch_bounds__(kBlock, 3) step_kernel_sky(const StepArgs a) {
   __syncthreads();
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= a.npoints) return;
-  LdsProfile T{lds + threadIdx.x, g_consts[a.cslot].NLayers};
+  LdsProfile T{lds + threadIdx.x, consts_of(&a).NLayers};
   Scalars s;
   int32_t score = 0;
   load_state<true>(a.state, a.np_pad, p, T, s);
@@ -953,7 +961,7 @@ __global__ void __launch_bounds__(kBlock, 2) step_kernel_coupled(const StepArgs 
   __syncthreads();
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= a.npoints) return;
-  const int NLc = g_consts[a.cslot].NLayers;
+  const int NLc = consts_of(&a).NLayers;
   LdsProfile T{lds + threadIdx.x, NLc};
   LdsProfile Tstale{lds + (size_t)NLc * kBlock + threadIdx.x, NLc};
   Scalars s;
@@ -973,7 +981,7 @@ __global__ void __launch_bounds__(kBlock, 2) step_kernel_coupled(const StepArgs 
 __global__ void __launch_bounds__(kBlock) init_kernel(const InitArgs a) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= a.npoints) return;
-  const RsConstants &c = g_consts[a.cslot];
+  const ConstsAS &c = consts_of(&a);
   const int N = c.NLayers;
   const double tair = a.f.tair[p];
   const double tobs = a.f.tsurfobs ? a.f.tsurfobs[p] : R4(-9999.9);
@@ -1188,17 +1196,12 @@ hipError_t rs_launch_humidity_fill(const double *tair, double *tdew, double *rhz
   return hipGetLastError();
 }
 
-hipError_t rs_upload_constants(int slot, const RsConstants *c, hipStream_t stream) {
-  if (slot < 0 || slot >= RS_CONST_SLOTS) return hipErrorInvalidValue;
-  /* transcendental tables (same for every plan; cheap enough to refresh) */
+hipError_t rs_upload_math_tables(hipStream_t stream) {
   hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(rs::c_gl_exp_tab), rs_gl_exp_tab,
                                         sizeof(rs_gl_exp_tab), 0, hipMemcpyHostToDevice, stream);
   if (e != hipSuccess) return e;
-  e = hipMemcpyToSymbolAsync(HIP_SYMBOL(rs::c_gl_log_tab), rs_gl_log_tab, sizeof(rs_gl_log_tab), 0,
-                             hipMemcpyHostToDevice, stream);
-  if (e != hipSuccess) return e;
-  return hipMemcpyToSymbolAsync(HIP_SYMBOL(rs::g_consts), c, sizeof(RsConstants),
-                                (size_t)slot * sizeof(RsConstants), hipMemcpyHostToDevice, stream);
+  return hipMemcpyToSymbolAsync(HIP_SYMBOL(rs::c_gl_log_tab), rs_gl_log_tab, sizeof(rs_gl_log_tab), 0,
+                                hipMemcpyHostToDevice, stream);
 }
 
 hipError_t rs_launch_step_sky(const rs::StepArgs &a, int NL, hipStream_t stream) {

@@ -20,7 +20,7 @@
 
 #define RS_REAL float
 #define RS_NS rs32
-#define RS_CONSTS RsConstantsF
+#define RS_CONSTS RsConstantsF __attribute__((address_space(4)))
 #define R4(x) (x##f)
 namespace rs32 {
 using rs::MathTab;
@@ -35,7 +35,11 @@ using rs::rs_sqrt;
 namespace rs32 {
 
 constexpr int kBlock = RS_BLOCK;
-__constant__ RsConstantsF g_constsf[RS_CONST_SLOTS];
+typedef RsConstantsF __attribute__((address_space(4))) ConstsAS;
+template <class Args>
+__device__ __forceinline__ const ConstsAS &consts_of(Args a) {
+  return *(const ConstsAS *)a->consts;
+}
 
 template <int NL>
 struct RegProfile {
@@ -80,7 +84,7 @@ __device__ __forceinline__ void run(const rs::StepArgs &a, Prof &T) {
 
   for (int32_t k = 0; k < nsteps; ++k) {
     asm volatile("" : "+s"(ka));
-    const RsConstantsF &c = g_constsf[ka->cslot];
+    const ConstsAS &c = consts_of(ka);
     const int32_t i = t0 + k;
     const int64_t row = (int64_t)k * ka->f.t_stride + row0;
     int64_t r = (int64_t)(i - 1);
@@ -146,7 +150,7 @@ __global__ void __launch_bounds__(kBlock, 4) step_kernel_f32_reg15(const rs::Ste
 __global__ void __launch_bounds__(kBlock, 4) step_kernel_f32_lds(const rs::StepArgs a) {
   extern __shared__ float ldsf[];
   if ((int64_t)blockIdx.x * kBlock + threadIdx.x >= a.npoints) return;
-  LdsProfile T{ldsf + threadIdx.x, g_constsf[a.cslot].NLayers};
+  LdsProfile T{ldsf + threadIdx.x, consts_of(&a).NLayers};
   run(a, T);
 }
 
@@ -154,7 +158,7 @@ __global__ void __launch_bounds__(kBlock, 4) step_kernel_f32_lds(const rs::StepA
 __global__ void __launch_bounds__(kBlock) init_kernel_f32(const rs::InitArgs a) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= a.npoints) return;
-  const RsConstantsF &c = g_constsf[a.cslot];
+  const ConstsAS &c = consts_of(&a);
   const int N = c.NLayers;
   const float tair = reinterpret_cast<const float *>(a.f.tair)[p];
   const float tobs = a.f.tsurfobs ? reinterpret_cast<const float *>(a.f.tsurfobs)[p] : -9999.9f;
@@ -216,14 +220,14 @@ __global__ void __launch_bounds__(kBlock) expand_kernel_f32(const rs::ExpandArgs
 
 static inline dim3 grid_for32(int64_t n) { return dim3((unsigned)((n + RS_BLOCK - 1) / RS_BLOCK)); }
 
-hipError_t rs32_upload_constants(int slot, const RsConstants *c, hipStream_t stream) {
-  if (slot < 0 || slot >= RS_CONST_SLOTS) return hipErrorInvalidValue;
-  static thread_local RsConstantsF f;
+size_t rs32_constants_bytes(void) { return sizeof(RsConstantsF); }
+
+hipError_t rs32_upload_constants(void *dst, const RsConstants *c, hipStream_t stream) {
+  RsConstantsF f;
   rs_constants_to_f32(*c, f);
-  hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(rs32::g_constsf), &f, sizeof(f),
-                                        (size_t)slot * sizeof(f), hipMemcpyHostToDevice, stream);
+  hipError_t e = hipMemcpyAsync(dst, &f, sizeof(f), hipMemcpyHostToDevice, stream);
   if (e != hipSuccess) return e;
-  return hipStreamSynchronize(stream); /* f is thread-local scratch */
+  return hipStreamSynchronize(stream); /* f is stack scratch */
 }
 
 hipError_t rs32_launch_step(const rs::StepArgs &a, int NL, int variant, hipStream_t stream) {

@@ -32,7 +32,8 @@
 
 #define RS_REAL double
 #define RS_NS rs
-#define RS_CONSTS RsConstants
+/* the constants are read as constant memory (scalar loads): rs_kernels.hip, consts_of */
+#define RS_CONSTS RsConstants __attribute__((address_space(4)))
 #define R4(x) ((double)(x##f))
 #include "rs_physics_body.inc"
 #undef RS_REAL

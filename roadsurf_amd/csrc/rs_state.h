@@ -31,9 +31,11 @@ enum RsStateSlot {
   RS_ST_TAIR_END,                /* atm%TairInitEnd (relaxation) */
   RS_ST_VZ_END,                  /* atm%VZInitEnd */
   RS_ST_RH_END,                  /* atm%RhzInitEnd */
-  RS_ST_BLSCORE,                 /* not model state: sort key of rs_hip_recluster = boundary-layer passes
-                                    beyond the mandatory 5 during the last launch (bits 0-18), bit 19
-                                    set if the point was in the unstable regime near its end */
+  RS_ST_BLSCORE,                 /* not model state: sort key of rs_hip_recluster (bl_score_key,
+                                    rs_kernels.hip): bits 0-18 boundary-layer passes beyond the
+                                    mandatory 5 during the last launch (saturating), bit 19 something
+                                    lies on the road, bit 20 the point was in the unstable regime near
+                                    the end of the launch; rs_cluster.hip sorts these 21 bits */
   /* ---- coupling (src/CouplingVariables.f90.inc); touched only by the coupled kernel ---- */
   RS_ST_CPL_ITER,                /* Coupling_iterations */
   RS_ST_CPL_FLAGS,               /* bit0 start_coupling_again, bit1 Coupling_failed, bit2 VeryColdSave */

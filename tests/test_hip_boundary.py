@@ -162,3 +162,36 @@ def test_runsimulation_is_reentrant_from_driver_threads():
     assert not errs
     for k in oh.F64_OUT:
         assert np.array_equal(out[k], ora[k]), k
+
+
+def test_more_concurrent_callers_than_any_fixed_plan_pool():
+    """roadrunner.cpp:490-497 starts `options.jobs` workers, each inside runsimulation at the
+    same time.  A plan holds its constants in its own device block (no table of slots), so the
+    number of simultaneous callers is unbounded: 24 threads, one point each, all released
+    together; every output must be the reference's (a call that could not get a plan would
+    leave -9999.0 everywhere)."""
+    import threading
+    L = lib.load()
+    n, SL = 24, 361
+    f = oh.synth_forcing(n, SL, seed=31)
+    s = abi.default_settings(SL); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
+    ora, _, _ = oh.run_oracle(_kind(), f, s, p, l)
+    g = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in f.items()}
+    out = {k: np.full((n, SL), np.nan) for k in oh.F64_OUT}
+    args = [_pointers(g, out, pt) for pt in range(n)]
+    gate = threading.Barrier(n)
+    errs = []
+
+    def work(pt):
+        try:
+            ip, op, _ = args[pt]
+            gate.wait()
+            L.runsimulation(C.byref(op), C.byref(ip), C.byref(s), C.byref(p), C.byref(l))
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(pt,)) for pt in range(n)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs
+    for k in oh.F64_OUT:
+        assert np.array_equal(out[k], ora[k]), k
