@@ -13,9 +13,16 @@ point (what an NWP source delivers).  Step-resolution forcing for 1 M points x
 on the device and consumed from HBM by the step kernel; the six outputs are
 written every time index (reference SaveOutput semantics) into a chunk buffer.
 
+The pass itself lives in roadsurf_amd/workload.py (SyntheticRun) and is the code the
+parity tests step at the same size (tests/test_hip_golden_and_scale.py).  Outputs stay
+attributable to points: with plan order on, the order row of every launch is kept
+(inside the timed region).  A second timed leg runs the same passes in natural order and
+is reported as `natural_order_value`.
+
 Multi-GPU: one process per GPU (torch.distributed.run), points sharded with no
 data-path collective; the only collectives are the timing barrier and the MAX
-over ranks.  Weak scaling: every GPU gets --points points.
+over ranks.  Default is STRONG scaling (BASELINE config 4: --total-points 1 000 000
+sharded over the GPUs); `--points N` gives every GPU N points (weak scaling).
 
 Prints ONE JSON line on rank 0.
 """
@@ -32,6 +39,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 ALGO_BYTES_PER_UNIT = 100.0    # 52 B read + 48 B written per point-timestep
+TRAFFIC_FILE = "profiles/r01_traffic.json"  # committed PMC summary the roofline's `traffic` is read from
 
 
 def effective_cpus() -> int:
@@ -77,8 +85,8 @@ def cpu_baseline(sample_points: int, simlen: int, seed: int):
 
 def measured_traffic(points: int, chunk: int):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
-    (profiles/r01_traffic.json), valid for the configuration it was collected on."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    (TRAFFIC_FILE), valid for the configuration it was collected on."""
+    path = os.path.join(ROOT, TRAFFIC_FILE)
     try:
         t = json.load(open(path))
     except (OSError, ValueError):
@@ -93,20 +101,24 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--points", type=int, default=1_000_000, help="points per GPU")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default=None,
+                    help="strong (default): --total-points are sharded over the GPUs (BASELINE config 4: "
+                         "1 M points over 1/2/4/8); weak: every GPU gets --points")
+    ap.add_argument("--total-points", type=int, default=1_000_000)
+    ap.add_argument("--points", type=int, default=None, help="points per GPU (implies --scaling weak)")
     ap.add_argument("--hours", type=int, default=48)
     ap.add_argument("--chunk", type=int, default=240, help="time indices per step-kernel launch")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 register profile, 2 LDS profile")
     ap.add_argument("--seed", type=int, default=20240110)
-    ap.add_argument("--overlap", action="store_true",
-                    help="double-buffer: expand window c+1 on a side stream while stepping window c "
-                         "(measured: no gain, the step kernel owns the whole register file; DESIGN.md 6)")
     ap.add_argument("--f32", action="store_true",
                     help="BASELINE config 5 flavour: fp32 state/forcing/outputs/arithmetic "
                          "(tolerance-gated, not the parity path); default is fp64")
     ap.add_argument("--cluster", type=int, default=1,
-                    help="1: re-sort the plan's slots by boundary-layer passes after every launch "
-                         "(rs_hip_recluster; windows are generated in slot order), 0: natural order")
+                    help="1: plan order - re-sort the plan's slots by boundary-layer passes after every "
+                         "launch (rs_hip_recluster; windows are generated in slot order, the order row "
+                         "of every launch is kept), 0: natural order only")
+    ap.add_argument("--no-natural-leg", action="store_true",
+                    help="skip the second timed leg (natural order) that gives natural_order_value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16384)
     args = ap.parse_args()
@@ -114,7 +126,7 @@ def main() -> None:
     import torch
     import torch.distributed as dist
 
-    from roadsurf_amd import abi, device, sharding
+    from roadsurf_amd import abi, device, sharding, workload
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -134,79 +146,22 @@ def main() -> None:
                   file=sys.stderr)
             dist.init_process_group("gloo")
 
-    spk = 120                      # 3600 s / DTSecs 30 s
-    simlen = args.hours * spk + 1  # examples/example1/src/InputSettings.cpp:98
+    scaling = args.scaling or ("weak" if args.points is not None else "strong")
+    if scaling == "weak":
+        per_gpu = args.points if args.points is not None else args.total_points
+        offset, n = sharding.weak_shard(per_gpu, rank)
+        total_points = per_gpu * world
+    else:
+        total_points = args.total_points if args.points is None else args.points * world
+        offset, n = sharding.strong_shard(total_points, world, rank)
+    simlen = args.hours * workload.SPK + 1  # examples/example1/src/InputSettings.cpp:98
     settings = abi.default_settings(simlen)
     params = abi.default_parameters()
-    n = args.points
     plan = device.Plan(n, settings, params, dev_index)
     if args.variant:
         plan.set_variant(args.variant)
-    wdtype = torch.float32 if args.f32 else torch.float64
     if args.f32:
         plan.set_precision(32)
-    npad = plan.np_pad
-    nknots = args.hours + 2
-    offset, _ = sharding.weak_shard(n, rank)
-    spec, knots = plan.synth_knots(args.seed, nknots, point_offset=offset, steps_per_knot=spk)
-    chunk = min(args.chunk, simlen)
-    overlap = args.overlap
-    nbuf = 2 if overlap else 1
-    wins = [device.ForcingWindow.empty(chunk, npad, dev, optional=(), dtype=wdtype) for _ in range(nbuf)]
-    out = device.OutputWindow.empty(chunk, npad, dev, dtype=wdtype)
-    # index-1 window for the init kernel: needs TsurfObs(1)
-    win0 = device.ForcingWindow.empty(1, npad, dev, optional=("tsurfobs",), dtype=wdtype)
-    pp = plan.point_params(plan.uniform_tbottom(2024, 1, 10))
-    main = plan.stream
-    side = torch.cuda.Stream(dev) if overlap else main
-    starts = list(range(1, simlen + 1, chunk))
-    ev_filled = [torch.cuda.Event() for _ in range(nbuf)]    # window b holds fresh forcing
-    ev_consumed = [torch.cuda.Event() for _ in range(nbuf)]  # step kernel is done with window b
-
-    cluster = bool(args.cluster) and not overlap
-    kbuf = torch.empty((chunk // spk + 3, 9, npad), dtype=torch.float64, device=dev) if cluster else None
-
-    def clustered_pass():
-        """Like the plain pass, with the plan's slots re-sorted after every launch: the knots
-        of each window are generated in the current slot order, so the window is born coalesced
-        in that order; the re-sort (hipCUB radix sort + state permutation) is inside the timing."""
-        plan.synth_knots_range(spec, kbuf, 0, 2, ordered=True)
-        plan.expand_range(spec, kbuf, 0, 2, win0, 1, 1)
-        plan.init_state(win0, pp)
-        for t0 in starts:
-            ns = min(chunk, simlen - t0 + 1)
-            k0 = (t0 - 1) // spk
-            nk = (t0 + ns - 2) // spk + 1 - k0 + 1
-            plan.synth_knots_range(spec, kbuf, k0, nk, ordered=True)
-            plan.expand_range(spec, kbuf, k0, nk, wins[0], t0, ns)
-            plan.step(wins[0], out, pp, t0, ns, out_row0=t0 - 1)
-            plan.recluster()
-
-    def one_pass():
-        """init -> per window: expand (HBM-bound, side stream) || step (VALU-bound, main stream).
-        Double-buffered: expansion of window c+1 overlaps stepping of window c."""
-        if cluster:
-            return clustered_pass()
-        plan.expand(spec, knots, win0, 1, 1)
-        plan.init_state(win0, pp)
-        if not overlap:
-            for t0 in starts:
-                ns = min(chunk, simlen - t0 + 1)
-                plan.expand(spec, knots, wins[0], t0, ns)
-                plan.step(wins[0], out, pp, t0, ns, out_row0=t0 - 1)
-            return
-        side.wait_stream(main)
-        for c, t0 in enumerate(starts):
-            b = c % 2
-            ns = min(chunk, simlen - t0 + 1)
-            if c >= 2:
-                side.wait_event(ev_consumed[b])
-            plan.expand(spec, knots, wins[b], t0, ns, stream=side)
-            ev_filled[b].record(side)
-            main.wait_event(ev_filled[b])
-            plan.step(wins[b], out, pp, t0, ns, out_row0=t0 - 1)
-            ev_consumed[b].record(main)
-        main.wait_stream(side)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -214,26 +169,41 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        one_pass()
-    fence()
-    plan.timing_reset()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        one_pass()
-    fence()
-    elapsed = time.perf_counter() - t_start
-    elapsed = sharding.max_over_ranks(
-        elapsed, dist if world > 1 else None,
-        dev if (world > 1 and dist.get_backend() == "nccl") else None)
-    step_ms, nlaunch = plan.timing_step_ms()
+    def timed_leg(plan_order: bool):
+        """W untimed + exactly K timed passes, barrier + synchronize on both sides, MAX over ranks."""
+        run = workload.SyntheticRun(plan, args.seed, args.hours, args.chunk, point_offset=offset,
+                                    plan_order=plan_order, f32=args.f32)
+        for _ in range(args.warmup):
+            run.run_pass()
+        fence()
+        plan.timing_reset()
+        t_start = time.perf_counter()
+        for _ in range(args.steps):
+            run.run_pass()
+        fence()
+        elapsed = time.perf_counter() - t_start
+        elapsed = sharding.max_over_ranks(
+            elapsed, dist if world > 1 else None,
+            dev if (world > 1 and dist.get_backend() == "nccl") else None)
+        step_ms, nlaunch = plan.timing_step_ms()
+        chunk = run.chunk
+        del run
+        torch.cuda.empty_cache()
+        return elapsed, step_ms, nlaunch, chunk
+
+    cluster = bool(args.cluster)
+    elapsed, step_ms, nlaunch, chunk = timed_leg(cluster)
+    natural = None
+    if cluster and not args.no_natural_leg:
+        natural = timed_leg(False)
     nfail = plan.failed_count()
 
-    units_per_pass = n * simlen
-    value = world * units_per_pass * args.steps / elapsed
-    # dominant kernel: step kernel, HIP events on its own stream around every launch
+    units_per_pass_job = total_points * simlen          # whole job, all ranks
+    units_per_pass_rank = n * simlen
+    value = units_per_pass_job * args.steps / elapsed
+    # dominant kernel: step kernel, HIP events on its own stream around every launch (this rank)
     avg_launch_s = step_ms / 1e3 / max(nlaunch, 1)
-    units_per_launch = units_per_pass * args.steps / max(nlaunch, 1)
+    units_per_launch = units_per_pass_rank * args.steps / max(nlaunch, 1)
     algo_bytes = 52.0 if args.f32 else ALGO_BYTES_PER_UNIT  # fp32: 6 x 4 + 4 read, 6 x 4 written
     achieved = algo_bytes * units_per_launch / avg_launch_s / 1e9
 
@@ -248,19 +218,23 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32" if args.f32 else "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{n} synthetic points per GPU x {args.hours} h (SimLen {simlen}, "
-                            f"DTSecs 30, NLayers 15), {'fp32' if args.f32 else 'fp64'}, outputs every time index",
+                "workload": f"{total_points} synthetic points x {args.hours} h (SimLen {simlen}, DTSecs 30, "
+                            f"NLayers 15), {'fp32' if args.f32 else 'fp64'}, outputs every time index, "
+                            f"attributable to points"
+                            + (" (per-launch order rows kept inside the timed region)" if cluster else ""),
+                "total_points": total_points,
                 "points_per_gpu": n,
                 "simlen": simlen,
                 "chunk_steps": chunk,
-                "overlap_expand_with_step": overlap, "recluster_after_every_launch": cluster,
+                "plan_order": cluster,
+                "order_rows_kept": cluster,
                 "kernel_variant": args.variant,
-                "parallelism": f"points sharded over {world} GPU(s), no collectives",
+                "parallelism": f"points sharded over {world} GPU(s) ({scaling} scaling), no collectives",
                 "failed_points": int(nfail),
             },
             "roofline": {
@@ -271,18 +245,27 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
+                "traffic_source": TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
                                   "mean per launch, averaged over the launches of a pass like "
                                   "avg_launch_ms)" if traffic else None,
                 "valu": valu,
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "launches": nlaunch,
                 "units_per_launch": units_per_launch,
-                "step_kernel_only_value": units_per_pass * args.steps / (step_ms / 1e3),
+                "step_kernel_only_value": units_per_pass_rank * args.steps / (step_ms / 1e3),
                 "note": "fp64-VALU-bound kernel (SURVEY.md 8d): the HBM fraction is reported "
                         "as the contract asks, the binding roofline is vector fp64 issue",
             },
         }
+        if natural is not None:
+            n_elapsed, n_step_ms, n_nlaunch, _ = natural
+            line["natural_order_value"] = units_per_pass_job * args.steps / n_elapsed
+            line["natural_order"] = {
+                "ms_per_step": n_elapsed / args.steps * 1e3,
+                "avg_launch_ms": n_step_ms / max(n_nlaunch, 1),
+                "step_kernel_only_value": units_per_pass_rank * args.steps / (n_step_ms / 1e3),
+                "note": "second timed leg, same W/K and fences: points in natural order, no re-sort",
+            }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, simlen, args.seed)
         print(json.dumps(line), flush=True)

@@ -404,6 +404,15 @@ int rs_hip_set_variant(RsPlan *plan, int32_t variant);
  *   rs_hip_recluster    asynchronous on the plan's stream; the order changes for the NEXT launch */
 const int32_t *rs_hip_plan_order(RsPlan *plan);
 int rs_hip_recluster(RsPlan *plan);
+/* Outputs stay attributable to points (SaveOutput is per point, src/InputOutput.f90:151-165):
+ *   rs_hip_plan_order_copy   copies the current order (int32[npoints_padded]) to a device buffer of
+ *                            the caller, asynchronously on the plan's stream - call it after the
+ *                            rs_hip_step of a launch and before rs_hip_recluster, and column s of
+ *                            that launch's output window is local point dst[s] (4 bytes per point and
+ *                            launch against the 48 bytes per point and time index of the outputs)
+ *   rs_hip_plan_reset_order  back to the identity (a new run over the same plan) */
+int rs_hip_plan_order_copy(RsPlan *plan, int32_t *dst_device);
+int rs_hip_plan_reset_order(RsPlan *plan);
 
 /* Device timing of the step kernel with HIP events recorded on the plan's
  * stream around every rs_hip_step launch since the last reset.  Returns the
@@ -427,6 +436,14 @@ typedef struct RsHostExtras {
   double albedo_surroundings;
 } RsHostExtras;
 
+/* `device` >= 0: that device.  `device` < 0 (what runsimulation_batch / runsimulation pass): the
+ * batch is cut into contiguous blocks of points over the device list - environment
+ * ROADSURF_HIP_DEVICES ("0,1,2,3", a device may repeat; default "all" visible devices), blocks of
+ * at least ROADSURF_HIP_MIN_SHARD points (default 4096), batches too small to split take the
+ * devices in turn - one host thread + stream + plan per block, no collective: the in-process
+ * counterpart of the reference driver's worker pool (examples/example1/src/roadrunner.cpp:423-501).
+ * rs_last_fanout(): number of blocks the calling thread's last call used. */
+int rs_last_fanout(void);
 int rs_host_run_batch(int32_t n, OutputPointers *outPointers,
                       const InputPointers *inPointers,
                       const RsConstants *consts,
@@ -501,6 +518,7 @@ typedef struct RsDriverOutput {
 
 /* local[n_points]: in lat, lon, sky_view (others ignored); out InitLenI, tair_relax,
  * VZ_relax, RH_relax, couplingIndexI, couplingTsurf as read_input leaves them.
+ * device >= 0: that device; device < 0: fan-out over the device list like rs_host_run_batch.
  * Returns 0 or <0 (rs_last_error). */
 int rs_driver_run(const RsDriverInput *in, const InputSettings *settings,
                   const InputParameters *params, LocalParameters *local,

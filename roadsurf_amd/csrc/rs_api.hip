@@ -268,6 +268,23 @@ int rs_hip_recluster(RsPlan *pl) {
   return 0;
 }
 
+int rs_hip_plan_order_copy(RsPlan *pl, int32_t *dst) {
+  if (!pl || !dst) return set_err("rs_hip_plan_order_copy: bad arguments");
+  if (!rs_hip_plan_order(pl)) return -1;
+  HIP_OK(hipSetDevice(pl->device));
+  HIP_OK(hipMemcpyAsync(dst, pl->order, (size_t)pl->np_pad * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                        pl->stream));
+  return 0;
+}
+
+int rs_hip_plan_reset_order(RsPlan *pl) {
+  if (!pl) return set_err("rs_hip_plan_reset_order: null plan");
+  if (!pl->order) return rs_hip_plan_order(pl) ? 0 : -1; /* allocated as the identity */
+  HIP_OK(hipSetDevice(pl->device));
+  HIP_OK(rs_cluster_identity(pl->order, pl->np_pad, pl->stream));
+  return 0;
+}
+
 int64_t rs_hip_plan_npoints(const RsPlan *pl) { return pl ? pl->npoints : 0; }
 int64_t rs_hip_plan_npoints_padded(const RsPlan *pl) { return pl ? pl->np_pad : 0; }
 size_t rs_hip_plan_state_bytes(const RsPlan *pl) {

@@ -1,0 +1,124 @@
+/* rs_devices.hpp — multi-GPU fan-out of the host-array entry points (internal).
+ *
+ * Points are independent, so a batch is cut into contiguous blocks of points,
+ * one block per HIP device, and every block runs the single-device path on its own host
+ * thread with its own stream and plan(s).  No collective, nothing crosses xGMI.  This is the
+ * in-process counterpart of the reference driver's worker pool
+ * (examples/example1/src/roadrunner.cpp:423-501, WorkQueue.h:16-129): there a worker owns a
+ * point at a time, here a worker owns a device and a block of points.
+ *
+ *   ROADSURF_HIP_DEVICES   comma-separated device indices ("0,1,2,3"; a device may be listed more
+ *                          than once: that many concurrent plans on it), or "all" (default)
+ *   ROADSURF_HIP_DEVICE    one device (kept from round 1; ROADSURF_HIP_DEVICES wins)
+ *   ROADSURF_HIP_MIN_SHARD a block is at least this many points (default 4096): small batches
+ *                          use fewer devices, one-point calls pick a device round-robin
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+extern "C" const char *rs_last_error(void);
+extern "C" void rs_host_set_error(const char *msg);
+
+namespace rsu {
+
+inline std::vector<int> device_list() {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return {};
+  std::vector<int> out;
+  const char *e = getenv("ROADSURF_HIP_DEVICES");
+  if (e && *e && strcmp(e, "all") != 0) {
+    const char *p = e;
+    while (*p) {
+      char *end = nullptr;
+      const long d = strtol(p, &end, 10);
+      if (end == p) break;
+      if (d >= 0 && d < ndev) out.push_back((int)d);
+      if (*end != ',') break;
+      p = end + 1;
+    }
+    if (!out.empty()) return out;
+  }
+  if (!(e && *e)) {
+    if (const char *one = getenv("ROADSURF_HIP_DEVICE")) {
+      const int d = atoi(one);
+      if (d >= 0 && d < ndev) return {d};
+    }
+  }
+  for (int d = 0; d < ndev; ++d) out.push_back(d);
+  return out;
+}
+
+struct Shard {
+  int device;
+  int64_t off, cnt;
+};
+
+/* contiguous block partition of n points over the listed devices, remainders to the first
+ * blocks (roadsurf_amd/sharding.py strong_shard is the same rule) */
+inline std::vector<Shard> make_shards(int64_t n, const std::vector<int> &devs) {
+  std::vector<Shard> s;
+  if (n < 1 || devs.empty()) return s;
+  int64_t min_shard = 4096;
+  if (const char *e = getenv("ROADSURF_HIP_MIN_SHARD"))
+    if (atoll(e) > 0) min_shard = atoll(e);
+  int64_t k = (int64_t)devs.size();
+  if (n / min_shard < k) k = n / min_shard;
+  if (k < 1) k = 1;
+  if (k == 1) {
+    /* a batch too small to split: successive calls take the devices in turn, so a caller that
+     * runs one point per worker thread (the reference driver) still spreads over the node */
+    static std::atomic<unsigned> turn{0};
+    const int d = devs[turn.fetch_add(1u) % devs.size()];
+    s.push_back(Shard{d, 0, n});
+    return s;
+  }
+  const int64_t base = n / k, rem = n % k;
+  int64_t off = 0;
+  for (int64_t i = 0; i < k; ++i) {
+    const int64_t cnt = base + (i < rem ? 1 : 0);
+    s.push_back(Shard{devs[(size_t)i], off, cnt});
+    off += cnt;
+  }
+  return s;
+}
+
+/* how many blocks the calling thread's last fan-out used (rs_last_fanout(), tests) */
+inline thread_local int g_last_fanout = 0;
+
+/* f(shard, nshards) -> rc on one host thread per shard; returns the first non-zero rc and
+ * re-raises that worker's rs_last_error() text in the calling thread */
+template <class F>
+inline int fan_out(const std::vector<Shard> &shards, F f) {
+  if (shards.empty()) {
+    rs_host_set_error("no HIP device visible - this library has no CPU path");
+    return -9;
+  }
+  g_last_fanout = (int)shards.size();
+  if (shards.size() == 1) return f(shards[0], 1);
+  std::vector<int> rc(shards.size(), 0);
+  std::vector<std::string> msg(shards.size());
+  std::vector<std::thread> th;
+  for (size_t i = 0; i < shards.size(); ++i)
+    th.emplace_back([&, i] {
+      rc[i] = f(shards[i], (int)shards.size());
+      if (rc[i] != 0) msg[i] = rs_last_error();
+    });
+  for (auto &t : th) t.join();
+  for (size_t i = 0; i < shards.size(); ++i)
+    if (rc[i] != 0) {
+      const std::string m = "device " + std::to_string(shards[i].device) + ", points " +
+                            std::to_string(shards[i].off) + "..: " + msg[i];
+      rs_host_set_error(m.c_str());
+      return rc[i];
+    }
+  return 0;
+}
+
+}  // namespace rsu

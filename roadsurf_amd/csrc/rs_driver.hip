@@ -38,6 +38,7 @@
 
 #include "../../include/roadsurf.h"
 #include "rs_devutil.hpp"
+#include "rs_devices.hpp"
 #include "rs_kernels.h"
 
 extern "C" void rs_host_set_error(const char *msg);
@@ -827,20 +828,21 @@ struct WindowCache {
   std::mutex m;
   void *p = nullptr;
   size_t bytes = 0;
-  int device = -1;
   bool busy = false;
-} g_wincache;
+} g_wincache[64]; /* one per device: the fan-out of rs_driver_run has a worker on each */
 
 struct WindowLease {
   void *p = nullptr;
   bool cached = false;
   hipStream_t stream = nullptr; /* the stream whose kernels use the block */
   ~WindowLease() { release(); }
-  hipError_t acquire(size_t bytes, int device) {
-    std::lock_guard<std::mutex> lk(g_wincache.m);
-    WindowCache &c = g_wincache;
+  int device = 0;
+  hipError_t acquire(size_t bytes, int dev) {
+    device = dev & 63;
+    WindowCache &c = g_wincache[device];
+    std::lock_guard<std::mutex> lk(c.m);
     if (!c.busy) {
-      if (c.p && (c.device != device || c.bytes < bytes)) {
+      if (c.p && c.bytes < bytes) {
         (void)hipFree(c.p);
         c.p = nullptr;
         c.bytes = 0;
@@ -852,7 +854,6 @@ struct WindowLease {
           return e;
         }
         c.bytes = bytes;
-        c.device = device;
       }
       c.busy = true;
       cached = true;
@@ -869,8 +870,8 @@ struct WindowLease {
      * stream is still alive here) */
     if (stream) (void)hipStreamSynchronize(stream);
     if (cached) {
-      std::lock_guard<std::mutex> lk(g_wincache.m);
-      g_wincache.busy = false;
+      std::lock_guard<std::mutex> lk(g_wincache[device].m);
+      g_wincache[device].busy = false;
     } else {
       (void)hipFree(p);
     }
@@ -950,15 +951,41 @@ int rs_driver_expand(const RsDriverInput *in, const InputSettings *st, LocalPara
 }
 
 void rs_driver_release_cache(void) {
-  std::lock_guard<std::mutex> lk(g_wincache.m);
-  if (g_wincache.busy || !g_wincache.p) return;
-  (void)hipFree(g_wincache.p);
-  g_wincache.p = nullptr;
-  g_wincache.bytes = 0;
+  for (int d = 0; d < 64; ++d) {
+    WindowCache &c = g_wincache[d];
+    std::lock_guard<std::mutex> lk(c.m);
+    if (c.busy || !c.p) continue;
+    if (hipSetDevice(d) != hipSuccess) continue;
+    (void)hipFree(c.p);
+    c.p = nullptr;
+    c.bytes = 0;
+  }
 }
 
+static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
+                            const InputParameters *params, LocalParameters *local,
+                            const RsDriverOutput *out, int32_t device, int64_t pbeg, int64_t pend);
+
+/* device >= 0: that device.  device < 0: the points are cut into contiguous blocks over the
+ * device list (rs_devices.hpp: ROADSURF_HIP_DEVICES, default every visible device), one host
+ * thread + stream + plans per device, no collective - the in-process counterpart of the
+ * reference driver's worker pool (examples/example1/src/roadrunner.cpp:423-501). */
 int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputParameters *params,
                   LocalParameters *local, const RsDriverOutput *out, int32_t device) {
+  if (!in || in->n_points < 1) return fail_msg("rs_driver_run: bad arguments", -1);
+  if (device >= 0) return driver_run_range(in, st, params, local, out, device, 0, in->n_points);
+  const std::vector<rsu::Shard> shards = rsu::make_shards(in->n_points, rsu::device_list());
+  return rsu::fan_out(shards, [&](const rsu::Shard &sh, int) {
+    return driver_run_range(in, st, params, local, out, sh.device, sh.off, sh.off + sh.cnt);
+  });
+}
+
+} /* extern "C" */
+
+/* points [pbeg, pend) of the input on one device */
+static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
+                            const InputParameters *params, LocalParameters *local,
+                            const RsDriverOutput *out, int32_t device, int64_t pbeg, int64_t pend) {
   Common c;
   if (int rc = prepare(in, st, c)) return rc;
   if (!params || !local || !out) return fail_msg("rs_driver_run: params, local and out are required", -1);
@@ -1000,7 +1027,7 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputP
     Pdef = (int64_t)(64e9 / ((double)L * NFLD * sizeof(double)));
     Pdef = std::max<int64_t>(4096, std::min<int64_t>(262144, Pdef / 4096 * 4096));
   }
-  const int P = (int)std::min<int64_t>(c.n, ep ? std::max(1, atoi(ep)) : Pdef);
+  const int P = (int)std::min<int64_t>(pend - pbeg, ep ? std::max(1, atoi(ep)) : Pdef);
   const int TC = coupled ? L : std::min(L, et ? std::max(1, atoi(et)) : 256);
 
   /* shared axes */
@@ -1029,8 +1056,8 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputP
     HOK(win.acquire((size_t)nwin * Ppad * TC * sizeof(double), device));
   }
   pt.lap(6);
-  for (int64_t p0 = 0; p0 < c.n; p0 += P) {
-    const int m = (int)std::min<int64_t>(P, c.n - p0);
+  for (int64_t p0 = pbeg; p0 < pend; p0 += P) {
+    const int m = (int)std::min<int64_t>(P, pend - p0);
     PlanGuard pg;
     pg.p = rs_hip_plan_create(device, m, &consts, stream);
     if (!pg.p) return -11;
@@ -1236,5 +1263,3 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputP
   pt.report();
   return 0;
 }
-
-} /* extern "C" */

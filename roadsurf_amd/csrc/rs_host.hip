@@ -24,8 +24,13 @@
 #include "../../include/roadsurf.h"
 #include "rs_kernels.h"
 #include "rs_devutil.hpp"
+#include "rs_devices.hpp"
 
 extern "C" void rs_host_set_error(const char *msg);
+static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const InputPointers *inPointers,
+                               const RsConstants *consts, const LocalParameters *localParam,
+                               const double *tbottom, const RsHostExtras *extras, int32_t device,
+                               int nthreads);
 
 namespace {
 
@@ -78,10 +83,9 @@ inline double *out_f64(const OutputPointers &op, int f) {
 
 extern "C" {
 
-int rs_host_default_device(void) {
-  const char *e = getenv("ROADSURF_HIP_DEVICE");
-  return e ? atoi(e) : 0;
-}
+/* -1: the device list of rs_devices.hpp (ROADSURF_HIP_DEVICES, default every visible device) */
+int rs_host_default_device(void) { return -1; }
+int rs_last_fanout(void) { return rsu::g_last_fanout; }
 
 int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointers *inPointers,
                       const RsConstants *consts, const LocalParameters *localParam,
@@ -90,6 +94,34 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
     rs_host_set_error("rs_host_run_batch: bad arguments");
     return -1;
   }
+  const int host_threads = rsu::host_threads(omp_get_num_procs());
+  if (device >= 0)
+    return run_batch_on_device(n, outPointers, inPointers, consts, localParam, tbottom, extras, device,
+                               host_threads);
+  /* fan out: one contiguous block of points per device, one host thread + stream + plan each */
+  const std::vector<rsu::Shard> shards = rsu::make_shards(n, rsu::device_list());
+  return rsu::fan_out(shards, [&](const rsu::Shard &sh, int nshards) {
+    RsHostExtras ex;
+    const RsHostExtras *exp = nullptr;
+    if (extras) {
+      ex = *extras; /* sun is a shared axis; the per-point arrays move with the block */
+      if (ex.sin_lat) ex.sin_lat += sh.off;
+      if (ex.cos_lat) ex.cos_lat += sh.off;
+      if (ex.lon_rad) ex.lon_rad += sh.off;
+      exp = &ex;
+    }
+    return run_batch_on_device((int32_t)sh.cnt, outPointers + sh.off, inPointers + sh.off, consts,
+                               localParam + sh.off, tbottom + sh.off, exp, sh.device,
+                               std::max(1, host_threads / nshards));
+  });
+}
+
+} /* extern "C" */
+
+static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const InputPointers *inPointers,
+                               const RsConstants *consts, const LocalParameters *localParam,
+                               const double *tbottom, const RsHostExtras *extras, int32_t device,
+                               int nthreads) {
   const int L = consts->SimLen;
   /* tile sizes: bounded pinned staging (~0.5 GB) whatever n and SimLen are */
   const char *ep = getenv("ROADSURF_HIP_TILE_POINTS"), *et = getenv("ROADSURF_HIP_CHUNK_STEPS");
@@ -149,8 +181,6 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
     HOK(d_hz_pt.alloc((size_t)P * 360 * sizeof(double)));
     HOK(d_hz.alloc((size_t)Ppad * 360 * sizeof(double)));
   }
-
-  [[maybe_unused]] const int nthreads = rsu::host_threads(omp_get_num_procs());
 
   /* ---- work items: (tile of points) x (chunk of time), processed as a two-stage pipeline.
    * While the GPU works on item k (H2D, transposes, kernels, D2H on `stream`), the host
@@ -350,5 +380,3 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
   }
   return rc;
 }
-
-} /* extern "C" */

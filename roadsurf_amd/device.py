@@ -218,6 +218,16 @@ class Plan:
                                         "data": (int(ptr), False), "version": 2}
         return torch.as_tensor(_View(), device=self.device)
 
+    def copy_order_to(self, dst: torch.Tensor) -> None:
+        """Keep the order the last launch was stepped in: dst int32[np_pad] on this device
+        (asynchronous on the plan's stream; call before recluster())."""
+        assert dst.dtype == torch.int32 and dst.numel() == self.np_pad and dst.is_contiguous()
+        lib.check(self.L.rs_hip_plan_order_copy(self._h, C.c_void_p(dst.data_ptr())),
+                  "rs_hip_plan_order_copy")
+
+    def reset_order(self) -> None:
+        lib.check(self.L.rs_hip_plan_reset_order(self._h), "rs_hip_plan_reset_order")
+
     def recluster(self) -> None:
         """Sort the slots by the boundary-layer passes of the last launch; later windows,
         per-point parameters and outputs are in the new slot order."""

@@ -1,0 +1,87 @@
+"""The BASELINE synthetic workload as ONE object, so that ``bench.py`` times exactly the code
+path the parity tests check (``tests/test_hip_golden_and_scale.py``).
+
+One pass = the hot path over every time index of the shard's points::
+
+    init kernel -> for every window of `chunk` indices:
+        hourly knots (in the plan's current slot order) -> expand to the DTSecs grid ->
+        step kernel -> [plan order: keep the order row of this launch, re-sort the slots]
+
+Outputs are attributable to points (reference ``SaveOutput`` is per point,
+src/InputOutput.f90:151-165): with plan order on, launch ``c`` wrote column ``s`` of its
+output window for local point ``orders[c, s]``; the row is copied (4 B per point and launch,
+inside the timed region) before the slots are re-sorted for the next launch.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import device, lib
+
+SPK = 120  # 3600 s / DTSecs 30 s: time indices per hourly knot
+
+
+class SyntheticRun:
+    def __init__(self, plan: device.Plan, seed: int, hours: int, chunk: int, point_offset: int = 0,
+                 plan_order: bool = True, f32: bool = False, year_month_day=(2024, 1, 10)):
+        self.plan, self.seed, self.hours = plan, seed, hours
+        self.simlen = hours * SPK + 1  # examples/example1/src/InputSettings.cpp:98
+        self.chunk = min(chunk, self.simlen)
+        self.plan_order = plan_order
+        dev, npad = plan.device, plan.np_pad
+        wdtype = torch.float32 if f32 else torch.float64
+        self.win = device.ForcingWindow.empty(self.chunk, npad, dev, optional=(), dtype=wdtype)
+        self.out = device.OutputWindow.empty(self.chunk, npad, dev, dtype=wdtype)
+        # index-1 window for the init kernel: needs TsurfObs(1)
+        self.win0 = device.ForcingWindow.empty(1, npad, dev, optional=("tsurfobs",), dtype=wdtype)
+        self.pp = plan.point_params(plan.uniform_tbottom(*year_month_day))
+        self.starts = list(range(1, self.simlen + 1, self.chunk))
+        self.spec = None
+        self.knots = None
+        if plan_order:
+            # knots are generated per window in the current slot order (130x smaller than the window)
+            self.spec = lib.RsSynthSpec(seed, point_offset, SPK, 0)
+            self.kbuf = torch.empty((self.chunk // SPK + 3, 9, npad), dtype=torch.float64, device=dev)
+            self.orders = torch.empty((len(self.starts), npad), dtype=torch.int32, device=dev)
+        else:
+            self.spec, self.knots = plan.synth_knots(seed, hours + 2, point_offset=point_offset,
+                                                     steps_per_knot=SPK)
+            self.orders = None
+
+    def run_pass(self, on_launch=None) -> None:
+        """Enqueue one pass on the plan's stream.  ``on_launch(c, t0, ns)`` is called after launch
+        ``c`` has been enqueued (tests read ``self.out`` and ``self.orders[c]`` there)."""
+        plan, spec = self.plan, self.spec
+        if self.plan_order:
+            plan.reset_order()
+            plan.synth_knots_range(spec, self.kbuf, 0, 2, ordered=True)
+            plan.expand_range(spec, self.kbuf, 0, 2, self.win0, 1, 1)
+        else:
+            plan.expand(spec, self.knots, self.win0, 1, 1)
+        plan.init_state(self.win0, self.pp)
+        for c, t0 in enumerate(self.starts):
+            ns = min(self.chunk, self.simlen - t0 + 1)
+            if self.plan_order:
+                k0 = (t0 - 1) // SPK
+                nk = (t0 + ns - 2) // SPK + 1 - k0 + 1
+                plan.synth_knots_range(spec, self.kbuf, k0, nk, ordered=True)
+                plan.expand_range(spec, self.kbuf, k0, nk, self.win, t0, ns)
+            else:
+                plan.expand(spec, self.knots, self.win, t0, ns)
+            plan.step(self.win, self.out, self.pp, t0, ns, out_row0=t0 - 1)
+            if self.plan_order:
+                plan.copy_order_to(self.orders[c])  # which point each column of this launch is
+                if on_launch:
+                    on_launch(c, t0, ns)
+                plan.recluster()
+            elif on_launch:
+                on_launch(c, t0, ns)
+
+    def slots_of(self, c: int, points: torch.Tensor) -> torch.Tensor:
+        """Columns of launch ``c``'s output window that hold the given local points."""
+        if not self.plan_order:
+            return points
+        order = self.orders[c].long()
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(order.numel(), device=order.device)
+        return inv[points]

@@ -195,3 +195,49 @@ def test_more_concurrent_callers_than_any_fixed_plan_pool():
     assert not errs
     for k in oh.F64_OUT:
         assert np.array_equal(out[k], ora[k]), k
+
+
+def test_batch_fans_out_over_the_device_list(monkeypatch):
+    """north_star: points shard over the GPUs of a node with per-GPU streams and no collective.
+    runsimulation_batch cuts the batch into contiguous blocks over ROADSURF_HIP_DEVICES, one host
+    thread + stream + plan per block (the worker pool of examples/example1/src/roadrunner.cpp:
+    423-501, per device instead of per point).  On a one-GPU box the list "0,0,0" gives three
+    concurrent plans on the same device: results must equal the single-plan run bit for bit, and
+    the reference."""
+    L = lib.load()
+    n, SL = 1000, 721
+    f = oh.synth_forcing(n, SL, seed=17)
+    f["tair"][777, 300] = -200.0  # a failing point in the last block
+    s = abi.default_settings(SL); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
+    ora, _, _ = oh.run_oracle(_kind(), f, s, p, l)
+
+    def run():
+        g = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in f.items()}
+        out = {k: np.full((n, SL), np.nan) for k in oh.F64_OUT}
+        ips = (abi.InputPointers * n)(); ops = (abi.OutputPointers * n)(); keep = []
+        for pt in range(n):
+            ips[pt], ops[pt], hz = _pointers(g, out, pt)
+            keep.append(hz)
+        larr = (abi.LocalParameters * n)(*([l] * n))
+        st = C.c_int32(99)
+        L.runsimulation_batch(n, ops, ips, C.byref(s), C.byref(p), larr, C.byref(st))
+        assert st.value == 0, lib.last_error()
+        return out, int(L.rs_last_fanout())
+
+    monkeypatch.setenv("ROADSURF_HIP_DEVICES", "0")
+    one, k1 = run()
+    assert k1 == 1
+    monkeypatch.setenv("ROADSURF_HIP_DEVICES", "0,0,0")
+    monkeypatch.setenv("ROADSURF_HIP_MIN_SHARD", "100")
+    three, k3 = run()
+    assert k3 == 3
+    for k in oh.F64_OUT:
+        assert np.array_equal(one[k], three[k]), k
+        assert np.array_equal(three[k], ora[k]), k
+    # an out-of-range entry is ignored, a batch below the minimum block is not split
+    monkeypatch.setenv("ROADSURF_HIP_DEVICES", "0,99")
+    monkeypatch.setenv("ROADSURF_HIP_MIN_SHARD", "4096")
+    small, k = run()
+    assert k == 1
+    for key in oh.F64_OUT:
+        assert np.array_equal(one[key], small[key])

@@ -245,3 +245,26 @@ def test_random_driver_case_matches_checker(seed, monkeypatch):
     for q in range(len(g["status"])):
         for f in LP_FIELDS:
             assert getattr(g["local"][q], f) == getattr(o["local"][q], f), (desc, q, f)
+
+
+def test_driver_run_fans_out_over_the_device_list(monkeypatch):
+    """rs_driver_run with device < 0 cuts the points into blocks over ROADSURF_HIP_DEVICES (one
+    worker thread, stream, window block and plans per entry).  "0,0" = two concurrent workers on
+    the one GPU of the test box: same bits as the single-device call, decisions included."""
+    from roadsurf_amd import lib
+    n = 600
+    src, L, t0, tf = dh.scenario(n, hours=6, seed=9, obs_hours=3)
+    s = _settings(L, use_relaxation=1)
+    p = abi.default_parameters()
+    a = driver.run(src, s, p, t0, tf, device=0)
+    monkeypatch.setenv("ROADSURF_HIP_DEVICES", "0,0")
+    monkeypatch.setenv("ROADSURF_HIP_MIN_SHARD", "64")
+    b = driver.run(src, s, p, t0, tf, device=-1)
+    assert lib.load().rs_last_fanout() == 2
+    for k in driver.OUT_FIELDS:
+        assert _same_bits(a[k], b[k]), k
+    assert np.array_equal(a["status"], b["status"])
+    assert np.array_equal(a["missing_index"], b["missing_index"])
+    for q in range(n):
+        for f in LP_FIELDS:
+            assert getattr(a["local"][q], f) == getattr(b["local"][q], f), (q, f)

@@ -93,51 +93,56 @@ def test_golden_skyview_on_gpu():
         assert np.array_equal(res[k][:, idx], z[f"sky_{k}"]), k
 
 
-def _synthetic_pass(plan, spec, knots, simlen, chunk, sample_cols, pp):
-    """One full pass; returns (checksum, sampled outputs [6][simlen][ncols], mins, maxs)."""
+def _synthetic_pass(run, sample_points):
+    """One full pass of roadsurf_amd.workload.SyntheticRun - the object bench.py times.
+    Returns (order-independent wrap-around checksum of all six outputs, the sampled points'
+    series [field][simlen][npoints_sampled] mapped back through the per-launch order rows,
+    mins, maxs)."""
     import torch
     from roadsurf_amd import device
+    plan = run.plan
     dev = plan.device
-    win = device.ForcingWindow.empty(chunk, plan.np_pad, dev, optional=())
-    win0 = device.ForcingWindow.empty(1, plan.np_pad, dev, optional=("tsurfobs",))
-    out = device.OutputWindow.empty(chunk, plan.np_pad, dev)
-    plan.expand(spec, knots, win0, 1, 1)
-    plan.init_state(win0, pp)
     n = plan.npoints
-    checksum = torch.zeros((), dtype=torch.int64, device=dev)
+    acc = {"sum": torch.zeros((), dtype=torch.int64, device=dev)}
     mins = {k: float("inf") for k in device.OUT_FIELDS}
     maxs = {k: float("-inf") for k in device.OUT_FIELDS}
-    cols = torch.as_tensor(sample_cols, device=dev)
+    pts = torch.as_tensor(sample_points, device=dev)
     sampled = {k: [] for k in device.OUT_FIELDS}
-    t0 = 1
-    while t0 <= simlen:
-        ns = min(chunk, simlen - t0 + 1)
-        plan.expand(spec, knots, win, t0, ns)
-        plan.step(win, out, pp, t0, ns, out_row0=t0 - 1)
+
+    def on_launch(c, t0, ns):
+        cols = run.slots_of(c, pts)
+        if run.plan_order:  # the kept order row is a permutation of the shard's points
+            o = run.orders[c][:n].long()
+            assert int(o.min()) == 0 and int(o.max()) == n - 1
+            assert int(torch.bincount(o, minlength=n).max()) == 1
         for k in device.OUT_FIELDS:
-            o = out.tensors[k][:ns, :n]
-            checksum += o.view(torch.int64).sum()
+            o = run.out.tensors[k][:ns, :n]
+            acc["sum"] += o.view(torch.int64).sum()
             mins[k] = min(mins[k], float(o.min())); maxs[k] = max(maxs[k], float(o.max()))
             assert not torch.isnan(o).any()
             sampled[k].append(o[:, cols].clone())
-        t0 += ns
+
+    run.run_pass(on_launch)
     plan.sync()
-    return int(checksum.item()), {k: torch.cat(v).cpu().numpy() for k, v in sampled.items()}, mins, maxs
+    return (int(acc["sum"].item()), {k: torch.cat(v).cpu().numpy() for k, v in sampled.items()},
+            mins, maxs)
 
 
 def test_full_size_properties_1M_points_48h():
-    from roadsurf_amd import device
+    """BASELINE config 3 at its size, in BOTH orders bench.py times: natural order, and plan order
+    (slots re-sorted after every launch, windows generated in slot order, order rows kept)."""
+    import torch
+    from roadsurf_amd import device, workload
     n, hours, seed, chunk = 1_000_000, 48, 20240110, 240
     L = hours * SPK + 1
     s = abi.default_settings(L); p = abi.default_parameters()
     plan = device.Plan(n, s, p, 0)
-    spec, knots = plan.synth_knots(seed, hours + 2, steps_per_knot=SPK)
-    pp = plan.point_params(plan.uniform_tbottom(2024, 1, 10))
     # sampled global ids: a contiguous block per region so that they can be re-run as shards
     blocks = [0, 333_312, 999_744]
     cols = np.concatenate([np.arange(b, b + 64) for b in blocks])
-    c1, samp1, mins, maxs = _synthetic_pass(plan, spec, knots, L, chunk, cols, pp)
-    c2, samp2, _, _ = _synthetic_pass(plan, spec, knots, L, chunk, cols, pp)
+    run = workload.SyntheticRun(plan, seed, hours, chunk, plan_order=False)
+    c1, samp1, mins, maxs = _synthetic_pass(run, cols)
+    c2, samp2, _, _ = _synthetic_pass(run, cols)
     assert c1 == c2, "two passes over the same inputs differ"
     for k in device.OUT_FIELDS:
         assert np.array_equal(samp1[k], samp2[k])
@@ -148,8 +153,25 @@ def test_full_size_properties_1M_points_48h():
                   ("deposit", p.MaxDepmms), ("ice2", p.MaxIcemms)):
         assert mins[k] >= 0.0 and maxs[k] <= hi, (k, mins[k], maxs[k])
     assert maxs["snow"] > 1 and maxs["ice"] > 1 and maxs["deposit"] > 0.1  # workload is not trivial
+    del run
+    torch.cuda.empty_cache()
+    # plan order, exactly as bench.py's headline leg runs it.  Points do not interact, so the
+    # multiset of outputs per launch is the same: the order-independent checksum must match, and
+    # the sampled points, found through the kept order rows, must carry the same bits
+    run = workload.SyntheticRun(plan, seed, hours, chunk, plan_order=True)
+    c3, samp3, mins3, maxs3 = _synthetic_pass(run, cols)
+    assert c3 == c1, "plan-order pass: checksum of all outputs differs from the natural-order pass"
+    assert mins3 == mins and maxs3 == maxs
+    for k in device.OUT_FIELDS:
+        assert np.array_equal(samp3[k], samp1[k]), ("plan order", k)
+    moved = int((run.orders[-1][:n].long() != torch.arange(n, device=plan.device)).sum())
+    assert moved > n // 2, "the slots were never re-sorted: this pass did not test plan order"
+    c4, samp4, _, _ = _synthetic_pass(run, cols)  # a second pass starts from the identity again
+    assert c4 == c1
+    assert plan.failed_count() == 0
+    del run
     plan.close()
-    # shard independence + oracle spot check: re-run each sampled block as its own tiny batch
+    # shard independence + reference spot check: re-run each sampled block as its own tiny batch
     l = abi.default_local(); l.InitLenI = 1
     for bi, b in enumerate(blocks):
         f = oh.synth_forcing(64, L, seed=seed, point_offset=b)
@@ -159,3 +181,5 @@ def test_full_size_properties_1M_points_48h():
             big = samp1[k][:, bi * 64:(bi + 1) * 64].T  # [64][L]
             assert np.array_equal(big, res[k]), ("shard independence", k, b)
             assert np.abs(big - ora[k]).max() < TOL, ("oracle", k, b)
+            assert np.array_equal(samp3[k][:, bi * 64:(bi + 1) * 64].T, ora[k]), \
+                ("plan order vs reference, bit for bit", k, b)
