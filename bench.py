@@ -117,6 +117,15 @@ def main() -> None:
                     help="1: plan order - re-sort the plan's slots by boundary-layer passes after every "
                          "launch (rs_hip_recluster; windows are generated in slot order, the order row "
                          "of every launch is kept), 0: natural order only")
+    ap.add_argument("--sort-key", choices=("forecast", "history"), default="forecast",
+                    help="plan order: sort by a forecast of the next window's boundary-layer regime and "
+                         "passes (rs_hip_recluster_forecast) or by the passes of the last launch")
+    ap.add_argument("--forecast-alpha", type=float, default=0.5)
+    ap.add_argument("--forecast-mode", type=int, default=1)
+    ap.add_argument("--plans-per-gpu", type=int, default=1,
+                    help="cut this GPU's points into K plans on K streams whose launches interleave: "
+                         "one plan's HBM-bound window expansion and re-sort run beside another's "
+                         "VALU-bound step kernel")
     ap.add_argument("--no-natural-leg", action="store_true",
                     help="skip the second timed leg (natural order) that gives natural_order_value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -157,11 +166,19 @@ def main() -> None:
     simlen = args.hours * workload.SPK + 1  # examples/example1/src/InputSettings.cpp:98
     settings = abi.default_settings(simlen)
     params = abi.default_parameters()
-    plan = device.Plan(n, settings, params, dev_index)
-    if args.variant:
-        plan.set_variant(args.variant)
-    if args.f32:
-        plan.set_precision(32)
+    K = max(1, args.plans_per_gpu)
+    plans, offsets = [], []
+    for j in range(K):
+        off_j, n_j = sharding.strong_shard(n, K, j)
+        st = torch.cuda.current_stream(dev) if K == 1 else torch.cuda.Stream(dev)
+        pl = device.Plan(n_j, settings, params, dev_index, stream=st)
+        if args.variant:
+            pl.set_variant(args.variant)
+        if args.f32:
+            pl.set_precision(32)
+        plans.append(pl)
+        offsets.append(offset + off_j)
+    plan = plans[0]
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -171,23 +188,38 @@ def main() -> None:
 
     def timed_leg(plan_order: bool):
         """W untimed + exactly K timed passes, barrier + synchronize on both sides, MAX over ranks."""
-        run = workload.SyntheticRun(plan, args.seed, args.hours, args.chunk, point_offset=offset,
-                                    plan_order=plan_order, f32=args.f32)
+        runs = [workload.SyntheticRun(pl, args.seed, args.hours, args.chunk, point_offset=o,
+                                      plan_order=plan_order, f32=args.f32,
+                                      forecast=args.sort_key == "forecast",
+                                      forecast_alpha=args.forecast_alpha, forecast_mode=args.forecast_mode)
+                for pl, o in zip(plans, offsets)]
+        run = runs[0]
+
+        def one_pass():
+            its = [r.iter_pass() for r in runs]
+            while its:  # launch c of every plan, then launch c+1 ...
+                its = [it for it in its if next(it, None) is not None]
+
         for _ in range(args.warmup):
-            run.run_pass()
+            one_pass()
         fence()
-        plan.timing_reset()
+        for pl in plans:
+            pl.timing_reset()
         t_start = time.perf_counter()
         for _ in range(args.steps):
-            run.run_pass()
+            one_pass()
         fence()
         elapsed = time.perf_counter() - t_start
         elapsed = sharding.max_over_ranks(
             elapsed, dist if world > 1 else None,
             dev if (world > 1 and dist.get_backend() == "nccl") else None)
-        step_ms, nlaunch = plan.timing_step_ms()
+        step_ms, nlaunch = 0.0, 0
+        for pl in plans:  # K > 1: launches of different plans overlap, their durations are summed
+            ms, nl = pl.timing_step_ms()
+            step_ms += ms
+            nlaunch += nl
         chunk = run.chunk
-        del run
+        del run, runs
         torch.cuda.empty_cache()
         return elapsed, step_ms, nlaunch, chunk
 
@@ -196,7 +228,7 @@ def main() -> None:
     natural = None
     if cluster and not args.no_natural_leg:
         natural = timed_leg(False)
-    nfail = plan.failed_count()
+    nfail = sum(pl.failed_count() for pl in plans)
 
     units_per_pass_job = total_points * simlen          # whole job, all ranks
     units_per_pass_rank = n * simlen
@@ -229,9 +261,11 @@ def main() -> None:
                             + (" (per-launch order rows kept inside the timed region)" if cluster else ""),
                 "total_points": total_points,
                 "points_per_gpu": n,
+                "plans_per_gpu": K,
                 "simlen": simlen,
                 "chunk_steps": chunk,
                 "plan_order": cluster,
+                "sort_key": args.sort_key if cluster else None,
                 "order_rows_kept": cluster,
                 "kernel_variant": args.variant,
                 "parallelism": f"points sharded over {world} GPU(s) ({scaling} scaling), no collectives",
@@ -269,7 +303,8 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, simlen, args.seed)
         print(json.dumps(line), flush=True)
-    plan.close()
+    for pl in plans:
+        pl.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -376,9 +376,17 @@ int rs_hip_set_precision(RsPlan *plan, int32_t bits);
  * 1 = bare Newton sequence for normal-range operands (default, same bits, see
  * rs_math.hpp), 2 = both evaluated and compared (-DRS_DIV_CHECK).  In mode 2
  * rs_hip_div_mismatch_count returns how many call-site evaluations disagreed
- * since the library was loaded (0 in the other modes). */
+ * with two finite results since the library was loaded (0 in the other modes). */
 int rs_hip_division_mode(void);
 int64_t rs_hip_div_mismatch_count(RsPlan *plan);
+/* mode 2: evaluations where one of the two results is inf/NaN (x/0, x/inf, inf/x: the bare
+ * sequence gives NaN there) - the operands the boundary-layer guard handles in the shipped build
+ * (roadsurf_amd/csrc/rs_physics_body.inc) - plus those that differ only in the sign of a zero
+ * result (-0.0/b; harmless, rs_math.hpp); rs_hip_div_mismatch_count counts different VALUES */
+int64_t rs_hip_div_special_count(RsPlan *plan);
+/* mode 2: the first 64 finite mismatches as {numerator or sqrt argument, denominator (0 for a
+ * square root), IEEE result, bare result}; out = host double[64][4] */
+int rs_hip_div_samples(RsPlan *plan, double *out);
 
 /* Kernel flavour: 0 auto (1 for the LEAN feature set with NLayers == 15, else 2), 1 register
  * profile, 2 LDS profile,
@@ -411,6 +419,27 @@ int rs_hip_recluster(RsPlan *plan);
  *                            that launch's output window is local point dst[s] (4 bytes per point and
  *                            launch against the 48 bytes per point and time index of the outputs)
  *   rs_hip_plan_reset_order  back to the identity (a new run over the same plan) */
+/* rs_hip_recluster_forecast: like rs_hip_recluster, but the sort key is a FORECAST of the next
+ * launch instead of the history of the last one.  What a point costs a wavefront is decided by its
+ * boundary-layer regime (stable: no sqrt/log; unstable: which path of log) and by how many passes
+ * its fixed point needs - functions of (Tsurf - Tair, wind speed) only (src/BoundaryLayer.f90:64-96).
+ * The forcing of the next window is known before it is stepped, so the key kernel runs the fixed
+ * point for each point at a few PREVIEW times of the next window (surface temperature = the carried
+ * one, moved along with the air temperature by `alpha`) and sorts by
+ *     (how many previews are unstable, how many of those take the table path of log, [cover],
+ *      predicted passes beyond the mandatory five).
+ * Rows are device pointers in the plan's CURRENT slot order, [npoints_padded] each. */
+#define RS_PREVIEW_MAX 8
+typedef struct RsPreview {
+  int32_t n;                             /* 1..RS_PREVIEW_MAX preview times */
+  const double *tair[RS_PREVIEW_MAX];    /* air temperature at preview time q */
+  const double *vz[RS_PREVIEW_MAX];      /* wind speed at preview time q */
+  int32_t hour[RS_PREVIEW_MAX];          /* hour of day at preview time q (calm limit day/night) */
+  const double *tair_now;                /* air temperature at the first index of the next window */
+  double alpha;                          /* Tsurf(preview) = Tsurf + alpha*(Tair(preview) - Tair_now) */
+  int32_t mode;                          /* bit 0: table-path count in the key, bit 1: cover bit */
+} RsPreview;
+int rs_hip_recluster_forecast(RsPlan *plan, const RsPreview *preview);
 int rs_hip_plan_order_copy(RsPlan *plan, int32_t *dst_device);
 int rs_hip_plan_reset_order(RsPlan *plan);
 

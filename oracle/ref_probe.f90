@@ -117,3 +117,11 @@ subroutine ref_probe_coupling_init(inPointers, outPointers, inSettings, inputPar
    rvals(3) = atm%TairR
    rvals(4) = coupling%RadCoeff
 end subroutine ref_probe_coupling_init
+
+!> Flush what the reference has written to standard output (unit 6) so far.  The tests silence
+!! the reference's diagnostics by pointing file descriptor 1 elsewhere for the duration of a call
+!! (tests/oracle_helpers.py, quiet_stdout); the Fortran runtime buffers unit 6, so the buffer has to
+!! be emptied before the descriptor is restored.
+subroutine ref_flush_stdout() bind(C, name='ref_flush_stdout')
+   flush (6)
+end subroutine ref_flush_stdout

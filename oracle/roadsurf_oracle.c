@@ -1270,3 +1270,20 @@ int oracle_probe_sun(int year, int month, int day, int hour, int minute, int sec
   *jde = JulianEphemerisDay(&in, 1);
   return calcElevationAzimuth(*jde, lat, lon, elevation, azimuth);
 }
+
+/* Host check of the product's uniform-denominator division (roadsurf_amd/csrc/rs_math.hpp,
+ * rs_div_u): q0 = a*rb, rem = fma(-b, q0, a), q = fma(rem, rb, q0) with rb = RN(1/b) must be
+ * the IEEE quotient a/b.  libm's fma is correctly rounded, like v_fma_f64.  Returns how many of
+ * the n numerators disagree (test infrastructure, tests/test_host_logic.py). */
+long oracle_div_u_mismatches(double b, const double *a, long n) {
+  const double rb = 1.0 / b;
+  long bad = 0;
+  for (long i = 0; i < n; ++i) {
+    const double q0 = a[i] * rb;
+    const double rem = fma(-b, q0, a[i]);
+    const double q = fma(rem, rb, q0);
+    const double want = a[i] / b;
+    if (memcmp(&q, &want, sizeof q) != 0 && !(q != q && want != want)) ++bad;
+  }
+  return bad;
+}

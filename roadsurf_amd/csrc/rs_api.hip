@@ -18,6 +18,7 @@
 
 #include "../../include/roadsurf.h"
 #include "rs_kernels.h"
+#include "rs_consts_dev.h"
 #include "rs_state.h"
 
 static thread_local char g_err[512] = "";
@@ -57,7 +58,7 @@ struct RsPlan {
   uint32_t *sort_keys = nullptr; /* [4][np_pad]: keys in/out, slots in/out */
   int variant = RS_VARIANT_AUTO;
   /* the plan's constants on the device (no table of slots: any number of plans may be alive) */
-  void *consts_dev = nullptr;   /* RsConstants */
+  void *consts_dev = nullptr;   /* RsConstantsDev (rs_consts_dev.h) */
   void *consts32_dev = nullptr; /* RsConstantsF, allocated by rs_hip_set_precision(32) */
   bool f32 = false; /* single-precision flavour: windows and state hold floats */
   std::vector<hipEvent_t> ev; /* start/stop pairs */
@@ -157,6 +158,13 @@ RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints, const RsConstants *c
     set_err("rs_hip_plan_create: NLayers=%d outside [5,%d]", consts->NLayers, RS_MAX_LAYERS);
     return nullptr;
   }
+  if (const char *bad = rs_consts_domain_error(*consts)) {
+    /* the kernels divide by these without IEEE's special-case handling (rs_math.hpp); the
+     * reference itself would be dividing by zero or by a non-finite number */
+    set_err("rs_hip_plan_create: parameter outside the model's domain (zero, negative or non-finite "
+            "where it is a divisor): %s", bad);
+    return nullptr;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     set_err("rs_hip_plan_create: no HIP device visible - this library has no CPU path");
@@ -178,8 +186,8 @@ RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints, const RsConstants *c
   pl->stream = (hipStream_t)stream;
   if (const char *ev = getenv("ROADSURF_HIP_VARIANT")) { /* tuning: default flavour of new plans */
     const int v = atoi(ev);
-    if (v >= 0 && v % 10 <= 3 && v / 10 <= 4 &&
-        !((v % 10 == RS_VARIANT_REG || v % 10 == RS_VARIANT_BT) && consts->NLayers != 15))
+    if (v >= 0 && v % 10 <= 2 && v / 10 <= 4 &&
+        !(v % 10 == RS_VARIANT_REG && consts->NLayers != 15))
       pl->variant = v;
   }
   const size_t bytes = (size_t)RS_NSTATE * pl->np_pad * sizeof(double);
@@ -191,9 +199,12 @@ RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints, const RsConstants *c
     return nullptr;
   }
   (void)hipMemsetAsync(pl->state, 0, bytes, pl->stream);
-  hipError_t ce = hipMalloc(&pl->consts_dev, sizeof(RsConstants));
+  RsConstantsDev cd;
+  rs_consts_dev_fill(pl->c, cd);
+  hipError_t ce = hipMalloc(&pl->consts_dev, sizeof(RsConstantsDev));
   if (ce == hipSuccess)
-    ce = hipMemcpyAsync(pl->consts_dev, &pl->c, sizeof(RsConstants), hipMemcpyHostToDevice, pl->stream);
+    ce = hipMemcpyAsync(pl->consts_dev, &cd, sizeof(RsConstantsDev), hipMemcpyHostToDevice, pl->stream);
+  if (ce == hipSuccess) ce = hipStreamSynchronize(pl->stream); /* cd is stack scratch */
   if (ce == hipSuccess) {
     std::lock_guard<std::mutex> lock(g_tables_mutex);
     if (!g_tables_up[device]) {
@@ -246,10 +257,7 @@ const int32_t *rs_hip_plan_order(RsPlan *pl) {
   return pl->order;
 }
 
-int rs_hip_recluster(RsPlan *pl) {
-  if (!pl) return set_err("rs_hip_recluster: null plan");
-  if (!rs_hip_plan_order(pl)) return -1;
-  HIP_OK(hipSetDevice(pl->device));
+static int recluster_buffers(RsPlan *pl) {
   const size_t state_bytes = (size_t)RS_NSTATE * pl->np_pad * sizeof(double);
   if (!pl->state_alt) {
     HIP_OK(hipMalloc(&pl->state_alt, state_bytes));
@@ -258,14 +266,51 @@ int rs_hip_recluster(RsPlan *pl) {
     pl->sort_tmp_bytes = rs_cluster_scratch_bytes(pl->npoints);
     HIP_OK(hipMalloc(&pl->sort_tmp, pl->sort_tmp_bytes ? pl->sort_tmp_bytes : 8));
   }
-  HIP_OK(rs_cluster_sort(pl->state, pl->f32, pl->np_pad, pl->npoints, pl->sort_keys, pl->sort_tmp,
-                         pl->sort_tmp_bytes, pl->stream));
+  return 0;
+}
+
+static int recluster_apply(RsPlan *pl) {
   HIP_OK(rs_cluster_apply(pl->state, pl->state_alt, pl->f32, pl->order, pl->order_alt,
                           pl->sort_keys + 3 * pl->np_pad, pl->np_pad, pl->npoints, pl->c.NLayers,
                           pl->c.use_coupling != 0, pl->stream));
   std::swap(pl->state, pl->state_alt);
   std::swap(pl->order, pl->order_alt);
   return 0;
+}
+
+int rs_hip_recluster_forecast(RsPlan *pl, const RsPreview *pv) {
+  if (!pl || !pv) return set_err("rs_hip_recluster_forecast: bad arguments");
+  if (pv->n < 1 || pv->n > RS_PREVIEW_MAX || !pv->tair_now)
+    return set_err("rs_hip_recluster_forecast: 1 <= n <= %d previews and tair_now are required",
+                   RS_PREVIEW_MAX);
+  for (int q = 0; q < pv->n; ++q)
+    if (!pv->tair[q] || !pv->vz[q]) return set_err("rs_hip_recluster_forecast: preview row %d is null", q);
+  if (!rs_hip_plan_order(pl)) return -1;
+  HIP_OK(hipSetDevice(pl->device));
+  if (recluster_buffers(pl)) return -1;
+  rs::ForecastArgs a;
+  a.consts = pl->consts_dev;
+  a.state = pl->state;
+  a.f32 = pl->f32 ? 1 : 0;
+  a.npoints = pl->npoints;
+  a.np_pad = pl->np_pad;
+  a.pv = *pv;
+  a.keys = pl->sort_keys;
+  a.slots = pl->sort_keys + 2 * pl->np_pad;
+  HIP_OK(rs_launch_forecast_keys(a, pl->stream));
+  HIP_OK(rs_cluster_sort_keys(pl->np_pad, pl->npoints, pl->sort_keys, pl->sort_tmp, pl->sort_tmp_bytes,
+                              pl->stream));
+  return recluster_apply(pl);
+}
+
+int rs_hip_recluster(RsPlan *pl) {
+  if (!pl) return set_err("rs_hip_recluster: null plan");
+  if (!rs_hip_plan_order(pl)) return -1;
+  HIP_OK(hipSetDevice(pl->device));
+  if (recluster_buffers(pl)) return -1;
+  HIP_OK(rs_cluster_sort(pl->state, pl->f32, pl->np_pad, pl->npoints, pl->sort_keys, pl->sort_tmp,
+                         pl->sort_tmp_bytes, pl->stream));
+  return recluster_apply(pl);
 }
 
 int rs_hip_plan_order_copy(RsPlan *pl, int32_t *dst) {
@@ -303,9 +348,9 @@ int rs_hip_set_precision(RsPlan *pl, int32_t bits) {
 }
 
 int rs_hip_set_variant(RsPlan *pl, int32_t variant) {
-  if (!pl || variant < 0 || variant % 10 > 3 || variant / 10 > 4)
+  if (!pl || variant < 0 || variant % 10 > 2 || variant / 10 > 4)
     return set_err("rs_hip_set_variant: bad arguments");
-  if ((variant % 10 == RS_VARIANT_REG || variant % 10 == RS_VARIANT_BT) && pl->c.NLayers != 15)
+  if (variant % 10 == RS_VARIANT_REG && pl->c.NLayers != 15)
     return set_err("register-profile kernel is built for NLayers == 15 only (got %d)",
                    pl->c.NLayers);
   pl->variant = variant;
@@ -495,12 +540,20 @@ int rs_hip_sync(RsPlan *pl) {
   return 0;
 }
 
-int64_t rs_hip_div_mismatch_count(RsPlan *pl) {
+static int64_t div_mismatch(RsPlan *pl, int which) {
   if (!pl) return -1;
   if (hipSetDevice(pl->device) != hipSuccess) return -1;
-  unsigned long long n = 0;
-  if (rs_read_div_mismatch(&n, pl->stream) != hipSuccess) return -1;
-  return (int64_t)n;
+  unsigned long long n[3] = {0, 0, 0};
+  if (rs_read_div_mismatch(n, pl->stream) != hipSuccess) return -1;
+  return which == 1 ? (int64_t)(n[1] + n[2]) : (int64_t)n[0];
+}
+int64_t rs_hip_div_mismatch_count(RsPlan *pl) { return div_mismatch(pl, 0); }
+int64_t rs_hip_div_special_count(RsPlan *pl) { return div_mismatch(pl, 1); }
+int rs_hip_div_samples(RsPlan *pl, double *out) {
+  if (!pl || !out) return set_err("rs_hip_div_samples: bad arguments");
+  HIP_OK(hipSetDevice(pl->device));
+  HIP_OK(rs_read_div_samples(out, pl->stream));
+  return 0;
 }
 
 int rs_hip_division_mode(void) {

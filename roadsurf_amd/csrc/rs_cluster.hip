@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int KEY_BITS = 21; /* rs_kernels.hip, bl_score_key: 19 bits of passes + regime + cover */
+constexpr int KEY_BITS = RS_SORT_KEY_BITS; /* rs_kernels.hip, bl_score_key: 19 bits of passes + regime + cover */
 
 template <typename T> /* element type of the state block: double, or float for fp32 plans */
 __global__ void __launch_bounds__(RS_BLOCK) keys_kernel(const T *__restrict__ state,
@@ -84,6 +84,14 @@ hipError_t rs_cluster_sort(const double *state, bool f32, int64_t np_pad, int64_
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   /* stable: points with equal scores keep their relative order */
+  return hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, kin, kout, sin, sout, (int)npoints, 0,
+                                            KEY_BITS, stream);
+}
+
+hipError_t rs_cluster_sort_keys(int64_t np_pad, int64_t npoints, uint32_t *scratch, void *tmp,
+                                size_t tmp_bytes, hipStream_t stream) {
+  uint32_t *kin = scratch, *kout = scratch + np_pad, *sin = scratch + 2 * np_pad,
+           *sout = scratch + 3 * np_pad;
   return hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, kin, kout, sin, sout, (int)npoints, 0,
                                             KEY_BITS, stream);
 }

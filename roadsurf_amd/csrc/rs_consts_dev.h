@@ -1,0 +1,55 @@
+/* rs_consts_dev.h - what a plan uploads as its constant block for the fp64 kernels: RsConstants
+ * (include/roadsurf.h, built by the Fortran host) plus derived values the kernels would otherwise
+ * recompute every time step: the reciprocals of the uniform denominators (rs_math.hpp, rs_div_u)
+ * and one uniform product.  Filled in C++ by rs_hip_plan_create; not part of the C-ABI. */
+#pragma once
+#include "../../include/roadsurf.h"
+
+struct RsConstantsDev : RsConstants {
+  double meltDen;   /* WatMHeat*WatDens, the denominator of `Melted` (src/Storage.f90:149,230) */
+  /* RN(1/x) of: 3600 (src/InputOutput.f90:111), 3364 (src/BoundaryLayer.f90:53), 1000
+   * (src/Storage.f90:422,427), IceMax 1.5 (src/Cond.f90:131), twoDT (src/BalanceModel.f90:241),
+   * DTSecs (src/Storage.f90:422), meltDen, logUstar and logCond (first pass of the boundary-layer
+   * loop, where PSIM = PSIH = 0: src/BoundaryLayer.f90:62,69-70) */
+  double r_3600, r_3364, r_1000, r_IceMax, r_twoDT, r_DTSecs, r_meltDen, r_logUstar, r_logCond;
+};
+
+static inline void rs_consts_dev_fill(const RsConstants &c, RsConstantsDev &d) {
+  static_cast<RsConstants &>(d) = c;
+  d.meltDen = c.WatMHeat * c.WatDens;
+  d.r_3600 = 1.0 / 3600.0;
+  d.r_3364 = 1.0 / 3364.0;
+  d.r_1000 = 1.0 / 1000.0;
+  d.r_IceMax = 1.0 / 1.5;
+  d.r_twoDT = 1.0 / c.twoDT;
+  d.r_DTSecs = 1.0 / c.DTSecs;
+  d.r_meltDen = 1.0 / d.meltDen;
+  d.r_logUstar = 1.0 / c.logUstar;
+  d.r_logCond = 1.0 / c.logCond;
+}
+
+/* Operand domain the bare division/sqrt sequences of rs_math.hpp rely on, as far as it is set by
+ * the PARAMETERS (the forcing side is bounded by CheckValues; the data-dependent denominators of
+ * the boundary-layer loop are covered by the guard in rs_physics_body.inc).  Returns NULL or the
+ * name of the first offending quantity; rs_hip_plan_create refuses such a plan. */
+static inline const char *rs_consts_domain_error(const RsConstants &c) {
+  const double lo = 1e-30, hi = 1e30;
+  auto pos = [&](double x) { return x > lo && x < hi; };          /* a positive denominator */
+  auto mag = [&](double x) { return (x > lo && x < hi) || (x < -lo && x > -hi); }; /* nonzero, finite */
+  if (!pos(c.DTSecs) || !pos(c.twoDT)) return "DTSecs";
+  if (!mag(c.logUstar)) return "logUstar = log(ZRefW/ZMom)";
+  if (!mag(c.logCond)) return "logCond = log(ZRefT/ZHeat)";
+  if (!(c.logMom > -hi && c.logMom < hi) || !(c.logHeat > -hi && c.logHeat < hi)) return "logMom/logHeat";
+  if (!pos(c.VK_Const)) return "VK_Const";
+  if (!pos(c.LVap) || !pos(c.LFus)) return "LVap/LFus";
+  if (!pos(c.WatMHeat * c.WatDens)) return "WatMHeat*WatDens";
+  if (!pos(c.HSfac1)) return "layer grid (ZDpth(2)-ZDpth(1))";
+  for (int j = 1; j <= c.NLayers; ++j) {
+    if (!pos(c.DyC[j])) return "DyC (layer grid)";
+    /* VSH = dryCap + WCont*CHWT with CHWT in [1.9e6, 4.3e6] (src/BalanceModel.f90:215-236) */
+    if (!(c.dryCap[j] >= 0.0) || !(c.WCont[j] >= 0.0) || !pos(c.dryCap[j] + c.WCont[j] * 1.9e6))
+      return "layer heat capacity (vsh/Poro/WCont)";
+    if (!(c.ZDpth[j + 1] - c.ZDpth[j] > lo)) return "layer grid (ZDpth)";
+  }
+  return nullptr;
+}

@@ -6,7 +6,7 @@
 
 #define RS_BLOCK 256
 
-enum { RS_VARIANT_AUTO = 0, RS_VARIANT_REG = 1, RS_VARIANT_LDS = 2, RS_VARIANT_BT = 3 };
+enum { RS_VARIANT_AUTO = 0, RS_VARIANT_REG = 1, RS_VARIANT_LDS = 2 };
 
 namespace rs {
 
@@ -29,6 +29,15 @@ struct InitArgs {
   int64_t npoints, np_pad;
 };
 
+struct ForecastArgs {
+  const void *consts; /* RsConstants (the predictor runs in fp64 for either flavour) */
+  const void *state;
+  int32_t f32;        /* the state block holds floats */
+  int64_t npoints, np_pad;
+  RsPreview pv;
+  uint32_t *keys, *slots;
+};
+
 struct KnotArgs {
   RsSynthSpec spec;
   double *knots;
@@ -46,7 +55,8 @@ struct ExpandArgs {
 
 }  // namespace rs
 
-hipError_t rs_read_div_mismatch(unsigned long long *out, hipStream_t stream);
+hipError_t rs_read_div_mismatch(unsigned long long *out /*[3]*/, hipStream_t stream);
+hipError_t rs_read_div_samples(double *out /*[64][4]*/, hipStream_t stream);
 hipError_t rs_launch_math_test(int fn, int64_t n, const double *x, double *y, hipStream_t stream);
 /* raw-series Tdew<->RH completion (needs the math tables: create a plan first) */
 hipError_t rs_launch_humidity_fill(const double *tair, double *tdew, double *rhz, int64_t n,
@@ -63,11 +73,17 @@ hipError_t rs_launch_expand(const rs::ExpandArgs &a, int32_t nintervals, hipStre
 hipError_t rs_launch_count_failed(const double *st, int64_t np_pad, int64_t npoints,
                                   unsigned long long *out, hipStream_t stream);
 
+hipError_t rs_launch_forecast_keys(const rs::ForecastArgs &a, hipStream_t stream);
+
 /* plan order (rs_cluster.hip) */
+#define RS_SORT_KEY_BITS 21
 hipError_t rs_cluster_identity(int32_t *order, int64_t np_pad, hipStream_t stream);
 size_t rs_cluster_scratch_bytes(int64_t npoints);
 hipError_t rs_cluster_sort(const double *state, bool f32, int64_t np_pad, int64_t npoints,
                            uint32_t *scratch, void *tmp, size_t tmp_bytes, hipStream_t stream);
+/* same with keys/slots already in scratch[0..np_pad) / scratch[2*np_pad..) */
+hipError_t rs_cluster_sort_keys(int64_t np_pad, int64_t npoints, uint32_t *scratch, void *tmp,
+                                size_t tmp_bytes, hipStream_t stream);
 hipError_t rs_cluster_apply(const double *state_src, double *state_dst, bool f32,
                             const int32_t *order_src, int32_t *order_dst, const uint32_t *perm,
                             int64_t np_pad, int64_t npoints, int nlayers, bool coupled,

@@ -44,7 +44,7 @@ constexpr int kBlock = RS_BLOCK;
  * compiler cannot hoist ~220 uniform doubles (= 440 SGPRs, against 102 available) out of the
  * loop and then spill them into VGPR lanes; loaded at the point of use they cost one s_load
  * each and no live range. */
-typedef RsConstants __attribute__((address_space(4))) ConstsAS;
+typedef RsConstantsDev __attribute__((address_space(4))) ConstsAS;
 template <class Args>
 __device__ __forceinline__ const ConstsAS &consts_of(Args a) {
   return *(const ConstsAS *)a->consts;
@@ -231,7 +231,7 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
     double tair = f.tair, vz = f.vz, rhz = f.rhz;
     /* src/Initialization.f90:121-123: VZ(1) is raised to 0.4 in the input array */
     if (i == 1 && vz < R4(0.4)) vz = R4(0.4);
-    const double prec_ts = rs_div(f.prec, 3600.0) * c.DTSecs; /* src/InputOutput.f90:111,186 */
+    const double prec_ts = RS_DIVC(f.prec, 3600.0, r_3600) * c.DTSecs; /* src/InputOutput.f90:111,186 */
 
     double sw_dir = 0.0, lw_net = 0.0;
     if (SKY) {
@@ -305,214 +305,6 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
     if (k + 1 < nsteps) nxt = load_forcing<FULL>(ka, row0, lane, k + 1);
     model_step_ground(c, s, T, tbot, tair, fx, f.depth);
     store_outputs(ka, i, row0, lane, s, true);
-  }
-}
-
-/* ---- block-level compaction of the boundary-layer tail ------------------------------
- * CalcBLCondAndLE iterates at least 5 times and then until |dBLCond| < 0.001
- * (src/BoundaryLayer.f90:64-96).  On the synthetic workload 80 % of the point-steps stop at
- * 5, the mean is 5.5, but the tail reaches 35 (tools/bl_iterations.py) - and a wavefront
- * runs until its slowest lane is done: measured, the iterations beyond the fifth cost 26 %
- * of the kernel with ~3 % of the lanes doing useful work in them.
- * Here every lane does its 5 mandatory iterations; lanes that have not converged park their
- * loop state in LDS, and after a workgroup barrier the parked items are handed out DENSELY
- * to the first n lanes of one (rotating) wavefront, which finish them and leave the results
- * in LDS for the owners.  The arithmetic per item is the same instruction sequence in the
- * same order whichever lane executes it, so results are bit-identical.  Cost per
- * workgroup-step: one tail instead of four, two barriers, ~20 LDS accesses. */
-struct BlTailShared {
-  double item[7][kBlock]; /* dT, den0, vkvz, avk, PSIM, PSIH, BLCond of a parked lane */
-  double res[3][kBlock];  /* PSIM, PSIH, BLCond when its loop has exited */
-  int32_t trips[kBlock];  /* passes it took */
-  int32_t count[2];       /* parked items of the even / odd time index */
-};
-
-/* All threads of the workgroup call this once per time index (barriers inside); `active`
- * lanes have a point to step, the others only take part as workers. */
-__device__ __forceinline__ Fluxes fluxes_block_tail(const ConstsAS &c, const MathTab &mt,
-                                                    Scalars &s, bool active, double tair, double vz,
-                                                    double rhz, double prec_ts, double sw, double lw,
-                                                    int32_t phase, int32_t hour, BlTailShared &sh,
-                                                    int32_t k) {
-  Fluxes fx;
-  fx.blcond = fx.le = fx.evap = fx.rnet = fx.trffric = 0.0;
-  fx.trips = 5;
-  BlInv v;
-  BlVar x;
-  BlAux a;
-  v.dT = v.den0 = v.vkvz = v.avk = 0.0;
-  x.PSIM = x.PSIH = x.BLCond = 0.0;
-  a.AirDens = a.AirHCap = a.PsychC = a.WatDen = 0.0;
-  bool need = false, unstable = false;
-  int32_t passes = 5;
-  if (active) {
-    fluxes_pre(c, mt, s, tair, vz, rhz, prec_ts, phase, hour, fx);
-    bl_setup(c, s.tsurf, tair, vz, v, x, a);
-    bool done = false;
-    const double stab_num = bl_stab_num(c);
-#pragma unroll
-    for (int j = 1; j <= 5; ++j) done = bl_iteration(c, mt, v, x, j, stab_num, &unstable);
-    need = !done && RS_BL_MAXIT > 5;
-  }
-  const int par = k & 1;
-  /* slots: one LDS atomic per wavefront */
-  const unsigned long long m = __ballot(need);
-  int slot = 0;
-  if (m) {
-    const unsigned wl = __lane_id();
-    const int pre = __popcll(m & ((1ull << wl) - 1ull));
-    int base = 0;
-    if (need && pre == 0) base = atomicAdd(&sh.count[par], __popcll(m));
-    base = __shfl(base, __ffsll((long long)m) - 1);
-    if (need) {
-      slot = base + pre;
-      sh.item[0][slot] = v.dT;
-      sh.item[1][slot] = v.den0;
-      sh.item[2][slot] = v.vkvz;
-      sh.item[3][slot] = v.avk;
-      sh.item[4][slot] = x.PSIM;
-      sh.item[5][slot] = x.PSIH;
-      sh.item[6][slot] = x.BLCond;
-    }
-  }
-  __syncthreads();
-  const int n = sh.count[par];
-  if (threadIdx.x == 0) sh.count[par ^ 1] = 0; /* nobody touches it between these barriers */
-  /* the worker wavefront rotates over workgroups and time so that the four SIMDs of a CU
-   * share the tails (wave w of every resident workgroup sits on SIMD w) */
-  const int w = (int)((threadIdx.x - 64u * ((blockIdx.x + (unsigned)k) & 3u)) & (kBlock - 1));
-  if (w < n) {
-    BlInv wv;
-    BlVar wx;
-    wv.dT = sh.item[0][w];
-    wv.den0 = sh.item[1][w];
-    wv.vkvz = sh.item[2][w];
-    wv.avk = sh.item[3][w];
-    wx.PSIM = sh.item[4][w];
-    wx.PSIH = sh.item[5][w];
-    wx.BLCond = sh.item[6][w];
-    const double stab_num = bl_stab_num(c);
-    int j = 6;
-    for (; j <= RS_BL_MAXIT; ++j)
-      if (bl_iteration(c, mt, wv, wx, j, stab_num)) break;
-    sh.res[0][w] = wx.PSIM;
-    sh.res[1][w] = wx.PSIH;
-    sh.res[2][w] = wx.BLCond;
-    sh.trips[w] = j;
-  }
-  __syncthreads();
-  if (need) {
-    x.PSIM = sh.res[0][slot];
-    x.PSIH = sh.res[1][slot];
-    x.BLCond = sh.res[2][slot];
-    passes = sh.trips[slot];
-    unstable = true; /* a parked loop is in the unstable regime for all practical purposes */
-  }
-  if (active) {
-    fx.trips = passes + (unstable ? 64 : 0);
-    fx.blcond = x.BLCond;
-    bl_finish(c, mt, a, x, s.tsurf, tair, vz, rhz, s.wat, fx.le, fx.evap);
-    fluxes_post(c, s, sw, lw, CouplingInputs(), fx);
-  }
-  return fx;
-}
-
-/* time_loop with the boundary-layer tail compacted over the workgroup.  Same statements as
- * time_loop; what differs is that every thread of the workgroup stays in the loop (lanes
- * without a point, or whose point has failed, are predicated off instead of leaving), because
- * the barriers in fluxes_block_tail need all of them. */
-template <bool FULL, class Prof>
-__device__ __forceinline__ void time_loop_bt(const MathTab &mt, Prof &T, Scalars &s,
-                                             BlTailShared &sh, bool valid, int32_t &score) {
-  KernArgs ka = kernargs();
-  const uint32_t lane = threadIdx.x;
-  const int64_t row0 = (int64_t)blockIdx.x * kBlock;
-  const int32_t nsteps = ka->nsteps, t0 = ka->t0;
-  double tbot = 0.0;
-  int32_t initlen = 0;
-  bool relax = false;
-  double tairR = 0, vzR = 0, rhR = 0;
-  Forcing nxt;
-  nxt.tair = nxt.tdew = nxt.vz = nxt.rhz = nxt.prec = nxt.sw = nxt.lw = 0.0;
-  nxt.tsurfobs = nxt.depth = R4(-9999.9);
-  nxt.phase = nxt.hour = 0;
-  if (valid) {
-    tbot = (ka->pp.tbottom + row0)[lane];
-    if (FULL) {
-      initlen = ka->pp.initlen ? (ka->pp.initlen + row0)[lane] : 0;
-      if (consts_of(ka).use_relaxation && ka->pp.tair_relax) {
-        /* setInputParam, src/InputOutput.f90:19-26: targets pass through REAL(4) */
-        tairR = (double)(float)(ka->pp.tair_relax + row0)[lane];
-        vzR = (double)(float)(ka->pp.vz_relax + row0)[lane];
-        rhR = (double)(float)(ka->pp.rh_relax + row0)[lane];
-        relax = !(tairR < R4(-100.0) || tairR > R4(100.0) || vzR < R4(0.0) || vzR > R4(100.0) ||
-                  rhR < R4(0.0) || rhR > 110);
-      }
-    }
-    nxt = load_forcing<FULL>(ka, row0, lane, 0);
-  }
-  for (int32_t k = 0; k < nsteps; ++k) {
-    asm volatile("" : "+s"(ka));
-    const ConstsAS &c = consts_of(ka);
-    const int32_t i = t0 + k;
-    const Forcing f = nxt;
-    /* a failed point has left the loop in the reference: its outputs stay -9999.0 */
-    const bool active = valid && !s.failed;
-    double tair = f.tair, vz = f.vz, rhz = f.rhz;
-    double prec_ts = 0.0;
-    if (active) {
-      /* src/Initialization.f90:121-123: VZ(1) is raised to 0.4 in the input array */
-      if (i == 1 && vz < R4(0.4)) vz = R4(0.4);
-      prec_ts = rs_div(f.prec, 3600.0) * c.DTSecs; /* src/InputOutput.f90:111,186 */
-      if (i < c.SimLen) {
-        Forcing chk = f;
-        chk.vz = vz;
-        if (check_values(chk, s.tsurf, FULL && ka->f.tdew != nullptr)) s.failed = true;
-        if (FULL) {
-          /* SetCurrentValues obs forcing, src/InputOutput.f90:116-148 */
-          if ((i <= initlen || c.force_tsurf) && f.tsurfobs > R4(-100.0)) {
-            T.set(1, f.tsurfobs);
-            T.set(2, f.tsurfobs);
-            const double depth = (c.tsurfOutputDepth >= R4(0.0)) ? c.tsurfOutputDepth : f.depth;
-            s.tsurf = surface_temperature(c, T, tbot, depth);
-          }
-          /* RelaxationOperations, src/Relaxation.f90:10-47 */
-          if (relax) {
-            if (i == initlen) {
-              s.tair_end = tair;
-              s.vz_end = vz;
-              s.rh_end = rhz;
-            }
-            if (i > initlen) {
-              const double den = (double)(4.f * 3600.f);
-              const double e = rs_exp(mt, rs_div(-((c.DTSecs * i) - (c.DTSecs * initlen)), den));
-              tair = tair - (tairR - s.tair_end) * e;
-              vz = vz - (vzR - s.vz_end) * e;
-              rhz = rhz - (rhR - s.rh_end) * e;
-              if (rhz > R4(100.)) rhz = R4(100.0);
-            }
-          }
-        }
-      } else {
-        /* lastValues, src/InputOutput.f90:169-198 */
-        if (FULL) s.tsurf = surface_temperature(c, T, tbot, f.depth);
-      }
-      if (!FULL) { /* TmpNw(1:2) == Tmp(1:2) whenever observation forcing cannot act */
-        s.tnw1 = T.get(1);
-        s.tnw2 = T.get(2);
-      }
-    }
-    const Fluxes fx = fluxes_block_tail(c, mt, s, active, tair, vz, rhz, prec_ts, f.sw, f.lw,
-                                        f.phase, f.hour, sh, k);
-    if (valid && k + 1 < nsteps) nxt = load_forcing<FULL>(ka, row0, lane, k + 1);
-    if (active) {
-      score += (fx.trips & 63) - 5;
-      if ((fx.trips & 64) && k >= nsteps - RS_REGIME_WINDOW) score |= 1 << 30;
-      model_step_ground(c, s, T, tbot, tair, fx, f.depth);
-      store_outputs(ka, i, row0, lane, s, true);
-    } else if (valid) {
-      store_outputs(ka, i, row0, lane, s, false);
-    }
   }
 }
 
@@ -815,7 +607,7 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Pr
       if (q.on) cp.in_phase = (c.SimLen - 1 >= q.cs && c.SimLen - 1 <= q.ce);
     }
     double tair = f.tair, vz = f.vz, rhz = f.rhz;
-    const double prec_ts = rs_div(f.prec, 3600.0) * c.DTSecs;
+    const double prec_ts = RS_DIVC(f.prec, 3600.0, r_3600) * c.DTSecs;
     if (i < c.SimLen && relax) {
       if (i == initlen) { s.tair_end = tair; s.vz_end = vz; s.rh_end = rhz; }
       if (i > initlen) {
@@ -888,35 +680,6 @@ __global__ void __launch_bounds__(kBlock, WPE) step_kernel_reg(const StepArgs a)
   time_loop<FULL>(mt, T, s, score);
   store_state<FULL>(a.state, a.np_pad, p, T, s);
   a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
-}
-
-/* Register profile + block-level tail compaction (the default for NLayers = 15). */
-template <int NL, bool FULL>
-__global__ void __launch_bounds__(kBlock, 4) step_kernel_bt(const StepArgs a) {
-  __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
-  __shared__ BlTailShared sh;
-  const MathTab mt = fill_math_tables(math_lds);
-  if (threadIdx.x < 2) sh.count[threadIdx.x] = 0;
-  __syncthreads();
-  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const bool valid = p < a.npoints; /* no early exit: the time loop has workgroup barriers */
-  RegProfile<NL> T;
-  Scalars s;
-  if (valid) {
-    load_state<FULL>(a.state, a.np_pad, p, T, s);
-  } else {
-#pragma unroll
-    for (int j = 1; j <= NL; ++j) T.set(j, 0.0);
-    s.tnw1 = s.tnw2 = s.tsurf = s.wat = s.snow = s.ice = s.ice2 = s.dep = 0.0;
-    s.q2melt = s.t4melt = s.albedo = s.tair_end = s.vz_end = s.rh_end = 0.0;
-    s.verycold = s.failed = false;
-  }
-  int32_t score = 0;
-  time_loop_bt<FULL>(mt, T, s, sh, valid, score);
-  if (valid) {
-    store_state<FULL>(a.state, a.np_pad, p, T, s);
-    a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
-  }
 }
 
 template <bool FULL, int WPE>
@@ -1171,14 +934,90 @@ __global__ void __launch_bounds__(kBlock) count_failed_kernel(const double *st, 
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
 }
 
+/* Sort key of rs_hip_recluster_forecast (include/roadsurf.h): CalcBLCondAndLE's fixed point
+ * (src/BoundaryLayer.f90:64-96) run at the preview times of the NEXT window, with the carried
+ * surface temperature moved along with the air temperature.  A predictor: plain IEEE division,
+ * OCML sqrt/log - it only orders the slots, no model value depends on it. */
+__global__ void __launch_bounds__(kBlock) forecast_key_kernel(const ForecastArgs a) {
+  const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (s >= a.npoints) return;
+  const ConstsAS &c = consts_of(&a);
+  const int64_t np = a.np_pad;
+  auto st = [&](int row) -> double {
+    return a.f32 ? (double)((const float *)a.state)[(int64_t)row * np + s]
+                 : ((const double *)a.state)[(int64_t)row * np + s];
+  };
+  const double ts_now = st(RS_ST_TSURF);
+  const int32_t cover = (st(RS_ST_WAT) > 0.0 || st(RS_ST_SNOW) > 0.0 || st(RS_ST_ICE) > 0.0 ||
+                         st(RS_ST_ICE2) > 0.0 || st(RS_ST_DEP) > 0.0) ? 1 : 0;
+  const double ta_now = a.pv.tair_now[s];
+  const double stab_num = -c.VK_Const * c.ZRefT * c.Grav;
+  int32_t unst = 0, farc = 0, extra = 0;
+  for (int q = 0; q < a.pv.n; ++q) {
+    const double ta = a.pv.tair[q][s];
+    double vz = a.pv.vz[q][s];
+    const double hour = (double)a.pv.hour[q];
+    const double calm = (hour >= c.NightOn || hour <= c.NightOff) ? c.CalmLimNgt : c.CalmLimDay;
+    if (vz < calm) vz = calm;
+    const double ts = ts_now + a.pv.alpha * (ta - ta_now);
+    const double TaK = ta + R4(273.15);
+    const double dens = R4(100000.0) / (R4(287.05) * TaK);
+    const double hcap = R4(1005.0) + (TaK - R4(250.0)) * (TaK - R4(250.0)) / R4(3364.);
+    const double avc = hcap * dens;
+    const double dT = ts - ta, den0 = avc * TaK, vkvz = c.VK_Const * vz, avk = avc * c.VK_Const;
+    double psim = 0.0, psih = 0.0, bl = 0.0;
+    int32_t nnear = 0, nfar = 0, j = 1;
+    for (; j <= RS_BL_MAXIT; ++j) {
+      const double old = bl;
+      const double us = vkvz / (c.logUstar + psim);
+      bl = avk * us / (c.logCond + psih);
+      double stab = stab_num * bl * dT / (den0 * (us * us * us));
+      if (stab > 1) stab = 1;
+      if (stab > 0) {
+        psih = R4(4.7) * stab;
+        psim = psih;
+      } else {
+        const double arg = (1.0 + ::sqrt(1.0 - 16.0 * stab)) * 0.5;
+        /* glibc's log takes its polynomial path for 1 - 2^-4 <= x < 1 + 0x1.09p-4, the table
+         * path otherwise (rs_math.hpp): a wavefront with both kinds of lanes pays for both */
+        if (arg < 1.064453125) ++nnear; else ++nfar;
+        psih = -2.0 * ::log(arg);
+        psim = R4(0.6) * psih;
+      }
+      if (j >= 5 && fabs(bl - old) < R4(0.001)) break;
+    }
+    if (j > RS_BL_MAXIT) j = RS_BL_MAXIT;
+    extra += j - 5;
+    if (nnear + nfar > 0) {
+      ++unst;
+      if (nfar >= nnear) ++farc;
+    }
+  }
+  if (extra > 4095) extra = 4095;
+  uint32_t key = (uint32_t)unst;                                  /* 0..8: 4 bits */
+  key = (key << 4) | (uint32_t)((a.pv.mode & 1) ? farc : 0);      /* 4 bits */
+  key = (key << 1) | (uint32_t)((a.pv.mode & 2) ? cover : 0);     /* 1 bit */
+  key = (key << 12) | (uint32_t)extra;                            /* 12 bits: 21 in all */
+  /* descending: the expensive points get the low slots (longest job first, rs_cluster.hip) */
+  a.keys[s] = ((1u << RS_SORT_KEY_BITS) - 1u) - key;
+  a.slots[s] = (uint32_t)s;
+}
+
 }  // namespace rs
 
 /* ---- launchers (host) --------------------------------------------------- */
 
 static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + RS_BLOCK - 1) / RS_BLOCK)); }
 
-hipError_t rs_read_div_mismatch(unsigned long long *out, hipStream_t stream) {
-  hipError_t e = hipMemcpyFromSymbolAsync(out, HIP_SYMBOL(rs::g_div_mismatch), sizeof(*out), 0,
+hipError_t rs_read_div_mismatch(unsigned long long *out /*[3]*/, hipStream_t stream) {
+  hipError_t e = hipMemcpyFromSymbolAsync(out, HIP_SYMBOL(rs::g_div_mismatch), 3 * sizeof(*out), 0,
+                                          hipMemcpyDeviceToHost, stream);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(stream);
+}
+
+hipError_t rs_read_div_samples(double *out /*[64][4]*/, hipStream_t stream) {
+  hipError_t e = hipMemcpyFromSymbolAsync(out, HIP_SYMBOL(rs::g_div_samples), 64 * 4 * sizeof(double), 0,
                                           hipMemcpyDeviceToHost, stream);
   if (e != hipSuccess) return e;
   return hipStreamSynchronize(stream);
@@ -1204,6 +1043,11 @@ hipError_t rs_upload_math_tables(hipStream_t stream) {
                                 hipMemcpyHostToDevice, stream);
 }
 
+hipError_t rs_launch_forecast_keys(const rs::ForecastArgs &a, hipStream_t stream) {
+  hipLaunchKernelGGL(rs::forecast_key_kernel, grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
+  return hipGetLastError();
+}
+
 hipError_t rs_launch_step_sky(const rs::StepArgs &a, int NL, hipStream_t stream) {
   const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
   hipLaunchKernelGGL(rs::step_kernel_sky, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
@@ -1226,13 +1070,7 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
   /* measured (tools/bench_driver_path.py, 1 M points): the FULL feature set spills 128 VGPRs in the
    * register flavour at 4 waves/SIMD and is 6 % faster with the profile in LDS; LEAN is 3 %
    * faster in registers */
-  if (variant == RS_VARIANT_BT) {
-    if (NL != 15) return hipErrorInvalidValue;
-    if (full)
-      hipLaunchKernelGGL((rs::step_kernel_bt<15, true>), g, b, 0, stream, a);
-    else
-      hipLaunchKernelGGL((rs::step_kernel_bt<15, false>), g, b, 0, stream, a);
-  } else if (variant == RS_VARIANT_REG) {
+  if (variant == RS_VARIANT_REG) {
     if (NL != 15) return hipErrorInvalidValue;
     if (wpe == 0) wpe = 4;
 #define RS_REG(W)                                                                        \

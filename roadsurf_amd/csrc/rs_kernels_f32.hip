@@ -22,9 +22,15 @@
 #define RS_NS rs32
 #define RS_CONSTS RsConstantsF __attribute__((address_space(4)))
 #define R4(x) (x##f)
+#define RS_DIVC(a, b, rb) rs_div(a, b)
+#define RS_BL_GUARD 0
+#define RS_MELTDEN (c.WatMHeat * c.WatDens)
 namespace rs32 {
 using rs::MathTab;
 using rs::rs_div;
+using rs::rs_dv;
+using rs::rs_dvb;
+using rs::rs_sq;
 using rs::rs_exp;
 using rs::rs_fabs;
 using rs::rs_log;

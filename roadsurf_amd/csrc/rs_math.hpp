@@ -90,12 +90,38 @@ __device__ __forceinline__ MathTab fill_math_tables(double *lds) {
  * model's own guards and by CheckValues), so the bare sequence below returns
  * the same bits in 8 instructions.  Likewise sqrt (argument 1 - 16*Stab >= 1).
  *
+ * (One operand the short sequence does not reproduce even in range: -0.0 / b gives +0.0.  No
+ * call site can tell: numerators are sums or products of non-negative quantities behind `> 0`
+ * guards, except prec/3600, where the sign of a zero is lost in `<= MinPrecmm` and `wat + rain`,
+ * and the stability parameter's -VK*ZRefT*g*BLCond*(Ts - Ta), which is -0.0 for Ts == Ta: both
+ * zeros fail `Stab > 0`, and 1 - 16*Stab is 1.0 for either.)
+ *
  * This is an assumption about the DATA, so it is checked, not trusted: the
  * library built with -DRS_DIV_CHECK evaluates both forms at every call site and
  * counts disagreements in a device counter; tests/test_hip_fastdiv.py runs the
  * 1 M-point x 48 h workload through that build and requires the count to be 0.
  * -DRS_IEEE_DIV switches every call site back to the compiler's expansion. */
-static __device__ unsigned long long g_div_mismatch = 0ull;
+/* [0]: both results finite, different VALUES - the kind that would silently change a result;
+ * [2]: +0.0 against -0.0 (the bare sequence loses the sign of a zero numerator, see above);
+ * [1]: one of them inf/NaN - x/0, x/inf, inf/x, where the bare sequence
+ * gives NaN: the operands the boundary-layer guard exists for (rs_physics_body.inc) */
+static __device__ unsigned long long g_div_mismatch[3] = {0ull, 0ull, 0ull};
+/* the first RS_DIV_SAMPLES finite mismatches: {numerator (or sqrt argument), denominator (0 for
+ * sqrt), IEEE result, bare result} */
+#define RS_DIV_SAMPLES 64
+static __device__ double g_div_samples[RS_DIV_SAMPLES][4];
+__device__ __forceinline__ void div_check_note(double q, double f, double a = 0.0, double b = 0.0) {
+  if (__double_as_longlong(q) == __double_as_longlong(f) || (q != q && f != f)) return;
+  const bool special = !(__builtin_fabs(q) < __builtin_inf()) || !(__builtin_fabs(f) < __builtin_inf());
+  const int kind = special ? 1 : (q == f ? 2 : 0); /* q == f with different bits: two zeros */
+  const unsigned long long k = atomicAdd(&g_div_mismatch[kind], 1ull);
+  if (kind == 0 && k < RS_DIV_SAMPLES) {
+    g_div_samples[k][0] = a;
+    g_div_samples[k][1] = b;
+    g_div_samples[k][2] = q;
+    g_div_samples[k][3] = f;
+  }
+}
 
 __device__ __forceinline__ double div_bare(double a, double b) {
   double r = __builtin_amdgcn_rcp(b);
@@ -126,8 +152,7 @@ __device__ __forceinline__ double rs_div(double a, double b) {
   return a / b;
 #elif defined(RS_DIV_CHECK)
   const double q = a / b, f = div_bare(a, b);
-  if (__double_as_longlong(q) != __double_as_longlong(f) && !(q != q && f != f))
-    atomicAdd(&g_div_mismatch, 1ull);
+  div_check_note(q, f, a, b);
   return q;
 #else
   return div_bare(a, b);
@@ -139,12 +164,61 @@ __device__ __forceinline__ double rs_sqrt(double x) {
   return ::sqrt(x);
 #elif defined(RS_DIV_CHECK)
   const double q = ::sqrt(x), f = sqrt_bare(x);
-  if (__double_as_longlong(q) != __double_as_longlong(f) && !(q != q && f != f))
-    atomicAdd(&g_div_mismatch, 1ull);
+  div_check_note(q, f, x, 0.0);
   return q;
 #else
   return sqrt_bare(x);
 #endif
+}
+
+/* a / b for a UNIFORM denominator b whose reciprocal rb = RN(1/b) was computed once on the host
+ * (rs_consts_dev.h): the last three steps of the sequence above with rb in place of the refined
+ * v_rcp_f64 - q = a*rb is within an ulp of a/b, rem = a - b*q is exact in the fma, and
+ * q + rem*rb rounds to the correctly rounded quotient (Markstein's final-step theorem; rb is
+ * closer to 1/b than the two-step Newton iterate it replaces).  3 instructions instead of 8 and
+ * no quarter-rate v_rcp_f64.  Checked like rs_div: the RS_DIV_CHECK build compares every
+ * evaluation with a / b, and tests/test_host_logic.py checks the same formula on the host for
+ * every constant on 1e6 numerators. */
+__device__ __forceinline__ double rs_div_u(double a, double b, double rb) {
+#if defined(RS_IEEE_DIV)
+  return a / b;
+#else
+  const double q0 = a * rb;
+  const double rem = __builtin_fma(-b, q0, a);
+  const double f = __builtin_fma(rem, rb, q0);
+#if defined(RS_DIV_CHECK)
+  const double q = a / b;
+  div_check_note(q, f, a, b);
+  return q;
+#else
+  return f;
+#endif
+#endif
+}
+
+/* IEEE flavour on request (the boundary-layer guard, rs_physics_body.inc): IEEE = true is the
+ * compiler's full expansion (v_div_scale / v_div_fmas / v_div_fixup), exact for every operand */
+template <bool IEEE>
+__device__ __forceinline__ double rs_dv(double a, double b) {
+  if (IEEE) return a / b;
+  return rs_div(a, b);
+}
+/* the data-dependent divisions of the boundary-layer loop (rs_physics_body.inc): with
+ * -DRS_BL_FIXUP the bare sequence is followed by v_div_fixup_f64, which supplies IEEE's results for
+ * zero / infinite / NaN operands and the sign of a zero quotient */
+template <bool IEEE>
+__device__ __forceinline__ double rs_dvb(double a, double b) {
+  if (IEEE) return a / b;
+#if defined(RS_BL_FIXUP) && !defined(RS_IEEE_DIV) && !defined(RS_DIV_CHECK)
+  return __builtin_amdgcn_div_fixup(div_bare(a, b), b, a);
+#else
+  return rs_div(a, b);
+#endif
+}
+template <bool IEEE>
+__device__ __forceinline__ double rs_sq(double x) {
+  if (IEEE) return ::sqrt(x);
+  return rs_sqrt(x);
 }
 
 __device__ __forceinline__ double rs_fabs(double x) { return __builtin_fabs(x); }
@@ -155,6 +229,12 @@ __device__ __forceinline__ float rs_fabs(float x) { return __builtin_fabsf(x); }
 struct MathTab;
 __device__ __forceinline__ float rs_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 __device__ __forceinline__ float rs_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+template <bool IEEE>
+__device__ __forceinline__ float rs_dv(float a, float b) { return rs_div(a, b); }
+template <bool IEEE>
+__device__ __forceinline__ float rs_dvb(float a, float b) { return rs_div(a, b); }
+template <bool IEEE>
+__device__ __forceinline__ float rs_sq(float x) { return rs_sqrt(x); }
 __device__ __forceinline__ float rs_exp(const MathTab &, float x) { return __expf(x); }
 __device__ __forceinline__ float rs_log(const MathTab &, float x) { return __logf(x); }
 

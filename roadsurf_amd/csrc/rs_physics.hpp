@@ -28,17 +28,24 @@
 #include <hip/hip_runtime.h>
 #include "../../include/roadsurf.h"
 #include "rs_math.hpp"
+#include "rs_consts_dev.h"
 
 
 #define RS_REAL double
 #define RS_NS rs
 /* the constants are read as constant memory (scalar loads): rs_kernels.hip, consts_of */
-#define RS_CONSTS RsConstants __attribute__((address_space(4)))
+#define RS_CONSTS RsConstantsDev __attribute__((address_space(4)))
+/* a / b with b uniform and its reciprocal in the constant block */
+#define RS_DIVC(a, b, rb) rs_div_u(a, b, c.rb)
+#define RS_BL_GUARD 1
+#define RS_MELTDEN c.meltDen /* WatMHeat*WatDens, the same IEEE product formed once on the host */
 #define R4(x) ((double)(x##f))
 #include "rs_physics_body.inc"
 #undef RS_REAL
 #undef RS_NS
 #undef RS_CONSTS
+#undef RS_BL_GUARD
+#undef RS_MELTDEN
 
 namespace rs {
 

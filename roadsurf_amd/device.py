@@ -228,6 +228,19 @@ class Plan:
     def reset_order(self) -> None:
         lib.check(self.L.rs_hip_plan_reset_order(self._h), "rs_hip_plan_reset_order")
 
+    def recluster_forecast(self, tair_rows, vz_rows, hours, tair_now, alpha: float = 0.5,
+                           mode: int = 1) -> None:
+        """Sort the slots by a forecast of the next launch (rs_hip_recluster_forecast): rows are
+        tensors [np_pad] in the CURRENT slot order at the preview times, hours the hour of day."""
+        pv = lib.RsPreview()
+        pv.n = len(tair_rows)
+        for q, (ta, vz, h) in enumerate(zip(tair_rows, vz_rows, hours)):
+            pv.tair[q] = ta.data_ptr(); pv.vz[q] = vz.data_ptr(); pv.hour[q] = int(h)
+        pv.tair_now = tair_now.data_ptr()
+        pv.alpha = alpha
+        pv.mode = mode
+        lib.check(self.L.rs_hip_recluster_forecast(self._h, C.byref(pv)), "rs_hip_recluster_forecast")
+
     def recluster(self) -> None:
         """Sort the slots by the boundary-layer passes of the last launch; later windows,
         per-point parameters and outputs are in the new slot order."""
@@ -281,7 +294,8 @@ def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputPara
     skyv = np.array([l.sky_view for l in local])
     sky_on = bool(((skyv < 1.0) & (skyv > -0.01)).any())
     need_full = (not lean_if_possible) or initlen.max() > 1 or settings.force_tsurf == 1 or \
-        relax_on or coupled or sky_on or settings.tsurfOutputDepth >= 0 or (forcing["depth"] >= 0).any()
+        relax_on or coupled or sky_on or settings.tsurfOutputDepth >= 0 or (forcing["depth"] >= 0).any() \
+        or bool(((forcing["tdew"] < -90.0) | (forcing["tdew"] > 100.0)).any())  # the LEAN kernels skip the Tdew check
 
     def pad_t(a, dtype):  # [n, L] -> device [L, npad]
         t = torch.zeros((L, npad), dtype=dtype, device=dev)

@@ -74,6 +74,15 @@ class RsHostExtras(C.Structure):
                [("albedo_surroundings", C.c_double)]
 
 
+RS_PREVIEW_MAX = 8
+
+
+class RsPreview(C.Structure):
+    _fields_ = [("n", C.c_int32), ("tair", C.c_void_p * RS_PREVIEW_MAX), ("vz", C.c_void_p * RS_PREVIEW_MAX),
+                ("hour", C.c_int32 * RS_PREVIEW_MAX), ("tair_now", C.c_void_p), ("alpha", C.c_double),
+                ("mode", C.c_int32)]
+
+
 class RsSynthSpec(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("point_offset", C.c_int64),
                 ("steps_per_knot", C.c_int32), ("start_hour", C.c_int32), ("order", C.c_void_p)]
@@ -88,7 +97,7 @@ EXPORTS = (
     "rs_hip_plan_npoints", "rs_hip_plan_npoints_padded", "rs_hip_plan_state_bytes",
     "rs_hip_init_state", "rs_hip_step", "rs_hip_state_download", "rs_hip_state_upload",
     "rs_hip_failed_count", "rs_hip_sync", "rs_hip_synth_knots", "rs_hip_expand_forcing", "rs_hip_expand_forcing_on",
-    "rs_hip_plan_order", "rs_hip_recluster", "rs_hip_plan_order_copy", "rs_hip_plan_reset_order", "rs_hip_set_variant", "rs_hip_set_precision", "rs_hip_test_math", "rs_hip_division_mode", "rs_hip_div_mismatch_count", "rs_hip_timing_reset", "rs_hip_timing_step_ms",
+    "rs_hip_plan_order", "rs_hip_recluster", "rs_hip_recluster_forecast", "rs_hip_plan_order_copy", "rs_hip_plan_reset_order", "rs_hip_set_variant", "rs_hip_set_precision", "rs_hip_test_math", "rs_hip_division_mode", "rs_hip_div_mismatch_count", "rs_hip_div_special_count", "rs_hip_div_samples", "rs_hip_timing_reset", "rs_hip_timing_step_ms",
     "rs_host_run_batch", "rs_last_fanout", "rs_driver_run", "rs_driver_expand", "rs_driver_release_cache", "rs_abi_version", "rs_abi_sizeof", "rs_fortran_sizeof",
 )
 
@@ -159,12 +168,16 @@ def load() -> C.CDLL:
     L.rs_hip_plan_order.argtypes = [C.c_void_p]
     L.rs_hip_plan_order.restype = C.c_void_p
     L.rs_hip_recluster.argtypes = [C.c_void_p]
+    L.rs_hip_recluster_forecast.argtypes = [C.c_void_p, P(RsPreview)]
     L.rs_hip_plan_order_copy.argtypes = [C.c_void_p, C.c_void_p]
     L.rs_hip_plan_reset_order.argtypes = [C.c_void_p]
     L.rs_hip_set_variant.argtypes = [C.c_void_p, C.c_int32]
     L.rs_hip_set_precision.argtypes = [C.c_void_p, C.c_int32]
     L.rs_hip_div_mismatch_count.argtypes = [C.c_void_p]
     L.rs_hip_div_mismatch_count.restype = C.c_int64
+    L.rs_hip_div_special_count.argtypes = [C.c_void_p]
+    L.rs_hip_div_special_count.restype = C.c_int64
+    L.rs_hip_div_samples.argtypes = [C.c_void_p, C.c_void_p]
     L.rs_hip_test_math.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
     L.rs_hip_timing_reset.argtypes = [C.c_void_p]
     L.rs_hip_timing_step_ms.argtypes = [C.c_void_p, P(C.c_int32)]

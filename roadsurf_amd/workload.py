@@ -23,11 +23,15 @@ SPK = 120  # 3600 s / DTSecs 30 s: time indices per hourly knot
 
 class SyntheticRun:
     def __init__(self, plan: device.Plan, seed: int, hours: int, chunk: int, point_offset: int = 0,
-                 plan_order: bool = True, f32: bool = False, year_month_day=(2024, 1, 10)):
+                 plan_order: bool = True, f32: bool = False, year_month_day=(2024, 1, 10),
+                 forecast: bool = True, forecast_alpha: float = 0.5, forecast_mode: int = 1):
         self.plan, self.seed, self.hours = plan, seed, hours
         self.simlen = hours * SPK + 1  # examples/example1/src/InputSettings.cpp:98
         self.chunk = min(chunk, self.simlen)
         self.plan_order = plan_order
+        # sort key of the re-sort: forecast of the next window (rs_hip_recluster_forecast) or the
+        # history of the last one (rs_hip_recluster)
+        self.forecast, self.forecast_alpha, self.forecast_mode = forecast, forecast_alpha, forecast_mode
         dev, npad = plan.device, plan.np_pad
         wdtype = torch.float32 if f32 else torch.float64
         self.win = device.ForcingWindow.empty(self.chunk, npad, dev, optional=(), dtype=wdtype)
@@ -51,6 +55,12 @@ class SyntheticRun:
     def run_pass(self, on_launch=None) -> None:
         """Enqueue one pass on the plan's stream.  ``on_launch(c, t0, ns)`` is called after launch
         ``c`` has been enqueued (tests read ``self.out`` and ``self.orders[c]`` there)."""
+        for _ in self.iter_pass(on_launch):
+            pass
+
+    def iter_pass(self, on_launch=None):
+        """run_pass as a generator that yields after every launch has been enqueued, so that a
+        caller can interleave the launches of several plans (one stream each) from one thread."""
         plan, spec = self.plan, self.spec
         if self.plan_order:
             plan.reset_order()
@@ -73,9 +83,30 @@ class SyntheticRun:
                 plan.copy_order_to(self.orders[c])  # which point each column of this launch is
                 if on_launch:
                     on_launch(c, t0, ns)
-                plan.recluster()
+                self._resort(t0 + ns)
             elif on_launch:
                 on_launch(c, t0, ns)
+            yield c
+
+    def _resort(self, t_next: int) -> None:
+        """Re-sort the slots for the window that starts at index t_next."""
+        plan = self.plan
+        if t_next > self.simlen:
+            return
+        if not self.forecast:
+            plan.recluster()
+            return
+        # previews = the hourly knots that fall into the next window, generated in the CURRENT
+        # order; field 0 is Tair, field 2 is VZ (rs_synth.h); the window starts on a knot when
+        # chunk is a multiple of SPK, else the nearest earlier knot stands in for "now"
+        ns = min(self.chunk, self.simlen - t_next + 1)
+        k0 = (t_next - 1) // SPK
+        k1 = (t_next + ns - 2) // SPK + 1
+        nk = min(k1 - k0 + 1, 8)
+        plan.synth_knots_range(self.spec, self.kbuf, k0, nk, ordered=True)
+        hours = [(self.spec.start_hour + k0 + q) % 24 for q in range(nk)]
+        plan.recluster_forecast([self.kbuf[q, 0] for q in range(nk)], [self.kbuf[q, 2] for q in range(nk)],
+                                hours, self.kbuf[0, 0], self.forecast_alpha, self.forecast_mode)
 
     def slots_of(self, c: int, points: torch.Tensor) -> torch.Tensor:
         """Columns of launch ``c``'s output window that hold the given local points."""

@@ -174,3 +174,30 @@ def point_pointers(f: dict, p: int, out: dict | None = None):
                       ("c_IceOut", "ice"), ("c_DepositOut", "deposit"), ("c_Ice2Out", "ice2")):
         setattr(op, name, out[key][row].ctypes.data_as(abi.c_double_p))
     return ip, op, (hz, out)
+
+
+class quiet_stdout:
+    """Silence what the reference's Fortran prints to unit 6 (file descriptor 1) inside the block:
+    it reports every bad value and every non-converged boundary-layer loop
+    (src/BoundaryLayer.f90:71-74,98-101, src/InputOutput.f90:63-65), millions of lines on
+    adversarial inputs."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        self._null = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(self._null, 1)
+        return self
+
+    def __exit__(self, *exc):
+        for so in (REF_SO, REF_CPL_SO):  # the Fortran runtime buffers unit 6: empty it first
+            if os.path.exists(so):
+                try:
+                    C.CDLL(so).ref_flush_stdout()
+                except AttributeError:
+                    pass
+        C.CDLL(None).fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._null)
+        os.close(self._saved)
+        return False

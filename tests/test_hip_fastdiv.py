@@ -66,3 +66,145 @@ def test_bare_division_equals_ieee_on_full_workload():
     _, m1, m2 = line.split()
     print(line)
     assert int(m1) == 0 and int(m2) == 0
+
+
+# ---- adversarial operands ----------------------------------------------------------------------
+# Everything CheckValues admits (src/InputOutput.f90:45-84) and every parameter set plan creation
+# admits must give the reference's bits, not only the synthetic workload.
+
+def _adversarial_case():
+    import numpy as np
+    import oracle_helpers as oh
+    from roadsurf_amd import abi
+    n, L = 768, 1441
+    f = oh.synth_forcing(n, L, seed=77)
+    rng = np.random.default_rng(5)
+    g = n // 3
+    # A: |Ts - Ta| ~ 100 K in calm air (VZ at or below the calm limit): PSIM/PSIH run to about -4,
+    #    the loop's denominators logUstar + PSIM, logCond + PSIH pass through zero (the reference
+    #    prints 'UStar negative' a million times on this case), up to 40 passes
+    f["tair"][:g] = -60.0 + 30.0 * rng.random((g, 1))
+    f["tsurfobs"][:g, 0] = 10.0 + 5.0 * rng.random(g)
+    f["vz"][:g] = np.where(rng.random((g, L)) < 0.5, 0.0, f["vz"][:g] * 0.05)
+    f["rhz"][:g] = 0.0
+    f["prec"][:g] = 0.0
+    # B: the stable mirror image, and wind at the top of the accepted range
+    f["tair"][g:2 * g] = 30.0 + 40.0 * rng.random((g, 1))
+    f["tsurfobs"][g:2 * g, 0] = -30.0
+    f["vz"][g:2 * g] = 100.0 * rng.random((g, L))
+    f["rhz"][g:2 * g] = 120.0
+    # C: forcing parked at the edges of its accepted interval, hopping between them every 2 h
+    sl = slice(2 * g, n)
+    m = n - 2 * g
+    edge = lambda lo, hi: np.repeat(np.where(rng.random((m, L // 240 + 1)) < 0.5, lo, hi), 240, axis=1)[:, :L]
+    f["tair"][sl] = np.where(rng.random((m, 1)) < 0.5, -90.0, 100.0) * np.ones((1, L))
+    f["tair"][sl][:, 1:] *= 0.999  # the edge itself at index 1, a hair inside afterwards
+    f["vz"][sl] = edge(-1.0, 100.0)
+    f["rhz"][sl] = edge(-0.1, 120.0)
+    f["prec"][sl] = edge(0.0, 500.0) * (rng.random((m, L)) < 0.05)
+    f["sw"][sl] = edge(-0.1, 1400.0)
+    f["lw"][sl] = edge(-0.1, 1000.0)
+    f["precphase"][sl] = rng.integers(-1, 8, (m, L)).astype(np.int32)
+    f["tsurfobs"][sl, 0] = f["tair"][sl, 0]
+    f["tdew"][:] = f["tair"] - 1.0
+    s = abi.default_settings(L)
+    p = abi.default_parameters()
+    # extreme but accepted parameters: calm limits near zero, rough momentum / smooth heat
+    # surface, black-body road
+    p.CalmLimDay = 0.1; p.CalmLimNgt = 0.02; p.ZMom = 1.0; p.ZHeat = 1e-5
+    p.Emiss = 1.0
+    l = abi.default_local(); l.InitLenI = 1
+    return f, s, p, l
+
+
+ADV_SCRIPT = r'''
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+from roadsurf_amd import device, lib
+import test_hip_fastdiv as T
+L = lib.load()
+assert L.rs_hip_division_mode() == 2, "not the cross-check build"
+f, s, p, l = T._adversarial_case()
+res, nfail = device.run_points(f, s, p, l, lean_if_possible=False)
+plan = device.Plan(16, s, p, 0)
+print("DIVCHECK", L.rs_hip_div_mismatch_count(plan._h), L.rs_hip_div_special_count(plan._h), nfail)
+import numpy as np
+smp = np.zeros((64, 4))
+L.rs_hip_div_samples(plan._h, smp.ctypes.data)
+for r in smp[:12]:
+    if r[2] != r[3]:
+        print("SAMPLE a=%%r b=%%r ieee=%%r bare=%%r" %% tuple(float(x) for x in r))
+'''
+
+
+def _same(a, b):
+    import numpy as np
+    # NaN payloads are outside the contract (x86 and gfx950 disagree on the sign of a generated NaN)
+    return np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.skipif(not os.path.exists(LIBCHK), reason="build with `make -C roadsurf_amd divcheck`")
+def test_adversarial_operands_match_the_reference_in_both_builds():
+    import numpy as np
+    import oracle_helpers as oh
+    from roadsurf_amd import device
+    f, s, p, l = _adversarial_case()
+    with oh.quiet_stdout():  # 'UStar negative' x 3 million
+        ora, _, _ = oh.run_oracle("ref" if oh.have_ref() else "port", f, s, p, l)
+    for lean in (True, False):
+        res, nfail = device.run_points(f, s, p, l, lean_if_possible=lean)
+        for k in oh.F64_OUT:
+            assert _same(res[k], ora[k]), (k, lean, int((res[k] != ora[k]).sum()))
+    alive = (ora["tsurf"][:, -1] != -9999.0).sum()
+    assert alive > 150 and nfail > 0   # some points blow up and are failed, like in the reference
+    assert np.isfinite(ora["tsurf"]).all()
+    env = dict(os.environ, ROADSURF_HIP_LIB=LIBCHK)
+    r = subprocess.run([sys.executable, "-c", ADV_SCRIPT % {"root": ROOT}], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [x for x in r.stdout.splitlines() if x.startswith("DIVCHECK")][-1]
+    print(line)
+    print("\n".join(x for x in r.stdout.splitlines() if x.startswith("SAMPLE")))
+    # no evaluation with two finite results may differ; the non-finite ones (x/0 and the like,
+    # where the bare sequence gives NaN) are what the boundary-layer guard redoes in the product
+    assert int(line.split()[1]) == 0
+
+
+def test_infinite_latent_heat_is_absorbed_like_in_the_reference():
+    """ZRefW = 0 makes logMom = logHeat = log(1) = 0 (src/Initialization.f90:330-331); with
+    Ts == Ta the unstable branch returns PSIM = PSIH = -0, the aerodynamic resistance is 0 and
+    LE = x/0 = +inf, which `LE > 0 and no water -> LE = 0` turns back into a finite state
+    (src/BoundaryLayer.f90:126-128,183-187).  The bare division sequence yields NaN for x/0; the
+    guard of rs_physics_body.inc redoes such a lane with IEEE division."""
+    import numpy as np
+    import oracle_helpers as oh
+    from roadsurf_amd import abi, device
+    n, L = 300, 241
+    f = oh.synth_forcing(n, L, seed=3)
+    f["tsurfobs"][:, 0] = f["tair"][:, 0]
+    f["prec"][:] = 0.0
+    s = abi.default_settings(L); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
+    p.ZRefW = 0.0; p.ZeroDisp = -1.0
+    ora, _, _ = oh.run_oracle("ref" if oh.have_ref() else "port", f, s, p, l)
+    assert np.isfinite(ora["tsurf"]).all() and (ora["tsurf"] != -9999.0).all()
+    for variant in (1, 2):
+        res, nfail = device.run_points(f, s, p, l, variant=variant)
+        assert nfail == 0
+        for k in oh.F64_OUT:
+            assert np.array_equal(res[k], ora[k]), (k, variant)
+
+
+def test_parameters_outside_the_models_domain_are_refused():
+    """A divisor that is zero, negative or non-finite (the reference would divide by it anyway)
+    fails plan creation loudly instead of running the bare sequences outside their domain."""
+    import oracle_helpers as oh  # noqa: F401
+    from roadsurf_amd import abi, device
+    s = abi.default_settings(100)
+    for name, val in (("WatMHeat", 0.0), ("LVap", 0.0), ("VK_Const", 0.0)):
+        p = abi.default_parameters()
+        setattr(p, name, val)
+        with pytest.raises(RuntimeError, match="domain"):
+            device.Plan(8, s, p, 0)
+    p = abi.default_parameters(); p.ZMom = 10.0; p.ZRefW = 0.0   # logUstar = log(1) = 0
+    with pytest.raises(RuntimeError, match="logUstar"):
+        device.Plan(8, s, p, 0)

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import golden_helpers as gh
+import oracle_helpers as oh
 from roadsurf_amd import abi, lib, sharding
 
 
@@ -107,3 +108,39 @@ def test_fortran_sun_table_against_oracle_solar_position():
             assert abs(elev - el.value) < 1e-9
         else:
             assert elev <= 1e-9
+
+
+def test_uniform_reciprocal_division_is_ieee_division():
+    """The kernels divide by uniform constants with a host-made reciprocal and two fused
+    multiply-adds (rs_math.hpp, rs_div_u; constants in rs_consts_dev.h).  The same formula on the
+    host (libm fma is correctly rounded like v_fma_f64) must give the IEEE quotient for every
+    constant the kernels use, on numerators spanning the magnitudes the model produces."""
+    ol = oh.load("port")
+    ol.oracle_div_u_mismatches.restype = C.c_long
+    ol.oracle_div_u_mismatches.argtypes = [C.c_double, C.c_void_p, C.c_long]
+    s = abi.default_settings(5761); p = abi.default_parameters()
+    c = lib.build_constants(s, p)
+    dens = {"3600": 3600.0, "3364": 3364.0, "1000": 1000.0, "IceMax": 1.5, "twoDT": c.twoDT,
+            "DTSecs": c.DTSecs, "meltDen": c.WatMHeat * c.WatDens, "logUstar": c.logUstar,
+            "logCond": c.logCond}
+    for dt in (10.0, 60.0, 7.0):  # other time steps, other roughness lengths
+        s2 = abi.default_settings(100); s2.DTSecs = dt
+        p2 = abi.default_parameters(); p2.ZMom = 0.03 * dt; p2.ZHeat = 0.0007 * dt
+        c2 = lib.build_constants(s2, p2)
+        dens.update({f"twoDT{dt}": c2.twoDT, f"DTSecs{dt}": c2.DTSecs, f"logUstar{dt}": c2.logUstar,
+                     f"logCond{dt}": c2.logCond})
+    rng = np.random.default_rng(7)
+    n = 1_000_000
+    mant = rng.uniform(1.0, 2.0, n)
+    expo = rng.integers(-40, 41, n)
+    a = np.ascontiguousarray(np.ldexp(mant, expo) * rng.choice([-1.0, 1.0], n))
+    a[:3] = [0.0, 1.0, 3600.0]
+    for name, b in dens.items():
+        bad = ol.oracle_div_u_mismatches(b, a.ctypes.data, n)
+        assert bad == 0, (name, b, bad)
+    # the one operand the short sequences (rs_div_u and rs_div alike) do not reproduce: -0.0 / b
+    # gives +0.0 where IEEE gives -0.0.  No call site can tell: every numerator is a product or sum
+    # of non-negative quantities behind a `> 0` guard, except prec/3600, whose sign of zero is lost
+    # in `<= MinPrecmm` and `wat + rain` (rs_math.hpp).
+    mz = np.array([-0.0])
+    assert ol.oracle_div_u_mismatches(3600.0, mz.ctypes.data, 1) == 1

@@ -5,7 +5,7 @@ OUT=gpurun_out/pmcq_${1:-x}
 shift || true
 mkdir -p $OUT
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/err.txt || { tail -20 $OUT/err.txt; exit 1; }
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-natural-leg "$@" > $OUT/bench.json 2> $OUT/err.txt || { tail -20 $OUT/err.txt; exit 1; }
 python3 tools/summarize_pmc.py $OUT | grep -E "step_kernel" 
 python3 - <<PY
 import json
