@@ -437,9 +437,14 @@ typedef struct RsPreview {
   int32_t hour[RS_PREVIEW_MAX];          /* hour of day at preview time q (calm limit day/night) */
   const double *tair_now;                /* air temperature at the first index of the next window */
   double alpha;                          /* Tsurf(preview) = Tsurf + alpha*(Tair(preview) - Tair_now) */
-  int32_t mode;                          /* bit 0: table-path count in the key, bit 1: cover bit */
+  int32_t mode;                          /* key fields in priority order as decimal digits: 1 unstable
+                                            previews, 2 table-path previews, 3 cover, 4 predicted extra
+                                            passes (e.g. 1234); 0..3 = 14, 124, 134, 1234 */
 } RsPreview;
 int rs_hip_recluster_forecast(RsPlan *plan, const RsPreview *preview);
+/* A plan that is only ever sorted by forecast can tell the step kernels not to keep the history
+ * score (a few vector instructions per boundary-layer pass); rs_hip_recluster then refuses. */
+int rs_hip_set_history_score(RsPlan *plan, int32_t on);
 int rs_hip_plan_order_copy(RsPlan *plan, int32_t *dst_device);
 int rs_hip_plan_reset_order(RsPlan *plan);
 

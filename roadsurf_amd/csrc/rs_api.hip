@@ -60,6 +60,7 @@ struct RsPlan {
   /* the plan's constants on the device (no table of slots: any number of plans may be alive) */
   void *consts_dev = nullptr;   /* RsConstantsDev (rs_consts_dev.h) */
   void *consts32_dev = nullptr; /* RsConstantsF, allocated by rs_hip_set_precision(32) */
+  bool history_score = true; /* the step kernels leave the sort key of rs_hip_recluster */
   bool f32 = false; /* single-precision flavour: windows and state hold floats */
   std::vector<hipEvent_t> ev; /* start/stop pairs */
   size_t ev_used = 0;
@@ -305,6 +306,8 @@ int rs_hip_recluster_forecast(RsPlan *pl, const RsPreview *pv) {
 
 int rs_hip_recluster(RsPlan *pl) {
   if (!pl) return set_err("rs_hip_recluster: null plan");
+  if (!pl->history_score)
+    return set_err("rs_hip_recluster: the plan's history score is switched off (rs_hip_set_history_score)");
   if (!rs_hip_plan_order(pl)) return -1;
   HIP_OK(hipSetDevice(pl->device));
   if (recluster_buffers(pl)) return -1;
@@ -344,6 +347,12 @@ int rs_hip_set_precision(RsPlan *pl, int32_t bits) {
     HIP_OK(rs32_upload_constants(pl->consts32_dev, &pl->c, pl->stream));
   }
   pl->f32 = (bits == 32);
+  return 0;
+}
+
+int rs_hip_set_history_score(RsPlan *pl, int32_t on) {
+  if (!pl) return set_err("rs_hip_set_history_score: null plan");
+  pl->history_score = on != 0;
   return 0;
 }
 
@@ -470,7 +479,7 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
   else if (coupled)
     le = rs_launch_step_coupled(a, pl->c.NLayers, pl->stream);
   else
-    le = rs_launch_step(a, pl->c.NLayers, full, pl->variant, pl->stream);
+    le = rs_launch_step(a, pl->c.NLayers, full, pl->variant, pl->history_score, pl->stream);
   if (le != hipSuccess) /* the pair stays unused: ev_used has not advanced */
     return set_err("rs_hip_step: kernel launch failed: %s", hipGetErrorString(le));
   if (pl->timing) {

@@ -63,7 +63,7 @@ hipError_t rs_launch_humidity_fill(const double *tair, double *tdew, double *rhz
                                    hipStream_t stream);
 /* exp/log tables of the device (same for every plan) */
 hipError_t rs_upload_math_tables(hipStream_t stream);
-hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
+hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant, bool score,
                           hipStream_t stream);
 hipError_t rs_launch_step_coupled(const rs::StepArgs &a, int NL, hipStream_t stream);
 hipError_t rs_launch_step_sky(const rs::StepArgs &a, int NL, hipStream_t stream);
@@ -76,7 +76,7 @@ hipError_t rs_launch_count_failed(const double *st, int64_t np_pad, int64_t npoi
 hipError_t rs_launch_forecast_keys(const rs::ForecastArgs &a, hipStream_t stream);
 
 /* plan order (rs_cluster.hip) */
-#define RS_SORT_KEY_BITS 21
+#define RS_SORT_KEY_BITS 24
 hipError_t rs_cluster_identity(int32_t *order, int64_t np_pad, hipStream_t stream);
 size_t rs_cluster_scratch_bytes(int64_t npoints);
 hipError_t rs_cluster_sort(const double *state, bool f32, int64_t np_pad, int64_t npoints,

@@ -182,7 +182,7 @@ __device__ __forceinline__ void store_outputs(KernArgs ka, int32_t i, int64_t ro
  * for one point over absolute indices [t0, t0+nsteps). */
 /* SKY: sky view / local horizons (src/ModRadiation.f90, examples/example1/src/Simulation.f90:
  * 151-162) in the lock-step loop; with coupling the general kernel below does it. */
-template <bool FULL, class Prof, bool SKY = false>
+template <bool FULL, class Prof, bool SKY = false, bool SCORE = true>
 __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s, int32_t &score) {
   static_assert(FULL || !SKY, "sky view belongs to the FULL feature set");
   KernArgs ka = kernargs();
@@ -294,11 +294,13 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
         s.failed = true; /* the reference would `stop` the process here */
     }
     const Fluxes fx =
-        model_step_fluxes(c, mt, s, tair, vz, rhz, prec_ts, sw_in, lw_in, f.phase, f.hour);
+        model_step_fluxes<SCORE>(c, mt, s, tair, vz, rhz, prec_ts, sw_in, lw_in, f.phase, f.hour);
     /* scheduling hint (bl_score_key): extra passes of this launch; bit 30 of the counter = the
      * point was in the unstable regime at some index of the launch's last RS_REGIME_WINDOW */
-    score += (fx.trips & 63) - 5;
-    if ((fx.trips & 64) && k >= nsteps - RS_REGIME_WINDOW) score |= 1 << 30;
+    if (SCORE) {
+      score += (fx.trips & 63) - 5;
+      if ((fx.trips & 64) && k >= nsteps - RS_REGIME_WINDOW) score |= 1 << 30;
+    }
     /* next index's forcing: issued here, half a step before its first use, so the
      * HBM latency hides under the ground/storage half without holding 14 VGPRs
      * across the boundary-layer iteration */
@@ -666,7 +668,7 @@ __device__ __forceinline__ double bl_score_key(int32_t score, const Scalars &s) 
   return (double)(lo | (covered << 19) | (((score >> 30) & 1) << 20));
 }
 
-template <int NL, bool FULL, int WPE>
+template <int NL, bool FULL, int WPE, bool SCORE = true>
 __global__ void __launch_bounds__(kBlock, WPE) step_kernel_reg(const StepArgs a) {
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
   const MathTab mt = fill_math_tables(math_lds);
@@ -677,9 +679,9 @@ __global__ void __launch_bounds__(kBlock, WPE) step_kernel_reg(const StepArgs a)
   Scalars s;
   int32_t score = 0;
   load_state<FULL>(a.state, a.np_pad, p, T, s);
-  time_loop<FULL>(mt, T, s, score);
+  time_loop<FULL, RegProfile<NL>, false, SCORE>(mt, T, s, score);
   store_state<FULL>(a.state, a.np_pad, p, T, s);
-  a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
+  if (SCORE) a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
 }
 
 template <bool FULL, int WPE>
@@ -948,8 +950,11 @@ __global__ void __launch_bounds__(kBlock) forecast_key_kernel(const ForecastArgs
                  : ((const double *)a.state)[(int64_t)row * np + s];
   };
   const double ts_now = st(RS_ST_TSURF);
-  const int32_t cover = (st(RS_ST_WAT) > 0.0 || st(RS_ST_SNOW) > 0.0 || st(RS_ST_ICE) > 0.0 ||
-                         st(RS_ST_ICE2) > 0.0 || st(RS_ST_DEP) > 0.0) ? 1 : 0;
+  const bool has_snow = st(RS_ST_SNOW) > 0.0, has_ice = st(RS_ST_ICE) > 0.0 || st(RS_ST_ICE2) > 0.0,
+             has_wet = st(RS_ST_WAT) > 0.0 || st(RS_ST_DEP) > 0.0;
+  const int32_t cover = (has_snow || has_ice || has_wet) ? 1 : 0;
+  /* which storage branches the point will take (src/Storage.f90): snow is the longest chain */
+  const int32_t sclass = has_snow ? 3 : has_ice ? 2 : has_wet ? 1 : 0;
   const double ta_now = a.pv.tair_now[s];
   const double stab_num = -c.VK_Const * c.ZRefT * c.Grav;
   int32_t unst = 0, farc = 0, extra = 0;
@@ -994,10 +999,25 @@ __global__ void __launch_bounds__(kBlock) forecast_key_kernel(const ForecastArgs
     }
   }
   if (extra > 4095) extra = 4095;
-  uint32_t key = (uint32_t)unst;                                  /* 0..8: 4 bits */
-  key = (key << 4) | (uint32_t)((a.pv.mode & 1) ? farc : 0);      /* 4 bits */
-  key = (key << 1) | (uint32_t)((a.pv.mode & 2) ? cover : 0);     /* 1 bit */
-  key = (key << 12) | (uint32_t)extra;                            /* 12 bits: 21 in all */
+  /* key fields, most significant first, named by the decimal digits of `mode`:
+   * 1 unstable previews (4 bits), 2 of which on the table path of log (4 bits), 3 cover (1 bit),
+   * 4 predicted extra passes (12 bits), 5 storage class snow > ice > wet > bare (2 bits).  Modes 0..3 are shorthands for 14, 124, 134, 1234. */
+  int32_t m = a.pv.mode;
+  m = (m == 0) ? 14 : (m == 1) ? 124 : (m == 2) ? 134 : (m == 3) ? 1234 : m;
+  int32_t div = 1;
+  while (m / div >= 10) div *= 10;
+  uint32_t key = 0;
+  int bits = 0;
+  for (; div >= 1; div /= 10) {
+    const int d = (m / div) % 10;
+    if (d == 1) { key = (key << 4) | (uint32_t)unst; bits += 4; }
+    else if (d == 2) { key = (key << 4) | (uint32_t)farc; bits += 4; }
+    else if (d == 3) { key = (key << 1) | (uint32_t)cover; bits += 1; }
+    else if (d == 4) { key = (key << 12) | (uint32_t)extra; bits += 12; }
+    else if (d == 5) { key = (key << 2) | (uint32_t)sclass; bits += 2; }
+  }
+  if (bits < RS_SORT_KEY_BITS) key <<= (RS_SORT_KEY_BITS - bits); /* left-aligned in the sorted bits */
+  else key >>= (bits - RS_SORT_KEY_BITS);
   /* descending: the expensive points get the low slots (longest job first, rs_cluster.hip) */
   a.keys[s] = ((1u << RS_SORT_KEY_BITS) - 1u) - key;
   a.slots[s] = (uint32_t)s;
@@ -1060,7 +1080,7 @@ hipError_t rs_launch_step_coupled(const rs::StepArgs &a, int NL, hipStream_t str
   return hipGetLastError();
 }
 
-hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
+hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant, bool score,
                           hipStream_t stream) {
   const dim3 g = grid_for(a.npoints), b(RS_BLOCK);
   /* variant = flavour + 10 * waves-per-SIMD bound (0 = default for the flavour) */
@@ -1077,8 +1097,10 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
   if (wpe == W) {                                                                        \
     if (full)                                                                            \
       hipLaunchKernelGGL((rs::step_kernel_reg<15, true, W>), g, b, 0, stream, a);        \
-    else                                                                                 \
+    else if (score || W != 4)                                                            \
       hipLaunchKernelGGL((rs::step_kernel_reg<15, false, W>), g, b, 0, stream, a);       \
+    else /* no history score wanted (forecast order): the default flavour without it */   \
+      hipLaunchKernelGGL((rs::step_kernel_reg<15, false, 4, false>), g, b, 0, stream, a);\
   }
     RS_REG(2) RS_REG(3) RS_REG(4)
   } else {

@@ -165,6 +165,9 @@ class Plan:
         """32: fp32 flavour (LEAN features, float windows); 64: the parity path."""
         lib.check(self.L.rs_hip_set_precision(self._h, bits), "rs_hip_set_precision")
 
+    def set_history_score(self, on: bool) -> None:
+        lib.check(self.L.rs_hip_set_history_score(self._h, 1 if on else 0), "rs_hip_set_history_score")
+
     def set_variant(self, v: int) -> None:
         lib.check(self.L.rs_hip_set_variant(self._h, v), "rs_hip_set_variant")
 

@@ -24,7 +24,7 @@ SPK = 120  # 3600 s / DTSecs 30 s: time indices per hourly knot
 class SyntheticRun:
     def __init__(self, plan: device.Plan, seed: int, hours: int, chunk: int, point_offset: int = 0,
                  plan_order: bool = True, f32: bool = False, year_month_day=(2024, 1, 10),
-                 forecast: bool = True, forecast_alpha: float = 0.5, forecast_mode: int = 1):
+                 forecast: bool = True, forecast_alpha: float = 0.5, forecast_mode: int = 3124):
         self.plan, self.seed, self.hours = plan, seed, hours
         self.simlen = hours * SPK + 1  # examples/example1/src/InputSettings.cpp:98
         self.chunk = min(chunk, self.simlen)
@@ -32,6 +32,7 @@ class SyntheticRun:
         # sort key of the re-sort: forecast of the next window (rs_hip_recluster_forecast) or the
         # history of the last one (rs_hip_recluster)
         self.forecast, self.forecast_alpha, self.forecast_mode = forecast, forecast_alpha, forecast_mode
+        plan.set_history_score(not (plan_order and forecast))  # nobody reads it then
         dev, npad = plan.device, plan.np_pad
         wdtype = torch.float32 if f32 else torch.float64
         self.win = device.ForcingWindow.empty(self.chunk, npad, dev, optional=(), dtype=wdtype)

