@@ -107,7 +107,9 @@ def main() -> None:
     ap.add_argument("--total-points", type=int, default=1_000_000)
     ap.add_argument("--points", type=int, default=None, help="points per GPU (implies --scaling weak)")
     ap.add_argument("--hours", type=int, default=48)
-    ap.add_argument("--chunk", type=int, default=240, help="time indices per step-kernel launch")
+    ap.add_argument("--chunk", type=int, default=0,
+                    help="time indices per step-kernel launch; 0 = auto: 120 for >= 750 000 points on "
+                         "the GPU, 240 for smaller shards (measured, tools/exp_small.sh)")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 register profile, 2 LDS profile")
     ap.add_argument("--seed", type=int, default=20240110)
     ap.add_argument("--f32", action="store_true",
@@ -122,10 +124,11 @@ def main() -> None:
                          "passes (rs_hip_recluster_forecast) or by the passes of the last launch")
     ap.add_argument("--forecast-alpha", type=float, default=0.5)
     ap.add_argument("--forecast-mode", type=int, default=3124)
-    ap.add_argument("--plans-per-gpu", type=int, default=1,
+    ap.add_argument("--plans-per-gpu", type=int, default=0,
                     help="cut this GPU's points into K plans on K streams whose launches interleave: "
                          "one plan's HBM-bound window expansion and re-sort run beside another's "
-                         "VALU-bound step kernel")
+                         "VALU-bound step kernel, and the tail of one launch under the head of the next. "
+                         "0 = auto: 4 from 200 000 points on the GPU, 2 from 100 000, else 1")
     ap.add_argument("--no-natural-leg", action="store_true",
                     help="skip the second timed leg (natural order) that gives natural_order_value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -166,7 +169,11 @@ def main() -> None:
     simlen = args.hours * workload.SPK + 1  # examples/example1/src/InputSettings.cpp:98
     settings = abi.default_settings(simlen)
     params = abi.default_parameters()
-    K = max(1, args.plans_per_gpu)
+    # measured on MI355X (tools/exp_plans.sh, tools/exp_small.sh): 4 plans from 200 000
+    # points, 2 from 100 000; launches of 120 indices for a full GPU, 240 for small shards
+    K = args.plans_per_gpu if args.plans_per_gpu > 0 else (4 if n >= 200_000 else 2 if n >= 100_000 else 1)
+    if args.chunk <= 0:
+        args.chunk = 120 if n >= 750_000 else 240
     plans, offsets = [], []
     for j in range(K):
         off_j, n_j = sharding.strong_shard(n, K, j)
@@ -205,6 +212,9 @@ def main() -> None:
         fence()
         for pl in plans:
             pl.timing_reset()
+        ref = torch.cuda.Event(enable_timing=True)
+        ref.record(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
         t_start = time.perf_counter()
         for _ in range(args.steps):
             one_pass()
@@ -213,18 +223,25 @@ def main() -> None:
         elapsed = sharding.max_over_ranks(
             elapsed, dist if world > 1 else None,
             dev if (world > 1 and dist.get_backend() == "nccl") else None)
-        step_ms, nlaunch = 0.0, 0
-        for pl in plans:  # K > 1: launches of different plans overlap, their durations are summed
-            ms, nl = pl.timing_step_ms()
-            step_ms += ms
-            nlaunch += nl
+        # HIP events around every step launch, on the stream it was launched on.  With K > 1 the
+        # launches of different plans overlap in time: `busy_ms` is the union of their intervals
+        # (the time the device spent running step kernels), `step_ms` the plain sum of durations
+        iv = []
+        for pl in plans:
+            iv += pl.timing_intervals(ref)
+        step_ms, nlaunch = sum(b - a for a, b in iv), len(iv)
+        busy_ms, end = 0.0, float("-inf")
+        for a, b in sorted(iv):
+            if b > end:
+                busy_ms += b - max(a, end)
+                end = b
         chunk = run.chunk
         del run, runs
         torch.cuda.empty_cache()
-        return elapsed, step_ms, nlaunch, chunk
+        return elapsed, step_ms, nlaunch, chunk, busy_ms
 
     cluster = bool(args.cluster)
-    elapsed, step_ms, nlaunch, chunk = timed_leg(cluster)
+    elapsed, step_ms, nlaunch, chunk, busy_ms = timed_leg(cluster)
     natural = None
     if cluster and not args.no_natural_leg:
         natural = timed_leg(False)
@@ -233,11 +250,16 @@ def main() -> None:
     units_per_pass_job = total_points * simlen          # whole job, all ranks
     units_per_pass_rank = n * simlen
     value = units_per_pass_job * args.steps / elapsed
-    # dominant kernel: step kernel, HIP events on its own stream around every launch (this rank)
+    # dominant kernel: step kernel, HIP events on its own stream around every launch (this rank).
+    # achieved = algorithmic bytes of the launches / time the device spent in them.  With one plan
+    # that is bytes per launch / average launch duration; with K plans on K streams the launches
+    # overlap (that is the point: one plan's window expansion hides under another's step kernel),
+    # so the denominator is the union of the launch intervals, not their sum
     avg_launch_s = step_ms / 1e3 / max(nlaunch, 1)
     units_per_launch = units_per_pass_rank * args.steps / max(nlaunch, 1)
     algo_bytes = 52.0 if args.f32 else ALGO_BYTES_PER_UNIT  # fp32: 6 x 4 + 4 read, 6 x 4 written
-    achieved = algo_bytes * units_per_launch / avg_launch_s / 1e9
+    achieved = algo_bytes * units_per_pass_rank * args.steps / (busy_ms / 1e3) / 1e9
+    concurrency = step_ms / busy_ms
 
     traffic, valu = (None, None) if args.f32 else measured_traffic(n, chunk)
     if rank == 0:
@@ -286,18 +308,24 @@ def main() -> None:
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "launches": nlaunch,
                 "units_per_launch": units_per_launch,
-                "step_kernel_only_value": units_per_pass_rank * args.steps / (step_ms / 1e3),
+                "busy_ms": busy_ms,
+                "concurrent_launches": concurrency,
+                "per_launch_achieved": algo_bytes * units_per_launch / avg_launch_s / 1e9,
+                "method": "achieved = algorithmic bytes of all step launches / union of their HIP-event "
+                          "intervals (busy_ms); = units_per_launch x bytes / avg_launch_ms x "
+                          "concurrent_launches; per_launch_achieved is the single-launch figure",
+                "step_kernel_only_value": units_per_pass_rank * args.steps / (busy_ms / 1e3),
                 "note": "fp64-VALU-bound kernel (SURVEY.md 8d): the HBM fraction is reported "
                         "as the contract asks, the binding roofline is vector fp64 issue",
             },
         }
         if natural is not None:
-            n_elapsed, n_step_ms, n_nlaunch, _ = natural
+            n_elapsed, n_step_ms, n_nlaunch, _, n_busy = natural
             line["natural_order_value"] = units_per_pass_job * args.steps / n_elapsed
             line["natural_order"] = {
                 "ms_per_step": n_elapsed / args.steps * 1e3,
                 "avg_launch_ms": n_step_ms / max(n_nlaunch, 1),
-                "step_kernel_only_value": units_per_pass_rank * args.steps / (n_step_ms / 1e3),
+                "step_kernel_only_value": units_per_pass_rank * args.steps / (n_busy / 1e3),
                 "note": "second timed leg, same W/K and fences: points in natural order, no re-sort",
             }
         if world == 1 and not args.no_cpu_baseline:

@@ -453,6 +453,13 @@ int rs_hip_plan_reset_order(RsPlan *plan);
  * summed milliseconds (synchronises on the last event) and the launch count. */
 int rs_hip_timing_reset(RsPlan *plan);
 double rs_hip_timing_step_ms(RsPlan *plan, int32_t *nlaunches);
+/* The same launches as intervals [start, stop] in milliseconds after `ref_event` (a hipEvent_t
+ * with timing enabled that the caller recorded on this device before the launches).  With several
+ * plans stepping concurrently on one device (one stream each) their step kernels overlap in time;
+ * the union of all plans' intervals is the time during which the device ran step kernels.  Returns
+ * the number of launches (at most `cap` are written) or < 0. */
+int32_t rs_hip_timing_intervals(RsPlan *plan, void *ref_event, double *start_ms, double *stop_ms,
+                                int32_t cap);
 int64_t rs_hip_plan_npoints_padded(const RsPlan *plan);
 
 /* ------------------------------------------------------------------------

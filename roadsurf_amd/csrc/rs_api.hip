@@ -510,6 +510,24 @@ double rs_hip_timing_step_ms(RsPlan *pl, int32_t *nlaunches) {
   return total;
 }
 
+int32_t rs_hip_timing_intervals(RsPlan *pl, void *ref_event, double *start_ms, double *stop_ms,
+                                int32_t cap) {
+  if (!pl || !ref_event || !start_ms || !stop_ms) return set_err("rs_hip_timing_intervals: bad arguments");
+  if (hipSetDevice(pl->device) != hipSuccess) return -1;
+  const int32_t n = (int32_t)(pl->ev_used / 2);
+  if (n == 0) return 0;
+  if (hipEventSynchronize(pl->ev[pl->ev_used - 1]) != hipSuccess) return -1;
+  for (int32_t i = 0; i < n && i < cap; ++i) {
+    float a = 0.f, b = 0.f;
+    if (hipEventElapsedTime(&a, (hipEvent_t)ref_event, pl->ev[2 * (size_t)i]) != hipSuccess ||
+        hipEventElapsedTime(&b, (hipEvent_t)ref_event, pl->ev[2 * (size_t)i + 1]) != hipSuccess)
+      return set_err("rs_hip_timing_intervals: hipEventElapsedTime failed");
+    start_ms[i] = a;
+    stop_ms[i] = b;
+  }
+  return n;
+}
+
 int rs_hip_state_download(RsPlan *pl, double *host, size_t bytes) {
   if (!pl || !host || bytes != rs_hip_plan_state_bytes(pl))
     return set_err("rs_hip_state_download: bad arguments");

@@ -185,6 +185,17 @@ class Plan:
         ms = self.L.rs_hip_timing_step_ms(self._h, C.byref(n))
         return float(ms), int(n.value)
 
+    def timing_intervals(self, ref_event: torch.cuda.Event):
+        """[(start_ms, stop_ms)] of the step launches since timing_reset(), after ref_event."""
+        import numpy as np
+        cap = 65536
+        a = np.zeros(cap); b = np.zeros(cap)
+        n = self.L.rs_hip_timing_intervals(self._h, C.c_void_p(ref_event.cuda_event), C.c_void_p(a.ctypes.data),
+                                           C.c_void_p(b.ctypes.data), cap)
+        if n < 0:
+            raise RuntimeError("rs_hip_timing_intervals failed: " + lib.last_error())
+        return list(zip(a[:n].tolist(), b[:n].tolist()))
+
     def state(self) -> torch.Tensor:
         """Carried state block as a host tensor [RS_NSTATE, np_pad]."""
         nb = self.L.rs_hip_plan_state_bytes(self._h)
