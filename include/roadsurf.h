@@ -152,6 +152,19 @@ void runsimulation_batch(int32_t n, OutputPointers *outPointers,
                          const InputSettings *inSettings,
                          const InputParameters *inputParam,
                          const LocalParameters *localParam, int32_t *status);
+/* Same, plus what the reference only prints: first_failed[n] (or NULL) receives per point 0, or the
+ * 1-based time index at which CheckValues failed it ("BAD input value!" / "Abnormal surface
+ * temperature", src/InputOutput.f90:63-65,80-81); outputs after that index read -9999.0.
+ * Environment ROADSURF_HIP_WRITEBACK=1 makes both entries (and runsimulation) write the
+ * reference's in-place edits of the INPUT arrays back to the caller: the SW_dir clamp of
+ * CheckValues and, with sky view, SW / SW_dir / LW as ModRadiationBySurroundings leaves them
+ * (the VZ(1) >= 0.4 edit of src/Initialization.f90:121-123 is always written). */
+void runsimulation_batch_ex(int32_t n, OutputPointers *outPointers,
+                            const InputPointers *inPointers,
+                            const InputSettings *inSettings,
+                            const InputParameters *inputParam,
+                            const LocalParameters *localParam, int32_t *status,
+                            int32_t *first_failed);
 
 /* ------------------------------------------------------------------------
  * Model constants: everything that is uniform over points once settings and
@@ -317,12 +330,28 @@ int rs_hip_init_state(RsPlan *plan, const RsForcing *f, const RsPointParams *pp)
 int rs_hip_step(RsPlan *plan, const RsForcing *f, const RsOutputs *o,
                 const RsPointParams *pp, int32_t t0, int32_t nsteps);
 
+/* The reference edits its INPUT arrays in place (SURVEY.md 8b "Ownership"): CheckValues clamps
+ * SW_dir(i) to SW(i) (src/InputOutput.f90:75-77) and the sky-view correction rewrites SW(i),
+ * SW_dir(i), LW(i) (src/ModRadiation.f90:57-71).  The device forcing windows are never modified;
+ * a caller that wants those edits gives three device streams laid out like the forcing window of
+ * the NEXT rs_hip_step calls (row 0 = index t0, `t_stride` elements per row), pre-filled with the
+ * original values: the sky-view kernels then store SW_dir (every stepped index) and SW, LW (points
+ * with 0 <= sky_view < 1) as the reference leaves them; with coupling the last replay wins, as in
+ * the reference.  All NULL switches it off.  Without sky view the only edit is the SW_dir clamp,
+ * which needs no device work (rs_host_run_batch does it on the host). */
+int rs_hip_set_writeback(RsPlan *plan, double *sw, double *sw_dir, double *lw, int64_t t_stride);
+
 /* Copy the carried state block device->host / host->device (checkpointing,
  * tests).  Layout: [RS_NSTATE][npoints_padded] doubles. */
 int rs_hip_state_download(RsPlan *plan, double *host, size_t bytes);
 int rs_hip_state_upload(RsPlan *plan, const double *host, size_t bytes);
 /* Number of points with the sticky failure flag set (src/InputOutput.f90:66). */
 int64_t rs_hip_failed_count(RsPlan *plan);
+/* Per point (host int32[npoints], in local point order whatever the plan order is): 0, or the
+ * 1-based time index at which CheckValues raised simulation_failed - the step of that index was
+ * still taken and saved, later outputs read -9999.0 (examples/example1/src/Simulation.f90:58,
+ * src/InputOutput.f90:55-82).  The reference only prints this ("BAD input value!"). */
+int rs_hip_first_failed_index(RsPlan *plan, int32_t *first_failed);
 int rs_hip_sync(RsPlan *plan);
 
 /* Synthetic forcing: hourly knots from a counter-based hash,
@@ -475,6 +504,13 @@ typedef struct RsHostExtras {
   const double *cos_lat;
   const double *lon_rad;
   double albedo_surroundings;
+  /* out, [n] or NULL: per point 0, or the 1-based time index at which its run was failed
+   * (rs_hip_first_failed_index) */
+  int32_t *first_failed;
+  /* 1: write the reference's in-place edits of the caller's input arrays back
+   * (src/InputOutput.f90:75-77: SW_dir(i) = min(SW_dir(i), SW(i)) at every checked index;
+   * src/ModRadiation.f90:57-71: SW, SW_dir, LW as the sky-view correction leaves them) */
+  int32_t writeback;
 } RsHostExtras;
 
 /* `device` >= 0: that device.  `device` < 0 (what runsimulation_batch / runsimulation pass): the

@@ -60,6 +60,7 @@ struct RsPlan {
   /* the plan's constants on the device (no table of slots: any number of plans may be alive) */
   void *consts_dev = nullptr;   /* RsConstantsDev (rs_consts_dev.h) */
   void *consts32_dev = nullptr; /* RsConstantsF, allocated by rs_hip_set_precision(32) */
+  rs::Writeback wb{nullptr, nullptr, nullptr, 0};
   bool history_score = true; /* the step kernels leave the sort key of rs_hip_recluster */
   bool f32 = false; /* single-precision flavour: windows and state hold floats */
   std::vector<hipEvent_t> ev; /* start/stop pairs */
@@ -350,6 +351,14 @@ int rs_hip_set_precision(RsPlan *pl, int32_t bits) {
   return 0;
 }
 
+int rs_hip_set_writeback(RsPlan *pl, double *sw, double *sw_dir, double *lw, int64_t t_stride) {
+  if (!pl) return set_err("rs_hip_set_writeback: null plan");
+  if ((sw || sw_dir || lw) && (!sw || !sw_dir || !lw || t_stride < pl->npoints))
+    return set_err("rs_hip_set_writeback: all three streams and t_stride >= npoints, or all NULL");
+  pl->wb = rs::Writeback{sw, sw_dir, lw, t_stride};
+  return 0;
+}
+
 int rs_hip_set_history_score(RsPlan *pl, int32_t on) {
   if (!pl) return set_err("rs_hip_set_history_score: null plan");
   pl->history_score = on != 0;
@@ -455,6 +464,8 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
   a.np_pad = pl->np_pad;
   a.t0 = t0;
   a.nsteps = nsteps;
+  a.wb = pl->wb;
+  if (a.wb.sw_dir && !skyview) a.wb = rs::Writeback{nullptr, nullptr, nullptr, 0};
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (pl->timing) {
     if (pl->ev_used + 2 > pl->ev.size()) {
@@ -558,6 +569,29 @@ int64_t rs_hip_failed_count(RsPlan *pl) {
     return -1;
   if (hipStreamSynchronize(pl->stream) != hipSuccess) return -1;
   return (int64_t)h;
+}
+
+int rs_hip_first_failed_index(RsPlan *pl, int32_t *out) {
+  if (!pl || !out) return set_err("rs_hip_first_failed_index: bad arguments");
+  HIP_OK(hipSetDevice(pl->device));
+  const size_t esz = pl->f32 ? sizeof(float) : sizeof(double);
+  std::vector<char> row((size_t)pl->np_pad * esz);
+  HIP_OK(hipMemcpyAsync(row.data(), (const char *)pl->state + (size_t)RS_ST_FAILED * pl->np_pad * esz,
+                        row.size(), hipMemcpyDeviceToHost, pl->stream));
+  std::vector<int32_t> order;
+  if (pl->order) { /* slot -> local point */
+    order.resize((size_t)pl->np_pad);
+    HIP_OK(hipMemcpyAsync(order.data(), pl->order, order.size() * sizeof(int32_t), hipMemcpyDeviceToHost,
+                          pl->stream));
+  }
+  HIP_OK(hipStreamSynchronize(pl->stream));
+  for (int64_t s = 0; s < pl->npoints; ++s) {
+    const double v = pl->f32 ? (double)reinterpret_cast<const float *>(row.data())[s]
+                             : reinterpret_cast<const double *>(row.data())[s];
+    const int64_t p = pl->order ? order[(size_t)s] : s;
+    if (p >= 0 && p < pl->npoints) out[p] = (int32_t)v;
+  }
+  return 0;
 }
 
 int rs_hip_sync(RsPlan *pl) {

@@ -108,6 +108,7 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
       if (ex.sin_lat) ex.sin_lat += sh.off;
       if (ex.cos_lat) ex.cos_lat += sh.off;
       if (ex.lon_rad) ex.lon_rad += sh.off;
+      if (ex.first_failed) ex.first_failed += sh.off;
       exp = &ex;
     }
     return run_batch_on_device((int32_t)sh.cnt, outPointers + sh.off, inPointers + sh.off, consts,
@@ -171,6 +172,21 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
   HOK(d_pp32.alloc((size_t)Ppad * 2 * sizeof(int32_t)));
   std::vector<double> pp64((size_t)Ppad * NPP64);
   std::vector<int32_t> pp32((size_t)Ppad * 2);
+  const bool writeback = extras && extras->writeback;
+  int32_t *first_failed = extras ? extras->first_failed : nullptr;
+  /* sky view + writeback: SW, SW_dir, LW as the reference leaves them come back from the device
+   * (rs_hip_set_writeback); [3][Ppad*TC] windows, their [3][P*TC] transposes, two pinned sets */
+  const bool wb_dev = writeback && skyview;
+  Dev d_wb_tp, d_wb_pt;
+  Pinned h_wb, h_wb2;
+  if (wb_dev) {
+    HOK(d_wb_tp.alloc(tp_elems * 3 * sizeof(double)));
+    HOK(d_wb_pt.alloc(in_elems * 3 * sizeof(double)));
+    HOK(h_wb.alloc(in_elems * 3 * sizeof(double)));
+    HOK(h_wb2.alloc(in_elems * 3 * sizeof(double)));
+  }
+  double *hwb_b[2] = {(double *)h_wb.p, (double *)h_wb2.p};
+  std::vector<int32_t> ff_tile((size_t)P);
   Dev d_sun, d_hz_pt, d_hz;
   Pinned h_hz;
   if (skyview) {
@@ -235,13 +251,43 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
     const int m = it.m, len = it.len, t0 = it.t0;
     const int64_t p0 = it.p0;
 #pragma omp parallel for schedule(static) num_threads(nthreads)
-    for (int p = 0; p < m; ++p)
+    for (int p = 0; p < m; ++p) {
       for (int f = 0; f < 6; ++f)
         std::memcpy(out_f64(outPointers[p0 + p], f) + (t0 - 1), hout + ((size_t)f * m + p) * len,
                     (size_t)len * sizeof(double));
+      if (wb_dev) { /* the reference edits these "const" inputs in place (src/ModRadiation.f90:57-71) */
+        const InputPointers &ip = inPointers[p0 + p];
+        const double *hw = hwb_b[buf];
+        std::memcpy(const_cast<double *>(ip.c_SW) + (t0 - 1), hw + ((size_t)0 * m + p) * len, (size_t)len * sizeof(double));
+        std::memcpy(const_cast<double *>(ip.c_SW_dir) + (t0 - 1), hw + ((size_t)1 * m + p) * len, (size_t)len * sizeof(double));
+        std::memcpy(const_cast<double *>(ip.c_LW) + (t0 - 1), hw + ((size_t)2 * m + p) * len, (size_t)len * sizeof(double));
+      }
+    }
+  };
+  /* end of a tile: per-point failure index, and - without sky view - the one in-place edit the
+   * reference makes to its inputs, on the host: CheckValues ran for every index up to the one
+   * that failed the point (or SimLen-1) and clamped SW_dir there (src/InputOutput.f90:75-77) */
+  auto finish_tile = [&](RsPlan *pl, int64_t p0, int m) -> int {
+    if (!first_failed && !(writeback && !wb_dev)) return 0;
+    if (rs_hip_first_failed_index(pl, ff_tile.data()) != 0) return -15;
+    if (first_failed) std::memcpy(first_failed + p0, ff_tile.data(), (size_t)m * sizeof(int32_t));
+    if (writeback && !wb_dev) {
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+      for (int p = 0; p < m; ++p) {
+        const InputPointers &ip = inPointers[p0 + p];
+        if (!ip.c_SW_dir) continue;
+        const int lim = ff_tile[p] > 0 ? std::min(ff_tile[p], L - 1) : L - 1;
+        double *sd = const_cast<double *>(ip.c_SW_dir);
+        for (int t = 0; t < lim; ++t)
+          if (sd[t] > ip.c_SW[t]) sd[t] = ip.c_SW[t];
+      }
+    }
+    return 0;
   };
 
   RsPlan *plan = nullptr, *retired = nullptr; /* retired: its last item is still in flight */
+  int64_t retired_p0 = 0;
+  int retired_m = 0;
   struct PlanGuard {
     RsPlan **a, **b;
     ~PlanGuard() {
@@ -343,11 +389,25 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
     oo.t_stride = mp;
     oo.decimate = 1;
     oo.row0 = t0 - 1;
+    if (wb_dev) { /* pre-filled with the caller's values: a point that fails keeps them from there on */
+      double *w = (double *)d_wb_tp.p;
+      HOK(hipMemcpyAsync(w, fo.sw, fs * sizeof(double), hipMemcpyDeviceToDevice, stream));
+      HOK(hipMemcpyAsync(w + fs, fo.sw_dir, fs * sizeof(double), hipMemcpyDeviceToDevice, stream));
+      HOK(hipMemcpyAsync(w + 2 * fs, fo.lw, fs * sizeof(double), hipMemcpyDeviceToDevice, stream));
+      if (rs_hip_set_writeback(plan, w, w + fs, w + 2 * fs, mp) != 0) return -16;
+    }
     if (t0 == 1 && rs_hip_init_state(plan, &fo, &pp) != 0) return -12;
     if (rs_hip_step(plan, &fo, &oo, &pp, t0, len) != 0) return -13;
     for (int f = 0; f < 6; ++f)
       HOK(transpose((const double *)d_out_tp.p + (size_t)f * fs,
                     (double *)d_out_pt.p + (size_t)f * m * len, len, m, mp, len, stream));
+    if (wb_dev) {
+      for (int f = 0; f < 3; ++f)
+        HOK(transpose((const double *)d_wb_tp.p + (size_t)f * fs,
+                      (double *)d_wb_pt.p + (size_t)f * m * len, len, m, mp, len, stream));
+      HOK(hipMemcpyAsync(hwb_b[buf], d_wb_pt.p, (size_t)3 * m * len * sizeof(double),
+                         hipMemcpyDeviceToHost, stream));
+    }
     HOK(hipMemcpyAsync(hout_b[buf], d_out_pt.p, (size_t)6 * m * len * sizeof(double),
                        hipMemcpyDeviceToHost, stream));
     HOK(hipEventRecord(done[buf], stream));
@@ -362,14 +422,18 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
     if (rc != 0) break;
     if (k >= 1) { /* item k-1 used the other staging set */
       HOK(hipEventSynchronize(done[buf ^ 1]));
+      scatter(items[k - 1], buf ^ 1);
       if (retired) {
+        rc = finish_tile(retired, retired_p0, retired_m);
         rs_hip_plan_destroy(retired);
         retired = nullptr;
+        if (rc != 0) break;
       }
-      scatter(items[k - 1], buf ^ 1);
     }
     if (items[k].last) { /* the next item starts a new tile with a new plan */
       retired = plan;
+      retired_p0 = items[k].p0;
+      retired_m = items[k].m;
       plan = nullptr;
     }
     if (k + 1 < N) gather(items[k + 1], buf ^ 1);
@@ -377,6 +441,7 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
   if (rc == 0) {
     HOK(hipEventSynchronize(done[(N - 1) & 1]));
     scatter(items[N - 1], (N - 1) & 1);
+    if (retired) rc = finish_tile(retired, retired_p0, retired_m);
   }
   return rc;
 }

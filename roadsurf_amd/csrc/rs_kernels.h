@@ -10,6 +10,13 @@ enum { RS_VARIANT_AUTO = 0, RS_VARIANT_REG = 1, RS_VARIANT_LDS = 2 };
 
 namespace rs {
 
+/* where the sky-view kernels leave the reference's in-place edits of the input arrays
+ * (rs_hip_set_writeback): rows like the forcing window's, all NULL = not wanted */
+struct Writeback {
+  double *sw, *sw_dir, *lw;
+  int64_t t_stride;
+};
+
 struct StepArgs {
   const void *consts; /* the plan's constants in HBM: RsConstants (fp64 kernels) or RsConstantsF
                          (fp32 kernels); read through the scalar cache (address space 4) */
@@ -19,6 +26,7 @@ struct StepArgs {
   double *state;
   int64_t npoints, np_pad;
   int32_t t0, nsteps;
+  Writeback wb;
 };
 
 struct InitArgs {

@@ -112,7 +112,7 @@ __device__ __forceinline__ void store_state(double *__restrict__ st, int64_t np,
   st[(int64_t)RS_ST_T4MELT * np + p] = s.t4melt;
   st[(int64_t)RS_ST_ALBEDO * np + p] = s.albedo;
   st[(int64_t)RS_ST_VERYCOLD * np + p] = s.verycold ? 1.0 : 0.0;
-  st[(int64_t)RS_ST_FAILED * np + p] = s.failed ? 1.0 : 0.0;
+  /* RS_ST_FAILED is written where the failure is detected (the index it happened at) */
   if (FULL) {
     st[(int64_t)RS_ST_TAIR_END * np + p] = s.tair_end;
     st[(int64_t)RS_ST_VZ_END * np + p] = s.vz_end;
@@ -216,6 +216,12 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
     }
   }
 
+  /* settings%simulation_failed (src/InputOutput.f90:66): sticky; the state block keeps the index
+   * it was raised at (rs_hip_first_failed_index) */
+  auto fail_at = [&](int32_t idx) {
+    s.failed = true;
+    ka->state[(int64_t)RS_ST_FAILED * ka->np_pad + row0 + lane] = (double)idx;
+  };
   Forcing nxt = load_forcing<FULL>(ka, row0, lane, 0);
   for (int32_t k = 0; k < nsteps; ++k) {
     asm volatile("" : "+s"(ka));
@@ -242,11 +248,11 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
     if (i < c.SimLen) {
       Forcing chk = f;
       chk.vz = vz;
-      if (check_values(chk, s.tsurf, FULL && ka->f.tdew != nullptr)) s.failed = true;
+      if (check_values(chk, s.tsurf, FULL && ka->f.tdew != nullptr)) fail_at(i);
       if (SKY) {
         if (sky_on && (sw_dir < R4(-0.1) || sw_dir > R4(4000.0) || lw_net < R4(-1000.0) ||
                        lw_net > R4(1000.0)))
-          s.failed = true;                      /* src/InputOutput.f90:68-74 */
+          fail_at(i);                           /* src/InputOutput.f90:68-74 */
         if (sw_dir > f.sw) sw_dir = f.sw;       /* :75-77 */
       }
       if (FULL) {
@@ -291,7 +297,18 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
                               ka->pp.albedo_surroundings,
                               ka->pp.horizons ? ka->pp.horizons + row0 + lane : nullptr, ka->np_pad,
                               sw_in, sw_dir, lw_in, lw_net))
-        s.failed = true; /* the reference would `stop` the process here */
+        fail_at(i); /* the reference would `stop` the process here */
+    }
+    if (SKY && ka->wb.sw_dir) {
+      /* the caller's arrays as the reference leaves them: SW_dir clamped by CheckValues
+       * (src/InputOutput.f90:75-77), SW / SW_dir / LW edited by ModRadiationBySurroundings
+       * (src/ModRadiation.f90:57-71) */
+      const int64_t wrow = (int64_t)k * ka->wb.t_stride + row0;
+      (ka->wb.sw_dir + wrow)[lane] = sw_dir;
+      if (sky_on) {
+        (ka->wb.sw + wrow)[lane] = sw_in;
+        (ka->wb.lw + wrow)[lane] = lw_in;
+      }
     }
     const Fluxes fx =
         model_step_fluxes<SCORE>(c, mt, s, tair, vz, rhz, prec_ts, sw_in, lw_in, f.phase, f.hour);
@@ -502,6 +519,10 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Pr
     }
   }
 
+  auto fail_at = [&](int32_t idx) {
+    s.failed = true;
+    st[(int64_t)RS_ST_FAILED * np + p] = (double)idx;
+  };
   int32_t i = t0;
   int32_t written_hi = t0 - 1; /* highest index this launch has saved an output for */
   bool stale_all = false; /* first step after a restore: TmpNw is the pre-restore profile */
@@ -524,10 +545,10 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Pr
       lw_net = ka->f.lw_net[off];
     }
     if (i < c.SimLen) {
-      if (check_values(f, s.tsurf, ka->f.tdew != nullptr)) s.failed = true;
+      if (check_values(f, s.tsurf, ka->f.tdew != nullptr)) fail_at(i);
       if (sky_on && (sw_dir < R4(-0.1) || sw_dir > R4(4000.0) || lw_net < R4(-1000.0) ||
                      lw_net > R4(1000.0)))
-        s.failed = true; /* src/InputOutput.f90:68-74 */
+        fail_at(i); /* src/InputOutput.f90:68-74 */
       if (sw_dir > f.sw) sw_dir = f.sw; /* :75-77 */
       if (q.on) {
         /* CouplingOperations1, src/Coupling.f90:10-96 */
@@ -630,7 +651,15 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Pr
                               ka->pp.albedo_surroundings,
                               ka->pp.horizons ? ka->pp.horizons + p : nullptr, np, sw_in, sw_dir,
                               lw_in, lw_net))
-        s.failed = true; /* the reference would `stop` the process here */
+        fail_at(i); /* the reference would `stop` the process here */
+    }
+    if (ka->wb.sw_dir) { /* in-place input edits of the reference; a replay overwrites them */
+      const int64_t woff = (int64_t)(i - t0) * ka->wb.t_stride + p;
+      ka->wb.sw_dir[woff] = sw_dir;
+      if (sky_on) {
+        ka->wb.sw[woff] = sw_in;
+        ka->wb.lw[woff] = lw_in;
+      }
     }
     const Fluxes fx = model_step_fluxes(c, mt, s, tair, vz, rhz, prec_ts, sw_in, lw_in, f.phase,
                                         f.hour, cp);

@@ -118,7 +118,10 @@ __device__ __forceinline__ void run(const rs::StepArgs &a, Prof &T) {
     f.tdew = 0.f; f.tsurfobs = -9999.9f; f.depth = -9999.9f;
     if (i == 1 && f.vz < 0.4f) f.vz = 0.4f;
     const float prec_ts = rs_div(f.prec, 3600.0f) * c.DTSecs;
-    if (i < c.SimLen && check_values(f, s.tsurf, false)) s.failed = true;
+    if (i < c.SimLen && check_values(f, s.tsurf, false)) {
+      s.failed = true;
+      st[(int64_t)RS_ST_FAILED * np + p] = (float)i; /* the index it was raised at */
+    }
     s.tnw1 = T.get(1);
     s.tnw2 = T.get(2);
     const Fluxes fx = model_step_fluxes(c, mt, s, f.tair, f.vz, f.rhz, prec_ts, f.sw, f.lw, f.phase,
@@ -139,7 +142,6 @@ __device__ __forceinline__ void run(const rs::StepArgs &a, Prof &T) {
   st[(int64_t)RS_ST_DEP * np + p] = s.dep; st[(int64_t)RS_ST_Q2MELT * np + p] = s.q2melt;
   st[(int64_t)RS_ST_T4MELT * np + p] = s.t4melt; st[(int64_t)RS_ST_ALBEDO * np + p] = s.albedo;
   st[(int64_t)RS_ST_VERYCOLD * np + p] = s.verycold ? 1.f : 0.f;
-  st[(int64_t)RS_ST_FAILED * np + p] = s.failed ? 1.f : 0.f;
   {
     const int32_t lo = score > 0x7ffff ? 0x7ffff : (score < 0 ? 0 : score);
     const int32_t covered = (s.wat > 0.f || s.snow > 0.f || s.ice > 0.f || s.ice2 > 0.f || s.dep > 0.f) ? 1 : 0;

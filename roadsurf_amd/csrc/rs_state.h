@@ -27,7 +27,9 @@ enum RsStateSlot {
   RS_ST_T4MELT,                  /* surf%T4Melt */
   RS_ST_ALBEDO,                  /* ground%Albedo */
   RS_ST_VERYCOLD,                /* surf%VeryCold as 0.0/1.0 */
-  RS_ST_FAILED,                  /* settings%simulation_failed as 0.0/1.0 */
+  RS_ST_FAILED,                  /* settings%simulation_failed: 0.0, or the (1-based) time index at which
+                                    CheckValues raised it (the step of that index still runs, the loop
+                                    exits after it: examples/example1/src/Simulation.f90:58) */
   RS_ST_TAIR_END,                /* atm%TairInitEnd (relaxation) */
   RS_ST_VZ_END,                  /* atm%VZInitEnd */
   RS_ST_RH_END,                  /* atm%RhzInitEnd */

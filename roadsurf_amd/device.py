@@ -177,6 +177,14 @@ class Plan:
     def failed_count(self) -> int:
         return int(self.L.rs_hip_failed_count(self._h))
 
+    def first_failed_index(self):
+        """numpy int32[npoints]: 0, or the 1-based index at which the point's run was failed."""
+        import numpy as np
+        out = np.zeros(self.npoints, np.int32)
+        lib.check(self.L.rs_hip_first_failed_index(self._h, C.c_void_p(out.ctypes.data)),
+                  "rs_hip_first_failed_index")
+        return out
+
     def timing_reset(self) -> None:
         self.L.rs_hip_timing_reset(self._h)
 

@@ -104,6 +104,8 @@ module RoadSurfHip
    type, bind(C), public :: RsHostExtras
       type(c_ptr) :: sun, sin_lat, cos_lat, lon_rad
       real(c_double) :: albedo_surroundings
+      type(c_ptr) :: first_failed
+      integer(c_int) :: writeback
    end type RsHostExtras
 
    interface
@@ -134,6 +136,7 @@ module RoadSurfHip
    end interface
 
    public :: rs_build_constants, rs_bottom_temperature, runsimulation, runsimulation_batch
+   public :: runsimulation_batch_ex
    public :: rs_fortran_sizeof, rs_sun_table, rs_point_geometry
 
 contains
@@ -436,6 +439,25 @@ contains
       type(InputParameters), intent(in) :: inputParam
       type(LocalParameters), intent(in) :: localParam(n)
       integer(c_int), intent(out) :: status
+      call runsimulation_batch_ex(n, outPointers, inPointers, inSettings, inputParam, localParam, status, &
+                                  c_null_ptr)
+   end subroutine runsimulation_batch
+
+   !> Same; first_failed (int32[n] or NULL) receives per point 0 or the 1-based time index at which
+   !! CheckValues failed it.  ROADSURF_HIP_WRITEBACK=1: the reference's in-place edits of the input
+   !! arrays (SW_dir clamp, sky-view SW/SW_dir/LW) are written back to the caller.
+   subroutine runsimulation_batch_ex(n, outPointers, inPointers, inSettings, inputParam, localParam, status, &
+                                     first_failed) bind(C, name='runsimulation_batch_ex')
+      integer(c_int), value :: n
+      type(OutputPointers), intent(inout) :: outPointers(n)
+      type(InputPointers), intent(in) :: inPointers(n)
+      type(InputSettings), intent(in) :: inSettings
+      type(InputParameters), intent(in) :: inputParam
+      type(LocalParameters), intent(in) :: localParam(n)
+      integer(c_int), intent(out) :: status
+      type(c_ptr), value :: first_failed
+      character(len=8) :: envv
+      integer :: envl, envs
 
       type(RsConstants) :: consts
       type(RsHostExtras) :: extras
@@ -478,6 +500,12 @@ contains
 
       extras%sun = c_null_ptr; extras%sin_lat = c_null_ptr; extras%cos_lat = c_null_ptr
       extras%lon_rad = c_null_ptr; extras%albedo_surroundings = inputParam%Albedo_surroundings
+      extras%first_failed = first_failed
+      extras%writeback = 0
+      call get_environment_variable('ROADSURF_HIP_WRITEBACK', envv, envl, envs)
+      if (envs == 0 .and. envl >= 1) then
+         if (envv(1:1) /= '0') extras%writeback = 1
+      end if
       if (any_sky) then
          ! the solar quantities that depend on time only are computed here, on the host, for
          ! the time axis of point 1; the device path needs that axis to be shared by all points
@@ -511,7 +539,7 @@ contains
                              rs_host_default_device())
       if (rc /= 0) status = rc
       deallocate (tbottom)
-   end subroutine runsimulation_batch
+   end subroutine runsimulation_batch_ex
 
    !> Drop-in for the reference's runsimulation (examples/example1/src/Simulation.f90:4-117).
    !! No status argument, as in the reference: on a device/runtime error the

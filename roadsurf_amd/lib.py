@@ -71,7 +71,7 @@ class RsPointParams(C.Structure):
 
 class RsHostExtras(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("sun", "sin_lat", "cos_lat", "lon_rad")] + \
-               [("albedo_surroundings", C.c_double)]
+               [("albedo_surroundings", C.c_double), ("first_failed", C.c_void_p), ("writeback", C.c_int32)]
 
 
 RS_PREVIEW_MAX = 8
@@ -91,13 +91,13 @@ class RsSynthSpec(C.Structure):
 #: every symbol ``include/roadsurf.h`` declares
 EXPORTS = (
     "rs_default_parameters", "rs_default_settings", "rs_default_local",
-    "runsimulation", "runsimulation_batch", "rs_build_constants", "rs_bottom_temperature",
+    "runsimulation", "runsimulation_batch", "runsimulation_batch_ex", "rs_build_constants", "rs_bottom_temperature",
     "rs_sun_table", "rs_point_geometry",
     "rs_last_error", "rs_hip_device_count", "rs_hip_plan_create", "rs_hip_plan_destroy",
     "rs_hip_plan_npoints", "rs_hip_plan_npoints_padded", "rs_hip_plan_state_bytes",
     "rs_hip_init_state", "rs_hip_step", "rs_hip_state_download", "rs_hip_state_upload",
-    "rs_hip_failed_count", "rs_hip_sync", "rs_hip_synth_knots", "rs_hip_expand_forcing", "rs_hip_expand_forcing_on",
-    "rs_hip_plan_order", "rs_hip_recluster", "rs_hip_recluster_forecast", "rs_hip_set_history_score", "rs_hip_plan_order_copy", "rs_hip_plan_reset_order", "rs_hip_set_variant", "rs_hip_set_precision", "rs_hip_test_math", "rs_hip_division_mode", "rs_hip_div_mismatch_count", "rs_hip_div_special_count", "rs_hip_div_samples", "rs_hip_timing_reset", "rs_hip_timing_step_ms", "rs_hip_timing_intervals",
+    "rs_hip_failed_count", "rs_hip_first_failed_index", "rs_hip_sync", "rs_hip_synth_knots", "rs_hip_expand_forcing", "rs_hip_expand_forcing_on",
+    "rs_hip_plan_order", "rs_hip_recluster", "rs_hip_recluster_forecast", "rs_hip_set_history_score", "rs_hip_set_writeback", "rs_hip_plan_order_copy", "rs_hip_plan_reset_order", "rs_hip_set_variant", "rs_hip_set_precision", "rs_hip_test_math", "rs_hip_division_mode", "rs_hip_div_mismatch_count", "rs_hip_div_special_count", "rs_hip_div_samples", "rs_hip_timing_reset", "rs_hip_timing_step_ms", "rs_hip_timing_intervals",
     "rs_host_run_batch", "rs_last_fanout", "rs_driver_run", "rs_driver_expand", "rs_driver_release_cache", "rs_abi_version", "rs_abi_sizeof", "rs_fortran_sizeof",
 )
 
@@ -145,6 +145,10 @@ def load() -> C.CDLL:
                                       P(abi.InputSettings), P(abi.InputParameters),
                                       P(abi.LocalParameters), P(C.c_int32)]
     L.runsimulation_batch.restype = None
+    L.runsimulation_batch_ex.argtypes = [C.c_int32, P(abi.OutputPointers), P(abi.InputPointers),
+                                         P(abi.InputSettings), P(abi.InputParameters),
+                                         P(abi.LocalParameters), P(C.c_int32), C.c_void_p]
+    L.runsimulation_batch_ex.restype = None
     L.rs_hip_plan_create.argtypes = [C.c_int32, C.c_int64, P(RsConstants), C.c_void_p]
     L.rs_hip_plan_create.restype = C.c_void_p
     L.rs_hip_plan_destroy.argtypes = [C.c_void_p]
@@ -160,6 +164,7 @@ def load() -> C.CDLL:
     L.rs_hip_state_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.rs_hip_state_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.rs_hip_sync.argtypes = [C.c_void_p]
+    L.rs_hip_first_failed_index.argtypes = [C.c_void_p, C.c_void_p]
     L.rs_hip_synth_knots.argtypes = [C.c_void_p, P(RsSynthSpec), C.c_void_p, C.c_int32, C.c_int32]
     L.rs_hip_expand_forcing.argtypes = [C.c_void_p, P(RsSynthSpec), C.c_void_p, C.c_int32,
                                         C.c_int32, P(RsForcing), C.c_int32, C.c_int32]
@@ -170,6 +175,7 @@ def load() -> C.CDLL:
     L.rs_hip_recluster.argtypes = [C.c_void_p]
     L.rs_hip_recluster_forecast.argtypes = [C.c_void_p, P(RsPreview)]
     L.rs_hip_set_history_score.argtypes = [C.c_void_p, C.c_int32]
+    L.rs_hip_set_writeback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.rs_hip_plan_order_copy.argtypes = [C.c_void_p, C.c_void_p]
     L.rs_hip_plan_reset_order.argtypes = [C.c_void_p]
     L.rs_hip_set_variant.argtypes = [C.c_void_p, C.c_int32]

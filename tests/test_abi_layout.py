@@ -39,7 +39,7 @@ def test_reference_struct_offsets():
 
 def test_library_exports_every_declared_symbol(hip_lib):
     header = open(os.path.join(ROOT, "include", "roadsurf.h")).read()
-    declared = set(re.findall(r"\b((?:rs_[a-z0-9_]+|runsimulation(?:_batch)?))\s*\(", header))
+    declared = set(re.findall(r"\b((?:rs_[a-z0-9_]+|runsimulation(?:_batch(?:_ex)?)?))\s*\(", header))
     declared -= {"rs_last_error()"}
     assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
     for sym in declared:
@@ -91,3 +91,117 @@ def test_product_never_imports_the_oracle():
                 assert "oracle/" not in txt.replace("the oracle", "") or fn in ("rs_synth.h",), \
                     os.path.join(dp, fn)
                 assert "liboracle" not in txt and "libroadsurf_ref" not in txt, os.path.join(dp, fn)
+
+
+REF_SRC = "/root/reference/examples/example1/src"
+
+
+def _run(cmd, cwd):
+    import subprocess
+    r = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True)
+    assert r.returncode == 0, " ".join(cmd) + "\n" + r.stdout[-1500:] + r.stderr[-3000:]
+    return r
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SRC), reason="build container only: needs /root/reference")
+def test_layout_against_the_reference_headers_compiled(tmp_path):
+    """The reference's own InputPointers.h / OutputPointers.h (they include nothing) compiled beside
+    include/roadsurf.h (ours in a namespace): sizeof and offsetof of every member must agree, checked
+    by the compiler.  (InputSettings.h / InputParameters.h / LocalParameters.h need jsoncpp, which
+    the image lacks; their layouts are pinned by the Fortran side: rs_fortran_sizeof and the
+    reference's .f90.inc files compiled into oracle/_ref.)"""
+    src = tmp_path / "layout.cpp"
+    members_in = ["inputLen", "c_tair", "c_tdew", "c_VZ", "c_Rhz", "c_prec", "c_SW", "c_LW", "c_SW_dir",
+                  "c_LW_net", "c_TSurfObs", "c_PrecPhase", "c_local_horizons", "c_Depth", "c_year",
+                  "c_month", "c_day", "c_hour", "c_minute", "c_second"]
+    members_out = ["outputLen", "c_TsurfOut", "c_SnowOut", "c_WaterOut", "c_IceOut", "c_DepositOut",
+                   "c_Ice2Out"]
+    lines = ["#include <cstddef>", "#include <cstdint>", "#include <stddef.h>", "#include <stdint.h>",
+             f'#include "{REF_SRC}/InputPointers.h"', f'#include "{REF_SRC}/OutputPointers.h"',
+             "namespace ours {", f'#include "{ROOT}/include/roadsurf.h"', "}",
+             "#define SAME(T, m) static_assert(offsetof(::T, m) == offsetof(ours::T, m) && "
+             "sizeof(((::T *)0)->m) == sizeof(((ours::T *)0)->m), #T \".\" #m)",
+             "static_assert(sizeof(::InputPointers) == sizeof(ours::InputPointers), \"InputPointers\");",
+             "static_assert(sizeof(::OutputPointers) == sizeof(ours::OutputPointers), \"OutputPointers\");"]
+    lines += [f"SAME(InputPointers, {m});" for m in members_in]
+    lines += [f"SAME(OutputPointers, {m});" for m in members_out]
+    lines += ["int main() { return 0; }"]
+    src.write_text("\n".join(lines) + "\n")
+    _run(["g++", "-std=c++17", "-Wall", "-fsyntax-only", str(src)], tmp_path)
+    # and the check does bite: a shifted member must not compile
+    bad = tmp_path / "bad.cpp"
+    bad.write_text(src.read_text().replace("SAME(InputPointers, c_tdew);",
+                                           "static_assert(offsetof(::InputPointers, c_tdew) == "
+                                           "offsetof(ours::InputPointers, c_VZ), \"shifted\");"))
+    import subprocess
+    assert subprocess.run(["g++", "-std=c++17", "-fsyntax-only", str(bad)], capture_output=True).returncode != 0
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SRC), reason="build container only: needs /root/reference")
+def test_reference_declaration_of_runsimulation_links_against_the_library(tmp_path, hip_lib):
+    """A translation unit that declares `runsimulation` exactly as the reference's driver does
+    (examples/example1/src/roadrunner.cpp:22-29), over the reference's own pointer structs, links
+    against libroadsurf_hip.so: same symbol, C linkage, five by-reference arguments.  (Only the
+    address is taken: no GPU here.)"""
+    src = tmp_path / "link.cpp"
+    src.write_text(f'''
+#include "{REF_SRC}/InputPointers.h"
+#include "{REF_SRC}/OutputPointers.h"
+struct InputSettings; struct InputParameters; struct LocalParameters;
+// The fortran API
+extern "C"
+{{
+  void runsimulation(OutputPointers* pOutputPointers,
+                     const InputPointers* pInputPointers,
+                     const InputSettings* pSettings,
+                     const InputParameters* pInputParams,
+                     const LocalParameters* lParameters);
+}}
+#include <cstdio>
+int main() {{
+  void (*f)(OutputPointers*, const InputPointers*, const InputSettings*, const InputParameters*,
+            const LocalParameters*) = &runsimulation;
+  std::printf("%d\\n", f != nullptr);
+  return 0;
+}}
+''')
+    libdir = os.path.join(ROOT, "roadsurf_amd", "lib")
+    exe = tmp_path / "link"
+    _run(["g++", "-std=c++17", str(src), "-o", str(exe), f"-L{libdir}", "-lroadsurf_hip",
+          f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined"], tmp_path)
+    r = _run([str(exe)], tmp_path)
+    assert r.stdout.strip() == "1"
+
+
+def test_reference_module_names_resolve_for_fortran_callers(tmp_path, hip_lib):
+    """Caller code written against the reference says `use RoadSurfVariables` (and `use RoadSurf`):
+    it must compile against this library's module files and see the five Bind(C) types with the
+    reference's component names, plus the entry points."""
+    import shutil
+    if shutil.which("amdflang") is None:
+        pytest.skip("no Fortran compiler")
+    moddir = os.path.join(ROOT, "roadsurf_amd", "build")
+    src = tmp_path / "caller.f90"
+    src.write_text('''
+subroutine caller(outp, inp, n)
+   use, intrinsic :: iso_c_binding
+   use RoadSurfVariables
+   use RoadSurf
+   implicit none
+   integer(c_int), value :: n
+   type(OutputPointers), intent(inout) :: outp(n)
+   type(InputPointers), intent(in) :: inp(n)
+   type(InputSettings) :: s
+   type(InputParameters) :: p
+   type(LocalParameters) :: l(n)
+   integer(c_int) :: status
+   s%SimLen = inp(1)%inputLen; s%use_coupling = 0; s%use_relaxation = 0; s%force_tsurf = 0
+   s%DTSecs = 30.0d0; s%tsurfOutputDepth = -9999.9d0; s%NLayers = 15; s%coupling_minutes = 180
+   s%couplingEffectReduction = 14400.0d0; s%outputStep = 60
+   p%NightOn = 19.0d0; p%MinIcemms = 0.0d0
+   l(:)%sky_view = 1.0d0; l(:)%InitLenI = 1; l(:)%couplingIndexI = -9999
+   call runsimulation(outp(1), inp(1), s, p, l(1))
+   call runsimulation_batch(n, outp, inp, s, p, l, status)
+end subroutine caller
+''')
+    _run(["amdflang", "-c", f"-I{moddir}", str(src), "-o", str(tmp_path / "caller.o")], tmp_path)

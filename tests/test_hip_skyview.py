@@ -76,3 +76,100 @@ def test_sky_view_with_coupling_and_c_abi():
     assert st.value == 0, lib.last_error()
     for k in oh.F64_OUT:
         assert np.array_equal(out[k], ora[k]), k
+
+
+def _batch_arrays(g, out, n):
+    ips = (abi.InputPointers * n)(); ops = (abi.OutputPointers * n)(); keep = []
+    for pt in range(n):
+        ip, op, kp = oh.point_pointers(g, pt, out)
+        hzrow = np.ascontiguousarray(g["local_horizons"][pt])
+        ip.c_local_horizons = hzrow.ctypes.data_as(abi.c_double_p)
+        ips[pt], ops[pt] = ip, op
+        keep.append((kp, hzrow))
+    return ips, ops, keep
+
+
+@pytest.mark.parametrize("coupled", [False, True], ids=["plain", "coupling"])
+def test_writeback_of_the_in_place_input_edits(coupled, monkeypatch):
+    """The reference edits the caller's input arrays (Ownership): SW_dir is clamped to
+    SW at every checked index (src/InputOutput.f90:75-77) and the sky-view correction rewrites SW,
+    SW_dir and LW (src/ModRadiation.f90:57-71); a point that fails keeps its arrays from there on.
+    With ROADSURF_HIP_WRITEBACK=1 runsimulation_batch leaves the same bits in those arrays as the
+    reference's run does (the harness hands its mutated inputs back); without it they are untouched."""
+    L_ = lib.load()
+    n, SL = 96, 1441
+    f, ls = _sky_case(n, SL, 21, summer=True)
+    f["tair"][5, 700] = -200.0          # fails at index 701: arrays beyond stay as they were
+    ls[7].sky_view = 1.0                # no sky view for this one: only the SW_dir clamp
+    p = abi.default_parameters()
+    s = abi.default_settings(SL)
+    kind = "ref" if oh.have_ref() else "port"
+    if coupled:
+        base, _, _ = oh.run_oracle("port", f, s, p, ls)
+        rs = np.random.RandomState(3)
+        for i, li in enumerate(ls):
+            li.couplingIndexI = 900; li.InitLenI = 900
+            li.couplingTsurf = float(base["tsurf"][i, 899] + rs.choice([0.0, 1.5, -2.0]))
+        f["tsurfobs"][:, :] = np.where(base["tsurf"] > -9000, base["tsurf"] + 0.2, -9999.9)
+        s = abi.default_settings(SL); s.use_coupling = 1
+        kind = "ref_cpl" if os.path.exists(oh.REF_CPL_SO) else "port"
+    ora, fmut, _ = oh.run_oracle(kind, f, s, p, ls)
+    assert (fmut["sw"] != f["sw"]).mean() > 0.05 and (fmut["sw_dir"] != f["sw_dir"]).mean() > 0.05
+
+    def run():
+        g = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in f.items()}
+        out = {k: np.full((n, SL), np.nan) for k in oh.F64_OUT}
+        ips, ops, keep = _batch_arrays(g, out, n)
+        larr = (abi.LocalParameters * n)(*ls)
+        st = C.c_int32(99)
+        ff = np.full(n, -1, np.int32)
+        L_.runsimulation_batch_ex(n, ops, ips, C.byref(s), C.byref(p), larr, C.byref(st),
+                                  C.c_void_p(ff.ctypes.data))
+        assert st.value == 0, lib.last_error()
+        return g, out, ff
+
+    monkeypatch.setenv("ROADSURF_HIP_WRITEBACK", "1")
+    monkeypatch.setenv("ROADSURF_HIP_TILE_POINTS", "40")   # three tiles
+    g, out, ff = run()
+    for k in oh.F64_OUT:
+        assert np.array_equal(out[k], ora[k]), k
+    for k in ("sw", "sw_dir", "lw", "vz"):
+        assert np.array_equal(g[k], fmut[k]), (k, int((g[k] != fmut[k]).sum()))
+    for k in ("tair", "rhz", "prec", "lw_net", "tsurfobs"):
+        assert np.array_equal(g[k], f[k]), k
+    want = np.zeros(n, np.int32); want[5] = 701
+    assert np.array_equal(ff, want)
+    monkeypatch.setenv("ROADSURF_HIP_WRITEBACK", "0")
+    g, out, _ = run()
+    for k in ("sw", "sw_dir", "lw"):
+        assert np.array_equal(g[k], f[k]), k
+
+
+def test_writeback_of_the_sw_dir_clamp_without_sky_view(monkeypatch):
+    L_ = lib.load()
+    n, SL = 50, 721
+    f = oh.synth_forcing(n, SL, seed=12)
+    rs = np.random.RandomState(4)
+    f["sw"] += 50.0
+    f["sw_dir"] = np.ascontiguousarray(f["sw"] * rs.uniform(0.5, 1.5, (n, SL)))
+    f["local_horizons"] = np.zeros((n, 360))
+    f["tair"][3, 100] = 150.0           # fails at index 101
+    f["rhz"][9, 0] = 130.0              # fails at index 1
+    s = abi.default_settings(SL); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
+    ora, fmut, _ = oh.run_oracle("ref" if oh.have_ref() else "port", f, s, p, l)
+    monkeypatch.setenv("ROADSURF_HIP_WRITEBACK", "1")
+    g = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in f.items()}
+    out = {k: np.full((n, SL), np.nan) for k in oh.F64_OUT}
+    ips, ops, keep = _batch_arrays(g, out, n)
+    larr = (abi.LocalParameters * n)(*([l] * n))
+    st = C.c_int32(99)
+    ff = np.full(n, -1, np.int32)
+    L_.runsimulation_batch_ex(n, ops, ips, C.byref(s), C.byref(p), larr, C.byref(st), C.c_void_p(ff.ctypes.data))
+    assert st.value == 0, lib.last_error()
+    for k in oh.F64_OUT:
+        assert np.array_equal(out[k], ora[k]), k
+    assert np.array_equal(g["sw_dir"], fmut["sw_dir"]) and (fmut["sw_dir"] != f["sw_dir"]).mean() > 0.2
+    assert ff[3] == 101 and ff[9] == 1 and (np.delete(ff, [3, 9]) == 0).all()
+    # the same numbers from the reference's outputs: the first index it left at -9999.0
+    first_missing = np.where((ora["tsurf"] == -9999.0).any(1), (ora["tsurf"] == -9999.0).argmax(1), 0)
+    assert np.array_equal(ff, first_missing.astype(np.int32))
