@@ -315,8 +315,8 @@ def main() -> None:
                           "intervals (busy_ms); = units_per_launch x bytes / avg_launch_ms x "
                           "concurrent_launches; per_launch_achieved is the single-launch figure",
                 "step_kernel_only_value": units_per_pass_rank * args.steps / (busy_ms / 1e3),
-                "note": "fp64-VALU-bound kernel (SURVEY.md 8d): the HBM fraction is reported "
-                        "as the contract asks, the binding roofline is vector fp64 issue",
+                "note": ("fp32" if args.f32 else "fp64") + "-VALU-bound kernel (SURVEY.md 8d): the HBM fraction "
+                        "is reported as the contract asks, the binding roofline is vector-ALU issue",
             },
         }
         if natural is not None:

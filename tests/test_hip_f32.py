@@ -11,7 +11,7 @@ brackets, tolerances ~3x above them):
 import os
 import sys
 
-import numpy as np
+import numpy as np  # noqa: E402
 import pytest
 
 import oracle_helpers as oh
@@ -61,3 +61,83 @@ def test_fp32_plan_order_changes_no_value():
     b = run_f32(n, L, seed, chunk=120, cluster=True)
     for k in ("tsurf", "snow", "water", "ice", "deposit", "ice2"):
         assert np.array_equal(a[k], b[k]), k
+
+
+# ---- BASELINE config 5 at its shape: 7-day hindcast (SimLen 20 161), 1.25 M points per GPU -------
+# (10 M points over 8 GPUs; examples/example1/src/InputSettings.cpp:98 gives SimLen = 1 + 168*3600/30)
+#
+# SURVEY.md 8d proposes 0.05 K / 0.05 mm as the tolerance "to be justified empirically".  Measured
+# (tools/f32_7d.py, 2 048 points x 7 d, two seeds; in brackets) and gated here at a few times that:
+#   * 99.999 % of the point-steps are within 0.05 K of the fp64 reference  [beyond: 2.1e-6, 7.8e-7]
+#   * the rest are short transients after a melt-out branch went the other way (rs_math.hpp):
+#     0.2-0.3 % of the points ever leave the 0.05 K band, for a median of 3-6 minutes, the longest
+#     12 minutes, never further than 0.17 K; they decay - days 6-7 are at rms 3e-6 K: no drift
+#   * Tsurf rms 1.5e-4 K, 99.9th percentile 6e-5 K; storages rms < 4e-5 mm, max 0.06 mm
+# A pointwise 0.05 K bound cannot hold for arithmetic that differs at all (the reference's own
+# storage logic amplifies a last-bit difference to 0.2 K); the distribution does.
+HOURS7, L7 = 168, 168 * 120 + 1
+
+
+@pytest.mark.parametrize("seed", [20240110, 777])
+def test_fp32_seven_day_distribution_gate(seed):
+    from f32_experiment import run_f32
+    n = 2048
+    f = oh.synth_forcing(n, L7, seed=seed)
+    s = abi.default_settings(L7); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
+    ora, _, _ = oh.run_oracle("ref" if oh.have_ref() else "port", f, s, p, l)
+    res = run_f32(n, L7, seed)
+    d = np.abs(res["tsurf"] - ora["tsurf"])
+    over = d > 0.05
+    runs = [0]
+    for q in np.where(over.any(1))[0]:
+        x = np.flatnonzero(np.diff(np.concatenate([[0], over[q].astype(np.int8), [0]])))
+        runs += list(x[1::2] - x[0::2])
+    print("seed %d: rms %.2e p99.9 %.2e max %.3f frac>0.05K %.2e points ever %.4f longest %.0f min" %
+          (seed, np.sqrt((d ** 2).mean()), np.percentile(d, 99.9), d.max(), over.mean(),
+           over.any(1).mean(), max(runs) * 0.5))
+    assert over.mean() < 1e-5                     # 99.999 % of the point-steps within 0.05 K
+    assert over.any(1).mean() < 0.015 and max(runs) * 30 < 2 * 3600   # few points, short transients
+    assert d.max() < 0.5 and np.sqrt((d ** 2).mean()) < 5e-4 and np.percentile(d, 99.9) < 3e-4
+    last2 = d[:, -2 * 2880:]
+    assert np.sqrt((last2 ** 2).mean()) < 2e-4    # no drift: the last two days are as good as the first
+    for k in ("snow", "water", "ice", "deposit", "ice2"):
+        e = np.abs(res[k] - ora[k])
+        assert np.sqrt((e ** 2).mean()) < 2e-4 and e.max() < 0.2 and (e > 0.05).mean() < 1e-6, k
+
+
+def test_fp32_config5_shape_properties_1250000_points_7_days():
+    """The shape itself: 1.25 M points (one GPU's share of 10 M over 8) x SimLen 20 161 in fp32
+    through the object bench.py times - no NaN, storages within their limits, deterministic,
+    plan order value-neutral (checksum and sampled points equal to the natural-order pass)."""
+    import torch
+    from roadsurf_amd import device, workload
+    from test_hip_golden_and_scale import _synthetic_pass
+    n, seed, chunk = 1_250_000, 20240110, 240
+    s = abi.default_settings(L7); p = abi.default_parameters()
+    plan = device.Plan(n, s, p, 0)
+    plan.set_precision(32)
+    cols = np.concatenate([np.arange(b, b + 64) for b in (0, 600_000, 1_249_920)])
+    run = workload.SyntheticRun(plan, seed, HOURS7, chunk, plan_order=False, f32=True)
+    assert run.simlen == L7
+    c1, samp1, mins, maxs = _synthetic_pass(run, cols, itype=torch.int32)
+    del run
+    torch.cuda.empty_cache()
+    assert plan.failed_count() == 0
+    assert -100.0 <= mins["tsurf"] and maxs["tsurf"] <= 100.0
+    for k, hi in (("snow", p.MaxSnowmms), ("water", p.MaxWatmms), ("ice", p.MaxIcemms),
+                  ("deposit", p.MaxDepmms), ("ice2", p.MaxIcemms)):
+        assert mins[k] >= 0.0 and maxs[k] <= hi * (1 + 1e-6), (k, mins[k], maxs[k])
+    assert maxs["snow"] > 1 and maxs["ice"] > 1
+    run = workload.SyntheticRun(plan, seed, HOURS7, chunk, plan_order=True, f32=True)
+    c2, samp2, mins2, maxs2 = _synthetic_pass(run, cols, itype=torch.int32)
+    assert c2 == c1 and mins2 == mins and maxs2 == maxs
+    for k in device.OUT_FIELDS:
+        assert np.array_equal(samp1[k], samp2[k]), k
+    del run
+    plan.close()
+    # the sampled blocks against the fp64 reference: same gate as above, on this run's own points
+    l = abi.default_local(); l.InitLenI = 1
+    f = oh.synth_forcing(64, L7, seed=seed, point_offset=600_000)
+    ora, _, _ = oh.run_oracle("ref" if oh.have_ref() else "port", f, s, p, l)
+    d = np.abs(samp1["tsurf"][:, 64:128].T.astype(np.float64) - ora["tsurf"])
+    assert (d > 0.05).mean() < 1e-4 and d.max() < 0.5

@@ -93,7 +93,7 @@ def test_golden_skyview_on_gpu():
         assert np.array_equal(res[k][:, idx], z[f"sky_{k}"]), k
 
 
-def _synthetic_pass(run, sample_points):
+def _synthetic_pass(run, sample_points, itype=None):
     """One full pass of roadsurf_amd.workload.SyntheticRun - the object bench.py times.
     Returns (order-independent wrap-around checksum of all six outputs, the sampled points'
     series [field][simlen][npoints_sampled] mapped back through the per-launch order rows,
@@ -103,6 +103,7 @@ def _synthetic_pass(run, sample_points):
     plan = run.plan
     dev = plan.device
     n = plan.npoints
+    itype = itype or torch.int64   # integer view of the output element: int32 for fp32 plans
     acc = {"sum": torch.zeros((), dtype=torch.int64, device=dev)}
     mins = {k: float("inf") for k in device.OUT_FIELDS}
     maxs = {k: float("-inf") for k in device.OUT_FIELDS}
@@ -117,7 +118,7 @@ def _synthetic_pass(run, sample_points):
             assert int(torch.bincount(o, minlength=n).max()) == 1
         for k in device.OUT_FIELDS:
             o = run.out.tensors[k][:ns, :n]
-            acc["sum"] += o.view(torch.int64).sum()
+            acc["sum"] += o.view(itype).sum(dtype=torch.int64)
             mins[k] = min(mins[k], float(o.min())); maxs[k] = max(maxs[k], float(o.max()))
             assert not torch.isnan(o).any()
             sampled[k].append(o[:, cols].clone())
