@@ -330,6 +330,29 @@ int rs_hip_init_state(RsPlan *plan, const RsForcing *f, const RsPointParams *pp)
 int rs_hip_step(RsPlan *plan, const RsForcing *f, const RsOutputs *o,
                 const RsPointParams *pp, int32_t t0, int32_t nsteps);
 
+/* Coupling with time-chunked windows.  rs_hip_step with coupling wants the whole series in one
+ * window, because a point replays its coupling window (src/Coupling.f90:61-78).  The pair below
+ * lets a caller keep windows of a few hundred indices:
+ *   rs_hip_step_cpl    like rs_hip_step for a chunk [t0, t0+nsteps) of a coupled plan, in lock step:
+ *                      saves the state at a point's couplingStartI, runs the first pass of its
+ *                      window, decides at couplingEndI (Coupling_control), applies the decaying
+ *                      corrections behind it - but never replays: a point that must replay PARKS
+ *                      behind its window (and takes no step in later rs_hip_step_cpl calls) until
+ *   rs_hip_cpl_replay  has run its replays: the window `f` must cover every parked point's
+ *                      [couplingStartI, couplingEndI + 1] (t0 <= min start, t0+nsteps-1 >= max end + 1 unless that
+ *                      is beyond SimLen: the reference runs CheckValues on the index behind the
+ *                      window before it rewinds, examples/example1/src/Simulation.f90:59-66);
+ *                      rounds of the general kernel over the compacted list of points that still
+ *                      ask for a replay, until none does (`rounds` = how many, <= 25).
+ * A point only ever steps the index it is due for (it remembers it), so the caller then simply
+ * continues - or, if the points' windows end at different indices, re-issues - the chunks from
+ * min(couplingEndI) + 1 on: points that are ahead wait.  No sky view here (that combination goes
+ * through rs_hip_step).  Outputs of replayed indices are overwritten, as in the reference. */
+int rs_hip_step_cpl(RsPlan *plan, const RsForcing *f, const RsOutputs *o,
+                    const RsPointParams *pp, int32_t t0, int32_t nsteps);
+int rs_hip_cpl_replay(RsPlan *plan, const RsForcing *f, const RsOutputs *o,
+                      const RsPointParams *pp, int32_t t0, int32_t nsteps, int32_t *rounds);
+
 /* The reference edits its INPUT arrays in place (SURVEY.md 8b "Ownership"): CheckValues clamps
  * SW_dir(i) to SW(i) (src/InputOutput.f90:75-77) and the sky-view correction rewrites SW(i),
  * SW_dir(i), LW(i) (src/ModRadiation.f90:57-71).  The device forcing windows are never modified;

@@ -61,6 +61,11 @@ struct RsPlan {
   void *consts_dev = nullptr;   /* RsConstantsDev (rs_consts_dev.h) */
   void *consts32_dev = nullptr; /* RsConstantsF, allocated by rs_hip_set_precision(32) */
   rs::Writeback wb{nullptr, nullptr, nullptr, 0};
+  /* coupling rounds: scratch for the list of points that replay their window */
+  int32_t *cpl_flags = nullptr, *cpl_list = nullptr, *cpl_count = nullptr;
+  void *cpl_tmp = nullptr;
+  size_t cpl_tmp_bytes = 0;
+  int32_t cpl_rounds_last = 0; /* replay rounds of the last coupled rs_hip_step (diagnostics) */
   bool history_score = true; /* the step kernels leave the sort key of rs_hip_recluster */
   bool f32 = false; /* single-precision flavour: windows and state hold floats */
   std::vector<hipEvent_t> ev; /* start/stop pairs */
@@ -240,6 +245,10 @@ void rs_hip_plan_destroy(RsPlan *pl) {
   if (pl->state_alt) (void)hipFree(pl->state_alt);
   if (pl->sort_tmp) (void)hipFree(pl->sort_tmp);
   if (pl->sort_keys) (void)hipFree(pl->sort_keys);
+  if (pl->cpl_flags) (void)hipFree(pl->cpl_flags);
+  if (pl->cpl_list) (void)hipFree(pl->cpl_list);
+  if (pl->cpl_count) (void)hipFree(pl->cpl_count);
+  if (pl->cpl_tmp) (void)hipFree(pl->cpl_tmp);
   delete pl;
 }
 
@@ -406,6 +415,38 @@ int rs_hip_init_state(RsPlan *pl, const RsForcing *f, const RsPointParams *pp) {
   return 0;
 }
 
+/* The replay rounds of a coupled run: while some points ask for another replay of their coupling
+ * window (start_coupling_again), those points - compacted into full wavefronts - rewind, replay
+ * the window and park again (step_kernel_coupled with cpl_stop).  `a` describes a window that
+ * covers every such point's [couplingStartI, couplingEndI]. */
+static int cpl_replay_rounds(RsPlan *pl, rs::StepArgs a) {
+  if (!pl->cpl_list) {
+    HIP_OK(hipMalloc(&pl->cpl_flags, (size_t)2 * pl->np_pad * sizeof(int32_t)));
+    HIP_OK(hipMalloc(&pl->cpl_list, (size_t)pl->np_pad * sizeof(int32_t)));
+    HIP_OK(hipMalloc(&pl->cpl_count, sizeof(int32_t)));
+    pl->cpl_tmp_bytes = rs_cpl_select_scratch_bytes(pl->npoints);
+    HIP_OK(hipMalloc(&pl->cpl_tmp, pl->cpl_tmp_bytes ? pl->cpl_tmp_bytes : 8));
+  }
+  a.cpl_stop = 1;
+  pl->cpl_rounds_last = 0;
+  for (int round = 0; round < 64; ++round) { /* the reference stops at 25 */
+    HIP_OK(rs_cpl_select_again(pl->state, pl->np_pad, pl->npoints, pl->cpl_flags, pl->cpl_list,
+                               pl->cpl_count, pl->cpl_tmp, pl->cpl_tmp_bytes, pl->stream));
+    int32_t n_again = 0;
+    HIP_OK(hipMemcpyAsync(&n_again, pl->cpl_count, sizeof(n_again), hipMemcpyDeviceToHost, pl->stream));
+    HIP_OK(hipStreamSynchronize(pl->stream));
+    if (n_again == 0) break;
+    if (getenv("ROADSURF_HIP_DRIVER_TIMING"))
+      fprintf(stderr, "coupling round %d: %d of %lld points replay\n", round + 1, n_again,
+              (long long)pl->npoints);
+    a.cpl_list = pl->cpl_list;
+    a.cpl_nlist = n_again;
+    HIP_OK(rs_launch_step_coupled(a, pl->c.NLayers, pl->stream));
+    pl->cpl_rounds_last = round + 1;
+  }
+  return 0;
+}
+
 int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPointParams *pp,
                 int32_t t0, int32_t nsteps) {
   if (!pl) return set_err("rs_hip_step: null plan");
@@ -466,6 +507,9 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
   a.nsteps = nsteps;
   a.wb = pl->wb;
   if (a.wb.sw_dir && !skyview) a.wb = rs::Writeback{nullptr, nullptr, nullptr, 0};
+  a.cpl_list = nullptr;
+  a.cpl_nlist = 0;
+  a.cpl_stop = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (pl->timing) {
     if (pl->ev_used + 2 > pl->ev.size()) {
@@ -487,9 +531,24 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
     le = rs32_launch_step(a, pl->c.NLayers, pl->variant, pl->stream);
   else if (skyview && !coupled)
     le = rs_launch_step_sky(a, pl->c.NLayers, pl->stream); /* lock-step FULL + sky view */
-  else if (coupled)
+  else if (coupled) {
+    /* Rounds instead of "every wavefront replays until its slowest lane is through"
+     * (src/Coupling.f90:61-78,324: up to 25 replays of a window of up to 360 indices, per point):
+     *   1. every point steps to the end of its coupling window and parks there;
+     *   2. while some points ask for another replay: those points, compacted into full
+     *      wavefronts, rewind, replay their window and park again;
+     *   3. every point goes on from behind its window to the end of the series.
+     * A point's arithmetic is the same sequence whichever round executes it. */
+    a.cpl_stop = 1;
     le = rs_launch_step_coupled(a, pl->c.NLayers, pl->stream);
-  else
+    if (le == hipSuccess && cpl_replay_rounds(pl, a) != 0) return -1;
+    if (le == hipSuccess) {
+      a.cpl_list = nullptr;
+      a.cpl_nlist = 0;
+      a.cpl_stop = 0;
+      le = rs_launch_step_coupled(a, pl->c.NLayers, pl->stream);
+    }
+  } else
     le = rs_launch_step(a, pl->c.NLayers, full, pl->variant, pl->history_score, pl->stream);
   if (le != hipSuccess) /* the pair stays unused: ev_used has not advanced */
     return set_err("rs_hip_step: kernel launch failed: %s", hipGetErrorString(le));
@@ -497,6 +556,58 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
     HIP_OK(hipEventRecord(e1, pl->stream));
     pl->ev_used += 2;
   }
+  return 0;
+}
+
+/* common validation + argument block of the two chunked-coupling entry points */
+static int cpl_args(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPointParams *pp,
+                    int32_t t0, int32_t nsteps, const char *who, rs::StepArgs &a) {
+  if (!pl) return set_err("%s: null plan", who);
+  if (check_forcing(pl, f, who)) return -1;
+  if (!pp || !pp->tbottom || !pp->coupling_index || !pp->coupling_tsurf)
+    return set_err("%s: tbottom, coupling_index and coupling_tsurf are required", who);
+  if (!pl->c.use_coupling) return set_err("%s: the plan's settings have use_coupling = 0", who);
+  if (pl->f32) return set_err("%s: coupling needs the fp64 flavour", who);
+  if (pp->sky_view) return set_err("%s: sky view with coupling runs through rs_hip_step (whole series)", who);
+  if (pl->c.use_relaxation && pp->tair_relax && (!pp->vz_relax || !pp->rh_relax || !pp->initlen))
+    return set_err("%s: relaxation needs tair_relax, vz_relax, rh_relax and initlen", who);
+  if (!o || !o->tsurf || !o->snow || !o->water || !o->ice || !o->deposit || !o->ice2)
+    return set_err("%s: all six output streams are required", who);
+  if (o->t_stride < pl->npoints || o->decimate < 1) return set_err("%s: bad output window", who);
+  if (t0 < 1 || nsteps < 1 || (int64_t)t0 + nsteps - 1 > pl->c.SimLen)
+    return set_err("%s: window [%d,%d) outside [1,SimLen=%d]", who, t0, t0 + nsteps, pl->c.SimLen);
+  a.consts = pl->consts_dev;
+  a.f = *f;
+  a.o = *o;
+  a.pp = *pp;
+  a.state = pl->state;
+  a.npoints = pl->npoints;
+  a.np_pad = pl->np_pad;
+  a.t0 = t0;
+  a.nsteps = nsteps;
+  a.wb = rs::Writeback{nullptr, nullptr, nullptr, 0};
+  a.cpl_list = nullptr;
+  a.cpl_nlist = 0;
+  a.cpl_stop = 0;
+  return 0;
+}
+
+int rs_hip_step_cpl(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPointParams *pp,
+                    int32_t t0, int32_t nsteps) {
+  rs::StepArgs a;
+  if (cpl_args(pl, f, o, pp, t0, nsteps, "rs_hip_step_cpl", a)) return -1;
+  HIP_OK(hipSetDevice(pl->device));
+  HIP_OK(rs_launch_step_cpl(a, pl->c.NLayers, pl->stream));
+  return 0;
+}
+
+int rs_hip_cpl_replay(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPointParams *pp,
+                      int32_t t0, int32_t nsteps, int32_t *rounds) {
+  rs::StepArgs a;
+  if (cpl_args(pl, f, o, pp, t0, nsteps, "rs_hip_cpl_replay", a)) return -1;
+  HIP_OK(hipSetDevice(pl->device));
+  if (cpl_replay_rounds(pl, a)) return -1;
+  if (rounds) *rounds = pl->cpl_rounds_last;
   return 0;
 }
 

@@ -96,6 +96,36 @@ hipError_t rs_cluster_sort_keys(int64_t np_pad, int64_t npoints, uint32_t *scrat
                                             KEY_BITS, stream);
 }
 
+namespace {
+__global__ void __launch_bounds__(RS_BLOCK) again_flags_kernel(const double *__restrict__ state,
+                                                               int64_t np_pad, int64_t npoints,
+                                                               int32_t *flags, int32_t *iota) {
+  const int64_t p = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
+  if (p >= npoints) return;
+  flags[p] = ((int32_t)state[(int64_t)RS_ST_CPL_FLAGS * np_pad + p]) & 1; /* start_coupling_again */
+  iota[p] = (int32_t)p;
+}
+}  // namespace
+
+size_t rs_cpl_select_scratch_bytes(int64_t npoints) {
+  size_t bytes = 0;
+  int32_t *x = nullptr;
+  (void)hipcub::DeviceSelect::Flagged(nullptr, bytes, x, x, x, x, (int)npoints);
+  return bytes;
+}
+
+/* flags: scratch int32[2*npoints] (flags, then the identity list to select from) */
+hipError_t rs_cpl_select_again(const double *state, int64_t np_pad, int64_t npoints, int32_t *flags,
+                               int32_t *list, int32_t *count_dev, void *tmp, size_t tmp_bytes,
+                               hipStream_t stream) {
+  int32_t *iota = flags + npoints;
+  hipLaunchKernelGGL(again_flags_kernel, grid1(npoints), dim3(RS_BLOCK), 0, stream, state, np_pad,
+                     npoints, flags, iota);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return hipcub::DeviceSelect::Flagged(tmp, tmp_bytes, iota, flags, list, count_dev, (int)npoints, stream);
+}
+
 /* nlayers: NLayers of the plan; coupled: also move the coupling block (saved state etc.) */
 hipError_t rs_cluster_apply(const double *state_src, double *state_dst, bool f32,
                             const int32_t *order_src, int32_t *order_dst, const uint32_t *perm,

@@ -27,6 +27,10 @@ struct StepArgs {
   int64_t npoints, np_pad;
   int32_t t0, nsteps;
   Writeback wb;
+  /* coupling rounds (step_kernel_coupled): thread g works on point cpl_list[g] (NULL: point g);
+   * cpl_stop: a point parks right after the Coupling_control of its window end */
+  const int32_t *cpl_list;
+  int32_t cpl_nlist, cpl_stop;
 };
 
 struct InitArgs {
@@ -74,6 +78,12 @@ hipError_t rs_upload_math_tables(hipStream_t stream);
 hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant, bool score,
                           hipStream_t stream);
 hipError_t rs_launch_step_coupled(const rs::StepArgs &a, int NL, hipStream_t stream);
+hipError_t rs_launch_step_cpl(const rs::StepArgs &a, int NL, hipStream_t stream);
+/* list of the points whose coupling asks for another replay (start_coupling_again): list[0..*count) */
+size_t rs_cpl_select_scratch_bytes(int64_t npoints);
+hipError_t rs_cpl_select_again(const double *state, int64_t np_pad, int64_t npoints, int32_t *flags,
+                               int32_t *list, int32_t *count_dev, void *tmp, size_t tmp_bytes,
+                               hipStream_t stream);
 hipError_t rs_launch_step_sky(const rs::StepArgs &a, int NL, hipStream_t stream);
 hipError_t rs_launch_init(const rs::InitArgs &a, hipStream_t stream);
 hipError_t rs_launch_knots(const rs::KnotArgs &a, int32_t nknots, hipStream_t stream);

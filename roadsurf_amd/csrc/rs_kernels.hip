@@ -178,155 +178,6 @@ __device__ __forceinline__ void store_outputs(KernArgs ka, int32_t i, int64_t ro
   (ka->o.ice2 + row)[lane] = valid ? s.ice2 : miss;
 }
 
-/* The time loop of runsimulation (examples/example1/src/Simulation.f90:57-115)
- * for one point over absolute indices [t0, t0+nsteps). */
-/* SKY: sky view / local horizons (src/ModRadiation.f90, examples/example1/src/Simulation.f90:
- * 151-162) in the lock-step loop; with coupling the general kernel below does it. */
-template <bool FULL, class Prof, bool SKY = false, bool SCORE = true>
-__device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s, int32_t &score) {
-  static_assert(FULL || !SKY, "sky view belongs to the FULL feature set");
-  KernArgs ka = kernargs();
-  const uint32_t lane = threadIdx.x;
-  const int64_t row0 = (int64_t)blockIdx.x * kBlock; /* first point of this workgroup */
-  const int32_t nsteps = ka->nsteps, t0 = ka->t0;
-  const double tbot = (ka->pp.tbottom + row0)[lane];
-  double skyv = R4(1.0), sinlat = 0, coslat = 0, lonrad = 0;
-  bool sky_on = false;
-  if (SKY) {
-    skyv = (ka->pp.sky_view + row0)[lane];
-    sky_on = (skyv < R4(1.0) && skyv > R4(-0.01));
-    if (sky_on) {
-      sinlat = (ka->pp.sin_lat + row0)[lane];
-      coslat = (ka->pp.cos_lat + row0)[lane];
-      lonrad = (ka->pp.lon_rad + row0)[lane];
-    }
-  }
-  int32_t initlen = 0;
-  bool relax = false;
-  double tairR = 0, vzR = 0, rhR = 0;
-  if (FULL) {
-    initlen = ka->pp.initlen ? (ka->pp.initlen + row0)[lane] : 0;
-    if (consts_of(ka).use_relaxation && ka->pp.tair_relax) {
-      /* setInputParam, src/InputOutput.f90:19-26: targets pass through REAL(4) */
-      tairR = (double)(float)(ka->pp.tair_relax + row0)[lane];
-      vzR = (double)(float)(ka->pp.vz_relax + row0)[lane];
-      rhR = (double)(float)(ka->pp.rh_relax + row0)[lane];
-      relax = !(tairR < R4(-100.0) || tairR > R4(100.0) || vzR < R4(0.0) || vzR > R4(100.0) ||
-                rhR < R4(0.0) || rhR > 110);
-    }
-  }
-
-  /* settings%simulation_failed (src/InputOutput.f90:66): sticky; the state block keeps the index
-   * it was raised at (rs_hip_first_failed_index) */
-  auto fail_at = [&](int32_t idx) {
-    s.failed = true;
-    ka->state[(int64_t)RS_ST_FAILED * ka->np_pad + row0 + lane] = (double)idx;
-  };
-  Forcing nxt = load_forcing<FULL>(ka, row0, lane, 0);
-  for (int32_t k = 0; k < nsteps; ++k) {
-    asm volatile("" : "+s"(ka));
-    const ConstsAS &c = consts_of(ka);
-    const int32_t i = t0 + k;
-    const Forcing f = nxt;
-
-    if (s.failed) { /* loop has exited in the reference: outputs stay -9999.0 */
-      if (k + 1 < nsteps) nxt = load_forcing<FULL>(ka, row0, lane, k + 1);
-      store_outputs(ka, i, row0, lane, s, false);
-      continue;
-    }
-    double tair = f.tair, vz = f.vz, rhz = f.rhz;
-    /* src/Initialization.f90:121-123: VZ(1) is raised to 0.4 in the input array */
-    if (i == 1 && vz < R4(0.4)) vz = R4(0.4);
-    const double prec_ts = RS_DIVC(f.prec, 3600.0, r_3600) * c.DTSecs; /* src/InputOutput.f90:111,186 */
-
-    double sw_dir = 0.0, lw_net = 0.0;
-    if (SKY) {
-      const int64_t row = (int64_t)k * ka->f.t_stride + row0;
-      sw_dir = (ka->f.sw_dir + row)[lane];
-      lw_net = (ka->f.lw_net + row)[lane];
-    }
-    if (i < c.SimLen) {
-      Forcing chk = f;
-      chk.vz = vz;
-      if (check_values(chk, s.tsurf, FULL && ka->f.tdew != nullptr)) fail_at(i);
-      if (SKY) {
-        if (sky_on && (sw_dir < R4(-0.1) || sw_dir > R4(4000.0) || lw_net < R4(-1000.0) ||
-                       lw_net > R4(1000.0)))
-          fail_at(i);                           /* src/InputOutput.f90:68-74 */
-        if (sw_dir > f.sw) sw_dir = f.sw;       /* :75-77 */
-      }
-      if (FULL) {
-        /* SetCurrentValues obs forcing, src/InputOutput.f90:116-148 */
-        if ((i <= initlen || c.force_tsurf) && f.tsurfobs > R4(-100.0)) {
-          T.set(1, f.tsurfobs);
-          T.set(2, f.tsurfobs);
-          const double depth = (c.tsurfOutputDepth >= R4(0.0)) ? c.tsurfOutputDepth : f.depth;
-          s.tsurf = surface_temperature(c, T, tbot, depth);
-        }
-        /* RelaxationOperations, src/Relaxation.f90:10-47 */
-        if (relax) {
-          if (i == initlen) {
-            s.tair_end = tair;
-            s.vz_end = vz;
-            s.rh_end = rhz;
-          }
-          if (i > initlen) {
-            const double den = (double)(4.f * 3600.f);
-            const double e = rs_exp(mt, rs_div(-((c.DTSecs * i) - (c.DTSecs * initlen)), den));
-            tair = tair - (tairR - s.tair_end) * e;
-            vz = vz - (vzR - s.vz_end) * e;
-            rhz = rhz - (rhR - s.rh_end) * e;
-            if (rhz > R4(100.)) rhz = R4(100.0);
-          }
-        }
-      }
-    } else {
-      /* lastValues, src/InputOutput.f90:169-198: no checks, no obs forcing, no
-       * relaxation; the pre-step surface temperature uses depth(SimLen) only */
-      if (FULL) s.tsurf = surface_temperature(c, T, tbot, f.depth);
-    }
-    if (!FULL) { /* TmpNw(1:2) == Tmp(1:2) whenever observation forcing cannot act */
-      s.tnw1 = T.get(1);
-      s.tnw2 = T.get(2);
-    }
-    double sw_in = f.sw, lw_in = f.lw;
-    if (SKY && sky_on) {
-      /* the reference runs this between PrecipitationToStorage and BalanceModelOneStep
-       * (Simulation.f90:151-162); the two do not share data, so the order is free */
-      if (!sky_view_radiation(ka->f.sun + (int64_t)k * 4, sinlat, coslat, lonrad, skyv,
-                              ka->pp.albedo_surroundings,
-                              ka->pp.horizons ? ka->pp.horizons + row0 + lane : nullptr, ka->np_pad,
-                              sw_in, sw_dir, lw_in, lw_net))
-        fail_at(i); /* the reference would `stop` the process here */
-    }
-    if (SKY && ka->wb.sw_dir) {
-      /* the caller's arrays as the reference leaves them: SW_dir clamped by CheckValues
-       * (src/InputOutput.f90:75-77), SW / SW_dir / LW edited by ModRadiationBySurroundings
-       * (src/ModRadiation.f90:57-71) */
-      const int64_t wrow = (int64_t)k * ka->wb.t_stride + row0;
-      (ka->wb.sw_dir + wrow)[lane] = sw_dir;
-      if (sky_on) {
-        (ka->wb.sw + wrow)[lane] = sw_in;
-        (ka->wb.lw + wrow)[lane] = lw_in;
-      }
-    }
-    const Fluxes fx =
-        model_step_fluxes<SCORE>(c, mt, s, tair, vz, rhz, prec_ts, sw_in, lw_in, f.phase, f.hour);
-    /* scheduling hint (bl_score_key): extra passes of this launch; bit 30 of the counter = the
-     * point was in the unstable regime at some index of the launch's last RS_REGIME_WINDOW */
-    if (SCORE) {
-      score += (fx.trips & 63) - 5;
-      if ((fx.trips & 64) && k >= nsteps - RS_REGIME_WINDOW) score |= 1 << 30;
-    }
-    /* next index's forcing: issued here, half a step before its first use, so the
-     * HBM latency hides under the ground/storage half without holding 14 VGPRs
-     * across the boundary-layer iteration */
-    if (k + 1 < nsteps) nxt = load_forcing<FULL>(ka, row0, lane, k + 1);
-    model_step_ground(c, s, T, tbot, tair, fx, f.depth);
-    store_outputs(ka, i, row0, lane, s, true);
-  }
-}
-
 /* ---- coupling: src/Coupling.f90 -------------------------------------------------
  * Per-point state machine that re-runs the point's coupling window with a scaled
  * short- or long-wave input until the simulated surface temperature at the end of
@@ -458,6 +309,258 @@ __device__ __forceinline__ void store_coupling(double *st, int64_t np, int64_t p
   st[(int64_t)RS_ST_CPL_LASTOBS * np + p] = q.lastobs;
 }
 
+/* The time loop of runsimulation (examples/example1/src/Simulation.f90:57-115)
+ * for one point over absolute indices [t0, t0+nsteps). */
+/* SKY: sky view / local horizons (src/ModRadiation.f90, examples/example1/src/Simulation.f90:
+ * 151-162) in the lock-step loop; with coupling the general kernel below does it. */
+/* CPL: coupling in lock step (src/Coupling.f90), for everything except the replays themselves:
+ * the state is saved at the window start (:172-210), the window's first pass runs in the coupling
+ * phase, Coupling_control decides at the window end (:98-141,292-481) - a point that has to replay
+ * PARKS there (start_coupling_again set, RS_ST_CPL_RESUME = window end + 1) and takes no further
+ * step in lock step until the replay rounds (step_kernel_coupled over the compacted list of parked
+ * points, rs_hip_cpl_replay) have cleared it - and behind the window the radiation corrections
+ * decay (:80-88).  A lane steps index i only if i == its RS_ST_CPL_RESUME, so launches may
+ * overlap in time: points that are ahead wait for the others. */
+template <bool FULL, class Prof, bool SKY = false, bool SCORE = true, bool CPL = false>
+__device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s, int32_t &score) {
+  static_assert(FULL || !SKY, "sky view belongs to the FULL feature set");
+  static_assert(FULL || !CPL, "coupling belongs to the FULL feature set");
+  KernArgs ka = kernargs();
+  const uint32_t lane = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * kBlock; /* first point of this workgroup */
+  const int32_t nsteps = ka->nsteps, t0 = ka->t0;
+  const double tbot = (ka->pp.tbottom + row0)[lane];
+  double skyv = R4(1.0), sinlat = 0, coslat = 0, lonrad = 0;
+  bool sky_on = false;
+  if (SKY) {
+    skyv = (ka->pp.sky_view + row0)[lane];
+    sky_on = (skyv < R4(1.0) && skyv > R4(-0.01));
+    if (sky_on) {
+      sinlat = (ka->pp.sin_lat + row0)[lane];
+      coslat = (ka->pp.cos_lat + row0)[lane];
+      lonrad = (ka->pp.lon_rad + row0)[lane];
+    }
+  }
+  int32_t initlen = 0;
+  bool relax = false;
+  double tairR = 0, vzR = 0, rhR = 0;
+  if (FULL) {
+    initlen = ka->pp.initlen ? (ka->pp.initlen + row0)[lane] : 0;
+    if (consts_of(ka).use_relaxation && ka->pp.tair_relax) {
+      /* setInputParam, src/InputOutput.f90:19-26: targets pass through REAL(4) */
+      tairR = (double)(float)(ka->pp.tair_relax + row0)[lane];
+      vzR = (double)(float)(ka->pp.vz_relax + row0)[lane];
+      rhR = (double)(float)(ka->pp.rh_relax + row0)[lane];
+      relax = !(tairR < R4(-100.0) || tairR > R4(100.0) || vzR < R4(0.0) || vzR > R4(100.0) ||
+                rhR < R4(0.0) || rhR > 110);
+    }
+  }
+
+  /* settings%simulation_failed (src/InputOutput.f90:66): sticky; the state block keeps the index
+   * it was raised at (rs_hip_first_failed_index) */
+  auto fail_at = [&](int32_t idx) {
+    s.failed = true;
+    ka->state[(int64_t)RS_ST_FAILED * ka->np_pad + row0 + lane] = (double)idx;
+  };
+  /* coupling, lock-step part: what a lane needs every step stays in registers, the rest of
+   * CouplingVariables lives in the state block and is touched at the two events only */
+  bool cpl_on = false, parked = false;
+  int32_t cpl_cs = -99, cpl_ce = -99, next_i = t0;
+  double cpl_lastobs = 0.0, cpl_swcorr = 0.0, cpl_lwcorr = 0.0;
+  if (CPL) {
+    double *st = ka->state;
+    const int64_t np = ka->np_pad, p = row0 + lane;
+    const int32_t cidx = ka->pp.coupling_index ? (ka->pp.coupling_index + row0)[lane] : 0;
+    /* setInputParam + initCouplingTimes, src/InputOutput.f90:30-36, src/Coupling.f90:486-534 */
+    cpl_on = consts_of(ka).use_coupling && ka->pp.coupling_index &&
+             !((ka->pp.coupling_tsurf + row0)[lane] < -100 || cidx < 1);
+    if (cpl_on) {
+      cpl_ce = cidx;
+      cpl_cs = ((double)cidx <= consts_of(ka).cplLenR) ? 1 : cidx - consts_of(ka).cplLenI;
+    }
+    cpl_lastobs = st[(int64_t)RS_ST_CPL_LASTOBS * np + p];
+    cpl_swcorr = st[(int64_t)RS_ST_CPL_SWCORR * np + p];
+    cpl_lwcorr = st[(int64_t)RS_ST_CPL_LWCORR * np + p];
+    parked = (((int32_t)st[(int64_t)RS_ST_CPL_FLAGS * np + p]) & 1) != 0;
+    next_i = (int32_t)st[(int64_t)RS_ST_CPL_RESUME * np + p];
+  }
+  Forcing nxt = load_forcing<FULL>(ka, row0, lane, 0);
+  for (int32_t k = 0; k < nsteps; ++k) {
+    asm volatile("" : "+s"(ka));
+    const ConstsAS &c = consts_of(ka);
+    const int32_t i = t0 + k;
+    const Forcing f = nxt;
+
+    if (CPL && (parked || i != next_i)) { /* parked behind its window, or ahead of this launch */
+      if (k + 1 < nsteps) nxt = load_forcing<FULL>(ka, row0, lane, k + 1);
+      continue;
+    }
+    if (CPL) next_i = i + 1;
+    if (s.failed) { /* loop has exited in the reference: outputs stay -9999.0 */
+      if (k + 1 < nsteps) nxt = load_forcing<FULL>(ka, row0, lane, k + 1);
+      store_outputs(ka, i, row0, lane, s, false);
+      continue;
+    }
+    double tair = f.tair, vz = f.vz, rhz = f.rhz;
+    /* src/Initialization.f90:121-123: VZ(1) is raised to 0.4 in the input array */
+    if (i == 1 && vz < R4(0.4)) vz = R4(0.4);
+    const double prec_ts = RS_DIVC(f.prec, 3600.0, r_3600) * c.DTSecs; /* src/InputOutput.f90:111,186 */
+
+    double sw_dir = 0.0, lw_net = 0.0;
+    if (SKY) {
+      const int64_t row = (int64_t)k * ka->f.t_stride + row0;
+      sw_dir = (ka->f.sw_dir + row)[lane];
+      lw_net = (ka->f.lw_net + row)[lane];
+    }
+    CouplingInputs cp;
+    if (i < c.SimLen) {
+      Forcing chk = f;
+      chk.vz = vz;
+      if (check_values(chk, s.tsurf, FULL && ka->f.tdew != nullptr)) fail_at(i);
+      if (SKY) {
+        if (sky_on && (sw_dir < R4(-0.1) || sw_dir > R4(4000.0) || lw_net < R4(-1000.0) ||
+                       lw_net > R4(1000.0)))
+          fail_at(i);                           /* src/InputOutput.f90:68-74 */
+        if (sw_dir > f.sw) sw_dir = f.sw;       /* :75-77 */
+      }
+      if (CPL && cpl_on) {
+        /* CouplingOperations1, src/Coupling.f90:10-96, first pass of the window */
+        cp.in_phase = (i >= cpl_cs && i <= cpl_ce);
+        if (i == cpl_cs) { /* Coupling_iterations == 0 here: saveDataForCoupling :172-210 */
+          double *st = ka->state;
+          const int64_t np = ka->np_pad, p = row0 + lane;
+          st[(int64_t)RS_ST_CPL_SAVE_TSURF * np + p] = s.tsurf;
+          st[(int64_t)RS_ST_CPL_SAVE_WAT * np + p] = s.wat;
+          st[(int64_t)RS_ST_CPL_SAVE_ICE2 * np + p] = s.ice2;
+          st[(int64_t)RS_ST_CPL_SAVE_DEP * np + p] = s.dep;
+          st[(int64_t)RS_ST_CPL_SAVE_SNOW * np + p] = s.snow;
+          st[(int64_t)RS_ST_CPL_SAVE_ALBEDO * np + p] = s.albedo;
+          const int32_t fl = ((int32_t)st[(int64_t)RS_ST_CPL_FLAGS * np + p]) & 3;
+          st[(int64_t)RS_ST_CPL_FLAGS * np + p] = (double)(fl | (s.verycold ? 4 : 0));
+          const int N = T.nlayers();
+          for (int j = 1; j <= N; ++j) st[(int64_t)(RS_ST_CPL_SAVE_TMP0 + j - 1) * np + p] = T.get(j);
+          /* SW/LWRadCof = 1, SW/LW_correction = 0: what the registers hold before the window end */
+        }
+        if (i > cpl_ce) {
+          const double e = rs_exp(mt, rs_div(-((c.DTSecs * i) - (c.DTSecs * cpl_ce)), c.cplReduction));
+          cp.sw_cof = R4(1.0) + cpl_swcorr * e;
+          cp.lw_cof = R4(1.0) + cpl_lwcorr * e;
+        }
+        if (cp.in_phase) {
+          /* snowIceCheck :259-289 */
+          if (cpl_lastobs > c.TLimMeltSnow && s.snow > R4(0.00)) { s.wat = s.wat + s.snow; s.snow = R4(0.00); }
+          if (cpl_lastobs > c.TLimMeltIce && s.ice > R4(0.00)) { s.wat = s.wat + s.ice; s.ice = R4(0.00); }
+          if (cpl_lastobs > c.TLimMeltIce && s.ice2 > R4(0.00)) s.ice2 = R4(0.00);
+          if (cpl_lastobs > c.TLimMeltDep && s.dep > R4(0.00)) { s.wat = s.wat + s.dep; s.dep = R4(0.00); }
+        }
+      }
+      if (FULL) {
+        /* SetCurrentValues obs forcing, src/InputOutput.f90:116-148 */
+        if ((i <= initlen || c.force_tsurf) && f.tsurfobs > R4(-100.0) &&
+            (!CPL || !cpl_on || i < cpl_cs)) {
+          T.set(1, f.tsurfobs);
+          T.set(2, f.tsurfobs);
+          const double depth = (c.tsurfOutputDepth >= R4(0.0)) ? c.tsurfOutputDepth : f.depth;
+          s.tsurf = surface_temperature(c, T, tbot, depth);
+        }
+        /* RelaxationOperations, src/Relaxation.f90:10-47 */
+        if (relax) {
+          if (i == initlen) {
+            s.tair_end = tair;
+            s.vz_end = vz;
+            s.rh_end = rhz;
+          }
+          if (i > initlen) {
+            const double den = (double)(4.f * 3600.f);
+            const double e = rs_exp(mt, rs_div(-((c.DTSecs * i) - (c.DTSecs * initlen)), den));
+            tair = tair - (tairR - s.tair_end) * e;
+            vz = vz - (vzR - s.vz_end) * e;
+            rhz = rhz - (rhR - s.rh_end) * e;
+            if (rhz > R4(100.)) rhz = R4(100.0);
+          }
+        }
+      }
+    } else {
+      /* lastValues, src/InputOutput.f90:169-198: no checks, no obs forcing, no
+       * relaxation; the pre-step surface temperature uses depth(SimLen) only */
+      if (FULL) s.tsurf = surface_temperature(c, T, tbot, f.depth);
+      /* coupling%inCouplingPhase and SW/LWRadCof keep their last values: those of index SimLen-1 */
+      if (CPL && cpl_on) {
+        const int32_t j = c.SimLen - 1;
+        cp.in_phase = (j >= cpl_cs && j <= cpl_ce);
+        if (j > cpl_ce) {
+          const double e = rs_exp(mt, rs_div(-((c.DTSecs * j) - (c.DTSecs * cpl_ce)), c.cplReduction));
+          cp.sw_cof = R4(1.0) + cpl_swcorr * e;
+          cp.lw_cof = R4(1.0) + cpl_lwcorr * e;
+        } else if (j >= cpl_cs) { /* the window reaches the end of the series: as the last pass left them */
+          cp.sw_cof = ka->state[(int64_t)RS_ST_CPL_SWCOF * ka->np_pad + row0 + lane];
+          cp.lw_cof = ka->state[(int64_t)RS_ST_CPL_LWCOF * ka->np_pad + row0 + lane];
+        }
+      }
+    }
+    if (CPL) cp.last_tsurf_obs = cpl_lastobs;
+    if (!FULL) { /* TmpNw(1:2) == Tmp(1:2) whenever observation forcing cannot act */
+      s.tnw1 = T.get(1);
+      s.tnw2 = T.get(2);
+    }
+    double sw_in = f.sw, lw_in = f.lw;
+    if (SKY && sky_on) {
+      /* the reference runs this between PrecipitationToStorage and BalanceModelOneStep
+       * (Simulation.f90:151-162); the two do not share data, so the order is free */
+      if (!sky_view_radiation(ka->f.sun + (int64_t)k * 4, sinlat, coslat, lonrad, skyv,
+                              ka->pp.albedo_surroundings,
+                              ka->pp.horizons ? ka->pp.horizons + row0 + lane : nullptr, ka->np_pad,
+                              sw_in, sw_dir, lw_in, lw_net))
+        fail_at(i); /* the reference would `stop` the process here */
+    }
+    if (SKY && ka->wb.sw_dir) {
+      /* the caller's arrays as the reference leaves them: SW_dir clamped by CheckValues
+       * (src/InputOutput.f90:75-77), SW / SW_dir / LW edited by ModRadiationBySurroundings
+       * (src/ModRadiation.f90:57-71) */
+      const int64_t wrow = (int64_t)k * ka->wb.t_stride + row0;
+      (ka->wb.sw_dir + wrow)[lane] = sw_dir;
+      if (sky_on) {
+        (ka->wb.sw + wrow)[lane] = sw_in;
+        (ka->wb.lw + wrow)[lane] = lw_in;
+      }
+    }
+    const Fluxes fx =
+        model_step_fluxes<SCORE>(c, mt, s, tair, vz, rhz, prec_ts, sw_in, lw_in, f.phase, f.hour, cp);
+    /* scheduling hint (bl_score_key): extra passes of this launch; bit 30 of the counter = the
+     * point was in the unstable regime at some index of the launch's last RS_REGIME_WINDOW */
+    if (SCORE) {
+      score += (fx.trips & 63) - 5;
+      if ((fx.trips & 64) && k >= nsteps - RS_REGIME_WINDOW) score |= 1 << 30;
+    }
+    /* next index's forcing: issued here, half a step before its first use, so the
+     * HBM latency hides under the ground/storage half without holding 14 VGPRs
+     * across the boundary-layer iteration */
+    if (k + 1 < nsteps) nxt = load_forcing<FULL>(ka, row0, lane, k + 1);
+    model_step_ground(c, s, T, tbot, tair, fx, f.depth, cp);
+    store_outputs(ka, i, row0, lane, s, true);
+    if (CPL && cpl_on && i < c.SimLen && i == cpl_ce) {
+      /* CheckEndCoupling + CouplingOperations2, src/Coupling.f90:98-141 (Coupling_failed is
+       * .false. before the first decision) */
+      double *st = ka->state;
+      const int64_t np = ka->np_pad, p = row0 + lane;
+      Coupling q;
+      load_coupling(st, np, p, q);
+      q.cs = cpl_cs; q.ce = cpl_ce; q.on = true;
+      if (!q.failed) {
+        if (q.iter == 0) q.tend1 = s.tsurf;
+        coupling_control(q, s.tsurf);
+        q.iter = q.iter + 1;
+        store_coupling(st, np, p, q);
+        cpl_swcorr = q.swcorr;
+        cpl_lwcorr = q.lwcorr;
+        cpl_lastobs = q.lastobs; /* went to Kelvin and back in Coupling_control */
+        parked = q.again; /* replays its window in the rounds; RS_ST_CPL_RESUME = i + 1 */
+      }
+    }
+  }
+  if (CPL) ka->state[(int64_t)RS_ST_CPL_RESUME * ka->np_pad + row0 + lane] = (double)next_i;
+}
+
 /* Per-lane gather of the forcing of absolute index i (window row i - t0). */
 __device__ __forceinline__ Forcing gather_forcing(KernArgs ka, int64_t p, int32_t i, int32_t t0) {
   Forcing o;
@@ -523,8 +626,11 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Pr
     s.failed = true;
     st[(int64_t)RS_ST_FAILED * np + p] = (double)idx;
   };
-  int32_t i = t0;
-  int32_t written_hi = t0 - 1; /* highest index this launch has saved an output for */
+  /* rounds (rs_hip_step): the point resumes where it stopped; a parked point (resume = window
+   * end + 1, start_coupling_again set) rewinds to its window start in the first iteration */
+  const int32_t resume = (int32_t)st[(int64_t)RS_ST_CPL_RESUME * np + p];
+  int32_t i = resume > t0 ? resume : t0;
+  int32_t written_hi = i - 1; /* highest index the point has saved an output for */
   bool stale_all = false; /* first step after a restore: TmpNw is the pre-restore profile */
   while (i < tend) {
     if (s.failed) {
@@ -678,9 +784,14 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Pr
       if (q.iter == 0) q.tend1 = s.tsurf;
       coupling_control(q, s.tsurf);
       q.iter = q.iter + 1;
+      if (ka->cpl_stop) { /* park: the next round decides between a replay and going on */
+        ++i;
+        break;
+      }
     }
     ++i;
   }
+  st[(int64_t)RS_ST_CPL_RESUME * np + p] = (double)i;
 }
 
 /* RS_ST_BLSCORE from the loop's counter: bits 0-18 extra passes (saturating), bit 19 cover,
@@ -747,14 +858,32 @@ __global__ void __launch_bounds__(kBlock, 3) step_kernel_sky(const StepArgs a) {
   a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
 }
 
+/* FULL feature set + coupling in lock step (time_loop<CPL>): everything of a coupled run except
+ * the replays.  LDS profile (any NLayers). */
+__global__ void __launch_bounds__(kBlock, 3) step_kernel_cpl(const StepArgs a) {
+  extern __shared__ double lds[]; /* [NLayers][kBlock] */
+  __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
+  const MathTab mt = fill_math_tables(math_lds);
+  __syncthreads();
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= a.npoints) return;
+  LdsProfile T{lds + threadIdx.x, consts_of(&a).NLayers};
+  Scalars s;
+  int32_t score = 0;
+  load_state<true>(a.state, a.np_pad, p, T, s);
+  time_loop<true, LdsProfile, false, false, true>(mt, T, s, score);
+  store_state<true>(a.state, a.np_pad, p, T, s);
+}
+
 /* Coupled variant: LDS profile (any NLayers), FULL feature set + coupling. */
 __global__ void __launch_bounds__(kBlock, 2) step_kernel_coupled(const StepArgs a) {
   extern __shared__ double lds[]; /* [2][NLayers][kBlock]: profile, stale TmpNw */
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
   const MathTab mt = fill_math_tables(math_lds);
   __syncthreads();
-  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (p >= a.npoints) return;
+  const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (g >= (a.cpl_list ? (int64_t)a.cpl_nlist : a.npoints)) return;
+  const int64_t p = a.cpl_list ? (int64_t)a.cpl_list[g] : g;
   const int NLc = consts_of(&a).NLayers;
   LdsProfile T{lds + threadIdx.x, NLc};
   LdsProfile Tstale{lds + (size_t)NLc * kBlock + threadIdx.x, NLc};
@@ -842,6 +971,7 @@ __global__ void __launch_bounds__(kBlock) init_kernel(const InitArgs a) {
   st[(int64_t)RS_ST_CPL_LWCORR * np + p] = R4(0.0);
   st[(int64_t)RS_ST_CPL_TEND1 * np + p] = 0.0;
   st[(int64_t)RS_ST_CPL_LASTOBS * np + p] = a.pp.coupling_tsurf ? a.pp.coupling_tsurf[p] : R4(-9999.0);
+  st[(int64_t)RS_ST_CPL_RESUME * np + p] = 1.0;
 }
 
 /* Hourly knots of the synthetic workload, [knot][RS_KNOT_FIELDS][np_pad]. */
@@ -1103,9 +1233,17 @@ hipError_t rs_launch_step_sky(const rs::StepArgs &a, int NL, hipStream_t stream)
   return hipGetLastError();
 }
 
+hipError_t rs_launch_step_cpl(const rs::StepArgs &a, int NL, hipStream_t stream) {
+  const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
+  hipLaunchKernelGGL(rs::step_kernel_cpl, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
+  return hipGetLastError();
+}
+
 hipError_t rs_launch_step_coupled(const rs::StepArgs &a, int NL, hipStream_t stream) {
   const size_t lds = 2 * (size_t)NL * RS_BLOCK * sizeof(double);
-  hipLaunchKernelGGL(rs::step_kernel_coupled, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
+  const int64_t n = a.cpl_list ? (int64_t)a.cpl_nlist : a.npoints;
+  if (n < 1) return hipSuccess;
+  hipLaunchKernelGGL(rs::step_kernel_coupled, grid_for(n), dim3(RS_BLOCK), lds, stream, a);
   return hipGetLastError();
 }
 

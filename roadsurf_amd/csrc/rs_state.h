@@ -53,6 +53,9 @@ enum RsStateSlot {
   RS_ST_CPL_LWCORR,              /* LW_correction */
   RS_ST_CPL_TEND1,               /* Tsurf_end_coup1 */
   RS_ST_CPL_LASTOBS,             /* lastTsurfObs */
+  RS_ST_CPL_RESUME,              /* next time index the point will step (the rounds of rs_hip_step with
+                                    coupling: a point parks behind its coupling window until its replays
+                                    are through) */
   RS_ST_CPL_SAVE_TSURF,          /* TSurfAveSave */
   RS_ST_CPL_SAVE_WAT,            /* SrfWatmmsSave */
   RS_ST_CPL_SAVE_ICE2,           /* SrfIce2mmsSave (SrfIcemms is never saved, src/Coupling.f90:194-195) */

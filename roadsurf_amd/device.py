@@ -161,6 +161,24 @@ class Plan:
         lib.check(self.L.rs_hip_step(self._h, C.byref(f), C.byref(o), C.byref(pp), t0, nsteps),
                   "rs_hip_step")
 
+    def step_cpl(self, window: ForcingWindow, out: OutputWindow, pp, t0: int, nsteps: int,
+                 window_row: int = 0, out_row0: int | None = None) -> None:
+        """A chunk of a coupled run in lock step (rs_hip_step_cpl): no replays, points park."""
+        f = window.struct(window_row)
+        o = out.struct((t0 - 1 + out.decimate - 1) // out.decimate if out_row0 is None else out_row0)
+        lib.check(self.L.rs_hip_step_cpl(self._h, C.byref(f), C.byref(o), C.byref(pp), t0, nsteps),
+                  "rs_hip_step_cpl")
+
+    def cpl_replay(self, window: ForcingWindow, out: OutputWindow, pp, t0: int, nsteps: int,
+                   window_row: int = 0, out_row0: int | None = None) -> int:
+        """The replay rounds of the parked points over [t0, t0+nsteps) (rs_hip_cpl_replay)."""
+        f = window.struct(window_row)
+        o = out.struct((t0 - 1 + out.decimate - 1) // out.decimate if out_row0 is None else out_row0)
+        rounds = C.c_int32(0)
+        lib.check(self.L.rs_hip_cpl_replay(self._h, C.byref(f), C.byref(o), C.byref(pp), t0, nsteps,
+                                           C.byref(rounds)), "rs_hip_cpl_replay")
+        return int(rounds.value)
+
     def set_precision(self, bits: int) -> None:
         """32: fp32 flavour (LEAN features, float windows); 64: the parity path."""
         lib.check(self.L.rs_hip_set_precision(self._h, bits), "rs_hip_set_precision")
@@ -376,12 +394,36 @@ def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputPara
         pp = plan.point_params(tb)
     out = OutputWindow.empty(L, npad, dev)
     plan.init_state(win, pp)
-    chunk = L if coupled else (chunk or L)
-    t0 = 1
-    while t0 <= L:
-        ns = min(chunk, L - t0 + 1)
-        plan.step(win, out, pp, t0, ns, window_row=t0 - 1, out_row0=0)
-        t0 += ns
+    if coupled and chunk and not sky_on:
+        # time-chunked coupling: lock-step chunks up to the last coupling-window end, the replay
+        # rounds over the window block, then the chunks from the first window end on (points whose
+        # window ends later wait there; include/roadsurf.h, rs_hip_step_cpl)
+        ci = np.array([l.couplingIndexI for l in local]); ct = np.array([l.couplingTsurf for l in local])
+        on = ~((ct < -100) | (ci < 1))
+        cpl_len = int(settings.coupling_minutes * 60 / settings.DTSecs)
+        cs = np.where(ci <= settings.coupling_minutes * 60 / settings.DTSecs, 1, ci - cpl_len)
+        stages = [(1, L)]
+        if on.any():
+            ce_max, ce_min, cs_min = int(ci[on].max()), int(ci[on].min()), int(cs[on].min())
+            # the replay window reaches one index beyond the last window end: a point that replays
+            # has CheckValues run on index couplingEndI+1 before it rewinds (Simulation.f90:59-66)
+            stages = [(1, min(ce_max, L)), ("replay", cs_min, min(ce_max + 1, L)), (ce_min + 1, L)]
+        for st in stages:
+            if st[0] == "replay":
+                plan.cpl_replay(win, out, pp, st[1], st[2] - st[1] + 1, window_row=st[1] - 1, out_row0=0)
+                continue
+            t0 = st[0]
+            while t0 <= st[1]:
+                ns = min(chunk, st[1] - t0 + 1)
+                plan.step_cpl(win, out, pp, t0, ns, window_row=t0 - 1, out_row0=0)
+                t0 += ns
+    else:
+        chunk = L if coupled else (chunk or L)
+        t0 = 1
+        while t0 <= L:
+            ns = min(chunk, L - t0 + 1)
+            plan.step(win, out, pp, t0, ns, window_row=t0 - 1, out_row0=0)
+            t0 += ns
     plan.sync()
     res = {k: out.tensors[k][:, :n].T.contiguous().cpu().numpy() for k in OUT_FIELDS}
     nfail = plan.failed_count()

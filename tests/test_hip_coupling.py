@@ -107,3 +107,39 @@ def test_coupling_window_must_be_whole_series():
     with pytest.raises(RuntimeError, match="whole series"):
         plan.step(win, out, pp, 1, 100)
     plan.close()
+
+
+@pytest.mark.parametrize("chunk", [97, 256])
+def test_chunked_coupling_equals_whole_series_and_the_reference(chunk):
+    """rs_hip_step_cpl / rs_hip_cpl_replay: lock-step chunks that park a point behind its coupling
+    window, replay rounds over the compacted list of parked points, lock-step chunks again.  Every
+    case of _cases - relaxation on, a 60-minute window, coupling switched off for some points, and
+    (case 3) a different coupling index for every point, where points that are ahead wait for the
+    others - must give the whole-series run's bits, which are the reference's."""
+    from roadsurf_amd import device
+    n, L = 384, 2881
+    cases, base = _cases(n, L, 4242)
+    for k, (f2, s, p, ls) in enumerate(cases):
+        ora, _, _ = oh.run_oracle(_kind(), f2, s, p, ls)
+        res, nfail = device.run_points(f2, s, p, ls, chunk=chunk)
+        for q in oh.F64_OUT:
+            assert np.array_equal(res[q], ora[q]), (k, q, int((res[q] != ora[q]).sum()))
+
+
+def test_chunked_coupling_with_failing_points():
+    """A point that fails inside its coupling window - in the first pass or in a replay - keeps the
+    outputs earlier passes saved beyond the failure (SaveOutput only ever overwrites)."""
+    from roadsurf_amd import device
+    n, L = 256, 1441
+    cases, _ = _cases(n, L, 11)
+    f2, s, p, ls = cases[0]
+    ci = L // 2
+    f2["tair"][3, ci - 100] = -200.0      # bad value inside the window: fails in the first pass
+    f2["tair"][9, ci + 50] = 150.0        # behind the window
+    f2["tair"][17, 5] = -200.0            # before the window
+    ora, _, _ = oh.run_oracle(_kind(), f2, s, p, ls)
+    whole, _ = device.run_points(f2, s, p, ls)
+    parts, _ = device.run_points(f2, s, p, ls, chunk=128)
+    for q in oh.F64_OUT:
+        assert np.array_equal(whole[q], ora[q]), q
+        assert np.array_equal(parts[q], ora[q]), q
