@@ -1022,13 +1022,17 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
   /* Tile of points: large enough to fill the chip (256 CUs x 4 workgroups of 256 points is
    * 262144 points per round).  With coupling the windows hold the whole series (a point
    * replays its coupling window), so the tile follows from a 64 GB window budget. */
+  /* Coupling without sky view runs time-chunked too (rs_hip_step_cpl / rs_hip_cpl_replay): lock-step
+   * chunks that park a point behind its coupling window, replay rounds over a window-sized block,
+   * lock-step chunks again.  Coupling WITH sky view keeps the whole series in one window. */
+  const bool cpl_chunked = coupled && !skyview && !getenv("ROADSURF_HIP_CPL_WHOLE");
   int64_t Pdef = 524288;
-  if (coupled) {
+  if (coupled && !cpl_chunked) {
     Pdef = (int64_t)(64e9 / ((double)L * NFLD * sizeof(double)));
     Pdef = std::max<int64_t>(4096, std::min<int64_t>(262144, Pdef / 4096 * 4096));
   }
   const int P = (int)std::min<int64_t>(pend - pbeg, ep ? std::max(1, atoi(ep)) : Pdef);
-  const int TC = coupled ? L : std::min(L, et ? std::max(1, atoi(et)) : 256);
+  const int TC = (coupled && !cpl_chunked) ? L : std::min(L, et ? std::max(1, atoi(et)) : 256);
 
   /* shared axes */
   Dev d_hour, d_sun;
@@ -1050,10 +1054,15 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
   pt.lap(0);
   WindowLease win;
   win.stream = stream;
+  const int nwin = skyview ? NFLD : NFLD - 2;
+  size_t win_bytes = 0;
   {
     const int64_t Ppad = ((int64_t)P + RS_BLOCK - 1) / RS_BLOCK * RS_BLOCK;
-    const int nwin = skyview ? NFLD : NFLD - 2;
-    HOK(win.acquire((size_t)nwin * Ppad * TC * sizeof(double), device));
+    /* chunked coupling: the replay block spans a coupling window plus the index behind it
+     * (usually more rows than a chunk); a tile whose windows are spread further re-leases below */
+    const int rows0 = cpl_chunked ? std::max(TC, std::min(L, c.cplLen + 2)) : TC;
+    win_bytes = (size_t)nwin * Ppad * rows0 * sizeof(double);
+    HOK(win.acquire(win_bytes, device));
   }
   pt.lap(6);
   for (int64_t p0 = pbeg; p0 < pend; p0 += P) {
@@ -1117,8 +1126,30 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
       pp.horizons = d_hz.as<double>();
     }
 
+    /* chunked coupling: where the tile's coupling windows lie (the decisions are back in `local`) */
+    int cs_min = 0, ce_min = 0, ce_max = 0;
+    bool any_on = false;
+    if (cpl_chunked) {
+      for (int p = 0; p < m; ++p) {
+        const LocalParameters &lp = local[p0 + p];
+        if (lp.couplingTsurf < -100 || lp.couplingIndexI < 1) continue; /* src/InputOutput.f90:34-36 */
+        const int ce = lp.couplingIndexI;
+        /* initCouplingTimes, src/Coupling.f90:512-517 */
+        const int cs = ((double)ce <= (double)(st->coupling_minutes * 60) / st->DTSecs) ? 1 : ce - c.cplLen;
+        if (!any_on) { cs_min = cs; ce_min = ce_max = ce; any_on = true; }
+        cs_min = std::min(cs_min, cs); ce_min = std::min(ce_min, ce); ce_max = std::max(ce_max, ce);
+      }
+    }
+    const int r_lo = cs_min, r_hi = std::min(ce_max + 1, L); /* replay block, 1-based inclusive */
+    const int WR = (cpl_chunked && any_on) ? std::max(TC, r_hi - r_lo + 1) : TC;
+    if ((size_t)nwin * mp * WR * sizeof(double) > win_bytes) {
+      win.release();
+      win_bytes = (size_t)nwin * mp * WR * sizeof(double);
+      HOK(win.acquire(win_bytes, device));
+    }
+
     /* windows */
-    const size_t fs = (size_t)mp * TC;
+    const size_t fs = (size_t)mp * WR;
     Dev d_phase, d_out, d_outpt;
     HOK(d_phase.alloc(fs * sizeof(int32_t)));
     hipLaunchKernelGGL(fill_i32_kernel, grid1((int64_t)fs), dim3(RS_BLOCK), 0, stream,
@@ -1185,8 +1216,19 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
       HOK(hipGetLastError());
     }
     pt.lap(3);
-    for (int t0 = 1; t0 <= L; t0 += TC) {
-      const int len = std::min(TC, L - t0 + 1);
+    /* one window [t0, t0+len): raw series -> step-resolution forcing on the device */
+    int walk_at = 0; /* 0-based index the per-point raw walks are positioned at */
+    auto expand_window = [&](int t0, int len, RsForcing &fo) -> int {
+      if (T.any_pp && walk_at != t0 - 1) { /* not the continuation of the last window: re-position */
+        hipLaunchKernelGGL(pp_init_kernel, grid1(mp), dim3(RS_BLOCK), 0, stream, T.S);
+        HOK(hipGetLastError());
+        if (t0 > 1) {
+          hipLaunchKernelGGL(pp_advance_kernel, grid1(mp), dim3(RS_BLOCK), 0, stream, T.S, (int32_t)0,
+                             (int32_t)(t0 - 1));
+          HOK(hipGetLastError());
+        }
+        walk_at = t0 - 1;
+      }
       ea.i0 = t0 - 1;
       ea.nsteps = len;
       launch_expand_raw(T.any_pp, mp, ea, stream);
@@ -1195,8 +1237,8 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
         hipLaunchKernelGGL(pp_advance_kernel, grid1(mp), dim3(RS_BLOCK), 0, stream, T.S,
                            (int32_t)(t0 - 1), (int32_t)len);
         HOK(hipGetLastError());
+        walk_at = t0 - 1 + len;
       }
-      RsForcing fo;
       std::memset(&fo, 0, sizeof(fo));
       fo.tair = ea.out[R_TAIR]; fo.tdew = ea.out[R_TDEW]; fo.vz = ea.out[R_VZ];
       fo.rhz = ea.out[R_RHZ]; fo.prec = ea.out[R_PREC]; fo.sw = ea.out[R_SW]; fo.lw = ea.out[R_LW];
@@ -1211,6 +1253,36 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
         fo.lw_net = ea.out[R_LWNET];
         fo.sun = d_sun.as<double>() + (size_t)(t0 - 1) * 4;
       }
+      return 0;
+    };
+    if (cpl_chunked) {
+      /* stage 1: lock step to the last window end; stage 2: the replay rounds over the block
+       * [first window start, last window end + 1]; stage 3: lock step from behind the first
+       * window end (points whose window ends later wait there: they step only the index they
+       * are due for) */
+      RsForcing fo;
+      const int s1_hi = any_on ? std::min(ce_max, L) : L;
+      for (int t0 = 1; t0 <= s1_hi; t0 += TC) {
+        const int len = std::min(TC, s1_hi - t0 + 1);
+        if (int rc = expand_window(t0, len, fo)) return rc;
+        if (t0 == 1 && rs_hip_init_state(pg.p, &fo, &pp) != 0) return -12;
+        if (rs_hip_step_cpl(pg.p, &fo, &oo, &pp, t0, len) != 0) return -13;
+      }
+      if (any_on) {
+        if (int rc = expand_window(r_lo, r_hi - r_lo + 1, fo)) return rc;
+        int32_t rounds = 0;
+        if (rs_hip_cpl_replay(pg.p, &fo, &oo, &pp, r_lo, r_hi - r_lo + 1, &rounds) != 0) return -13;
+        for (int t0 = ce_min + 1; t0 <= L; t0 += TC) {
+          const int len = std::min(TC, L - t0 + 1);
+          if (int rc = expand_window(t0, len, fo)) return rc;
+          if (rs_hip_step_cpl(pg.p, &fo, &oo, &pp, t0, len) != 0) return -13;
+        }
+      }
+    } else
+    for (int t0 = 1; t0 <= L; t0 += TC) {
+      const int len = std::min(TC, L - t0 + 1);
+      RsForcing fo;
+      if (int rc = expand_window(t0, len, fo)) return rc;
       if (!cluster) {
         if (t0 == 1 && rs_hip_init_state(pg.p, &fo, &pp) != 0) return -12;
         if (rs_hip_step(pg.p, &fo, &oo, &pp, t0, len) != 0) return -13;

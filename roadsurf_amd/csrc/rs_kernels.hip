@@ -26,6 +26,9 @@
 #include "rs_synth.h"
 #include "rs_kernels.h"
 
+#ifndef RS_CPL_WAVES
+#define RS_CPL_WAVES 2 /* waves per SIMD the general (per-lane time index) kernel is compiled for */
+#endif
 #ifndef RS_REGIME_WINDOW
 #define RS_REGIME_WINDOW 30 /* indices at the end of a launch that define a point's regime
                                (rs_hip_recluster; 8 ... 90 measured equal) */
@@ -578,10 +581,16 @@ __device__ __forceinline__ Forcing gather_forcing(KernArgs ka, int64_t p, int32_
 /* runsimulation's loop with coupling (examples/example1/src/Simulation.f90:57-115):
  * CheckValues -> CouplingOperations1 (may rewind i) -> SetCurrentValues -> relaxation ->
  * roadModelOneStep -> SaveOutput -> CheckEndCoupling. */
+/* the stale TmpNw of a replay's first step, parked in the state block (one column per point) */
+struct GlobalProfile {
+  const double *col;
+  int64_t stride;
+  __device__ __forceinline__ double get(int j) const { return col[(int64_t)(j - 1) * stride]; }
+};
+
 template <class Prof>
-__device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Prof &Tstale,
-                                                  Scalars &s, Coupling &q, double *st, int64_t np,
-                                                  int64_t p) {
+__device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Scalars &s,
+                                                  Coupling &q, double *st, int64_t np, int64_t p) {
   KernArgs ka = kernargs();
   const uint32_t lane = threadIdx.x;
   const int64_t row0 = (int64_t)blockIdx.x * kBlock;
@@ -684,7 +693,8 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Pr
           s.albedo = st[(int64_t)RS_ST_CPL_SAVE_ALBEDO * np + p];
           s.verycold = (((int32_t)st[(int64_t)RS_ST_CPL_FLAGS * np + p]) & 4) != 0;
           for (int j = 1; j <= N; ++j) {
-            Tstale.set(j, T.get(j)); /* TmpNw keeps the end-of-window profile */
+            /* TmpNw keeps the end-of-window profile */
+            st[(int64_t)(RS_ST_CPL_STALE_TMP0 + j - 1) * np + p] = T.get(j);
             T.set(j, st[(int64_t)(RS_ST_CPL_SAVE_TMP0 + j - 1) * np + p]);
           }
           stale_all = true;
@@ -772,6 +782,7 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Pr
     if (stale_all) {
       /* observation forcing cannot follow a restore (i >= couplingStartI), so TmpNw(1:2)
        * are the stale values too */
+      const GlobalProfile Tstale{st + (int64_t)RS_ST_CPL_STALE_TMP0 * np + p, np};
       model_step_ground(c, s, T, tbot, tair, fx, f.depth, cp, &Tstale);
       stale_all = false;
     } else {
@@ -876,8 +887,8 @@ __global__ void __launch_bounds__(kBlock, 3) step_kernel_cpl(const StepArgs a) {
 }
 
 /* Coupled variant: LDS profile (any NLayers), FULL feature set + coupling. */
-__global__ void __launch_bounds__(kBlock, 2) step_kernel_coupled(const StepArgs a) {
-  extern __shared__ double lds[]; /* [2][NLayers][kBlock]: profile, stale TmpNw */
+__global__ void __launch_bounds__(kBlock, RS_CPL_WAVES) step_kernel_coupled(const StepArgs a) {
+  extern __shared__ double lds[]; /* [NLayers][kBlock] */
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
   const MathTab mt = fill_math_tables(math_lds);
   __syncthreads();
@@ -886,12 +897,11 @@ __global__ void __launch_bounds__(kBlock, 2) step_kernel_coupled(const StepArgs 
   const int64_t p = a.cpl_list ? (int64_t)a.cpl_list[g] : g;
   const int NLc = consts_of(&a).NLayers;
   LdsProfile T{lds + threadIdx.x, NLc};
-  LdsProfile Tstale{lds + (size_t)NLc * kBlock + threadIdx.x, NLc};
   Scalars s;
   Coupling q;
   load_state<true>(a.state, a.np_pad, p, T, s);
   load_coupling(a.state, a.np_pad, p, q);
-  time_loop_coupled(mt, T, Tstale, s, q, a.state, a.np_pad, p);
+  time_loop_coupled(mt, T, s, q, a.state, a.np_pad, p);
   store_state<true>(a.state, a.np_pad, p, T, s);
   store_coupling(a.state, a.np_pad, p, q);
 }
@@ -1240,7 +1250,7 @@ hipError_t rs_launch_step_cpl(const rs::StepArgs &a, int NL, hipStream_t stream)
 }
 
 hipError_t rs_launch_step_coupled(const rs::StepArgs &a, int NL, hipStream_t stream) {
-  const size_t lds = 2 * (size_t)NL * RS_BLOCK * sizeof(double);
+  const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
   const int64_t n = a.cpl_list ? (int64_t)a.cpl_nlist : a.npoints;
   if (n < 1) return hipSuccess;
   hipLaunchKernelGGL(rs::step_kernel_coupled, grid_for(n), dim3(RS_BLOCK), lds, stream, a);

@@ -63,7 +63,11 @@ enum RsStateSlot {
   RS_ST_CPL_SAVE_SNOW,           /* SrfSnowmmsSave */
   RS_ST_CPL_SAVE_ALBEDO,         /* AlbedoSave */
   RS_ST_CPL_SAVE_TMP0,           /* TmpSave(1..NLayers) at the next RS_MAX_LAYERS slots */
-  RS_NSTATE = RS_ST_CPL_SAVE_TMP0 + RS_MAX_LAYERS
+  RS_ST_CPL_STALE_TMP0 = RS_ST_CPL_SAVE_TMP0 + RS_MAX_LAYERS,
+                                 /* TmpNw as a restore leaves it: the profile of the END of the
+                                    window (Tmp is restored, TmpNw is not: src/Coupling.f90:245-247),
+                                    read by the first step of a replay only; RS_MAX_LAYERS slots */
+  RS_NSTATE = RS_ST_CPL_STALE_TMP0 + RS_MAX_LAYERS
 };
 
 #endif

@@ -201,9 +201,11 @@ def read_input(sources, settings: abi.InputSettings, start_time: int, forecast_t
 
 def run(sources, settings: abi.InputSettings, params: abi.InputParameters, start_time: int,
         forecast_time: int, local=None, cal: dict | None = None,
-        horizons: np.ndarray | None = None, device: int = 0) -> dict:
+        horizons: np.ndarray | None = None, device: int = 0, out: dict | None = None) -> dict:
     """read_input + runsimulation + save_output's decimation for all points.  Returns the six
-    outputs as [n][n_out] arrays plus ``status``, ``missing_index``, ``local`` and ``step``."""
+    outputs as [n][n_out] arrays plus ``status``, ``missing_index``, ``local`` and ``step``.
+    ``device`` < 0 fans the points out over ROADSURF_HIP_DEVICES; ``out`` = a result dict of an
+    earlier call with the same shapes, whose arrays are written again (no fresh allocation)."""
     L = _bind(rslib.load())
     if cal is None:
         cal = calendar(start_time, settings.SimLen, int(settings.DTSecs))
@@ -211,9 +213,12 @@ def run(sources, settings: abi.InputSettings, params: abi.InputParameters, start
     n = inp.n_points
     step, n_out = output_rows(settings)
     larr = _locals(n, local)
-    res = {k: np.full((n, n_out), np.nan) for k in OUT_FIELDS}
-    res["status"] = np.empty(n, np.int32)
-    res["missing_index"] = np.empty(n, np.int32)
+    if out is not None and out["tsurf"].shape == (n, n_out):
+        res = {k: out[k] for k in OUT_FIELDS + ("status", "missing_index")}
+    else:
+        res = {k: np.full((n, n_out), np.nan) for k in OUT_FIELDS}
+        res["status"] = np.empty(n, np.int32)
+        res["missing_index"] = np.empty(n, np.int32)
     out = RsDriverOutput()
     out.n_out = n_out
     for k in OUT_FIELDS:

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("ROADSURF_HIP_LIB") or os.path.join(_HERE, "lib", "lib
 
 RS_MAX_LAYERS = abi.RS_MAX_LAYERS
 RS_KNOT_FIELDS = 9
-RS_NSTATE = RS_MAX_LAYERS + 17 + 21 + RS_MAX_LAYERS
+RS_NSTATE = RS_MAX_LAYERS + 17 + 21 + 2 * RS_MAX_LAYERS
 
 _tbl = C.c_double * (RS_MAX_LAYERS + 2)
 

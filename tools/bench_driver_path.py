@@ -46,9 +46,13 @@ if mode == "skyview":
     for q in range(n):
         local[q].lat, local[q].lon, local[q].sky_view = 60.0 + (q % 97) * 0.05, 22.0 + (q % 89) * 0.05, sv[q]
     hz = rs.uniform(0, 20, (n, 360))
+r = None
 for rep in range(4):
     t0 = time.time()
-    r = driver.run(src, s, p, START, START + obs_h * 3600, cal=cal, local=local, horizons=hz)
+    # device -1: the library's own fan-out (ROADSURF_HIP_DEVICES / ROADSURF_HIP_PLANS_PER_DEVICE);
+    # the caller's result arrays are reused from the second call on
+    r = driver.run(src, s, p, START, START + obs_h * 3600, cal=cal, local=local, horizons=hz,
+                   device=int(os.environ.get("BENCH_DEVICE", "-1")), out=r)
     dt = time.time() - t0
     out_bytes = sum(r[k].nbytes for k in driver.OUT_FIELDS)
     print(f"rep {rep}: n={n} L={L} mode={mode}: {dt:.3f} s  -> {n * L / dt:.3e} point-timesteps/s "
