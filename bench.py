@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 ALGO_BYTES_PER_UNIT = 100.0    # 52 B read + 48 B written per point-timestep
-TRAFFIC_FILE = "profiles/r01_traffic.json"  # committed PMC summary the roofline's `traffic` is read from
+TRAFFIC_FILE = "profiles/r02_traffic.json"  # committed PMC summary the roofline's `traffic` is read from
 
 
 def effective_cpus() -> int:
@@ -83,7 +83,7 @@ def cpu_baseline(sample_points: int, simlen: int, seed: int):
     }
 
 
-def measured_traffic(points: int, chunk: int):
+def measured_traffic(points: int, chunk: int, plans: int):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
     (TRAFFIC_FILE), valid for the configuration it was collected on."""
     path = os.path.join(ROOT, TRAFFIC_FILE)
@@ -91,7 +91,7 @@ def measured_traffic(points: int, chunk: int):
         t = json.load(open(path))
     except (OSError, ValueError):
         return None, None
-    if t.get("points") != points or t.get("chunk_steps") != chunk:
+    if t.get("points") != points or t.get("chunk_steps") != chunk or t.get("plans_per_gpu") != plans:
         return None, None
     return t.get("traffic_bytes_per_launch"), t.get("derived")
 
@@ -261,7 +261,7 @@ def main() -> None:
     achieved = algo_bytes * units_per_pass_rank * args.steps / (busy_ms / 1e3) / 1e9
     concurrency = step_ms / busy_ms
 
-    traffic, valu = (None, None) if args.f32 else measured_traffic(n, chunk)
+    traffic, valu = (None, None) if args.f32 else measured_traffic(n, chunk, K)
     if rank == 0:
         line = {
             "metric": "point_timesteps_per_s",
