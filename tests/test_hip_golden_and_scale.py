@@ -172,6 +172,51 @@ def test_full_size_properties_1M_points_48h():
     assert plan.failed_count() == 0
     del run
     plan.close()
+    torch.cuda.empty_cache()
+    # bench.py's default at this size: FOUR plans of 250 000 points on four streams whose launches
+    # interleave (one plan's window expansion and re-sort under another's step kernel).  Same
+    # points, same values: the four checksums add up to the single plan's, the sampled blocks -
+    # found in whichever plan holds them, through that plan's order rows - carry the same bits
+    from roadsurf_amd import sharding
+    K = 4
+    plans, runs, offs = [], [], []
+    for j in range(K):
+        off, cnt = sharding.strong_shard(n, K, j)
+        pl = device.Plan(cnt, s, p, 0, stream=torch.cuda.Stream(plan.device))
+        plans.append(pl); offs.append(off)
+        runs.append(workload.SyntheticRun(pl, seed, hours, 120, point_offset=off, plan_order=True))
+    sums = [torch.zeros((), dtype=torch.int64, device=plan.device) for _ in range(K)]
+    got = {k: np.full((L, len(cols)), np.nan) for k in device.OUT_FIELDS}
+    pending = []
+
+    def hook(j):
+        run_j, off, cnt = runs[j], offs[j], plans[j].npoints
+        mine = [(q, c - off) for q, c in enumerate(cols) if off <= c < off + cnt]
+        local = torch.as_tensor([c for _, c in mine], device=plan.device, dtype=torch.long)
+
+        def on_launch(c, t0, ns):
+            with torch.cuda.stream(plans[j].stream):
+                slots = run_j.slots_of(c, local) if len(mine) else None
+                for k in device.OUT_FIELDS:
+                    o = run_j.out.tensors[k][:ns, :cnt]
+                    sums[j] += o.view(torch.int64).sum()
+                    if len(mine):
+                        pending.append((k, t0, ns, [q for q, _ in mine], o[:, slots].clone()))
+        return on_launch
+
+    its = [r.iter_pass(hook(j)) for j, r in enumerate(runs)]
+    while its:
+        its = [it for it in its if next(it, None) is not None]
+    torch.cuda.synchronize()
+    assert (sum(int(x.item()) for x in sums) - c1) % (1 << 64) == 0   # wrap-around sums
+    for k, t0, ns, qs, block in pending:
+        got[k][t0 - 1:t0 - 1 + ns, qs] = block.cpu().numpy()
+    for k in device.OUT_FIELDS:
+        assert np.array_equal(got[k], samp1[k]), ("four interleaved plans", k)
+    assert sum(pl.failed_count() for pl in plans) == 0
+    del runs
+    for pl in plans:
+        pl.close()
     # shard independence + reference spot check: re-run each sampled block as its own tiny batch
     l = abi.default_local(); l.InitLenI = 1
     for bi, b in enumerate(blocks):
