@@ -824,40 +824,50 @@ struct PhaseTimer {
  * 3-6 s, against 0.6 s for the whole simulation.  So the window block is kept per process and
  * reused by the next call (rs_driver_release_cache frees it); a concurrent second caller gets a
  * private allocation. */
+constexpr int WINCACHE_SLOTS = 8; /* concurrent rs_driver_run workers per device that keep a block */
 struct WindowCache {
   std::mutex m;
-  void *p = nullptr;
-  size_t bytes = 0;
-  bool busy = false;
-} g_wincache[64]; /* one per device: the fan-out of rs_driver_run has a worker on each */
+  void *p[WINCACHE_SLOTS] = {};
+  size_t bytes[WINCACHE_SLOTS] = {};
+  bool busy[WINCACHE_SLOTS] = {};
+} g_wincache[64]; /* per device: the fan-out of rs_driver_run has several workers on each */
 
 struct WindowLease {
   void *p = nullptr;
   bool cached = false;
   hipStream_t stream = nullptr; /* the stream whose kernels use the block */
   ~WindowLease() { release(); }
-  int device = 0;
+  int device = 0, slot = -1;
   hipError_t acquire(size_t bytes, int dev) {
     device = dev & 63;
     WindowCache &c = g_wincache[device];
     std::lock_guard<std::mutex> lk(c.m);
-    if (!c.busy) {
-      if (c.p && c.bytes < bytes) {
-        (void)hipFree(c.p);
-        c.p = nullptr;
-        c.bytes = 0;
+    /* a free slot that is large enough, else a free slot to (re)allocate */
+    int pick = -1;
+    for (int k = 0; k < WINCACHE_SLOTS && pick < 0; ++k)
+      if (!c.busy[k] && c.p[k] && c.bytes[k] >= bytes) pick = k;
+    for (int k = 0; k < WINCACHE_SLOTS && pick < 0; ++k)
+      if (!c.busy[k] && !c.p[k]) pick = k;
+    for (int k = 0; k < WINCACHE_SLOTS && pick < 0; ++k)
+      if (!c.busy[k]) pick = k;
+    if (pick >= 0) {
+      if (c.p[pick] && c.bytes[pick] < bytes) {
+        (void)hipFree(c.p[pick]);
+        c.p[pick] = nullptr;
+        c.bytes[pick] = 0;
       }
-      if (!c.p) {
-        hipError_t e = hipMalloc(&c.p, bytes);
+      if (!c.p[pick]) {
+        hipError_t e = hipMalloc(&c.p[pick], bytes);
         if (e != hipSuccess) {
-          c.p = nullptr;
+          c.p[pick] = nullptr;
           return e;
         }
-        c.bytes = bytes;
+        c.bytes[pick] = bytes;
       }
-      c.busy = true;
+      c.busy[pick] = true;
       cached = true;
-      p = c.p;
+      slot = pick;
+      p = c.p[pick];
       return hipSuccess;
     }
     cached = false;
@@ -871,7 +881,7 @@ struct WindowLease {
     if (stream) (void)hipStreamSynchronize(stream);
     if (cached) {
       std::lock_guard<std::mutex> lk(g_wincache[device].m);
-      g_wincache[device].busy = false;
+      g_wincache[device].busy[slot] = false;
     } else {
       (void)hipFree(p);
     }
@@ -954,11 +964,13 @@ void rs_driver_release_cache(void) {
   for (int d = 0; d < 64; ++d) {
     WindowCache &c = g_wincache[d];
     std::lock_guard<std::mutex> lk(c.m);
-    if (c.busy || !c.p) continue;
-    if (hipSetDevice(d) != hipSuccess) continue;
-    (void)hipFree(c.p);
-    c.p = nullptr;
-    c.bytes = 0;
+    for (int k = 0; k < WINCACHE_SLOTS; ++k) {
+      if (c.busy[k] || !c.p[k]) continue;
+      if (hipSetDevice(d) != hipSuccess) break;
+      (void)hipFree(c.p[k]);
+      c.p[k] = nullptr;
+      c.bytes[k] = 0;
+    }
   }
 }
 

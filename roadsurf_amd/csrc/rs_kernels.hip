@@ -21,6 +21,7 @@
  * sequential per point (explicit Euler in time), points are independent.
  */
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "rs_physics.hpp"
 #include "rs_state.h"
 #include "rs_synth.h"
@@ -1244,6 +1245,7 @@ hipError_t rs_launch_step_sky(const rs::StepArgs &a, int NL, hipStream_t stream)
 }
 
 hipError_t rs_launch_step_cpl(const rs::StepArgs &a, int NL, hipStream_t stream) {
+  /* LDS profile: a register-profile instance of this loop was measured twice as slow (spills) */
   const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
   hipLaunchKernelGGL(rs::step_kernel_cpl, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
   return hipGetLastError();
@@ -1263,13 +1265,14 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
   /* variant = flavour + 10 * waves-per-SIMD bound (0 = default for the flavour) */
   int wpe = variant / 10;
   variant %= 10;
-  if (variant == RS_VARIANT_AUTO) variant = (NL == 15 && !full) ? RS_VARIANT_REG : RS_VARIANT_LDS;
-  /* measured (tools/bench_driver_path.py, 1 M points): the FULL feature set spills 128 VGPRs in the
-   * register flavour at 4 waves/SIMD and is 6 % faster with the profile in LDS; LEAN is 3 %
-   * faster in registers */
+  if (variant == RS_VARIANT_AUTO) variant = (NL == 15) ? RS_VARIANT_REG : RS_VARIANT_LDS;
+  /* measured (tools/bench_driver_path.py relax, 1 M points, one plan): the FULL feature set in the
+   * register flavour at 3 waves/SIMD (168 VGPRs) 0.745 s, at 2 waves 0.80 s, at 4 waves (130 spilled
+   * VGPRs) 0.87 s; with the profile in LDS 0.86 s (3 waves) / 0.88 s (4 waves).  LEAN: registers,
+   * 4 waves */
   if (variant == RS_VARIANT_REG) {
     if (NL != 15) return hipErrorInvalidValue;
-    if (wpe == 0) wpe = 4;
+    if (wpe == 0) wpe = full ? 3 : 4;
 #define RS_REG(W)                                                                        \
   if (wpe == W) {                                                                        \
     if (full)                                                                            \
