@@ -14,7 +14,7 @@
  *                          many times (default 4): four blocks per device run on four host threads
  *                          and four streams, so that one block's PCIe copies and host-side
  *                          gather/scatter overlap the other's kernels (measured on one MI355X,
- *                          rs_driver_run, 1 M points x 48 h: relaxation 5.5e9 -> 9.3e9, coupling 3.8e9 -> 6.3e9
+ *                          rs_driver_run, 1 M points x 48 h: relaxation 5.5e9 -> 9.6e9, coupling 3.8e9 -> 6.3e9
  *                          point-timesteps/s)
  *   ROADSURF_HIP_MIN_SHARD a block is at least this many points (default 4096): small batches
  *                          use fewer devices, one-point calls pick a device round-robin
