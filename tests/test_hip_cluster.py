@@ -147,3 +147,38 @@ def test_full_feature_run_in_plan_order_with_per_point_parameters():
     for k in oh.F64_OUT:
         assert np.array_equal(res[k], ora[k]), (k, int((res[k] != ora[k]).sum()))
     plan.close()
+
+
+def test_forecast_recluster_is_a_value_neutral_permutation():
+    """rs_hip_recluster_forecast (the sort key bench.py uses): whatever the key says, slots are
+    permuted, never changed - outputs mapped back through the order rows equal the checker's
+    natural-order run bit for bit - and the most expensive points come first."""
+    import torch
+    import oracle_helpers as oh
+    from roadsurf_amd import abi, device, workload
+    n, hours = 3000, 12
+    L = hours * 120 + 1
+    s = abi.default_settings(L); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
+    f = oh.synth_forcing(n, L, seed=99)
+    ora, _, _ = oh.run_oracle("ref" if oh.have_ref() else "port", f, s, p, l)
+    plan = device.Plan(n, s, p, 0)
+    run = workload.SyntheticRun(plan, 99, hours, 120, plan_order=True, forecast=True)
+    got = {k: np.full((n, L), np.nan) for k in device.OUT_FIELDS}
+    moved = []
+
+    def on_launch(c, t0, ns):
+        order = run.orders[c][:n].long()
+        assert int(torch.bincount(order, minlength=n).max()) == 1
+        moved.append(int((order != torch.arange(n, device=order.device)).sum()))
+        idx = order.cpu().numpy()
+        for k in device.OUT_FIELDS:
+            got[k][idx, t0 - 1:t0 - 1 + ns] = run.out.tensors[k][:ns, :n].cpu().numpy().T
+    run.run_pass(on_launch)
+    plan.sync()
+    for k in device.OUT_FIELDS:
+        assert np.array_equal(got[k], ora[k]), k
+    assert moved[0] == 0 and max(moved) > n // 2
+    # a plan that gave up its history score cannot be sorted by history
+    with pytest.raises(RuntimeError, match="history score"):
+        plan.recluster()
+    plan.close()

@@ -175,6 +175,33 @@ def test_per_point_time_axes_match_checker():
         assert _same_bits(g[k], o[k]), k
 
 
+def test_per_point_time_axes_with_chunked_coupling(monkeypatch):
+    """Coupling is time-chunked in rs_driver_run: lock-step chunks, the replay block (which starts
+    BEFORE the last chunk ended), chunks again from behind the first coupling window.  With
+    per-point time axes the raw-series walks have to be re-positioned for every such jump; points
+    lose the tail of their observations, so their coupling windows end at different indices."""
+    n = 260
+    src, L, t0, tf = dh.scenario(n, hours=8, seed=37, obs_hours=5)
+    both = [dh.ragged(src[0], seed=9, drop=0.1), dh.ragged(src[1], seed=4)]
+    s = _settings(L, use_relaxation=1, use_coupling=1, coupling_minutes=90, outputStep=10)
+    p = abi.default_parameters()
+    o = dh.oracle_run(_kind(True), both, s, p, t0, tf)
+    ci = np.array([o["local"][q].couplingIndexI for q in range(n)])
+    ok = o["status"] == 0
+    assert len(set(ci[ok & (ci > 0)].tolist())) > 3      # windows end at different indices
+    for chunk, tile in ((64, 4096), (200, 100)):
+        monkeypatch.setenv("ROADSURF_HIP_CHUNK_STEPS", str(chunk))
+        monkeypatch.setenv("ROADSURF_HIP_TILE_POINTS", str(tile))
+        g = driver.run(both, s, p, t0, tf)
+        assert np.array_equal(g["status"], o["status"])
+        for k in driver.OUT_FIELDS:
+            assert _same_bits(g[k], o[k]), (chunk, k)
+    monkeypatch.setenv("ROADSURF_HIP_CPL_WHOLE", "1")     # round-1 organisation: same bits
+    g = driver.run(both, s, p, t0, tf)
+    for k in driver.OUT_FIELDS:
+        assert _same_bits(g[k], o[k]), ("whole", k)
+
+
 def test_identical_per_point_axes_equal_the_shared_axis(monkeypatch):
     n = 200
     src, L, t0, tf = dh.scenario(n, hours=6, seed=8, obs_hours=3)
