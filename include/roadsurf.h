@@ -348,6 +348,11 @@ int rs_hip_step(RsPlan *plan, const RsForcing *f, const RsOutputs *o,
  * continues - or, if the points' windows end at different indices, re-issues - the chunks from
  * min(couplingEndI) + 1 on: points that are ahead wait.  No sky view here (that combination goes
  * through rs_hip_step).  Outputs of replayed indices are overwritten, as in the reference. */
+/* With plan order (rs_hip_recluster) AND coupling: rs_hip_step_cpl / rs_hip_cpl_replay can write
+ * the outputs of slot s into column order[s] of the output window, i.e. in POINT order whatever
+ * the slots' order is (a replay rewrites rows of earlier launches, so a per-launch buffer in slot
+ * order does not do).  Meant for decimated outputs: the stores are scattered. */
+int rs_hip_set_output_by_point(RsPlan *plan, int32_t on);
 int rs_hip_step_cpl(RsPlan *plan, const RsForcing *f, const RsOutputs *o,
                     const RsPointParams *pp, int32_t t0, int32_t nsteps);
 int rs_hip_cpl_replay(RsPlan *plan, const RsForcing *f, const RsOutputs *o,
@@ -633,7 +638,7 @@ int rs_driver_expand(const RsDriverInput *in, const InputSettings *settings,
                      LocalParameters *local, double *merged, int32_t *status,
                      int32_t *missing_index, int32_t device);
 
-#define RS_ABI_VERSION 1
+#define RS_ABI_VERSION 2 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index) */
 int rs_abi_version(void);
 /* sizeof of the boundary structs as the C side / the Fortran side see them
  * (0 InputPointers, 1 OutputPointers, 2 InputSettings, 3 InputParameters,

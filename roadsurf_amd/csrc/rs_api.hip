@@ -66,6 +66,7 @@ struct RsPlan {
   void *cpl_tmp = nullptr;
   size_t cpl_tmp_bytes = 0;
   int32_t cpl_rounds_last = 0; /* replay rounds of the last coupled rs_hip_step (diagnostics) */
+  bool output_by_point = false; /* coupling kernels scatter their outputs through the plan order */
   bool history_score = true; /* the step kernels leave the sort key of rs_hip_recluster */
   bool f32 = false; /* single-precision flavour: windows and state hold floats */
   std::vector<hipEvent_t> ev; /* start/stop pairs */
@@ -368,6 +369,12 @@ int rs_hip_set_writeback(RsPlan *pl, double *sw, double *sw_dir, double *lw, int
   return 0;
 }
 
+int rs_hip_set_output_by_point(RsPlan *pl, int32_t on) {
+  if (!pl) return set_err("rs_hip_set_output_by_point: null plan");
+  pl->output_by_point = on != 0;
+  return 0;
+}
+
 int rs_hip_set_history_score(RsPlan *pl, int32_t on) {
   if (!pl) return set_err("rs_hip_set_history_score: null plan");
   pl->history_score = on != 0;
@@ -510,6 +517,7 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
   a.cpl_list = nullptr;
   a.cpl_nlist = 0;
   a.cpl_stop = 0;
+  a.out_index = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (pl->timing) {
     if (pl->ev_used + 2 > pl->ev.size()) {
@@ -589,6 +597,7 @@ static int cpl_args(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const Rs
   a.cpl_list = nullptr;
   a.cpl_nlist = 0;
   a.cpl_stop = 0;
+  a.out_index = (pl->output_by_point && pl->order) ? pl->order : nullptr;
   return 0;
 }
 

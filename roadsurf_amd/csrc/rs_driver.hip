@@ -450,7 +450,8 @@ __global__ void __launch_bounds__(RS_BLOCK) pp_advance_kernel(const SrcSet S, in
 __global__ void __launch_bounds__(RS_BLOCK) gather_params_kernel(
     const int32_t *__restrict__ order, int64_t npoints, const int32_t *initlen_p, int32_t *initlen_s,
     const double *tair_p, double *tair_s, const double *vz_p, double *vz_s, const double *rh_p,
-    double *rh_s) {
+    double *rh_s, const int32_t *cidx_p = nullptr, int32_t *cidx_s = nullptr,
+    const double *ctsurf_p = nullptr, double *ctsurf_s = nullptr) {
   const int64_t s = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
   if (s >= npoints) return;
   const int64_t p = order[s];
@@ -458,6 +459,10 @@ __global__ void __launch_bounds__(RS_BLOCK) gather_params_kernel(
   tair_s[s] = tair_p[p];
   vz_s[s] = vz_p[p];
   rh_s[s] = rh_p[p];
+  if (cidx_s) { /* coupling index and observation travel with the slot too */
+    cidx_s[s] = cidx_p[p];
+    ctsurf_s[s] = ctsurf_p[p];
+  }
 }
 
 /* output rows of one launch, written in slot order, into the natural-order result */
@@ -1195,10 +1200,17 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
 
     /* Plan order (rs_hip_recluster): with more than one launch per tile the slots
      * are re-sorted by regime after every launch; windows and per-point parameters are then
-     * produced in slot order and each launch's output rows are mapped back.  Not for the
-     * general kernel (coupling, sky view), which leaves no sort key. */
+     * produced in slot order and each launch's output rows are mapped back.  Time-chunked
+     * coupling CAN run that way too (ROADSURF_HIP_CLUSTER=2: the lock-step coupling kernel leaves
+     * the sort key; its outputs, and the replays', go straight to their point's column,
+     * rs_hip_set_output_by_point) but is not by default: measured 1.18 s against 0.98 s in natural
+     * order at 1 M points - the raw-series path gains little from the order (its gathers of
+     * 1 M-wide raw rows cost most of what coherence saves) and with coupling pays for it three
+     * times over (134 state rows to move, scattered output stores, replay lists in slot order).
+     * Not for sky view with coupling (general kernel over the whole series: no sort key). */
     const char *ec = getenv("ROADSURF_HIP_CLUSTER");
-    const bool cluster = !coupled && !skyview && TC < L && !(ec && atoi(ec) == 0);
+    const bool cluster = (!coupled || (cpl_chunked && ec && atoi(ec) == 2)) && !skyview && TC < L &&
+                         !(ec && atoi(ec) == 0);
     const int rows_c = TC / step + 2; /* output rows one launch can produce */
     Dev d_outc, d_pp_s;
     RsOutputs oc = oo;
@@ -1209,24 +1221,36 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
       const size_t cs = (size_t)rows_c * mp;
       oc.tsurf = cb; oc.snow = cb + cs; oc.water = cb + 2 * cs; oc.ice = cb + 3 * cs;
       oc.deposit = cb + 4 * cs; oc.ice2 = cb + 5 * cs;
-      HOK(d_pp_s.alloc((size_t)mp * (sizeof(int32_t) + 3 * sizeof(double))));
+      /* slot-order copies: 4 doubles (3 relaxation targets, coupling observation), 2 int32 */
+      HOK(d_pp_s.alloc((size_t)mp * (2 * sizeof(int32_t) + 4 * sizeof(double))));
       double *pd = d_pp_s.as<double>();
       pps.tair_relax = st->use_relaxation == 1 ? pd : nullptr;
       pps.vz_relax = st->use_relaxation == 1 ? pd + mp : nullptr;
       pps.rh_relax = st->use_relaxation == 1 ? pd + 2 * mp : nullptr;
-      pps.initlen = reinterpret_cast<int32_t *>(pd + 3 * mp);
-      HOK(hipMemsetAsync(d_pp_s.p, 0, (size_t)mp * (sizeof(int32_t) + 3 * sizeof(double)), stream));
+      pps.initlen = reinterpret_cast<int32_t *>(pd + 4 * mp);
+      if (coupled) {
+        pps.coupling_tsurf = pd + 3 * mp;
+        pps.coupling_index = reinterpret_cast<int32_t *>(pd + 4 * mp) + mp;
+      }
+      HOK(hipMemsetAsync(d_pp_s.p, 0, (size_t)mp * (2 * sizeof(int32_t) + 4 * sizeof(double)), stream));
     }
-
-    if (cluster) {
+    /* per-point parameters into the plan's current slot order */
+    auto gather_params = [&]() -> int {
       ea.order = rs_hip_plan_order(pg.p); /* identity until the first recluster */
       if (!ea.order) return -14;
+      double *pd = d_pp_s.as<double>();
       hipLaunchKernelGGL(gather_params_kernel, grid1(m), dim3(RS_BLOCK), 0, stream, ea.order, (int64_t)m,
-                         pp.initlen, const_cast<int32_t *>(pps.initlen), D.tair_relax.as<double>(),
-                         d_pp_s.as<double>(), D.vz_relax.as<double>(), d_pp_s.as<double>() + mp,
-                         D.rh_relax.as<double>(), d_pp_s.as<double>() + 2 * mp);
+                         pp.initlen, const_cast<int32_t *>(pps.initlen), D.tair_relax.as<double>(), pd,
+                         D.vz_relax.as<double>(), pd + mp, D.rh_relax.as<double>(), pd + 2 * mp,
+                         coupled ? pp.coupling_index : nullptr,
+                         coupled ? const_cast<int32_t *>(pps.coupling_index) : nullptr,
+                         coupled ? pp.coupling_tsurf : nullptr,
+                         coupled ? const_cast<double *>(pps.coupling_tsurf) : nullptr);
       HOK(hipGetLastError());
-    }
+      return 0;
+    };
+    if (cluster)
+      if (int rc = gather_params()) return rc;
     pt.lap(3);
     /* one window [t0, t0+len): raw series -> step-resolution forcing on the device */
     int walk_at = 0; /* 0-based index the per-point raw walks are positioned at */
@@ -1273,21 +1297,33 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
        * window end (points whose window ends later wait there: they step only the index they
        * are due for) */
       RsForcing fo;
+      /* plan order: the slots are re-sorted after every lock-step chunk; windows and per-point
+       * parameters are produced in slot order, outputs go to their point's column */
+      const RsPointParams &ppx = cluster ? pps : pp;
+      if (cluster && rs_hip_set_output_by_point(pg.p, 1) != 0) return -14;
+      auto resort = [&]() -> int {
+        if (!cluster) return 0;
+        if (rs_hip_recluster(pg.p) != 0) return -14;
+        return gather_params();
+      };
       const int s1_hi = any_on ? std::min(ce_max, L) : L;
       for (int t0 = 1; t0 <= s1_hi; t0 += TC) {
         const int len = std::min(TC, s1_hi - t0 + 1);
         if (int rc = expand_window(t0, len, fo)) return rc;
-        if (t0 == 1 && rs_hip_init_state(pg.p, &fo, &pp) != 0) return -12;
-        if (rs_hip_step_cpl(pg.p, &fo, &oo, &pp, t0, len) != 0) return -13;
+        if (t0 == 1 && rs_hip_init_state(pg.p, &fo, &ppx) != 0) return -12;
+        if (rs_hip_step_cpl(pg.p, &fo, &oo, &ppx, t0, len) != 0) return -13;
+        if (int rc = resort()) return rc;
       }
       if (any_on) {
         if (int rc = expand_window(r_lo, r_hi - r_lo + 1, fo)) return rc;
         int32_t rounds = 0;
-        if (rs_hip_cpl_replay(pg.p, &fo, &oo, &pp, r_lo, r_hi - r_lo + 1, &rounds) != 0) return -13;
+        if (rs_hip_cpl_replay(pg.p, &fo, &oo, &ppx, r_lo, r_hi - r_lo + 1, &rounds) != 0) return -13;
         for (int t0 = ce_min + 1; t0 <= L; t0 += TC) {
           const int len = std::min(TC, L - t0 + 1);
           if (int rc = expand_window(t0, len, fo)) return rc;
-          if (rs_hip_step_cpl(pg.p, &fo, &oo, &pp, t0, len) != 0) return -13;
+          if (rs_hip_step_cpl(pg.p, &fo, &oo, &ppx, t0, len) != 0) return -13;
+          if (t0 + len <= L)
+            if (int rc = resort()) return rc;
         }
       }
     } else
@@ -1315,13 +1351,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
       }
       if (t0 + len <= L) {
         if (rs_hip_recluster(pg.p) != 0) return -14;
-        ea.order = rs_hip_plan_order(pg.p);
-        hipLaunchKernelGGL(gather_params_kernel, grid1(m), dim3(RS_BLOCK), 0, stream, ea.order,
-                           (int64_t)m, pp.initlen, const_cast<int32_t *>(pps.initlen),
-                           D.tair_relax.as<double>(), d_pp_s.as<double>(), D.vz_relax.as<double>(),
-                           d_pp_s.as<double>() + mp, D.rh_relax.as<double>(),
-                           d_pp_s.as<double>() + 2 * mp);
-        HOK(hipGetLastError());
+        if (int rc = gather_params()) return rc;
       }
     }
     pt.lap(4);

@@ -31,6 +31,10 @@ struct StepArgs {
    * cpl_stop: a point parks right after the Coupling_control of its window end */
   const int32_t *cpl_list;
   int32_t cpl_nlist, cpl_stop;
+  /* coupling kernels: the outputs of slot s go to column out_index[s] of the output window
+   * (NULL: column s).  With the plan order as index the (decimated) outputs land in point order
+   * whatever order the slots are in (rs_hip_set_output_by_point). */
+  const int32_t *out_index;
 };
 
 struct InitArgs {

@@ -164,8 +164,13 @@ __device__ __forceinline__ Forcing load_forcing(KernArgs ka, int64_t row0, uint3
   return o;
 }
 
+template <bool SCATTER = false>
 __device__ __forceinline__ void store_outputs(KernArgs ka, int32_t i, int64_t row0, uint32_t lane,
                                               const Scalars &s, bool valid) {
+  if (SCATTER && ka->out_index) { /* column = out_index[slot]: point order whatever the plan order */
+    row0 = (int64_t)ka->out_index[row0 + lane];
+    lane = 0u;
+  }
   int64_t r = (int64_t)(i - 1);
   const int32_t dec = ka->o.decimate;
   if (dec > 1) {
@@ -402,7 +407,7 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
     if (CPL) next_i = i + 1;
     if (s.failed) { /* loop has exited in the reference: outputs stay -9999.0 */
       if (k + 1 < nsteps) nxt = load_forcing<FULL>(ka, row0, lane, k + 1);
-      store_outputs(ka, i, row0, lane, s, false);
+      store_outputs<CPL>(ka, i, row0, lane, s, false);
       continue;
     }
     double tair = f.tair, vz = f.vz, rhz = f.rhz;
@@ -541,7 +546,7 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
      * across the boundary-layer iteration */
     if (k + 1 < nsteps) nxt = load_forcing<FULL>(ka, row0, lane, k + 1);
     model_step_ground(c, s, T, tbot, tair, fx, f.depth, cp);
-    store_outputs(ka, i, row0, lane, s, true);
+    store_outputs<CPL>(ka, i, row0, lane, s, true);
     if (CPL && cpl_on && i < c.SimLen && i == cpl_ce) {
       /* CheckEndCoupling + CouplingOperations2, src/Coupling.f90:98-141 (Coupling_failed is
        * .false. before the first decision) */
@@ -647,7 +652,7 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Sc
       /* the reference's loop has exited: outputs it never saved stay -9999.0 - but a point
        * that fails in the middle of a coupling replay keeps, beyond the failure, what the
        * EARLIER passes saved there (src/InputOutput.f90:151-165 only ever overwrites) */
-      if (i > written_hi) store_outputs(ka, i, p, 0u, s, false);
+      if (i > written_hi) store_outputs<true>(ka, i, p, 0u, s, false);
       ++i;
       continue;
     }
@@ -789,7 +794,7 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Sc
     } else {
       model_step_ground(c, s, T, tbot, tair, fx, f.depth, cp);
     }
-    store_outputs(ka, i, p, 0u, s, true);
+    store_outputs<true>(ka, i, p, 0u, s, true);
     if (i > written_hi) written_hi = i;
     /* CheckEndCoupling + CouplingOperations2, src/Coupling.f90:98-141 */
     if (i < c.SimLen && q.on && i == q.ce && !q.failed) {
@@ -883,8 +888,9 @@ __global__ void __launch_bounds__(kBlock, 3) step_kernel_cpl(const StepArgs a) {
   Scalars s;
   int32_t score = 0;
   load_state<true>(a.state, a.np_pad, p, T, s);
-  time_loop<true, LdsProfile, false, false, true>(mt, T, s, score);
+  time_loop<true, LdsProfile, false, true, true>(mt, T, s, score);
   store_state<true>(a.state, a.np_pad, p, T, s);
+  a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s); /* parked lanes: cheap */
 }
 
 /* Coupled variant: LDS profile (any NLayers), FULL feature set + coupling. */

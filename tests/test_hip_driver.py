@@ -196,6 +196,11 @@ def test_per_point_time_axes_with_chunked_coupling(monkeypatch):
         assert np.array_equal(g["status"], o["status"])
         for k in driver.OUT_FIELDS:
             assert _same_bits(g[k], o[k]), (chunk, k)
+    monkeypatch.setenv("ROADSURF_HIP_CLUSTER", "2")        # coupling in plan order (not the default)
+    g = driver.run(both, s, p, t0, tf)
+    for k in driver.OUT_FIELDS:
+        assert _same_bits(g[k], o[k]), ("plan order", k)
+    monkeypatch.delenv("ROADSURF_HIP_CLUSTER")
     monkeypatch.setenv("ROADSURF_HIP_CPL_WHOLE", "1")     # round-1 organisation: same bits
     g = driver.run(both, s, p, t0, tf)
     for k in driver.OUT_FIELDS:
