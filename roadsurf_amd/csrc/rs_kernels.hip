@@ -647,6 +647,14 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Sc
   int32_t i = resume > t0 ? resume : t0;
   int32_t written_hi = i - 1; /* highest index the point has saved an output for */
   bool stale_all = false; /* first step after a restore: TmpNw is the pre-restore profile */
+  /* the forcing of index i+1 is fetched in the middle of step i (a replay that rewinds fetches its
+   * row again): with two waves per SIMD a load issued at its point of use would stall every step */
+  Forcing nxt;
+  int32_t nxt_i = -1;
+  if (i < tend && !s.failed) {
+    nxt = gather_forcing(ka, p, i, t0);
+    nxt_i = i;
+  }
   while (i < tend) {
     if (s.failed) {
       /* the reference's loop has exited: outputs it never saved stay -9999.0 - but a point
@@ -656,7 +664,7 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Sc
       ++i;
       continue;
     }
-    Forcing f = gather_forcing(ka, p, i, t0);
+    Forcing f = (nxt_i == i) ? nxt : gather_forcing(ka, p, i, t0);
     if (i == 1 && f.vz < R4(0.4)) f.vz = R4(0.4);
     CouplingInputs cp;
     double sw_dir = 0.0, lw_net = 0.0;
@@ -785,6 +793,10 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Sc
     }
     const Fluxes fx = model_step_fluxes(c, mt, s, tair, vz, rhz, prec_ts, sw_in, lw_in, f.phase,
                                         f.hour, cp);
+    if (i + 1 < tend) { /* next index's forcing, half a step ahead of its use */
+      nxt = gather_forcing(ka, p, i + 1, t0);
+      nxt_i = i + 1;
+    }
     if (stale_all) {
       /* observation forcing cannot follow a restore (i >= couplingStartI), so TmpNw(1:2)
        * are the stale values too */
