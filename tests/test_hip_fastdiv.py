@@ -209,3 +209,58 @@ def test_parameters_outside_the_models_domain_are_refused():
     p = abi.default_parameters(); p.ZMom = 10.0; p.ZRefW = 0.0   # logUstar = log(1) = 0
     with pytest.raises(RuntimeError, match="logUstar"):
         device.Plan(8, s, p, 0)
+
+
+FEATURE_SCRIPT = r'''
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np
+from roadsurf_amd import abi, device, driver, lib
+import oracle_helpers as oh
+import driver_helpers as dh
+from test_oracle_vs_golden import _coupling_case, _skyview_case
+import test_hip_coupling as TC
+import test_hip_skyview as TS
+L = lib.load()
+assert L.rs_hip_division_mode() == 2, "not the cross-check build"
+z, f, s, p, ls = _coupling_case(); device.run_points(f, s, p, ls)
+z, f, s, p, ls = _skyview_case(); device.run_points(f, s, p, ls)
+cases, _ = TC._cases(256, 1441, 4242)
+for f2, s2, p2, ls2 in cases:
+    device.run_points(f2, s2, p2, ls2)
+    device.run_points(f2, s2, p2, ls2, chunk=200)          # lock-step coupling kernel + replay rounds
+f3, ls3 = TS._sky_case(192, 1441, 99, summer=True, world=True)
+device.run_points(f3, abi.default_settings(1441), abi.default_parameters(), ls3)
+# calm wind exactly 0.0, RH 0, missing dew point: everything CheckValues admits
+f4 = oh.synth_forcing(512, 1441, seed=5)
+f4["vz"][:, 1:] = np.where(np.arange(1440)[None, :] %% 7 < 3, 0.0, f4["vz"][:, 1:])
+f4["rhz"][::2] = 0.0
+f4["tdew"][:] = -9999.9 * 0 + f4["tair"] - 2.0
+l = abi.default_local(); l.InitLenI = 1
+device.run_points(f4, abi.default_settings(1441), abi.default_parameters(), l, lean_if_possible=False)
+# the driver data path: relaxation, coupling, rejected points (their lanes step on missing values)
+src, Ld, t0, tf = dh.scenario(384, hours=12, seed=23)
+for kw in (dict(use_relaxation=1), dict(use_relaxation=1, use_coupling=1)):
+    sd = abi.default_settings(Ld)
+    for k, v in kw.items():
+        setattr(sd, k, v)
+    driver.run(src, sd, abi.default_parameters(), t0, tf)
+plan = device.Plan(16, abi.default_settings(100), abi.default_parameters(), 0)
+print("DIVCHECK", L.rs_hip_div_mismatch_count(plan._h), L.rs_hip_div_special_count(plan._h))
+'''
+
+
+@pytest.mark.skipif(not os.path.exists(LIBCHK), reason="build with `make -C roadsurf_amd divcheck`")
+def test_bare_division_equals_ieee_on_every_feature_path():
+    """ADVICE r01: the synthetic LEAN workload is not the only operand distribution.  The
+    cross-check build over the golden coupling and sky-view cases, the coupling cases in one launch
+    and in chunks (lock-step coupling kernel + replay rounds), sky view around the globe, calm wind
+    0.0 / RH 0, and the driver data path with relaxation, coupling and rejected points (whose lanes
+    step on -9999.9): no evaluation with two finite results may differ."""
+    env = dict(os.environ, ROADSURF_HIP_LIB=LIBCHK)
+    r = subprocess.run([sys.executable, "-c", FEATURE_SCRIPT % {"root": ROOT}], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [x for x in r.stdout.splitlines() if x.startswith("DIVCHECK")][-1]
+    print(line)
+    assert int(line.split()[1]) == 0
