@@ -1291,6 +1291,44 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
       }
       return 0;
     };
+    /* Re-sort of the slots for the window [t_next, t_next+len_next): by a FORECAST of that window
+     * (rs_hip_recluster_forecast) - air temperature and wind speed at three of its
+     * indices, produced from the raw series in the CURRENT slot order by the expansion kernel
+     * itself (only those two fields, one index each) - or, where the raw series have per-point time
+     * axes (their walks would have to be re-positioned for every preview), by the history of the
+     * last launch. */
+    Dev d_prev;
+    const char *ek = getenv("ROADSURF_HIP_SORT_KEY"); /* "history": round-1 key */
+    const bool forecast_key = !T.any_pp && !(ek && strcmp(ek, "history") == 0);
+    auto resort_for = [&](int t_next, int len_next) -> int {
+      if (!forecast_key) {
+        if (rs_hip_recluster(pg.p) != 0) return -14;
+        return gather_params();
+      }
+      if (!d_prev.p) HOK(d_prev.alloc((size_t)6 * mp * sizeof(double)));
+      const int idx[3] = {t_next, t_next + len_next / 2, t_next + len_next - 1};
+      ExpandRawArgs pe = ea; /* current order, same sources and decisions */
+      RsPreview pv;
+      std::memset(&pv, 0, sizeof(pv));
+      pv.n = 3;
+      for (int q = 0; q < 3; ++q) {
+        for (int f = 0; f < NFLD; ++f) pe.out[f] = nullptr;
+        pe.out[R_TAIR] = d_prev.as<double>() + (size_t)(2 * q) * mp;
+        pe.out[R_VZ] = d_prev.as<double>() + (size_t)(2 * q + 1) * mp;
+        pe.i0 = idx[q] - 1;
+        pe.nsteps = 1;
+        launch_expand_raw(false, mp, pe, stream);
+        HOK(hipGetLastError());
+        pv.tair[q] = pe.out[R_TAIR];
+        pv.vz[q] = pe.out[R_VZ];
+        pv.hour[q] = in->hour[idx[q] - 1];
+      }
+      pv.tair_now = pv.tair[0];
+      pv.alpha = 0.5;
+      pv.mode = 3124;
+      if (rs_hip_recluster_forecast(pg.p, &pv) != 0) return -14;
+      return gather_params();
+    };
     if (cpl_chunked) {
       /* stage 1: lock step to the last window end; stage 2: the replay rounds over the block
        * [first window start, last window end + 1]; stage 3: lock step from behind the first
@@ -1349,10 +1387,8 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
                            (int64_t)mp);
         HOK(hipGetLastError());
       }
-      if (t0 + len <= L) {
-        if (rs_hip_recluster(pg.p) != 0) return -14;
-        if (int rc = gather_params()) return rc;
-      }
+      if (t0 + len <= L)
+        if (int rc = resort_for(t0 + len, std::min(TC, L - (t0 + len) + 1))) return rc;
     }
     pt.lap(4);
     hipLaunchKernelGGL(blank_rejected_kernel, grid1(m), dim3(RS_BLOCK), 0, stream, ob, (int64_t)mp,
