@@ -139,23 +139,47 @@ __device__ __forceinline__ KernArgs kernargs() {
  * of the workgroup), `lane` is the 32-bit index of the point inside the
  * workgroup, so every access is global_load/store saddr + 32-bit voffset with no
  * 64-bit per-lane arithmetic. */
+/* base[lane] as saddr + 32-bit voffset.  Instruction selection works a basic block at a time and
+ * takes that form only when it sees the 32-bit lane offset being widened in the block of the
+ * access; a `lane * 8` from the kernel's entry block arrives as a 64-bit register pair and costs a
+ * 64-bit vector add per access.  LaneOff therefore forms the byte offset behind an asm barrier in
+ * the block that uses it (one v_lshlrev per group of accesses). */
+struct LaneOff {
+  uint32_t b8;
+  __device__ __forceinline__ explicit LaneOff(uint32_t lane) {
+    asm volatile("v_lshlrev_b32 %0, 3, %1" : "=v"(b8) : "v"(lane));
+  }
+  template <class T>
+  __device__ __forceinline__ T ld(const T *base) const {
+    static_assert(sizeof(T) == 8 || sizeof(T) == 4, "");
+    return *(const T *)((const char *)base + (sizeof(T) == 8 ? b8 : b8 >> 1));
+  }
+  template <class T>
+  __device__ __forceinline__ void st(T *base, T v) const {
+    static_assert(sizeof(T) == 8 || sizeof(T) == 4, "");
+    *(T *)((char *)base + (sizeof(T) == 8 ? b8 : b8 >> 1)) = v;
+  }
+};
+
 template <bool FULL>
 __device__ __forceinline__ Forcing load_forcing(KernArgs ka, int64_t row0, uint32_t lane,
                                                 int32_t k) {
   Forcing o;
   const int64_t row = (int64_t)k * ka->f.t_stride + row0;
-  o.tair = (ka->f.tair + row)[lane];
-  o.vz = (ka->f.vz + row)[lane];
-  o.rhz = (ka->f.rhz + row)[lane];
-  o.prec = (ka->f.prec + row)[lane];
-  o.sw = (ka->f.sw + row)[lane];
-  o.lw = (ka->f.lw + row)[lane];
-  o.phase = (ka->f.precphase + row)[lane];
-  o.hour = ka->f.hour_pstride ? (ka->f.hour + row)[lane] : ka->f.hour[k];
+  const LaneOff L(lane);
+  o.tair = L.ld(ka->f.tair + row);
+  o.vz = L.ld(ka->f.vz + row);
+  o.rhz = L.ld(ka->f.rhz + row);
+  o.prec = L.ld(ka->f.prec + row);
+  o.sw = L.ld(ka->f.sw + row);
+  o.lw = L.ld(ka->f.lw + row);
+  o.phase = L.ld(ka->f.precphase + row);
+  if (ka->f.hour_pstride) o.hour = L.ld(ka->f.hour + row);
+  else o.hour = ka->f.hour[k];
   if (FULL) {
-    o.tdew = ka->f.tdew ? (ka->f.tdew + row)[lane] : 0.0;
-    o.tsurfobs = ka->f.tsurfobs ? (ka->f.tsurfobs + row)[lane] : R4(-9999.9);
-    o.depth = ka->f.depth ? (ka->f.depth + row)[lane] : R4(-9999.9);
+    o.tdew = ka->f.tdew ? L.ld(ka->f.tdew + row) : 0.0;
+    o.tsurfobs = ka->f.tsurfobs ? L.ld(ka->f.tsurfobs + row) : R4(-9999.9);
+    o.depth = ka->f.depth ? L.ld(ka->f.depth + row) : R4(-9999.9);
   } else {
     o.tdew = 0.0;
     o.tsurfobs = R4(-9999.9);
@@ -164,27 +188,45 @@ __device__ __forceinline__ Forcing load_forcing(KernArgs ka, int64_t row0, uint3
   return o;
 }
 
-template <bool SCATTER = false>
-__device__ __forceinline__ void store_outputs(KernArgs ka, int32_t i, int64_t row0, uint32_t lane,
-                                              const Scalars &s, bool valid) {
-  if (SCATTER && ka->out_index) { /* column = out_index[slot]: point order whatever the plan order */
-    row0 = (int64_t)ka->out_index[row0 + lane];
-    lane = 0u;
-  }
-  int64_t r = (int64_t)(i - 1);
+/* Output row of time index i: false when the decimation skips it.  UNI: the index is the same in
+ * every lane (lock-step kernels) and the row is formed once per step, ahead of the divergent
+ * branches, so that it stays in scalar registers (a row computed at each store site is merged by
+ * the compiler into a per-lane value). */
+template <bool UNI>
+__device__ __forceinline__ bool output_row(KernArgs ka, int32_t i, int64_t &row) {
+  int32_t r = i - 1;
   const int32_t dec = ka->o.decimate;
   if (dec > 1) {
-    if (r % dec != 0) return;
+    if (r % dec != 0) return false;
     r /= dec;
   }
-  const int64_t row = (r - ka->o.row0) * ka->o.t_stride + row0;
+  if (UNI) r = __builtin_amdgcn_readfirstlane(r);
+  row = ((int64_t)r - ka->o.row0) * ka->o.t_stride;
+  return true;
+}
+
+template <bool SCATTER = false>
+__device__ __forceinline__ void store_outputs(KernArgs ka, int64_t row, int64_t row0, uint32_t lane,
+                                              const Scalars &s, bool valid) {
   const double miss = R4(-9999.0); /* src/Initialization.f90:404-411 */
-  (ka->o.tsurf + row)[lane] = valid ? s.tsurf : miss;
-  (ka->o.snow + row)[lane] = valid ? s.snow : miss;
-  (ka->o.water + row)[lane] = valid ? s.wat : miss;
-  (ka->o.ice + row)[lane] = valid ? s.ice : miss;
-  (ka->o.deposit + row)[lane] = valid ? s.dep : miss;
-  (ka->o.ice2 + row)[lane] = valid ? s.ice2 : miss;
+  if (SCATTER && ka->out_index) { /* column = out_index[slot]: point order whatever the plan order */
+    row += (int64_t)ka->out_index[row0 + lane];
+    ka->o.tsurf[row] = valid ? s.tsurf : miss;
+    ka->o.snow[row] = valid ? s.snow : miss;
+    ka->o.water[row] = valid ? s.wat : miss;
+    ka->o.ice[row] = valid ? s.ice : miss;
+    ka->o.deposit[row] = valid ? s.dep : miss;
+    ka->o.ice2[row] = valid ? s.ice2 : miss;
+    return;
+  }
+  row += row0;
+  const LaneOff L(lane);
+  L.st(ka->o.tsurf + row, valid ? s.tsurf : miss);
+  L.st(ka->o.snow + row, valid ? s.snow : miss);
+  L.st(ka->o.water + row, valid ? s.wat : miss);
+  L.st(ka->o.ice + row, valid ? s.ice : miss);
+  L.st(ka->o.deposit + row, valid ? s.dep : miss);
+  L.st(ka->o.ice2 + row, valid ? s.ice2 : miss);
 }
 
 /* ---- coupling: src/Coupling.f90 -------------------------------------------------
@@ -394,11 +436,18 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
     next_i = (int32_t)st[(int64_t)RS_ST_CPL_RESUME * np + p];
   }
   Forcing nxt = load_forcing<FULL>(ka, row0, lane, 0);
-  for (int32_t k = 0; k < nsteps; ++k) {
+  for (int32_t kv = 0; kv < nsteps; ++kv) {
     asm volatile("" : "+s"(ka));
     const ConstsAS &c = consts_of(ka);
+    /* the loop counter is wave-uniform, but lanes that `continue` (failed, parked) make the
+     * compiler keep it in a vector register, and with it every row offset: 64-bit vector
+     * multiplies and two 64-bit vector adds per load and store.  Read back as a scalar, the row
+     * arithmetic runs on the scalar unit and the accesses are saddr + 32-bit lane offset */
+    const int32_t k = __builtin_amdgcn_readfirstlane(kv);
     const int32_t i = t0 + k;
     const Forcing f = nxt;
+    int64_t orow = 0;
+    const bool owrite = output_row<true>(ka, i, orow);
 
     if (CPL && (parked || i != next_i)) { /* parked behind its window, or ahead of this launch */
       if (k + 1 < nsteps) nxt = load_forcing<FULL>(ka, row0, lane, k + 1);
@@ -407,7 +456,7 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
     if (CPL) next_i = i + 1;
     if (s.failed) { /* loop has exited in the reference: outputs stay -9999.0 */
       if (k + 1 < nsteps) nxt = load_forcing<FULL>(ka, row0, lane, k + 1);
-      store_outputs<CPL>(ka, i, row0, lane, s, false);
+      if (owrite) store_outputs<CPL>(ka, orow, row0, lane, s, false);
       continue;
     }
     double tair = f.tair, vz = f.vz, rhz = f.rhz;
@@ -418,8 +467,9 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
     double sw_dir = 0.0, lw_net = 0.0;
     if (SKY) {
       const int64_t row = (int64_t)k * ka->f.t_stride + row0;
-      sw_dir = (ka->f.sw_dir + row)[lane];
-      lw_net = (ka->f.lw_net + row)[lane];
+      const LaneOff L(lane);
+      sw_dir = L.ld(ka->f.sw_dir + row);
+      lw_net = L.ld(ka->f.lw_net + row);
     }
     CouplingInputs cp;
     if (i < c.SimLen) {
@@ -546,7 +596,7 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
      * across the boundary-layer iteration */
     if (k + 1 < nsteps) nxt = load_forcing<FULL>(ka, row0, lane, k + 1);
     model_step_ground(c, s, T, tbot, tair, fx, f.depth, cp);
-    store_outputs<CPL>(ka, i, row0, lane, s, true);
+    if (owrite) store_outputs<CPL>(ka, orow, row0, lane, s, true);
     if (CPL && cpl_on && i < c.SimLen && i == cpl_ce) {
       /* CheckEndCoupling + CouplingOperations2, src/Coupling.f90:98-141 (Coupling_failed is
        * .false. before the first decision) */
@@ -660,7 +710,8 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Sc
       /* the reference's loop has exited: outputs it never saved stay -9999.0 - but a point
        * that fails in the middle of a coupling replay keeps, beyond the failure, what the
        * EARLIER passes saved there (src/InputOutput.f90:151-165 only ever overwrites) */
-      if (i > written_hi) store_outputs<true>(ka, i, p, 0u, s, false);
+      int64_t orow;
+      if (i > written_hi && output_row<false>(ka, i, orow)) store_outputs<true>(ka, orow, p, 0u, s, false);
       ++i;
       continue;
     }
@@ -806,7 +857,8 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Sc
     } else {
       model_step_ground(c, s, T, tbot, tair, fx, f.depth, cp);
     }
-    store_outputs<true>(ka, i, p, 0u, s, true);
+    int64_t orow;
+    if (output_row<false>(ka, i, orow)) store_outputs<true>(ka, orow, p, 0u, s, true);
     if (i > written_hi) written_hi = i;
     /* CheckEndCoupling + CouplingOperations2, src/Coupling.f90:98-141 */
     if (i < c.SimLen && q.on && i == q.ce && !q.failed) {
