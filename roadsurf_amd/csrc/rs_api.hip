@@ -798,6 +798,7 @@ int rs_hip_expand_forcing_on(RsPlan *pl, const RsSynthSpec *spec, const double *
   a.start_hour = spec->start_hour;
   a.kfirst = kfirst;
   a.nsteps = nsteps;
+  a.r_spk = 1.0 / (double)spk;
   if (pl->f32) {
     if (f->depth || f->tdew) return set_err("rs_hip_expand_forcing: fp32 windows carry no Tdew/depth");
     HIP_OK(rs32_launch_expand(a, (t0 + nsteps - 2) / spk - kfirst + 1, (hipStream_t)stream));

@@ -67,6 +67,7 @@ struct ExpandArgs {
   int64_t npoints, np_pad;
   int32_t k0, t0, spk, start_hour;
   int32_t kfirst, nsteps;
+  double r_spk; /* RN(1 / spk): the interpolation's division has a uniform denominator (rs_div_u) */
 };
 
 }  // namespace rs

@@ -1103,12 +1103,20 @@ __global__ void __launch_bounds__(kBlock) expand_kernel(const ExpandArgs a) {
   const int32_t ph1 = need_b ? (int32_t)kb[8 * a.np_pad] : ph0;
   double *out[7] = {(double *)a.f.tair, (double *)a.f.tdew, (double *)a.f.vz, (double *)a.f.rhz,
                     (double *)a.f.prec, (double *)a.f.sw, (double *)a.f.lw};
+  /* rs_sy_lerp, k0 + (secs * (k1 - k0)) / span, with the difference taken once per interval and
+   * the division by the uniform span as rs_div_u (rs_math.hpp: exact for a denominator whose
+   * reciprocal is correctly rounded; the numerator is never -0.0 here because k1 - k0 is not) */
+  double dv[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) dv[q] = v1[q] - v0[q];
+  const double span = (double)a.spk;
   for (int32_t t = tlo; t < thi; ++t) {
     const int32_t r = t - k * a.spk;
+    const double secs = (double)r;
     const int64_t off = (int64_t)(t - (a.t0 - 1)) * a.f.t_stride + p;
 #pragma unroll
     for (int q = 0; q < 7; ++q)
-      if (out[q]) out[q][off] = (r == 0) ? v0[q] : rs_sy_lerp(v0[q], v1[q], r, a.spk);
+      if (out[q]) out[q][off] = (r == 0) ? v0[q] : v0[q] + rs_div_u(secs * dv[q], span, a.r_spk);
     if (a.f.tsurfobs) ((double *)a.f.tsurfobs)[off] = (t == 0) ? ts0 : -9999.9;
     if (a.f.depth) ((double *)a.f.depth)[off] = -9999.9;
     ((int32_t *)a.f.precphase)[off] = (r == 0) ? ph0 : ph1;

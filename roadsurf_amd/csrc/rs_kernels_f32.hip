@@ -211,12 +211,18 @@ __global__ void __launch_bounds__(kBlock) expand_kernel_f32(const rs::ExpandArgs
   const int32_t ph1 = need_b ? (int32_t)kb[8 * a.np_pad] : ph0;
   float *out[7] = {(float *)a.f.tair, (float *)a.f.tdew, (float *)a.f.vz, (float *)a.f.rhz,
                    (float *)a.f.prec, (float *)a.f.sw, (float *)a.f.lw};
+  double dv[7]; /* as in expand_kernel (rs_kernels.hip) */
+#pragma unroll
+  for (int q = 0; q < 7; ++q) dv[q] = v1[q] - v0[q];
+  const double span = (double)a.spk;
   for (int32_t t = tlo; t < thi; ++t) {
     const int32_t r = t - k * a.spk;
+    const double secs = (double)r;
     const int64_t off = (int64_t)(t - (a.t0 - 1)) * a.f.t_stride + p;
 #pragma unroll
     for (int q = 0; q < 7; ++q)
-      if (out[q]) out[q][off] = (float)((r == 0) ? v0[q] : rs_sy_lerp(v0[q], v1[q], r, a.spk));
+      if (out[q])
+        out[q][off] = (float)((r == 0) ? v0[q] : v0[q] + rs::rs_div_u(secs * dv[q], span, a.r_spk));
     if (a.f.tsurfobs) ((float *)a.f.tsurfobs)[off] = (t == 0) ? (float)ts0 : -9999.9f;
     ((int32_t *)a.f.precphase)[off] = (r == 0) ? ph0 : ph1;
     if (p == 0 && !a.f.hour_pstride)

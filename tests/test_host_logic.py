@@ -129,6 +129,8 @@ def test_uniform_reciprocal_division_is_ieee_division():
         c2 = lib.build_constants(s2, p2)
         dens.update({f"twoDT{dt}": c2.twoDT, f"DTSecs{dt}": c2.DTSecs, f"logUstar{dt}": c2.logUstar,
                      f"logCond{dt}": c2.logCond})
+    # spans of the forcing interpolation (expand_kernel: steps per knot = 3600 / DTSecs and others)
+    dens.update({f"spk{k}": float(k) for k in (2, 3, 7, 12, 60, 120, 240, 360, 3600)})
     rng = np.random.default_rng(7)
     n = 1_000_000
     mant = rng.uniform(1.0, 2.0, n)
