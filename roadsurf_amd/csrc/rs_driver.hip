@@ -1300,6 +1300,8 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     Dev d_prev;
     const char *ek = getenv("ROADSURF_HIP_SORT_KEY"); /* "history": round-1 key */
     const bool forecast_key = !T.any_pp && !(ek && strcmp(ek, "history") == 0);
+    /* nobody reads the step kernels' history score then: run the instances without it */
+    if (rs_hip_set_history_score(pg.p, (cluster && forecast_key && !cpl_chunked) ? 0 : 1) != 0) return -14;
     auto resort_for = [&](int t_next, int len_next) -> int {
       if (!forecast_key) {
         if (rs_hip_recluster(pg.p) != 0) return -14;

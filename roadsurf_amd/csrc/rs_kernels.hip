@@ -1353,8 +1353,10 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
     if (wpe == 0) wpe = full ? 3 : 4;
 #define RS_REG(W)                                                                        \
   if (wpe == W) {                                                                        \
-    if (full)                                                                            \
+    if (full && (score || W != 3))                                                       \
       hipLaunchKernelGGL((rs::step_kernel_reg<15, true, W>), g, b, 0, stream, a);        \
+    else if (full) /* no history score wanted: the default FULL flavour without it */     \
+      hipLaunchKernelGGL((rs::step_kernel_reg<15, true, 3, false>), g, b, 0, stream, a); \
     else if (score || W != 4)                                                            \
       hipLaunchKernelGGL((rs::step_kernel_reg<15, false, W>), g, b, 0, stream, a);       \
     else /* no history score wanted (forecast order): the default flavour without it */   \
