@@ -305,6 +305,10 @@ def main() -> None:
                                   "mean per launch, averaged over the launches of a pass like "
                                   "avg_launch_ms)" if traffic else None,
                 "valu": valu,
+                # measured pass time against the vector-issue time of its step launches (PMC figure of
+                # the committed profile, at the 2.4 GHz peak clock; the chip holds ~2.23 GHz here)
+                "valu_issue_frac": (valu["valu_issue_ms_per_pass_at_2.4GHz"] / (elapsed / args.steps * 1e3)
+                                    if valu and "valu_issue_ms_per_pass_at_2.4GHz" in valu else None),
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "launches": nlaunch,
                 "units_per_launch": units_per_launch,
