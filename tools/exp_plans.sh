@@ -1,8 +1,10 @@
 # sweep: plans per GPU x launch length (bench.py --plans-per-gpu / --chunk); prints one line per config
 set -e
 mkdir -p gpurun_out/exp1
-for cfg in ${CFGS:-"1 240" "2 240" "2 120" "3 120" "4 240" "4 120" "4 60" "6 120" "8 120"}; do
-set -- $cfg; K=$1; CH=$2
+# usage: exp_plans.sh [K:CHUNK ...]
+[ $# -gt 0 ] || set -- 1:240 2:240 2:120 3:120 4:240 4:120 4:60 6:120 8:120
+for cfg in "$@"; do
+IFS=: read K CH <<< "$cfg"
 python bench.py --no-cpu-baseline --no-natural-leg --plans-per-gpu $K --chunk $CH $EXTRA > gpurun_out/exp1/k${K}_c${CH}.json 2> gpurun_out/exp1/k${K}_c${CH}.err || { tail -5 gpurun_out/exp1/k${K}_c${CH}.err; exit 1; }
 python - <<PY
 import json
