@@ -353,6 +353,11 @@ int rs_hip_step(RsPlan *plan, const RsForcing *f, const RsOutputs *o,
  * the slots' order is (a replay rewrites rows of earlier launches, so a per-launch buffer in slot
  * order does not do).  Meant for decimated outputs: the stores are scattered. */
 int rs_hip_set_output_by_point(RsPlan *plan, int32_t on);
+/* closed = 1: every point's coupling window, replays included, is behind the plan (the caller has
+ * run rs_hip_cpl_replay over the last of them).  A re-sort then moves the coupling scalars only, not
+ * the state saved at the window start (saveDataForCoupling, src/Coupling.f90:172-210) nor the stale
+ * TmpNw profile: 32 instead of 68 rows at NLayers = 15.  Reset to 0 by rs_hip_init_state. */
+int rs_hip_coupling_windows_closed(RsPlan *plan, int32_t closed);
 int rs_hip_step_cpl(RsPlan *plan, const RsForcing *f, const RsOutputs *o,
                     const RsPointParams *pp, int32_t t0, int32_t nsteps);
 int rs_hip_cpl_replay(RsPlan *plan, const RsForcing *f, const RsOutputs *o,

@@ -67,6 +67,7 @@ struct RsPlan {
   size_t cpl_tmp_bytes = 0;
   int32_t cpl_rounds_last = 0; /* replay rounds of the last coupled rs_hip_step (diagnostics) */
   bool output_by_point = false; /* coupling kernels scatter their outputs through the plan order */
+  bool cpl_windows_closed = false; /* rs_hip_coupling_windows_closed: re-sorts leave the saved state */
   bool history_score = true; /* the step kernels leave the sort key of rs_hip_recluster */
   bool f32 = false; /* single-precision flavour: windows and state hold floats */
   std::vector<hipEvent_t> ev; /* start/stop pairs */
@@ -284,7 +285,7 @@ static int recluster_buffers(RsPlan *pl) {
 static int recluster_apply(RsPlan *pl) {
   HIP_OK(rs_cluster_apply(pl->state, pl->state_alt, pl->f32, pl->order, pl->order_alt,
                           pl->sort_keys + 3 * pl->np_pad, pl->np_pad, pl->npoints, pl->c.NLayers,
-                          pl->c.use_coupling != 0, pl->stream));
+                          pl->c.use_coupling == 0 ? 0 : pl->cpl_windows_closed ? 1 : 2, pl->stream));
   std::swap(pl->state, pl->state_alt);
   std::swap(pl->order, pl->order_alt);
   return 0;
@@ -375,6 +376,12 @@ int rs_hip_set_output_by_point(RsPlan *pl, int32_t on) {
   return 0;
 }
 
+int rs_hip_coupling_windows_closed(RsPlan *pl, int32_t closed) {
+  if (!pl) return set_err("rs_hip_coupling_windows_closed: null plan");
+  pl->cpl_windows_closed = closed != 0;
+  return 0;
+}
+
 int rs_hip_set_history_score(RsPlan *pl, int32_t on) {
   if (!pl) return set_err("rs_hip_set_history_score: null plan");
   pl->history_score = on != 0;
@@ -413,6 +420,7 @@ int rs_hip_init_state(RsPlan *pl, const RsForcing *f, const RsPointParams *pp) {
   a.state = pl->state;
   a.npoints = pl->npoints;
   a.np_pad = pl->np_pad;
+  pl->cpl_windows_closed = false; /* a new run: its coupling windows lie ahead */
   if (pl->f32) {
     if (f->depth) return set_err("rs_hip_init_state: the fp32 flavour has no output-depth support");
     HIP_OK(rs32_launch_init(a, pl->stream));

@@ -28,6 +28,29 @@ __global__ void __launch_bounds__(RS_BLOCK) keys_kernel(const T *__restrict__ st
   slots[s] = (uint32_t)s;
 }
 
+/* Which state rows a re-sort has to move (rs_state.h).  blockIdx.y counts the rows in use:
+ * the profile Tmp(1..NLayers), the scalars TmpNw(1)..BLSCORE, then - with coupling - the coupling
+ * scalars ITER..RESUME, and while coupling windows are still open also the saved state of
+ * saveDataForCoupling (6 scalars, TmpSave(1..NLayers)) and the stale TmpNw profile. */
+struct RowMap {
+  int32_t nlayers, nscal, ncpl, nsave; /* rows of each group; nsave counts the 6 scalars only */
+  __host__ __device__ int32_t total() const {
+    return nlayers + nscal + ncpl + nsave + (nsave ? 2 * nlayers : 0);
+  }
+  __device__ int64_t row(int32_t y) const {
+    if (y < nlayers) return y;
+    y -= nlayers;
+    if (y < nscal) return RS_ST_TNW1 + y;
+    y -= nscal;
+    if (y < ncpl) return RS_ST_CPL_ITER + y;
+    y -= ncpl;
+    if (y < nsave) return RS_ST_CPL_SAVE_TSURF + y;
+    y -= nsave;
+    if (y < nlayers) return RS_ST_CPL_SAVE_TMP0 + y;
+    return RS_ST_CPL_STALE_TMP0 + (y - nlayers);
+  }
+};
+
 /* dst[row][s] = src[row][perm[s]] for the carried state, order_dst[s] = order_src[perm[s]];
  * slots beyond npoints (padding) stay where they are */
 template <typename T>
@@ -37,14 +60,12 @@ __global__ void __launch_bounds__(RS_BLOCK) apply_kernel(const T *__restrict__ s
                                                          int32_t *__restrict__ order_dst,
                                                          const uint32_t *__restrict__ perm,
                                                          int64_t np_pad, int64_t npoints,
-                                                         int32_t nlayers) {
+                                                         const RowMap rows) {
   const int64_t s = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
   if (s >= np_pad) return;
   const int64_t from = (s < npoints) ? (int64_t)perm[s] : s;
   if (blockIdx.y == 0) order_dst[s] = order_src[from];
-  /* rows in use: the profile Tmp(1..NLayers), then everything from TmpNw(1) on */
-  const int64_t row = ((int)blockIdx.y < nlayers) ? blockIdx.y
-                                                  : (int64_t)RS_MAX_LAYERS + (blockIdx.y - nlayers);
+  const int64_t row = rows.row((int32_t)blockIdx.y);
   dst[row * np_pad + s] = src[row * np_pad + from];
 }
 
@@ -126,20 +147,25 @@ hipError_t rs_cpl_select_again(const double *state, int64_t np_pad, int64_t npoi
   return hipcub::DeviceSelect::Flagged(tmp, tmp_bytes, iota, flags, list, count_dev, (int)npoints, stream);
 }
 
-/* nlayers: NLayers of the plan; coupled: also move the coupling block (saved state etc.) */
+/* nlayers: NLayers of the plan; cpl_rows: 0 no coupling block, 1 the coupling scalars only (every
+ * coupling window is behind the plan: nothing reads the saved state any more), 2 everything */
 hipError_t rs_cluster_apply(const double *state_src, double *state_dst, bool f32,
                             const int32_t *order_src, int32_t *order_dst, const uint32_t *perm,
-                            int64_t np_pad, int64_t npoints, int nlayers, bool coupled,
+                            int64_t np_pad, int64_t npoints, int nlayers, int cpl_rows,
                             hipStream_t stream) {
   dim3 g = grid1(np_pad);
-  const int last = coupled ? RS_NSTATE - 1 : RS_ST_BLSCORE;
-  g.y = (unsigned)(nlayers + (last - RS_MAX_LAYERS + 1));
+  RowMap rows;
+  rows.nlayers = nlayers;
+  rows.nscal = RS_ST_BLSCORE - RS_ST_TNW1 + 1;
+  rows.ncpl = cpl_rows >= 1 ? RS_ST_CPL_RESUME - RS_ST_CPL_ITER + 1 : 0;
+  rows.nsave = cpl_rows >= 2 ? RS_ST_CPL_SAVE_ALBEDO - RS_ST_CPL_SAVE_TSURF + 1 : 0;
+  g.y = (unsigned)rows.total();
   if (f32)
     hipLaunchKernelGGL(apply_kernel<float>, g, dim3(RS_BLOCK), 0, stream,
                        reinterpret_cast<const float *>(state_src), reinterpret_cast<float *>(state_dst),
-                       order_src, order_dst, perm, np_pad, npoints, (int32_t)nlayers);
+                       order_src, order_dst, perm, np_pad, npoints, rows);
   else
     hipLaunchKernelGGL(apply_kernel<double>, g, dim3(RS_BLOCK), 0, stream, state_src, state_dst,
-                       order_src, order_dst, perm, np_pad, npoints, (int32_t)nlayers);
+                       order_src, order_dst, perm, np_pad, npoints, rows);
   return hipGetLastError();
 }

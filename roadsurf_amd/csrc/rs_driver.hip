@@ -1201,16 +1201,14 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     /* Plan order (rs_hip_recluster): with more than one launch per tile the slots
      * are re-sorted by regime after every launch; windows and per-point parameters are then
      * produced in slot order and each launch's output rows are mapped back.  Time-chunked
-     * coupling CAN run that way too (ROADSURF_HIP_CLUSTER=2: the lock-step coupling kernel leaves
-     * the sort key; its outputs, and the replays', go straight to their point's column,
-     * rs_hip_set_output_by_point) but is not by default: measured 1.18 s against 0.98 s in natural
-     * order at 1 M points - the raw-series path gains little from the order (its gathers of
-     * 1 M-wide raw rows cost most of what coherence saves) and with coupling pays for it three
-     * times over (134 state rows to move, scattered output stores, replay lists in slot order).
-     * Not for sky view with coupling (general kernel over the whole series: no sort key). */
+     * coupling runs that way too: the lock-step chunks are re-sorted like the uncoupled launches,
+     * and the coupling kernels' outputs - the replays' included - go straight to their point's
+     * column (rs_hip_set_output_by_point).  Measured at 1 M points, four plans: 0.90 s against
+     * 0.96 s in natural order with the history key (-12 % vector instructions in the lock-step
+     * kernel), see DESIGN.md 6 for the forecast key.  ROADSURF_HIP_CLUSTER=0 switches the order
+     * off.  Not for sky view with coupling (general kernel over the whole series: no sort key). */
     const char *ec = getenv("ROADSURF_HIP_CLUSTER");
-    const bool cluster = (!coupled || (cpl_chunked && ec && atoi(ec) == 2)) && !skyview && TC < L &&
-                         !(ec && atoi(ec) == 0);
+    const bool cluster = (!coupled || cpl_chunked) && !skyview && TC < L && !(ec && atoi(ec) == 0);
     const int rows_c = TC / step + 2; /* output rows one launch can produce */
     Dev d_outc, d_pp_s;
     RsOutputs oc = oo;
@@ -1341,8 +1339,9 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
        * parameters are produced in slot order, outputs go to their point's column */
       const RsPointParams &ppx = cluster ? pps : pp;
       if (cluster && rs_hip_set_output_by_point(pg.p, 1) != 0) return -14;
-      auto resort = [&]() -> int {
+      auto resort = [&](int t_next) -> int {
         if (!cluster) return 0;
+        if (forecast_key) return resort_for(t_next, std::min(TC, L - t_next + 1));
         if (rs_hip_recluster(pg.p) != 0) return -14;
         return gather_params();
       };
@@ -1352,18 +1351,23 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
         if (int rc = expand_window(t0, len, fo)) return rc;
         if (t0 == 1 && rs_hip_init_state(pg.p, &fo, &ppx) != 0) return -12;
         if (rs_hip_step_cpl(pg.p, &fo, &oo, &ppx, t0, len) != 0) return -13;
-        if (int rc = resort()) return rc;
+        /* the next lock-step chunk: the one behind this, or stage 3's first */
+        const int t_next = (t0 + len <= s1_hi) ? t0 + len : (any_on && ce_min + 1 <= L) ? ce_min + 1 : 0;
+        if (t_next > 0)
+          if (int rc = resort(t_next)) return rc;
       }
       if (any_on) {
         if (int rc = expand_window(r_lo, r_hi - r_lo + 1, fo)) return rc;
         int32_t rounds = 0;
         if (rs_hip_cpl_replay(pg.p, &fo, &oo, &ppx, r_lo, r_hi - r_lo + 1, &rounds) != 0) return -13;
+        /* every window is behind the plan: stage 3's re-sorts need not move the saved state */
+        if (rs_hip_coupling_windows_closed(pg.p, 1) != 0) return -14;
         for (int t0 = ce_min + 1; t0 <= L; t0 += TC) {
           const int len = std::min(TC, L - t0 + 1);
           if (int rc = expand_window(t0, len, fo)) return rc;
           if (rs_hip_step_cpl(pg.p, &fo, &oo, &ppx, t0, len) != 0) return -13;
           if (t0 + len <= L)
-            if (int rc = resort()) return rc;
+            if (int rc = resort(t0 + len)) return rc;
         }
       }
     } else

@@ -109,7 +109,7 @@ hipError_t rs_cluster_sort_keys(int64_t np_pad, int64_t npoints, uint32_t *scrat
                                 size_t tmp_bytes, hipStream_t stream);
 hipError_t rs_cluster_apply(const double *state_src, double *state_dst, bool f32,
                             const int32_t *order_src, int32_t *order_dst, const uint32_t *perm,
-                            int64_t np_pad, int64_t npoints, int nlayers, bool coupled,
+                            int64_t np_pad, int64_t npoints, int nlayers, int cpl_rows,
                             hipStream_t stream);
 
 /* fp32 flavour (rs_kernels_f32.hip) */

@@ -196,15 +196,39 @@ def test_per_point_time_axes_with_chunked_coupling(monkeypatch):
         assert np.array_equal(g["status"], o["status"])
         for k in driver.OUT_FIELDS:
             assert _same_bits(g[k], o[k]), (chunk, k)
-    monkeypatch.setenv("ROADSURF_HIP_CLUSTER", "2")        # coupling in plan order (not the default)
+    monkeypatch.setenv("ROADSURF_HIP_CLUSTER", "0")        # natural order (plan order is the default)
     g = driver.run(both, s, p, t0, tf)
     for k in driver.OUT_FIELDS:
-        assert _same_bits(g[k], o[k]), ("plan order", k)
+        assert _same_bits(g[k], o[k]), ("natural order", k)
     monkeypatch.delenv("ROADSURF_HIP_CLUSTER")
     monkeypatch.setenv("ROADSURF_HIP_CPL_WHOLE", "1")     # round-1 organisation: same bits
     g = driver.run(both, s, p, t0, tf)
     for k in driver.OUT_FIELDS:
         assert _same_bits(g[k], o[k]), ("whole", k)
+
+
+def test_shared_axis_chunked_coupling_in_plan_order(monkeypatch):
+    """Shared time axes: the lock-step chunks of the coupled run are re-sorted by the forecast key
+    (previews of the next chunk from the raw series), the replays run over the slots as sorted at
+    the end of stage 1, outputs go to their point's column.  Same bits as the reference, as in
+    natural order and as with the history key."""
+    n = 300
+    src, L, t0, tf = dh.scenario(n, hours=9, seed=41, obs_hours=5)
+    s = _settings(L, use_relaxation=1, use_coupling=1, coupling_minutes=120, outputStep=5)
+    p = abi.default_parameters()
+    o = dh.oracle_run(_kind(True), src, s, p, t0, tf)
+    ok = o["status"] == 0
+    assert ok.sum() > n // 2
+    monkeypatch.setenv("ROADSURF_HIP_CHUNK_STEPS", "60")
+    for env in (dict(), dict(ROADSURF_HIP_SORT_KEY="history"), dict(ROADSURF_HIP_CLUSTER="0")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = driver.run(src, s, p, t0, tf)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert np.array_equal(g["status"], o["status"]), env
+        for k in driver.OUT_FIELDS:
+            assert _same_bits(g[k], o[k]), (env, k, int((g[k] != o[k]).sum()))
 
 
 def test_identical_per_point_axes_equal_the_shared_axis(monkeypatch):
