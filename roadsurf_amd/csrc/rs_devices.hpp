@@ -25,6 +25,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -98,6 +99,16 @@ inline std::vector<Shard> make_shards(int64_t n, const std::vector<int> &devs) {
     off += cnt;
   }
   return s;
+}
+
+/* One block at a time uploads to a device.  The blocks of a fan-out start together; left alone
+ * they all upload together - at 1/K of the link each - and then all compute together, so the GPU
+ * idles through the whole upload and the link through the whole computation.  Taking turns, the
+ * first block computes while the second uploads, and the phases stay staggered down to the
+ * downloads (measured, rs_driver_run, 1 M points x 48 h: see DESIGN.md 6). */
+inline std::mutex &copy_gate(int device) {
+  static std::mutex gates[64];
+  return gates[device & 63];
 }
 
 /* how many blocks the calling thread's last fan-out used (rs_last_fanout(), tests) */

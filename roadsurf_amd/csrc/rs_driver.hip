@@ -58,7 +58,26 @@ struct PlanStep {
   int32_t rp;   /* rawPos */
   double num;   /* simtime[simPos] - rawtime[rawPos]      (JsonSource.cpp:116 ff.) */
   double den;   /* rawtime[rawPos+1] - rawtime[rawPos] */
+  double rden;  /* RN(1 / den) for the shared-axis plans (division by a uniform denominator,
+                   rs_math.hpp rs_div_u); 0 = not available: IEEE division */
 };
+
+/* A shared-axis plan entry, read as constant memory (address space 4): one scalar load of the
+ * 32-byte entry.  Through a generic pointer the compiler loads the two doubles with a VECTOR load
+ * from the uniform address (it cannot prove the array apart from the window it is writing) and
+ * the lane waits a vector-memory round trip per source and time index.  The plans are uploaded
+ * before any kernel of the run and never written on the device. */
+__device__ __forceinline__ PlanStep plan_at(const PlanStep *plan, int32_t i) {
+  const PlanStep __attribute__((address_space(4))) *q =
+      (const PlanStep __attribute__((address_space(4))) *)plan + i;
+  PlanStep st;
+  st.kind = q->kind;
+  st.rp = q->rp;
+  st.num = q->num;
+  st.den = q->den;
+  st.rden = q->rden;
+  return st;
+}
 
 struct SrcDev {
   const double *fld[NFLD]; /* [n_times][np_pad], nullptr = variable absent */
@@ -97,7 +116,21 @@ __device__ __forceinline__ bool source_value(const PlanStep &st, double a, doubl
   }
   if (!(a > thr && b > thr)) return false;
   /* raw[rawPos] + (simtime-rawtime[rawPos]) * (raw[rawPos+1]-raw[rawPos]) / (rawtime[rawPos+1]-rawtime[rawPos]) */
-  v = a + st.num * (b - a) / st.den;
+  const double x = st.num * (b - a);
+  double q;
+  /* shared axis: the denominator is uniform and comes with its correctly rounded reciprocal, so
+   * the quotient is two fused multiply-adds (Markstein; rs_math.hpp rs_div_u: the IEEE quotient
+   * for a numerator of moderate exponent - a zero numerator is +0.0 here, b - a cannot be -0.0
+   * unless b is, and then a + q is the same for either zero).  Anything else: IEEE division. */
+  const double ax = __builtin_fabs(x);
+  if (st.rden != 0.0 && !(ax >= 1e290) && !(ax > 0.0 && ax < 1e-290)) {
+    const double q0 = x * st.rden;
+    const double rem = __builtin_fma(-st.den, q0, x);
+    q = __builtin_fma(rem, st.rden, q0);
+  } else {
+    q = x / st.den;
+  }
+  v = a + q;
   return v > thr;
 }
 
@@ -139,6 +172,7 @@ __device__ __forceinline__ PlanStep pp_step(PpWalk &w, const SrcDev &sd, int64_t
   st.rp = 0;
   st.num = 0.0;
   st.den = 1.0;
+  st.rden = 0.0; /* per-lane denominators: IEEE division */
   if (w.rp + 1 >= w.len) return st; /* `while (rawPos+1 < rawLen ...)` is over */
   if (w.cached != w.rp) {
     w.tr = sd.ptimes[(int64_t)w.rp * np_pad + p];
@@ -190,25 +224,35 @@ __device__ __forceinline__ void walk_field(const SrcSet &S, int fld, int64_t p, 
     pw[s].tr = pw[s].tr1 = 0;
     if (PP && s < S.nsrc && S.src[s].ptimes) pp_begin(pw[s], S.src[s], p, rp0[s]);
   }
+  /* the variable's column and the plan of every source, once (fld indexes the kernel arguments
+   * dynamically: left inside, that is a scalar load per source and time index) */
+  const double *xs[RS_MAX_SOURCES];
+  const PlanStep *plans[RS_MAX_SOURCES];
+#pragma unroll
+  for (int s = 0; s < RS_MAX_SOURCES; ++s) {
+    xs[s] = (s < S.nsrc) ? S.src[s].fld[fld] : nullptr;
+    plans[s] = (s < S.nsrc) ? S.src[s].plan : nullptr;
+  }
+  const int64_t np_pad = S.np_pad;
   for (int32_t i = i0; i < i1; ++i) {
     double v = miss_r();
     uint32_t mask = 0;
 #pragma unroll
     for (int s = 0; s < RS_MAX_SOURCES; ++s) {
       if (s >= S.nsrc) continue;
-      const double *x = S.src[s].fld[fld];
+      const double *x = xs[s];
       PlanStep st;
       if (PP && S.src[s].ptimes) {
         /* the walk advances whether or not this source has the variable */
-        st = pp_step(pw[s], S.src[s], S.np_pad, p, S.sim0 + (int64_t)i * S.dt);
+        st = pp_step(pw[s], S.src[s], np_pad, p, S.sim0 + (int64_t)i * S.dt);
       } else {
         if (!x) continue;
-        st = S.src[s].plan[i]; /* uniform: scalar loads */
+        st = plan_at(plans[s], i); /* uniform: one scalar load */
       }
       if (!x || st.kind == K_NONE) continue;
       if (st.rp != cur[s]) {
-        a[s] = x[(int64_t)st.rp * S.np_pad + p];
-        b[s] = x[(int64_t)(st.rp + 1) * S.np_pad + p];
+        a[s] = x[(int64_t)st.rp * np_pad + p];
+        b[s] = x[(int64_t)(st.rp + 1) * np_pad + p];
         cur[s] = st.rp;
       }
       double vs;
@@ -242,7 +286,7 @@ __device__ __forceinline__ double merged_at(const SrcSet &S, int fld, int64_t p,
       st.kind = K_NONE;
       for (int32_t k = 0; k <= i; ++k) st = pp_step(w, S.src[s], S.np_pad, p, S.sim0 + (int64_t)k * S.dt);
     } else {
-      st = S.src[s].plan[i];
+      st = plan_at(S.src[s].plan, i);
     }
     if (st.kind == K_NONE) continue;
     const double a = x[(int64_t)st.rp * S.np_pad + p], b = x[(int64_t)(st.rp + 1) * S.np_pad + p];
@@ -521,7 +565,7 @@ int fail_hip(const char *what, hipError_t e) {
 void build_plan(const int64_t *rawtime, int rawLen, const std::vector<int64_t> &simtime,
                 std::vector<PlanStep> &plan) {
   const int simLen = (int)simtime.size();
-  plan.assign(simLen, PlanStep{K_NONE, 0, 0.0, 1.0});
+  plan.assign(simLen, PlanStep{K_NONE, 0, 0.0, 1.0, 0.0});
   if (rawLen == 0) return; /* JsonSource.cpp:233-237 */
   int rawPos = 0, simPos = 0;
   if (rawtime[0] < simtime[0]) {
@@ -536,13 +580,16 @@ void build_plan(const int64_t *rawtime, int rawLen, const std::vector<int64_t> &
   }
   while (rawPos + 1 < rawLen && simPos < simLen) {
     if (std::llabs(simtime[simPos] - rawtime[rawPos]) < 0.01) {
-      plan[simPos] = PlanStep{K_COPY, rawPos, 0.0, 1.0};
+      plan[simPos] = PlanStep{K_COPY, rawPos, 0.0, 1.0, 0.0};
       simPos++;
     } else if (std::llabs(simtime[simPos] - rawtime[rawPos + 1]) < 0.01) {
       rawPos++;
     } else {
-      plan[simPos] = PlanStep{K_INTERP, rawPos, (double)(simtime[simPos] - rawtime[rawPos]),
-                              (double)(rawtime[rawPos + 1] - rawtime[rawPos])};
+      const double den = (double)(rawtime[rawPos + 1] - rawtime[rawPos]);
+      /* a positive whole number of seconds below 2^53: its significand is never all ones, the
+       * one case rs_div_u's reciprocal does not cover; anything else divides the IEEE way */
+      const double rden = (den >= 1.0 && den < 9.0e15) ? 1.0 / den : 0.0;
+      plan[simPos] = PlanStep{K_INTERP, rawPos, (double)(simtime[simPos] - rawtime[rawPos]), den, rden};
       simPos++;
     }
   }
@@ -596,7 +643,7 @@ int prepare(const RsDriverInput *in, const InputSettings *st, Common &c) {
         for (int p = 0; p < c.n; ++p)
           if (rs.lengths[p] < 0 || rs.lengths[p] > rs.n_times)
             return fail_msg("rs_driver: lengths[p] outside 0..n_times", -1);
-      c.plans[s].assign(c.L, PlanStep{K_NONE, 0, 0.0, 1.0}); /* unused: the walk runs on the device */
+      c.plans[s].assign(c.L, PlanStep{K_NONE, 0, 0.0, 1.0, 0.0}); /* unused: the walk runs on the device */
     } else {
       if (rs.lengths) return fail_msg("rs_driver: lengths given without times_per_point", -1);
       build_plan(rs.times, rs.n_times, c.simtime, c.plans[s]);
@@ -1089,7 +1136,11 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     if (!pg.p) return -11;
     const int64_t mp = rs_hip_plan_npoints_padded(pg.p);
     TileRaw T;
-    if (int rc = upload_tile(in, c, p0, m, mp, T, stream)) return rc;
+    {
+      std::lock_guard<std::mutex> turn(rsu::copy_gate(device)); /* rs_devices.hpp: uploads take turns */
+      if (int rc = upload_tile(in, c, p0, m, mp, T, stream)) return rc;
+      HOK(hipStreamSynchronize(stream));
+    }
     pt.lap(1);
     TileDecisions D;
     if (int rc = decide_tile(c, st, T, D, stream)) return rc;

@@ -7,7 +7,8 @@ rows = []
 for fn in files:
     with open(fn) as f:
         for r in csv.DictReader(f):
-            rows.append((r["Kernel_Name"].split("(")[0], int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+            name = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+            rows.append((name.split("(")[0], int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
 rows.sort(key=lambda r: r[1])
 t0 = rows[0][1]; t1 = max(r[2] for r in rows)
 print(f"{len(rows)} dispatches over {(t1 - t0) / 1e6:.1f} ms")
