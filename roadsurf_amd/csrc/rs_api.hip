@@ -434,7 +434,11 @@ int rs_hip_init_state(RsPlan *pl, const RsForcing *f, const RsPointParams *pp) {
  * window (start_coupling_again), those points - compacted into full wavefronts - rewind, replay
  * the window and park again (step_kernel_coupled with cpl_stop).  `a` describes a window that
  * covers every such point's [couplingStartI, couplingEndI]. */
-static int cpl_replay_rounds(RsPlan *pl, rs::StepArgs a) {
+/* lockstep: the window is compact (every point's coupling window fills most of it) and ends before
+ * the final index, no sky view: the rounds run the lock-step loop over the list (time_loop<REPLAY>:
+ * scalar row arithmetic, coalesced outputs of the first pass' quality) instead of the general
+ * kernel, which carries a time index per lane. */
+static int cpl_replay_rounds(RsPlan *pl, rs::StepArgs a, bool lockstep = false) {
   if (!pl->cpl_list) {
     HIP_OK(hipMalloc(&pl->cpl_flags, (size_t)2 * pl->np_pad * sizeof(int32_t)));
     HIP_OK(hipMalloc(&pl->cpl_list, (size_t)pl->np_pad * sizeof(int32_t)));
@@ -456,7 +460,10 @@ static int cpl_replay_rounds(RsPlan *pl, rs::StepArgs a) {
               (long long)pl->npoints);
     a.cpl_list = pl->cpl_list;
     a.cpl_nlist = n_again;
-    HIP_OK(rs_launch_step_coupled(a, pl->c.NLayers, pl->stream));
+    if (lockstep)
+      HIP_OK(rs_launch_step_cpl_replay(a, pl->c.NLayers, pl->stream));
+    else
+      HIP_OK(rs_launch_step_coupled(a, pl->c.NLayers, pl->stream));
     pl->cpl_rounds_last = round + 1;
   }
   return 0;
@@ -623,7 +630,15 @@ int rs_hip_cpl_replay(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const 
   rs::StepArgs a;
   if (cpl_args(pl, f, o, pp, t0, nsteps, "rs_hip_cpl_replay", a)) return -1;
   HIP_OK(hipSetDevice(pl->device));
-  if (cpl_replay_rounds(pl, a)) return -1;
+  /* windows of cplLenI + 1 indices plus the index behind them: compact if the block is not much
+   * longer than one window; ROADSURF_HIP_CPL_REPLAY=general|lockstep overrides (tests) */
+  bool lockstep = (int64_t)nsteps * 4 <= ((int64_t)pl->c.cplLenI + 2) * 5;
+  if (const char *e = getenv("ROADSURF_HIP_CPL_REPLAY")) {
+    if (strcmp(e, "general") == 0) lockstep = false;
+    if (strcmp(e, "lockstep") == 0) lockstep = true;
+  }
+  if ((int64_t)t0 + nsteps - 1 >= pl->c.SimLen || pp->sky_view) lockstep = false;
+  if (cpl_replay_rounds(pl, a, lockstep)) return -1;
   if (rounds) *rounds = pl->cpl_rounds_last;
   return 0;
 }

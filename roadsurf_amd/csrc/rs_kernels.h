@@ -82,6 +82,7 @@ hipError_t rs_launch_humidity_fill(const double *tair, double *tdew, double *rhz
 hipError_t rs_upload_math_tables(hipStream_t stream);
 hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant, bool score,
                           hipStream_t stream);
+hipError_t rs_launch_step_cpl_replay(const rs::StepArgs &a, int NL, hipStream_t stream);
 hipError_t rs_launch_step_coupled(const rs::StepArgs &a, int NL, hipStream_t stream);
 hipError_t rs_launch_step_cpl(const rs::StepArgs &a, int NL, hipStream_t stream);
 /* list of the points whose coupling asks for another replay (start_coupling_again): list[0..*count) */

@@ -360,6 +360,15 @@ __device__ __forceinline__ void store_coupling(double *st, int64_t np, int64_t p
   st[(int64_t)RS_ST_CPL_LASTOBS * np + p] = q.lastobs;
 }
 
+/* the stale TmpNw of a replay's first step, parked in the state block (one column per point) */
+struct GlobalProfile {
+  const double *col;
+  int64_t stride;
+  __device__ __forceinline__ double get(int j) const { return col[(int64_t)(j - 1) * stride]; }
+};
+
+__device__ __forceinline__ Forcing gather_forcing(KernArgs ka, int64_t p, int32_t i, int32_t t0);
+
 /* The time loop of runsimulation (examples/example1/src/Simulation.f90:57-115)
  * for one point over absolute indices [t0, t0+nsteps). */
 /* SKY: sky view / local horizons (src/ModRadiation.f90, examples/example1/src/Simulation.f90:
@@ -372,13 +381,25 @@ __device__ __forceinline__ void store_coupling(double *st, int64_t np, int64_t p
  * points, rs_hip_cpl_replay) have cleared it - and behind the window the radiation corrections
  * decay (:80-88).  A lane steps index i only if i == its RS_ST_CPL_RESUME, so launches may
  * overlap in time: points that are ahead wait for the others. */
-template <bool FULL, class Prof, bool SKY = false, bool SCORE = true, bool CPL = false>
-__device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s, int32_t &score) {
+/* REPLAY (with CPL): one replay ROUND in lock step, for the points of the compacted list that asked
+ * for another replay (start_coupling_again): the launch covers [first window start, last window
+ * end + 1]; a lane waits for its window start, rewinds there - CheckValues of the index behind its
+ * window end, as the reference's loop does before CouplingOperations1 takes it back
+ * (examples/example1/src/Simulation.f90:62-71), then uploadDataForCoupling (src/Coupling.f90:
+ * 213-255) and the radiation coefficient (:61-78) -, runs its window in the coupling phase and lets
+ * Coupling_control decide again at the end.  `point` is the lane's slot: the list breaks the tie
+ * between thread and point, so accesses are base[point] with the row base on the scalar unit. */
+template <bool FULL, class Prof, bool SKY = false, bool SCORE = true, bool CPL = false,
+          bool REPLAY = false>
+__device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s, int32_t &score,
+                                          uint32_t point = 0u) {
   static_assert(FULL || !SKY, "sky view belongs to the FULL feature set");
   static_assert(FULL || !CPL, "coupling belongs to the FULL feature set");
+  static_assert(CPL || !REPLAY, "replays belong to coupling");
+  static_assert(!(REPLAY && SKY), "sky view with coupling runs in the general kernel");
   KernArgs ka = kernargs();
-  const uint32_t lane = threadIdx.x;
-  const int64_t row0 = (int64_t)blockIdx.x * kBlock; /* first point of this workgroup */
+  const uint32_t lane = REPLAY ? point : threadIdx.x;
+  const int64_t row0 = REPLAY ? 0 : (int64_t)blockIdx.x * kBlock; /* first point of this workgroup */
   const int32_t nsteps = ka->nsteps, t0 = ka->t0;
   const double tbot = (ka->pp.tbottom + row0)[lane];
   double skyv = R4(1.0), sinlat = 0, coslat = 0, lonrad = 0;
@@ -434,7 +455,14 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
     cpl_lwcorr = st[(int64_t)RS_ST_CPL_LWCORR * np + p];
     parked = (((int32_t)st[(int64_t)RS_ST_CPL_FLAGS * np + p]) & 1) != 0;
     next_i = (int32_t)st[(int64_t)RS_ST_CPL_RESUME * np + p];
+    if (REPLAY) { /* a listed point: parked behind its window, wanting it again */
+      parked = false;
+      next_i = cpl_cs;
+    }
   }
+  /* REPLAY: SWRadCof / LWRadCof of the window being replayed, and "TmpNw is the stale profile" */
+  double r_swcof = R4(1.0), r_lwcof = R4(1.0);
+  bool stale_now = false;
   Forcing nxt = load_forcing<FULL>(ka, row0, lane, 0);
   for (int32_t kv = 0; kv < nsteps; ++kv) {
     asm volatile("" : "+s"(ka));
@@ -456,7 +484,9 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
     if (CPL) next_i = i + 1;
     if (s.failed) { /* loop has exited in the reference: outputs stay -9999.0 */
       if (k + 1 < nsteps) nxt = load_forcing<FULL>(ka, row0, lane, k + 1);
-      if (owrite) store_outputs<CPL>(ka, orow, row0, lane, s, false);
+      /* a point that fails in the middle of a replay keeps, up to its window end, what the earlier
+       * passes saved there (src/InputOutput.f90:151-165 only ever overwrites) */
+      if (owrite && (!REPLAY || i > cpl_ce)) store_outputs<CPL>(ka, orow, row0, lane, s, false);
       continue;
     }
     double tair = f.tair, vz = f.vz, rhz = f.rhz;
@@ -473,9 +503,17 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
     }
     CouplingInputs cp;
     if (i < c.SimLen) {
-      Forcing chk = f;
-      chk.vz = vz;
-      if (check_values(chk, s.tsurf, FULL && ka->f.tdew != nullptr)) fail_at(i);
+      if (REPLAY && i == cpl_cs) {
+        /* the rewind: the reference's loop is at the index behind the window end when
+         * CouplingOperations1 takes it back, and that is the index CheckValues has just seen -
+         * with the surface temperature of the end of the window */
+        const Forcing g = gather_forcing(ka, row0 + lane, cpl_ce + 1, t0);
+        if (check_values(g, s.tsurf, FULL && ka->f.tdew != nullptr)) fail_at(cpl_ce + 1);
+      } else {
+        Forcing chk = f;
+        chk.vz = vz;
+        if (check_values(chk, s.tsurf, FULL && ka->f.tdew != nullptr)) fail_at(i);
+      }
       if (SKY) {
         if (sky_on && (sw_dir < R4(-0.1) || sw_dir > R4(4000.0) || lw_net < R4(-1000.0) ||
                        lw_net > R4(1000.0)))
@@ -485,7 +523,42 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
       if (CPL && cpl_on) {
         /* CouplingOperations1, src/Coupling.f90:10-96, first pass of the window */
         cp.in_phase = (i >= cpl_cs && i <= cpl_ce);
-        if (i == cpl_cs) { /* Coupling_iterations == 0 here: saveDataForCoupling :172-210 */
+        /* inCouplingPhase is set from the loop index BEFORE a rewind takes it back (:22-27 against
+         * :61-66): the step at the window start of a replay runs outside the coupling phase */
+        if (REPLAY && i == cpl_cs) cp.in_phase = false;
+        if (REPLAY && i == cpl_cs) {
+          /* uploadDataForCoupling :213-255: SrfIcemms, Q2Melt, T4Melt and TmpNw are NOT restored;
+           * TmpNw keeps the end-of-window profile for the first step */
+          double *st = ka->state;
+          const int64_t np = ka->np_pad, p = row0 + lane;
+          s.tsurf = st[(int64_t)RS_ST_CPL_SAVE_TSURF * np + p];
+          s.wat = st[(int64_t)RS_ST_CPL_SAVE_WAT * np + p];
+          s.ice2 = st[(int64_t)RS_ST_CPL_SAVE_ICE2 * np + p];
+          s.dep = st[(int64_t)RS_ST_CPL_SAVE_DEP * np + p];
+          s.snow = st[(int64_t)RS_ST_CPL_SAVE_SNOW * np + p];
+          s.albedo = st[(int64_t)RS_ST_CPL_SAVE_ALBEDO * np + p];
+          const int32_t fl = (int32_t)st[(int64_t)RS_ST_CPL_FLAGS * np + p];
+          s.verycold = (fl & 4) != 0;
+          st[(int64_t)RS_ST_CPL_FLAGS * np + p] = (double)(fl & ~1); /* start_coupling_again = .false. */
+          const int N = T.nlayers();
+          for (int j = 1; j <= N; ++j) {
+            st[(int64_t)(RS_ST_CPL_STALE_TMP0 + j - 1) * np + p] = T.get(j);
+            T.set(j, st[(int64_t)(RS_ST_CPL_SAVE_TMP0 + j - 1) * np + p]);
+          }
+          stale_now = true;
+          /* short-wave scaling by day, long-wave by night (:68-76; no sky view here) */
+          const double radcoeff = st[(int64_t)RS_ST_CPL_RADCOEFF * np + p];
+          if (f.sw > f.lw) {
+            r_swcof = radcoeff;
+            r_lwcof = R4(1.0);
+          } else {
+            r_swcof = R4(1.0);
+            r_lwcof = radcoeff;
+          }
+          st[(int64_t)RS_ST_CPL_SWCOF * np + p] = r_swcof; /* Coupling_control reads them at the end */
+          st[(int64_t)RS_ST_CPL_LWCOF * np + p] = r_lwcof;
+        }
+        if (!REPLAY && i == cpl_cs) { /* Coupling_iterations == 0 here: saveDataForCoupling :172-210 */
           double *st = ka->state;
           const int64_t np = ka->np_pad, p = row0 + lane;
           st[(int64_t)RS_ST_CPL_SAVE_TSURF * np + p] = s.tsurf;
@@ -504,6 +577,10 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
           const double e = rs_exp(mt, rs_div(-((c.DTSecs * i) - (c.DTSecs * cpl_ce)), c.cplReduction));
           cp.sw_cof = R4(1.0) + cpl_swcorr * e;
           cp.lw_cof = R4(1.0) + cpl_lwcorr * e;
+        }
+        if (REPLAY && i >= cpl_cs && i <= cpl_ce) {
+          cp.sw_cof = r_swcof;
+          cp.lw_cof = r_lwcof;
         }
         if (cp.in_phase) {
           /* snowIceCheck :259-289 */
@@ -595,7 +672,17 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
      * HBM latency hides under the ground/storage half without holding 14 VGPRs
      * across the boundary-layer iteration */
     if (k + 1 < nsteps) nxt = load_forcing<FULL>(ka, row0, lane, k + 1);
-    model_step_ground(c, s, T, tbot, tair, fx, f.depth, cp);
+    if (REPLAY) {
+      /* first step after the restore: CalcHCapHCond sees the pre-restore TmpNw in every layer
+       * (observation forcing cannot follow a restore, so layers 1-2 are stale too) */
+      const GlobalProfile Tstale{ka->state + (int64_t)RS_ST_CPL_STALE_TMP0 * ka->np_pad + row0 + lane,
+                                 ka->np_pad};
+      model_step_ground<Prof, GlobalProfile>(c, s, T, tbot, tair, fx, f.depth, cp,
+                                             stale_now ? &Tstale : nullptr);
+      stale_now = false;
+    } else {
+      model_step_ground(c, s, T, tbot, tair, fx, f.depth, cp);
+    }
     if (owrite) store_outputs<CPL>(ka, orow, row0, lane, s, true);
     if (CPL && cpl_on && i < c.SimLen && i == cpl_ce) {
       /* CheckEndCoupling + CouplingOperations2, src/Coupling.f90:98-141 (Coupling_failed is
@@ -637,13 +724,6 @@ __device__ __forceinline__ Forcing gather_forcing(KernArgs ka, int64_t p, int32_
 /* runsimulation's loop with coupling (examples/example1/src/Simulation.f90:57-115):
  * CheckValues -> CouplingOperations1 (may rewind i) -> SetCurrentValues -> relaxation ->
  * roadModelOneStep -> SaveOutput -> CheckEndCoupling. */
-/* the stale TmpNw of a replay's first step, parked in the state block (one column per point) */
-struct GlobalProfile {
-  const double *col;
-  int64_t stride;
-  __device__ __forceinline__ double get(int j) const { return col[(int64_t)(j - 1) * stride]; }
-};
-
 template <class Prof>
 __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Scalars &s,
                                                   Coupling &q, double *st, int64_t np, int64_t p) {
@@ -955,6 +1035,23 @@ __global__ void __launch_bounds__(kBlock, 3) step_kernel_cpl(const StepArgs a) {
   time_loop<true, LdsProfile, false, true, true>(mt, T, s, score);
   store_state<true>(a.state, a.np_pad, p, T, s);
   a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s); /* parked lanes: cheap */
+}
+
+/* One replay round in lock step over the compacted list (time_loop<REPLAY>). */
+__global__ void __launch_bounds__(kBlock, 3) step_kernel_cpl_replay(const StepArgs a) {
+  extern __shared__ double lds[]; /* [NLayers][kBlock] */
+  __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
+  const MathTab mt = fill_math_tables(math_lds);
+  __syncthreads();
+  const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (g >= (int64_t)a.cpl_nlist) return;
+  const int64_t p = (int64_t)a.cpl_list[g];
+  LdsProfile T{lds + threadIdx.x, consts_of(&a).NLayers};
+  Scalars s;
+  int32_t score = 0;
+  load_state<true>(a.state, a.np_pad, p, T, s);
+  time_loop<true, LdsProfile, false, false, true, true>(mt, T, s, score, (uint32_t)p);
+  store_state<true>(a.state, a.np_pad, p, T, s);
 }
 
 /* Coupled variant: LDS profile (any NLayers), FULL feature set + coupling. */
@@ -1326,6 +1423,13 @@ hipError_t rs_launch_step_cpl(const rs::StepArgs &a, int NL, hipStream_t stream)
   /* LDS profile: a register-profile instance of this loop was measured twice as slow (spills) */
   const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
   hipLaunchKernelGGL(rs::step_kernel_cpl, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t rs_launch_step_cpl_replay(const rs::StepArgs &a, int NL, hipStream_t stream) {
+  if (!a.cpl_list || a.cpl_nlist < 1) return hipSuccess;
+  const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
+  hipLaunchKernelGGL(rs::step_kernel_cpl_replay, grid_for(a.cpl_nlist), dim3(RS_BLOCK), lds, stream, a);
   return hipGetLastError();
 }
 

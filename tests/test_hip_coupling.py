@@ -109,14 +109,19 @@ def test_coupling_window_must_be_whole_series():
     plan.close()
 
 
+@pytest.mark.parametrize("replay", [None, "general", "lockstep"])
 @pytest.mark.parametrize("chunk", [97, 256])
-def test_chunked_coupling_equals_whole_series_and_the_reference(chunk):
+def test_chunked_coupling_equals_whole_series_and_the_reference(chunk, replay, monkeypatch):
     """rs_hip_step_cpl / rs_hip_cpl_replay: lock-step chunks that park a point behind its coupling
     window, replay rounds over the compacted list of parked points, lock-step chunks again.  Every
     case of _cases - relaxation on, a 60-minute window, coupling switched off for some points, and
     (case 3) a different coupling index for every point, where points that are ahead wait for the
-    others - must give the whole-series run's bits, which are the reference's."""
+    others - must give the whole-series run's bits, which are the reference's.  The replay rounds
+    run in lock step over the list where the block is compact, with the general kernel (a time index
+    per lane) where it is not; both are forced on every case here."""
     from roadsurf_amd import device
+    if replay:
+        monkeypatch.setenv("ROADSURF_HIP_CPL_REPLAY", replay)
     n, L = 384, 2881
     cases, base = _cases(n, L, 4242)
     for k, (f2, s, p, ls) in enumerate(cases):
@@ -126,10 +131,14 @@ def test_chunked_coupling_equals_whole_series_and_the_reference(chunk):
             assert np.array_equal(res[q], ora[q]), (k, q, int((res[q] != ora[q]).sum()))
 
 
-def test_chunked_coupling_with_failing_points():
+@pytest.mark.parametrize("replay", ["general", "lockstep"])
+def test_chunked_coupling_with_failing_points(replay, monkeypatch):
     """A point that fails inside its coupling window - in the first pass or in a replay - keeps the
-    outputs earlier passes saved beyond the failure (SaveOutput only ever overwrites)."""
+    outputs earlier passes saved beyond the failure (SaveOutput only ever overwrites).  A bad value
+    at the index BEHIND the window end is seen by CheckValues every time the loop arrives there,
+    i.e. right before each rewind: the step at the window start still runs, then the loop exits."""
     from roadsurf_amd import device
+    monkeypatch.setenv("ROADSURF_HIP_CPL_REPLAY", replay)
     n, L = 256, 1441
     cases, _ = _cases(n, L, 11)
     f2, s, p, ls = cases[0]
@@ -137,6 +146,8 @@ def test_chunked_coupling_with_failing_points():
     f2["tair"][3, ci - 100] = -200.0      # bad value inside the window: fails in the first pass
     f2["tair"][9, ci + 50] = 150.0        # behind the window
     f2["tair"][17, 5] = -200.0            # before the window
+    for q in (25, 26, 27, 28, 29, 30):    # at the index behind the window end (1-based ci + 1)
+        f2["tair"][q, ci] = -200.0
     ora, _, _ = oh.run_oracle(_kind(), f2, s, p, ls)
     whole, _ = device.run_points(f2, s, p, ls)
     parts, _ = device.run_points(f2, s, p, ls, chunk=128)
