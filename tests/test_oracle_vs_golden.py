@@ -179,6 +179,20 @@ def test_port_equals_reference_on_random_workload():
     assert np.array_equal(fa["vz"], fb["vz"])  # VZ(1) side effect
 
 
+@pytest.mark.skipif(not oh.have_ref(), reason="reference build not available")
+def test_port_equals_reference_on_random_parameter_sets():
+    """the restatement away from the reference's defaults: every physical parameter the path reads,
+    the time step, the layer count, the output depth, initialization length and relaxation drawn at
+    random (the cases of tests/test_hip_param_fuzz.py, which the HIP path must reproduce)"""
+    from test_hip_param_fuzz import _case
+    for seed in range(16):
+        f, s, p, ls = _case(seed)
+        a, _, _ = oh.run_oracle("ref", f, s, p, ls)
+        b, _, _ = oh.run_oracle("port", f, s, p, ls)
+        for k in oh.F64_OUT:
+            assert np.array_equal(a[k], b[k]), (seed, k)
+
+
 @pytest.mark.skipif(not os.path.exists(oh.REF_CPL_SO), reason="coupling-enabled reference build not available")
 def test_port_equals_reference_with_coupling():
     n, L = 300, 2881
