@@ -132,7 +132,12 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
   const bool skyview = extras && extras->sun;
   const int nf64 = skyview ? NF64 : NF64 - 2; /* SW_dir / LW_net travel only for sky view */
   const int P = std::min<int64_t>(n, ep ? std::max(1, atoi(ep)) : (coupled ? 4096 : 16384));
-  const int TC = coupled ? L : std::min(L, et ? std::max(1, atoi(et)) : 256);
+  /* time indices per pipeline item.  Measured on an MI355X box (16 CPUs, tools/exp_host.sh,
+   * 32 768 points x 48 h over four blocks): 256 -> 3.3e8, 128 -> 4.0e8, 64 -> 4.3e8, 32 -> 4.5e8,
+   * 16 -> 4.2e8, 8 -> 2.8e8 point-timesteps/s: short items keep the staging sets in the host's
+   * caches and the five-stage pipeline full; below 16 the per-item launches take over, and a small
+   * block (a few thousand points: a latency-bound step kernel) is served as well by 64 */
+  const int TC = coupled ? L : std::min(L, et ? std::max(1, atoi(et)) : (n >= 6144 ? 32 : 64));
   const int Ppad = (P + RS_BLOCK - 1) / RS_BLOCK * RS_BLOCK;
 
   int ndev = 0;

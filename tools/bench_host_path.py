@@ -17,10 +17,14 @@ for pt in range(n):
     ips[pt], ops[pt] = ip, op; keep.append(kp)
 larr = (abi.LocalParameters * n)(*([l] * n))
 st = C.c_int32(0)
-for rep in range(3):
+rates = []
+for rep in range(int(os.environ.get("REPS", "3"))):
     t = time.perf_counter()
     L.runsimulation_batch(n, ops, ips, C.byref(s), C.byref(p), larr, C.byref(st))
     dt = time.perf_counter() - t
     assert st.value == 0, lib.last_error()
+    rates.append(n * SL / dt)
     print(f"runsimulation_batch: {n} points x {SL}: {dt:.3f} s -> {n*SL/dt:.3e} point-timesteps/s "
           f"({n*SL*(11*8+2*4+6*8)/dt/1e9:.1f} GB/s over the boundary)")
+rates = sorted(rates[1:]) or rates
+print(f"summary: median {rates[len(rates)//2]:.3e} best {rates[-1]:.3e} worst {rates[0]:.3e} (first call excluded)")
