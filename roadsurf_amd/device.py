@@ -186,6 +186,12 @@ class Plan:
     def set_history_score(self, on: bool) -> None:
         lib.check(self.L.rs_hip_set_history_score(self._h, 1 if on else 0), "rs_hip_set_history_score")
 
+    def coupling_windows_closed(self, closed: bool = True) -> None:
+        """Every coupling window (replays included) is behind the plan: re-sorts move the coupling
+        scalars only (rs_hip_coupling_windows_closed)."""
+        lib.check(self.L.rs_hip_coupling_windows_closed(self._h, 1 if closed else 0),
+                  "rs_hip_coupling_windows_closed")
+
     def set_variant(self, v: int) -> None:
         lib.check(self.L.rs_hip_set_variant(self._h, v), "rs_hip_set_variant")
 
