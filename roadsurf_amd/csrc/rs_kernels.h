@@ -58,7 +58,7 @@ struct KnotArgs {
   RsSynthSpec spec;
   double *knots;
   int64_t npoints, np_pad;
-  int32_t k0;
+  int32_t k0, nknots;
 };
 
 struct ExpandArgs {

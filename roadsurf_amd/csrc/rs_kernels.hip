@@ -1156,20 +1156,23 @@ __global__ void __launch_bounds__(kBlock) init_kernel(const InitArgs a) {
 __global__ void __launch_bounds__(kBlock) synth_knots_kernel(const KnotArgs a) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= a.npoints) return;
-  const int32_t k = a.k0 + blockIdx.y;
   /* with a plan order (rs_hip_plan_order) slot p holds point order[p] */
   const int64_t gid = a.spec.point_offset + (a.spec.order ? (int64_t)a.spec.order[p] : p);
-  const RsSynthKnot q = rs_sy_knot(a.spec.seed, gid, k, a.spec.start_hour);
-  double *base = a.knots + ((int64_t)blockIdx.y * RS_KNOT_FIELDS) * a.np_pad + p;
-  base[0 * a.np_pad] = q.tair;
-  base[1 * a.np_pad] = q.tdew;
-  base[2 * a.np_pad] = q.vz;
-  base[3 * a.np_pad] = q.rhz;
-  base[4 * a.np_pad] = q.prec;
-  base[5 * a.np_pad] = q.sw;
-  base[6 * a.np_pad] = q.lw;
-  base[7 * a.np_pad] = q.tsurf0;
-  base[8 * a.np_pad] = (double)q.phase;
+  /* one thread makes all the knots of its point: the 17 draws the knots share are hashed once */
+  const RsSynthPoint pc = rs_sy_point(a.spec.seed, gid);
+  for (int32_t y = 0; y < a.nknots; ++y) {
+    const RsSynthKnot q = rs_sy_knot_of(&pc, a.spec.seed, gid, a.k0 + y, a.spec.start_hour);
+    double *base = a.knots + ((int64_t)y * RS_KNOT_FIELDS) * a.np_pad + p;
+    base[0 * a.np_pad] = q.tair;
+    base[1 * a.np_pad] = q.tdew;
+    base[2 * a.np_pad] = q.vz;
+    base[3 * a.np_pad] = q.rhz;
+    base[4 * a.np_pad] = q.prec;
+    base[5 * a.np_pad] = q.sw;
+    base[6 * a.np_pad] = q.lw;
+    base[7 * a.np_pad] = q.tsurf0;
+    base[8 * a.np_pad] = (double)q.phase;
+  }
 }
 
 /* Knots -> step resolution, the device twin of the reference driver's
@@ -1488,9 +1491,9 @@ hipError_t rs_launch_init(const rs::InitArgs &a, hipStream_t stream) {
 }
 
 hipError_t rs_launch_knots(const rs::KnotArgs &a, int32_t nknots, hipStream_t stream) {
-  dim3 g = grid_for(a.npoints);
-  g.y = (unsigned)nknots;
-  hipLaunchKernelGGL(rs::synth_knots_kernel, g, dim3(RS_BLOCK), 0, stream, a);
+  rs::KnotArgs b = a;
+  b.nknots = nknots;
+  hipLaunchKernelGGL(rs::synth_knots_kernel, grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, b);
   return hipGetLastError();
 }
 

@@ -68,54 +68,77 @@ typedef struct RsSynthKnot {
   int32_t phase;
 } RsSynthKnot;
 
-/* Hourly knot `k` (k = 0 is absolute time index 1) for global point id `gp`. */
-RS_HD RsSynthKnot rs_sy_knot(uint64_t seed, int64_t gp, int32_t k, int32_t start_hour) {
-  RsSynthKnot q;
-  const double tmean = -15.0 + 25.0 * rs_sy_u(seed, gp, -1, RS_SY_TMEAN);
-  const double tamp = 1.0 + 7.0 * rs_sy_u(seed, gp, -1, RS_SY_TAMP);
-  const double tph = 0.125 * (rs_sy_u(seed, gp, -1, RS_SY_TPH) - 0.5);
-  const double tsyn = 6.0 * rs_sy_u(seed, gp, -1, RS_SY_TSYN);
-  const double tsynph = rs_sy_u(seed, gp, -1, RS_SY_TSYNPH);
-  const double rhmean = 60.0 + 38.0 * rs_sy_u(seed, gp, -1, RS_SY_RHMEAN);
-  const double vzmean = 0.2 + 7.8 * rs_sy_u(seed, gp, -1, RS_SY_VZMEAN);
-  const double vzph = rs_sy_u(seed, gp, -1, RS_SY_VZPH);
-  const double s0 = 400.0 * rs_sy_u(seed, gp, -1, RS_SY_S0);
-  const double lwmean = 200.0 + 150.0 * rs_sy_u(seed, gp, -1, RS_SY_LWMEAN);
-  const double hod = (double)((k + start_hour) % 24);
-  const double day = rs_sy_psin((hod - 9.0) / 24.0 + tph);
+/* What a point's knots share: the draws with knot index -1.  Split from rs_sy_knot so that a
+ * caller that makes several knots of one point (the device generator) hashes them once. */
+typedef struct RsSynthPoint {
+  double tmean, tamp, tph, tsyn, tsynph, rhmean, vzmean, vzph, s0, lwmean, tdewd, pflag, prate, pmode, ts0;
+  int32_t pstart, pdur;
+} RsSynthPoint;
 
-  q.tair = tmean + tamp * day + tsyn * rs_sy_psin((double)k / 48.0 + tsynph) +
+RS_HD RsSynthPoint rs_sy_point(uint64_t seed, int64_t gp) {
+  RsSynthPoint c;
+  c.tmean = -15.0 + 25.0 * rs_sy_u(seed, gp, -1, RS_SY_TMEAN);
+  c.tamp = 1.0 + 7.0 * rs_sy_u(seed, gp, -1, RS_SY_TAMP);
+  c.tph = 0.125 * (rs_sy_u(seed, gp, -1, RS_SY_TPH) - 0.5);
+  c.tsyn = 6.0 * rs_sy_u(seed, gp, -1, RS_SY_TSYN);
+  c.tsynph = rs_sy_u(seed, gp, -1, RS_SY_TSYNPH);
+  c.rhmean = 60.0 + 38.0 * rs_sy_u(seed, gp, -1, RS_SY_RHMEAN);
+  c.vzmean = 0.2 + 7.8 * rs_sy_u(seed, gp, -1, RS_SY_VZMEAN);
+  c.vzph = rs_sy_u(seed, gp, -1, RS_SY_VZPH);
+  c.s0 = 400.0 * rs_sy_u(seed, gp, -1, RS_SY_S0);
+  c.lwmean = 200.0 + 150.0 * rs_sy_u(seed, gp, -1, RS_SY_LWMEAN);
+  c.tdewd = 0.5 + 4.5 * rs_sy_u(seed, gp, -1, RS_SY_TDEWD);
+  c.pflag = rs_sy_u(seed, gp, -1, RS_SY_PFLAG);
+  c.pstart = (int32_t)(42.0 * rs_sy_u(seed, gp, -1, RS_SY_PSTART));
+  c.pdur = 1 + (int32_t)(6.0 * rs_sy_u(seed, gp, -1, RS_SY_PDUR));
+  c.prate = 3.0 * rs_sy_u(seed, gp, -1, RS_SY_PRATE);
+  c.pmode = rs_sy_u(seed, gp, -1, RS_SY_PMODE);
+  c.ts0 = 2.0 * rs_sy_u(seed, gp, -1, RS_SY_TS0);
+  return c;
+}
+
+/* Hourly knot `k` (k = 0 is absolute time index 1) of the point whose shared draws are `c`. */
+RS_HD RsSynthKnot rs_sy_knot_of(const RsSynthPoint *c, uint64_t seed, int64_t gp, int32_t k,
+                                int32_t start_hour) {
+  RsSynthKnot q;
+  const double hod = (double)((k + start_hour) % 24);
+  const double day = rs_sy_psin((hod - 9.0) / 24.0 + c->tph);
+
+  q.tair = c->tmean + c->tamp * day + c->tsyn * rs_sy_psin((double)k / 48.0 + c->tsynph) +
            0.5 * (2.0 * rs_sy_u(seed, gp, k, RS_SY_N_TAIR) - 1.0);
-  q.tdew = q.tair - (0.5 + 4.5 * rs_sy_u(seed, gp, -1, RS_SY_TDEWD));
-  double rh = rhmean - 10.0 * day + 3.0 * (2.0 * rs_sy_u(seed, gp, k, RS_SY_N_RH) - 1.0);
+  q.tdew = q.tair - c->tdewd;
+  double rh = c->rhmean - 10.0 * day + 3.0 * (2.0 * rs_sy_u(seed, gp, k, RS_SY_N_RH) - 1.0);
   if (rh < 20.0) rh = 20.0;
   if (rh > 100.0) rh = 100.0;
   q.rhz = rh;
-  double vz = vzmean * (1.0 + 0.5 * rs_sy_psin(hod / 12.0 + vzph)) +
+  double vz = c->vzmean * (1.0 + 0.5 * rs_sy_psin(hod / 12.0 + c->vzph)) +
               (2.0 * rs_sy_u(seed, gp, k, RS_SY_N_VZ) - 1.0);
   if (vz < 0.05) vz = 0.05;
   q.vz = vz;
   double sun = rs_sy_psin((hod - 6.0) / 24.0);
-  q.sw = sun > 0.0 ? s0 * sun : 0.0;
-  q.lw = lwmean + 20.0 * (2.0 * rs_sy_u(seed, gp, k, RS_SY_N_LW) - 1.0);
+  q.sw = sun > 0.0 ? c->s0 * sun : 0.0;
+  q.lw = c->lwmean + 20.0 * (2.0 * rs_sy_u(seed, gp, k, RS_SY_N_LW) - 1.0);
 
   /* one precipitation event on ~30 % of the points */
   q.prec = 0.0;
   q.phase = -9999;
-  if (rs_sy_u(seed, gp, -1, RS_SY_PFLAG) < 0.3) {
-    const int32_t pstart = (int32_t)(42.0 * rs_sy_u(seed, gp, -1, RS_SY_PSTART));
-    const int32_t pdur = 1 + (int32_t)(6.0 * rs_sy_u(seed, gp, -1, RS_SY_PDUR));
-    if (k >= pstart && k < pstart + pdur) {
-      q.prec = 3.0 * rs_sy_u(seed, gp, -1, RS_SY_PRATE);
+  if (c->pflag < 0.3) {
+    if (k >= c->pstart && k < c->pstart + c->pdur) {
+      q.prec = c->prate;
       /* 40 % of the wet points leave the phase missing (model interprets it,
        * src/Cond.f90:221-245), the rest give an explicit form 0..6 per hour */
-      if (rs_sy_u(seed, gp, -1, RS_SY_PMODE) >= 0.4)
-        q.phase = (int32_t)(7.0 * rs_sy_u(seed, gp, k, RS_SY_N_PHASE));
+      if (c->pmode >= 0.4) q.phase = (int32_t)(7.0 * rs_sy_u(seed, gp, k, RS_SY_N_PHASE));
     }
   }
   /* initial surface temperature observation (index 1 only) */
-  q.tsurf0 = q.tair - 1.0 + 2.0 * rs_sy_u(seed, gp, -1, RS_SY_TS0);
+  q.tsurf0 = q.tair - 1.0 + c->ts0;
   return q;
+}
+
+/* Hourly knot `k` (k = 0 is absolute time index 1) for global point id `gp`. */
+RS_HD RsSynthKnot rs_sy_knot(uint64_t seed, int64_t gp, int32_t k, int32_t start_hour) {
+  const RsSynthPoint c = rs_sy_point(seed, gp);
+  return rs_sy_knot_of(&c, seed, gp, k, start_hour);
 }
 
 typedef struct RsSynthStep {
