@@ -1286,8 +1286,8 @@ __global__ void __launch_bounds__(kBlock) count_failed_kernel(const double *st, 
 
 /* Sort key of rs_hip_recluster_forecast (include/roadsurf.h): CalcBLCondAndLE's fixed point
  * (src/BoundaryLayer.f90:64-96) run at the preview times of the NEXT window, with the carried
- * surface temperature moved along with the air temperature.  A predictor: plain IEEE division,
- * OCML sqrt/log - it only orders the slots, no model value depends on it. */
+ * surface temperature moved along with the air temperature.  A predictor: single precision,
+ * hardware reciprocal/sqrt/log - it only orders the slots, no model value depends on it. */
 __global__ void __launch_bounds__(kBlock) forecast_key_kernel(const ForecastArgs a) {
   const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (s >= a.npoints) return;
@@ -1317,27 +1317,32 @@ __global__ void __launch_bounds__(kBlock) forecast_key_kernel(const ForecastArgs
     const double dens = R4(100000.0) / (R4(287.05) * TaK);
     const double hcap = R4(1005.0) + (TaK - R4(250.0)) * (TaK - R4(250.0)) / R4(3364.);
     const double avc = hcap * dens;
-    const double dT = ts - ta, den0 = avc * TaK, vkvz = c.VK_Const * vz, avk = avc * c.VK_Const;
-    double psim = 0.0, psih = 0.0, bl = 0.0;
+    /* the iteration itself in single precision with the hardware's reciprocal, square root and
+     * logarithm: a predictor needs the regime and the pass count, not the last bit (the exit test
+     * is 1e-3 on a conductance of order 1..50) */
+    const float dT = (float)(ts - ta), den0 = (float)(avc * TaK), vkvz = (float)(c.VK_Const * vz),
+                avk = (float)(avc * c.VK_Const), snum = (float)stab_num, lU = (float)c.logUstar,
+                lC = (float)c.logCond;
+    float psim = 0.f, psih = 0.f, bl = 0.f;
     int32_t nnear = 0, nfar = 0, j = 1;
     for (; j <= RS_BL_MAXIT; ++j) {
-      const double old = bl;
-      const double us = vkvz / (c.logUstar + psim);
-      bl = avk * us / (c.logCond + psih);
-      double stab = stab_num * bl * dT / (den0 * (us * us * us));
-      if (stab > 1) stab = 1;
-      if (stab > 0) {
-        psih = R4(4.7) * stab;
+      const float old = bl;
+      const float us = vkvz * __builtin_amdgcn_rcpf(lU + psim);
+      bl = avk * us * __builtin_amdgcn_rcpf(lC + psih);
+      float stab = snum * bl * dT * __builtin_amdgcn_rcpf(den0 * (us * us * us));
+      if (stab > 1.f) stab = 1.f;
+      if (stab > 0.f) {
+        psih = 4.7f * stab;
         psim = psih;
       } else {
-        const double arg = (1.0 + ::sqrt(1.0 - 16.0 * stab)) * 0.5;
+        const float arg = (1.f + __builtin_amdgcn_sqrtf(1.f - 16.f * stab)) * 0.5f;
         /* glibc's log takes its polynomial path for 1 - 2^-4 <= x < 1 + 0x1.09p-4, the table
          * path otherwise (rs_math.hpp): a wavefront with both kinds of lanes pays for both */
-        if (arg < 1.064453125) ++nnear; else ++nfar;
-        psih = -2.0 * ::log(arg);
-        psim = R4(0.6) * psih;
+        if (arg < 1.064453125f) ++nnear; else ++nfar;
+        psih = -2.f * __logf(arg);
+        psim = 0.6f * psih;
       }
-      if (j >= 5 && fabs(bl - old) < R4(0.001)) break;
+      if (j >= 5 && __builtin_fabsf(bl - old) < 0.001f) break;
     }
     if (j > RS_BL_MAXIT) j = RS_BL_MAXIT;
     extra += j - 5;
