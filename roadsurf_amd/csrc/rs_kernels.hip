@@ -1181,6 +1181,11 @@ __global__ void __launch_bounds__(kBlock) synth_knots_kernel(const KnotArgs a) {
  * interval (blockIdx.y): the two knot rows are read once, then up to
  * steps_per_knot rows are streamed out, each a coalesced 2-KiB store per block
  * and field. */
+/* TDEW/OBS/DEPTH: which optional streams the window has (compile time, so that the loop over the
+ * time indices is ONE basic block: the stores then take the scalar row base + 32-bit lane offset
+ * form, LaneOff).  At r = 0 the interpolation adds +-0.0 to the knot value, which returns it
+ * unchanged (no knot value is -0.0: rs_synth.h), so the first index needs no case of its own. */
+template <bool TDEW, bool OBS, bool DEPTH>
 __global__ void __launch_bounds__(kBlock) expand_kernel(const ExpandArgs a) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= a.npoints) return;
@@ -1192,37 +1197,43 @@ __global__ void __launch_bounds__(kBlock) expand_kernel(const ExpandArgs a) {
   const double *ka = a.knots + ((int64_t)(k - a.k0) * RS_KNOT_FIELDS) * a.np_pad + p;
   const double *kb = ka + (int64_t)RS_KNOT_FIELDS * a.np_pad;
   const bool need_b = (thi - 1) > k * a.spk; /* some r > 0 in range */
-  double v0[7], v1[7];
+  double v0[7], dv[7];
+  /* rs_sy_lerp, k0 + (secs * (k1 - k0)) / span, with the difference taken once per interval and
+   * the division by the uniform span as rs_div_u (rs_math.hpp: exact for a denominator whose
+   * reciprocal is correctly rounded; the numerator is never -0.0 here because k1 - k0 is not) */
 #pragma unroll
   for (int q = 0; q < 7; ++q) {
     v0[q] = ka[(int64_t)q * a.np_pad];
-    v1[q] = need_b ? kb[(int64_t)q * a.np_pad] : v0[q];
+    const double v1 = need_b ? kb[(int64_t)q * a.np_pad] : v0[q];
+    dv[q] = v1 - v0[q];
   }
   const double ts0 = ka[7 * a.np_pad];
   const int32_t ph0 = (int32_t)ka[8 * a.np_pad];
   const int32_t ph1 = need_b ? (int32_t)kb[8 * a.np_pad] : ph0;
-  double *out[7] = {(double *)a.f.tair, (double *)a.f.tdew, (double *)a.f.vz, (double *)a.f.rhz,
-                    (double *)a.f.prec, (double *)a.f.sw, (double *)a.f.lw};
-  /* rs_sy_lerp, k0 + (secs * (k1 - k0)) / span, with the difference taken once per interval and
-   * the division by the uniform span as rs_div_u (rs_math.hpp: exact for a denominator whose
-   * reciprocal is correctly rounded; the numerator is never -0.0 here because k1 - k0 is not) */
-  double dv[7];
-#pragma unroll
-  for (int q = 0; q < 7; ++q) dv[q] = v1[q] - v0[q];
   const double span = (double)a.spk;
+  const int64_t col0 = (int64_t)blockIdx.x * kBlock; /* the workgroup's first column: uniform */
   for (int32_t t = tlo; t < thi; ++t) {
     const int32_t r = t - k * a.spk;
     const double secs = (double)r;
-    const int64_t off = (int64_t)(t - (a.t0 - 1)) * a.f.t_stride + p;
+    const int64_t row = (int64_t)(t - (a.t0 - 1)) * a.f.t_stride + col0;
+    const LaneOff L(threadIdx.x);
+    double v[7];
 #pragma unroll
-    for (int q = 0; q < 7; ++q)
-      if (out[q]) out[q][off] = (r == 0) ? v0[q] : v0[q] + rs_div_u(secs * dv[q], span, a.r_spk);
-    if (a.f.tsurfobs) ((double *)a.f.tsurfobs)[off] = (t == 0) ? ts0 : -9999.9;
-    if (a.f.depth) ((double *)a.f.depth)[off] = -9999.9;
-    ((int32_t *)a.f.precphase)[off] = (r == 0) ? ph0 : ph1;
-    if (p == 0 && !a.f.hour_pstride)
-      ((int32_t *)a.f.hour)[t - (a.t0 - 1)] = rs_sy_hour(t + 1, a.spk, a.start_hour);
+    for (int q = 0; q < 7; ++q) v[q] = v0[q] + rs_div_u(secs * dv[q], span, a.r_spk);
+    L.st((double *)a.f.tair + row, v[0]);
+    if (TDEW) L.st((double *)a.f.tdew + row, v[1]);
+    L.st((double *)a.f.vz + row, v[2]);
+    L.st((double *)a.f.rhz + row, v[3]);
+    L.st((double *)a.f.prec + row, v[4]);
+    L.st((double *)a.f.sw + row, v[5]);
+    L.st((double *)a.f.lw + row, v[6]);
+    if (OBS) L.st((double *)a.f.tsurfobs + row, (t == 0) ? ts0 : -9999.9);
+    if (DEPTH) L.st((double *)a.f.depth + row, -9999.9);
+    L.st((int32_t *)a.f.precphase + row, (r == 0) ? ph0 : ph1);
   }
+  if (p == 0 && !a.f.hour_pstride)
+    for (int32_t t = tlo; t < thi; ++t)
+      ((int32_t *)a.f.hour)[t - (a.t0 - 1)] = rs_sy_hour(t + 1, a.spk, a.start_hour);
 }
 
 /* Unit-test kernel for rs_exp / rs_log (tests/test_hip_math.py). fn: 0 exp, 1 log. */
@@ -1505,7 +1516,13 @@ hipError_t rs_launch_knots(const rs::KnotArgs &a, int32_t nknots, hipStream_t st
 hipError_t rs_launch_expand(const rs::ExpandArgs &a, int32_t nintervals, hipStream_t stream) {
   dim3 g = grid_for(a.npoints);
   g.y = (unsigned)nintervals;
-  hipLaunchKernelGGL(rs::expand_kernel, g, dim3(RS_BLOCK), 0, stream, a);
+  const int m = (a.f.tdew ? 1 : 0) | (a.f.tsurfobs ? 2 : 0) | (a.f.depth ? 4 : 0);
+#define RS_EXPAND(M)                                                                          \
+  if (m == M)                                                                                 \
+    hipLaunchKernelGGL((rs::expand_kernel<(M & 1) != 0, (M & 2) != 0, (M & 4) != 0>), g,      \
+                       dim3(RS_BLOCK), 0, stream, a);
+  RS_EXPAND(0) RS_EXPAND(1) RS_EXPAND(2) RS_EXPAND(3) RS_EXPAND(4) RS_EXPAND(5) RS_EXPAND(6) RS_EXPAND(7)
+#undef RS_EXPAND
   return hipGetLastError();
 }
 

@@ -188,7 +188,9 @@ __global__ void __launch_bounds__(kBlock) init_kernel_f32(const rs::InitArgs a) 
   st[(int64_t)RS_ST_BLSCORE * np + p] = 0.f;
 }
 
-/* fp32 twin of expand_kernel: same knots (fp64), rounded once at the end. */
+/* fp32 twin of expand_kernel (rs_kernels.hip: one basic block per time index, stores with a scalar
+ * row base): same knots (fp64), rounded once at the end. */
+template <bool TDEW, bool OBS>
 __global__ void __launch_bounds__(kBlock) expand_kernel_f32(const rs::ExpandArgs a) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= a.npoints) return;
@@ -200,34 +202,41 @@ __global__ void __launch_bounds__(kBlock) expand_kernel_f32(const rs::ExpandArgs
   const double *ka = a.knots + ((int64_t)(k - a.k0) * RS_KNOT_FIELDS) * a.np_pad + p;
   const double *kb = ka + (int64_t)RS_KNOT_FIELDS * a.np_pad;
   const bool need_b = (thi - 1) > k * a.spk;
-  double v0[7], v1[7];
+  double v0[7], dv[7];
 #pragma unroll
   for (int q = 0; q < 7; ++q) {
     v0[q] = ka[(int64_t)q * a.np_pad];
-    v1[q] = need_b ? kb[(int64_t)q * a.np_pad] : v0[q];
+    const double v1 = need_b ? kb[(int64_t)q * a.np_pad] : v0[q];
+    dv[q] = v1 - v0[q];
   }
   const double ts0 = ka[7 * a.np_pad];
   const int32_t ph0 = (int32_t)ka[8 * a.np_pad];
   const int32_t ph1 = need_b ? (int32_t)kb[8 * a.np_pad] : ph0;
-  float *out[7] = {(float *)a.f.tair, (float *)a.f.tdew, (float *)a.f.vz, (float *)a.f.rhz,
-                   (float *)a.f.prec, (float *)a.f.sw, (float *)a.f.lw};
-  double dv[7]; /* as in expand_kernel (rs_kernels.hip) */
-#pragma unroll
-  for (int q = 0; q < 7; ++q) dv[q] = v1[q] - v0[q];
   const double span = (double)a.spk;
+  const int64_t col0 = (int64_t)blockIdx.x * kBlock;
   for (int32_t t = tlo; t < thi; ++t) {
     const int32_t r = t - k * a.spk;
     const double secs = (double)r;
-    const int64_t off = (int64_t)(t - (a.t0 - 1)) * a.f.t_stride + p;
+    const int64_t row = (int64_t)(t - (a.t0 - 1)) * a.f.t_stride + col0;
+    uint32_t b4; /* the lane's byte offset, formed in this block (rs_kernels.hip, LaneOff) */
+    asm volatile("v_lshlrev_b32 %0, 2, %1" : "=v"(b4) : "v"(threadIdx.x));
+    auto st = [&](const void *base, float v) { *(float *)((char *)((float *)base + row) + b4) = v; };
+    float v[7];
 #pragma unroll
-    for (int q = 0; q < 7; ++q)
-      if (out[q])
-        out[q][off] = (float)((r == 0) ? v0[q] : v0[q] + rs::rs_div_u(secs * dv[q], span, a.r_spk));
-    if (a.f.tsurfobs) ((float *)a.f.tsurfobs)[off] = (t == 0) ? (float)ts0 : -9999.9f;
-    ((int32_t *)a.f.precphase)[off] = (r == 0) ? ph0 : ph1;
-    if (p == 0 && !a.f.hour_pstride)
-      ((int32_t *)a.f.hour)[t - (a.t0 - 1)] = rs_sy_hour(t + 1, a.spk, a.start_hour);
+    for (int q = 0; q < 7; ++q) v[q] = (float)(v0[q] + rs::rs_div_u(secs * dv[q], span, a.r_spk));
+    st(a.f.tair, v[0]);
+    if (TDEW) st(a.f.tdew, v[1]);
+    st(a.f.vz, v[2]);
+    st(a.f.rhz, v[3]);
+    st(a.f.prec, v[4]);
+    st(a.f.sw, v[5]);
+    st(a.f.lw, v[6]);
+    if (OBS) st(a.f.tsurfobs, (t == 0) ? (float)ts0 : -9999.9f);
+    *(int32_t *)((char *)((int32_t *)a.f.precphase + row) + b4) = (r == 0) ? ph0 : ph1;
   }
+  if (p == 0 && !a.f.hour_pstride)
+    for (int32_t t = tlo; t < thi; ++t)
+      ((int32_t *)a.f.hour)[t - (a.t0 - 1)] = rs_sy_hour(t + 1, a.spk, a.start_hour);
 }
 
 }  // namespace rs32
@@ -264,6 +273,13 @@ hipError_t rs32_launch_init(const rs::InitArgs &a, hipStream_t stream) {
 hipError_t rs32_launch_expand(const rs::ExpandArgs &a, int32_t nintervals, hipStream_t stream) {
   dim3 g = grid_for32(a.npoints);
   g.y = (unsigned)nintervals;
-  hipLaunchKernelGGL(rs32::expand_kernel_f32, g, dim3(RS_BLOCK), 0, stream, a);
+  if (a.f.tdew && a.f.tsurfobs)
+    hipLaunchKernelGGL((rs32::expand_kernel_f32<true, true>), g, dim3(RS_BLOCK), 0, stream, a);
+  else if (a.f.tdew)
+    hipLaunchKernelGGL((rs32::expand_kernel_f32<true, false>), g, dim3(RS_BLOCK), 0, stream, a);
+  else if (a.f.tsurfobs)
+    hipLaunchKernelGGL((rs32::expand_kernel_f32<false, true>), g, dim3(RS_BLOCK), 0, stream, a);
+  else
+    hipLaunchKernelGGL((rs32::expand_kernel_f32<false, false>), g, dim3(RS_BLOCK), 0, stream, a);
   return hipGetLastError();
 }
