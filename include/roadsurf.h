@@ -633,6 +633,12 @@ typedef struct RsDriverOutput {
 int rs_driver_run(const RsDriverInput *in, const InputSettings *settings,
                   const InputParameters *params, LocalParameters *local,
                   const RsDriverOutput *out, int32_t device);
+/* Tiles: a call steps its points in tiles of ROADSURF_HIP_TILE_POINTS (default 524 288).  With
+ * coupling the forcing windows of a tile span [first coupling-window start, last window end + 1]
+ * of ITS points; a tile whose windows would exceed ROADSURF_HIP_WINDOW_BUDGET_MB (default 24 576)
+ * - stations whose observations ended hours apart - is cut in halves, down to 4 096 points.
+ * rs_driver_last_tiles(): tiles the calling thread's last call with device >= 0 stepped. */
+int rs_driver_last_tiles(void);
 /* rs_driver_run keeps its forcing-window block (up to 64 GB of HBM with coupling) for the next
  * call, because releasing and re-acquiring that much VRAM costs seconds (the driver wipes it).
  * This frees it. */

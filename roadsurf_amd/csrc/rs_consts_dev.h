@@ -3,6 +3,7 @@
  * recompute every time step: the reciprocals of the uniform denominators (rs_math.hpp, rs_div_u)
  * and one uniform product.  Filled in C++ by rs_hip_plan_create; not part of the C-ABI. */
 #pragma once
+#include <cstdlib>
 #include "../../include/roadsurf.h"
 
 struct RsConstantsDev : RsConstants {
@@ -12,6 +13,12 @@ struct RsConstantsDev : RsConstants {
    * DTSecs (src/Storage.f90:422), meltDen, logUstar and logCond (first pass of the boundary-layer
    * loop, where PSIM = PSIH = 0: src/BoundaryLayer.f90:62,69-70) */
   double r_3600, r_3364, r_1000, r_IceMax, r_twoDT, r_DTSecs, r_meltDen, r_logUstar, r_logCond;
+  /* 1: a bare, dry road stays bare whatever the limits say (road_condition's fast path,
+   * rs_physics_body.inc): no upper storage limit is negative */
+  int32_t bareFastOk;
+  /* CheckValues' bounds (src/InputOutput.f90:45-84; REAL(4) literals): 100, -0.1, -90, 120, -1,
+   * 4000, 1000, 500 - in the order check_values reads them */
+  double chk[8];
 };
 
 static inline void rs_consts_dev_fill(const RsConstants &c, RsConstantsDev &d) {
@@ -26,6 +33,10 @@ static inline void rs_consts_dev_fill(const RsConstants &c, RsConstantsDev &d) {
   d.r_meltDen = 1.0 / d.meltDen;
   d.r_logUstar = 1.0 / c.logUstar;
   d.r_logCond = 1.0 / c.logCond;
+  const float chk[8] = {100.0f, -0.1f, -90.0f, 120.0f, -1.0f, 4000.0f, 1000.0f, 500.0f};
+  for (int i = 0; i < 8; ++i) d.chk[i] = (double)chk[i];
+  d.bareFastOk = (c.MaxWatmms >= 0.0 && c.MaxSnowmms >= 0.0 && c.MaxIcemms >= 0.0 && c.MaxDepmms >= 0.0) ? 1 : 0;
+  if (getenv("ROADSURF_HIP_NO_BARE_FAST")) d.bareFastOk = 0; /* A/B switch: same bits either way */
 }
 
 /* Operand domain the bare division/sqrt sequences of rs_math.hpp rely on, as far as it is set by

@@ -1030,6 +1030,10 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
                             const InputParameters *params, LocalParameters *local,
                             const RsDriverOutput *out, int32_t device, int64_t pbeg, int64_t pend);
 
+/* tiles the calling thread's last single-device rs_driver_run stepped (tests: the window budget) */
+static thread_local int g_last_tiles = 0;
+int rs_driver_last_tiles(void) { return g_last_tiles; }
+
 /* device >= 0: that device.  device < 0: the points are cut into contiguous blocks over the
  * device list (rs_devices.hpp: ROADSURF_HIP_DEVICES, default every visible device), one host
  * thread + stream + plans per device, no collective - the in-process counterpart of the
@@ -1129,8 +1133,17 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     HOK(win.acquire(win_bytes, device));
   }
   pt.lap(6);
-  for (int64_t p0 = pbeg; p0 < pend; p0 += P) {
-    const int m = (int)std::min<int64_t>(P, pend - p0);
+  /* Budget of one worker's forcing windows.  Chunked coupling sizes its replay block from the
+   * tile's couplingIndexI values (known only after read_input has run on the device): one station
+   * that stopped reporting hours before the others stretches the block towards SimLen, and at the
+   * default tile that is > 100 GB per worker.  Such a tile is cut in halves until it fits. */
+  const char *eb = getenv("ROADSURF_HIP_WINDOW_BUDGET_MB");
+  const size_t win_budget = eb ? (size_t)std::max(1, atoi(eb)) << 20 : (size_t)24 << 30;
+  int Pcur = P;
+  g_last_tiles = 0;
+  for (int64_t p0 = pbeg, m_done = 0; p0 < pend; p0 += m_done) {
+    m_done = 0; /* a tile that has to be cut is started again at the same p0 */
+    const int m = (int)std::min<int64_t>(Pcur, pend - p0);
     PlanGuard pg;
     pg.p = rs_hip_plan_create(device, m, &consts, stream);
     if (!pg.p) return -11;
@@ -1210,6 +1223,10 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     }
     const int r_lo = cs_min, r_hi = std::min(ce_max + 1, L); /* replay block, 1-based inclusive */
     const int WR = (cpl_chunked && any_on) ? std::max(TC, r_hi - r_lo + 1) : TC;
+    if (cpl_chunked && WR > TC && (size_t)nwin * mp * WR * sizeof(double) > win_budget && m > 4096) {
+      Pcur = std::max(4096, (m / 2 + 4095) / 4096 * 4096);
+      continue;
+    }
     if ((size_t)nwin * mp * WR * sizeof(double) > win_bytes) {
       win.release();
       win_bytes = (size_t)nwin * mp * WR * sizeof(double);
@@ -1225,6 +1242,10 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     HOK(hipGetLastError());
     const size_t os = (size_t)mp * n_out;
     HOK(d_out.alloc((size_t)6 * os * sizeof(double)));
+    /* OutputData.cpp:5-13: rows the simulation never saves read -9999.0 */
+    hipLaunchKernelGGL(fill_f64_kernel, grid1((int64_t)(6 * os)), dim3(RS_BLOCK), 0, stream,
+                       d_out.as<double>(), (int64_t)(6 * os), -9999.0);
+    HOK(hipGetLastError());
     HOK(d_outpt.alloc((size_t)m * n_out * sizeof(double)));
 
     ExpandRawArgs ea;
@@ -1466,6 +1487,9 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     d_out.release();
     d_outpt.release();
     pt.lap(7);
+    m_done = m;
+    ++g_last_tiles;
+    Pcur = P; /* the next tile starts at full size again */
   }
   pt.report();
   return 0;

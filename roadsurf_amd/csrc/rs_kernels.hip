@@ -60,6 +60,13 @@ struct RegProfile {
   __device__ __forceinline__ constexpr int nlayers() const { return NL; }
   __device__ __forceinline__ double get(int j) const { return v[j - 1]; }
   __device__ __forceinline__ void set(int j, double x) { v[j - 1] = x; }
+  /* "the new profile exists here": without it the compiler sinks the update of the layers nothing in
+   * the rest of the step reads (3..N) behind the storages into the loop latch, where the layer
+   * constants no longer fit the scalar registers (124 v_readlane/v_writelane per step) */
+  __device__ __forceinline__ void pin() {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) asm volatile("" : "+v"(v[j]));
+  }
 };
 
 struct LdsProfile {
@@ -68,6 +75,7 @@ struct LdsProfile {
   __device__ __forceinline__ int nlayers() const { return n; }
   __device__ __forceinline__ double get(int j) const { return col[(j - 1) * kBlock]; }
   __device__ __forceinline__ void set(int j, double x) { col[(j - 1) * kBlock] = x; }
+  __device__ __forceinline__ void pin() {}
 };
 
 template <bool FULL, class Prof>
@@ -161,10 +169,55 @@ struct LaneOff {
   }
 };
 
-template <bool FULL>
+/* A32 windows (the launcher's choice: every stream of the window spans < 4 GiB): the whole offset
+ * of (row, point) fits the 32-bit vector offset, so the stream pointers are used as they come out
+ * of the kernel arguments - no 64-bit scalar add per stream and step (2 x 13 streams), one scalar
+ * multiply-add for the row and one vector add.  `slot` = row * t_stride + first point of the
+ * workgroup (uniform, < 2^29). */
+struct WinOff {
+  uint32_t b8;
+  __device__ __forceinline__ WinOff(uint32_t lane, uint32_t slot) {
+    const uint32_t sb = slot << 3;
+    asm volatile("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(b8) : "v"(lane), "s"(sb));
+  }
+  template <class T>
+  __device__ __forceinline__ T ld(const T *base) const {
+    static_assert(sizeof(T) == 8 || sizeof(T) == 4, "");
+    return *(const T *)((const char *)base + (sizeof(T) == 8 ? b8 : b8 >> 1));
+  }
+  template <class T>
+  __device__ __forceinline__ void st(T *base, T v) const {
+    static_assert(sizeof(T) == 8 || sizeof(T) == 4, "");
+    *(T *)((char *)base + (sizeof(T) == 8 ? b8 : b8 >> 1)) = v;
+  }
+};
+
+template <bool FULL, bool A32 = false>
 __device__ __forceinline__ Forcing load_forcing(KernArgs ka, int64_t row0, uint32_t lane,
                                                 int32_t k) {
   Forcing o;
+  if (A32) {
+    const WinOff L(lane, (uint32_t)k * (uint32_t)ka->f.t_stride + (uint32_t)row0);
+    o.tair = L.ld(ka->f.tair);
+    o.vz = L.ld(ka->f.vz);
+    o.rhz = L.ld(ka->f.rhz);
+    o.prec = L.ld(ka->f.prec);
+    o.sw = L.ld(ka->f.sw);
+    o.lw = L.ld(ka->f.lw);
+    o.phase = L.ld(ka->f.precphase);
+    if (ka->f.hour_pstride) o.hour = L.ld(ka->f.hour);
+    else o.hour = ka->f.hour[k];
+    if (FULL) {
+      o.tdew = ka->f.tdew ? L.ld(ka->f.tdew) : 0.0;
+      o.tsurfobs = ka->f.tsurfobs ? L.ld(ka->f.tsurfobs) : R4(-9999.9);
+      o.depth = ka->f.depth ? L.ld(ka->f.depth) : R4(-9999.9);
+    } else {
+      o.tdew = 0.0;
+      o.tsurfobs = R4(-9999.9);
+      o.depth = R4(-9999.9);
+    }
+    return o;
+  }
   const int64_t row = (int64_t)k * ka->f.t_stride + row0;
   const LaneOff L(lane);
   o.tair = L.ld(ka->f.tair + row);
@@ -205,10 +258,20 @@ __device__ __forceinline__ bool output_row(KernArgs ka, int32_t i, int64_t &row)
   return true;
 }
 
-template <bool SCATTER = false>
+template <bool SCATTER = false, bool A32 = false>
 __device__ __forceinline__ void store_outputs(KernArgs ka, int64_t row, int64_t row0, uint32_t lane,
                                               const Scalars &s, bool valid) {
   const double miss = R4(-9999.0); /* src/Initialization.f90:404-411 */
+  if (A32 && !SCATTER) {
+    const WinOff L(lane, (uint32_t)row + (uint32_t)row0);
+    L.st(ka->o.tsurf, valid ? s.tsurf : miss);
+    L.st(ka->o.snow, valid ? s.snow : miss);
+    L.st(ka->o.water, valid ? s.wat : miss);
+    L.st(ka->o.ice, valid ? s.ice : miss);
+    L.st(ka->o.deposit, valid ? s.dep : miss);
+    L.st(ka->o.ice2, valid ? s.ice2 : miss);
+    return;
+  }
   if (SCATTER && ka->out_index) { /* column = out_index[slot]: point order whatever the plan order */
     row += (int64_t)ka->out_index[row0 + lane];
     ka->o.tsurf[row] = valid ? s.tsurf : miss;
@@ -390,9 +453,10 @@ __device__ __forceinline__ Forcing gather_forcing(KernArgs ka, int64_t p, int32_
  * Coupling_control decide again at the end.  `point` is the lane's slot: the list breaks the tie
  * between thread and point, so accesses are base[point] with the row base on the scalar unit. */
 template <bool FULL, class Prof, bool SKY = false, bool SCORE = true, bool CPL = false,
-          bool REPLAY = false>
+          bool REPLAY = false, bool A32 = false>
 __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s, int32_t &score,
                                           uint32_t point = 0u) {
+  static_assert(!A32 || (!SKY && !CPL), "32-bit window offsets: the plain lock-step kernels only");
   static_assert(FULL || !SKY, "sky view belongs to the FULL feature set");
   static_assert(FULL || !CPL, "coupling belongs to the FULL feature set");
   static_assert(CPL || !REPLAY, "replays belong to coupling");
@@ -463,7 +527,7 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
   /* REPLAY: SWRadCof / LWRadCof of the window being replayed, and "TmpNw is the stale profile" */
   double r_swcof = R4(1.0), r_lwcof = R4(1.0);
   bool stale_now = false;
-  Forcing nxt = load_forcing<FULL>(ka, row0, lane, 0);
+  Forcing nxt = load_forcing<FULL, A32>(ka, row0, lane, 0);
   for (int32_t kv = 0; kv < nsteps; ++kv) {
     asm volatile("" : "+s"(ka));
     const ConstsAS &c = consts_of(ka);
@@ -478,15 +542,15 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
     const bool owrite = output_row<true>(ka, i, orow);
 
     if (CPL && (parked || i != next_i)) { /* parked behind its window, or ahead of this launch */
-      if (k + 1 < nsteps) nxt = load_forcing<FULL>(ka, row0, lane, k + 1);
+      if (k + 1 < nsteps) nxt = load_forcing<FULL, A32>(ka, row0, lane, k + 1);
       continue;
     }
     if (CPL) next_i = i + 1;
     if (s.failed) { /* loop has exited in the reference: outputs stay -9999.0 */
-      if (k + 1 < nsteps) nxt = load_forcing<FULL>(ka, row0, lane, k + 1);
+      if (k + 1 < nsteps) nxt = load_forcing<FULL, A32>(ka, row0, lane, k + 1);
       /* a point that fails in the middle of a replay keeps, up to its window end, what the earlier
        * passes saved there (src/InputOutput.f90:151-165 only ever overwrites) */
-      if (owrite && (!REPLAY || i > cpl_ce)) store_outputs<CPL>(ka, orow, row0, lane, s, false);
+      if (owrite && (!REPLAY || i > cpl_ce)) store_outputs<CPL, A32>(ka, orow, row0, lane, s, false);
       continue;
     }
     double tair = f.tair, vz = f.vz, rhz = f.rhz;
@@ -508,11 +572,11 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
          * CouplingOperations1 takes it back, and that is the index CheckValues has just seen -
          * with the surface temperature of the end of the window */
         const Forcing g = gather_forcing(ka, row0 + lane, cpl_ce + 1, t0);
-        if (check_values(g, s.tsurf, FULL && ka->f.tdew != nullptr)) fail_at(cpl_ce + 1);
+        if (check_values(c, g, s.tsurf, FULL && ka->f.tdew != nullptr)) fail_at(cpl_ce + 1);
       } else {
         Forcing chk = f;
         chk.vz = vz;
-        if (check_values(chk, s.tsurf, FULL && ka->f.tdew != nullptr)) fail_at(i);
+        if (check_values(c, chk, s.tsurf, FULL && ka->f.tdew != nullptr)) fail_at(i);
       }
       if (SKY) {
         if (sky_on && (sw_dir < R4(-0.1) || sw_dir > R4(4000.0) || lw_net < R4(-1000.0) ||
@@ -671,7 +735,7 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
     /* next index's forcing: issued here, half a step before its first use, so the
      * HBM latency hides under the ground/storage half without holding 14 VGPRs
      * across the boundary-layer iteration */
-    if (k + 1 < nsteps) nxt = load_forcing<FULL>(ka, row0, lane, k + 1);
+    if (k + 1 < nsteps) nxt = load_forcing<FULL, A32>(ka, row0, lane, k + 1);
     if (REPLAY) {
       /* first step after the restore: CalcHCapHCond sees the pre-restore TmpNw in every layer
        * (observation forcing cannot follow a restore, so layers 1-2 are stale too) */
@@ -681,9 +745,9 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
                                              stale_now ? &Tstale : nullptr);
       stale_now = false;
     } else {
-      model_step_ground(c, s, T, tbot, tair, fx, f.depth, cp);
+      model_step_ground<Prof, Prof, FULL>(c, s, T, tbot, tair, fx, f.depth, cp);
     }
-    if (owrite) store_outputs<CPL>(ka, orow, row0, lane, s, true);
+    if (owrite) store_outputs<CPL, A32>(ka, orow, row0, lane, s, true);
     if (CPL && cpl_on && i < c.SimLen && i == cpl_ce) {
       /* CheckEndCoupling + CouplingOperations2, src/Coupling.f90:98-141 (Coupling_failed is
        * .false. before the first decision) */
@@ -696,6 +760,10 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
         if (q.iter == 0) q.tend1 = s.tsurf;
         coupling_control(q, s.tsurf);
         q.iter = q.iter + 1;
+        /* a point that failed CheckValues at this very index still ran Coupling_control
+         * (CheckEndCoupling does not look at simulation_failed), but its loop exits before any rewind:
+         * it must not park - the rows behind its window stay -9999.0 - and must not be listed */
+        if (s.failed) q.again = false;
         store_coupling(st, np, p, q);
         cpl_swcorr = q.swcorr;
         cpl_lwcorr = q.lwcorr;
@@ -805,7 +873,7 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Sc
       lw_net = ka->f.lw_net[off];
     }
     if (i < c.SimLen) {
-      if (check_values(f, s.tsurf, ka->f.tdew != nullptr)) fail_at(i);
+      if (check_values(c, f, s.tsurf, ka->f.tdew != nullptr)) fail_at(i);
       if (sky_on && (sw_dir < R4(-0.1) || sw_dir > R4(4000.0) || lw_net < R4(-1000.0) ||
                      lw_net > R4(1000.0)))
         fail_at(i); /* src/InputOutput.f90:68-74 */
@@ -945,6 +1013,7 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Sc
       if (q.iter == 0) q.tend1 = s.tsurf;
       coupling_control(q, s.tsurf);
       q.iter = q.iter + 1;
+      if (s.failed) q.again = false; /* failed at this index: the loop exits, no rewind, not listed */
       if (ka->cpl_stop) { /* park: the next round decides between a replay and going on */
         ++i;
         break;
@@ -969,7 +1038,7 @@ __device__ __forceinline__ double bl_score_key(int32_t score, const Scalars &s) 
   return (double)(lo | (covered << 19) | (((score >> 30) & 1) << 20));
 }
 
-template <int NL, bool FULL, int WPE, bool SCORE = true>
+template <int NL, bool FULL, int WPE, bool SCORE = true, bool A32 = false>
 __global__ void __launch_bounds__(kBlock, WPE) step_kernel_reg(const StepArgs a) {
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
   const MathTab mt = fill_math_tables(math_lds);
@@ -980,7 +1049,7 @@ __global__ void __launch_bounds__(kBlock, WPE) step_kernel_reg(const StepArgs a)
   Scalars s;
   int32_t score = 0;
   load_state<FULL>(a.state, a.np_pad, p, T, s);
-  time_loop<FULL, RegProfile<NL>, false, SCORE>(mt, T, s, score);
+  time_loop<FULL, RegProfile<NL>, false, SCORE, false, false, A32>(mt, T, s, score);
   store_state<FULL>(a.state, a.np_pad, p, T, s);
   if (SCORE) a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
 }
@@ -1474,21 +1543,27 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
   if (variant == RS_VARIANT_REG) {
     if (NL != 15) return hipErrorInvalidValue;
     if (wpe == 0) wpe = full ? 3 : 4;
-#define RS_REG(W)                                                                        \
-  if (wpe == W) {                                                                        \
-    if (full && (score || W != 3))                                                       \
-      hipLaunchKernelGGL((rs::step_kernel_reg<15, true, W>), g, b, 0, stream, a);        \
-    else if (full) /* no history score wanted: the default FULL flavour without it */     \
-      hipLaunchKernelGGL((rs::step_kernel_reg<15, true, 3, false>), g, b, 0, stream, a); \
-    else if (score || W != 4)                                                            \
-      hipLaunchKernelGGL((rs::step_kernel_reg<15, false, W>), g, b, 0, stream, a);       \
-    else /* no history score wanted (forecast order): the default flavour without it */   \
-      hipLaunchKernelGGL((rs::step_kernel_reg<15, false, 4, false>), g, b, 0, stream, a);\
-  }
-    RS_REG(2) RS_REG(3) RS_REG(4)
+    if (wpe < 2 || wpe > 4) return hipErrorInvalidValue;
+    /* 32-bit window offsets (WinOff) where every stream of both windows spans < 4 GiB */
+    static const bool addr64 = getenv("ROADSURF_HIP_ADDR64") != nullptr; /* A/B switch */
+    const int64_t out_rows = ((int64_t)a.t0 + a.nsteps - 2) / a.o.decimate - a.o.row0 + 1;
+    const bool a32 = (uint64_t)a.f.t_stride * (uint64_t)a.nsteps < (1ull << 29) &&
+                     (uint64_t)a.o.t_stride * (uint64_t)(out_rows > 0 ? out_rows : 1) < (1ull << 29) &&
+                     !addr64;
+    /* the history score is only kept off in the default flavours (LEAN at 4 waves, FULL at 3) */
+    const bool sc = score || wpe != (full ? 3 : 4);
+#define RS_REG(F, W, S, A)                                                              \
+  if (full == F && wpe == W && sc == S && a32 == A)                                      \
+    hipLaunchKernelGGL((rs::step_kernel_reg<15, F, W, S, A>), g, b, 0, stream, a);
+#define RS_REG_A(F, W, S) RS_REG(F, W, S, false) RS_REG(F, W, S, true)
+    RS_REG_A(false, 2, true) RS_REG_A(false, 3, true) RS_REG_A(false, 4, true) RS_REG_A(false, 4, false)
+    RS_REG_A(true, 2, true) RS_REG_A(true, 3, true) RS_REG_A(true, 4, true) RS_REG_A(true, 3, false)
+#undef RS_REG_A
+#undef RS_REG
   } else {
     const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
     if (wpe == 0) wpe = 4;
+    if (wpe < 3 || wpe > 4) return hipErrorInvalidValue; /* no instance: nothing would be launched */
 #define RS_LDS(W)                                                                        \
   if (wpe == W) {                                                                        \
     if (full)                                                                            \

@@ -25,6 +25,8 @@
 #define RS_DIVC(a, b, rb) rs_div(a, b)
 #define RS_BL_GUARD 0
 #define RS_MELTDEN (c.WatMHeat * c.WatDens)
+#define RS_CHK(c, i, lit) (lit)
+#define RS_BARE_FAST(c) ((c).MaxWatmms >= 0.f && (c).MaxSnowmms >= 0.f && (c).MaxIcemms >= 0.f && (c).MaxDepmms >= 0.f)
 namespace rs32 {
 using rs::MathTab;
 using rs::rs_div;
@@ -33,6 +35,10 @@ using rs::rs_dvb;
 using rs::rs_sq;
 using rs::rs_exp;
 using rs::rs_fabs;
+using rs::rs_fmax;
+using rs::rs_fmin;
+using rs::rs_is_pos_zero;
+using rs::rs_wave_all;
 using rs::rs_log;
 using rs::rs_sqrt;
 }  // namespace rs32
@@ -53,6 +59,7 @@ struct RegProfile {
   __device__ __forceinline__ constexpr int nlayers() const { return NL; }
   __device__ __forceinline__ float get(int j) const { return v[j - 1]; }
   __device__ __forceinline__ void set(int j, float x) { v[j - 1] = x; }
+  __device__ __forceinline__ void pin() {}
 };
 struct LdsProfile {
   float *col;
@@ -60,6 +67,7 @@ struct LdsProfile {
   __device__ __forceinline__ int nlayers() const { return n; }
   __device__ __forceinline__ float get(int j) const { return col[(j - 1) * kBlock]; }
   __device__ __forceinline__ void set(int j, float x) { col[(j - 1) * kBlock] = x; }
+  __device__ __forceinline__ void pin() {}
 };
 
 typedef const rs::StepArgs __attribute__((address_space(4))) *KernArgs;
@@ -118,7 +126,7 @@ __device__ __forceinline__ void run(const rs::StepArgs &a, Prof &T) {
     f.tdew = 0.f; f.tsurfobs = -9999.9f; f.depth = -9999.9f;
     if (i == 1 && f.vz < 0.4f) f.vz = 0.4f;
     const float prec_ts = rs_div(f.prec, 3600.0f) * c.DTSecs;
-    if (i < c.SimLen && check_values(f, s.tsurf, false)) {
+    if (i < c.SimLen && check_values(c, f, s.tsurf, false)) {
       s.failed = true;
       st[(int64_t)RS_ST_FAILED * np + p] = (float)i; /* the index it was raised at */
     }

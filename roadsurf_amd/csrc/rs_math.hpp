@@ -221,6 +221,27 @@ __device__ __forceinline__ double rs_sq(double x) {
   return rs_sqrt(x);
 }
 
+/* x is +0.0, by its bits (x == 0 would admit -0.0) */
+__device__ __forceinline__ bool rs_is_pos_zero(double x) { return __double_as_longlong(x) == 0; }
+__device__ __forceinline__ bool rs_is_pos_zero(float x) { return __float_as_int(x) == 0; }
+/* true in every ACTIVE lane of the wavefront (lanes that have left the time step do not vote) */
+__device__ __forceinline__ bool rs_wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
+
+/* IEEE maxNum / minNum: the other operand where one is a (quiet) NaN.  The instruction itself:
+ * __builtin_fmax makes the compiler canonicalise every operand that comes from memory first
+ * (v_max_f64 x, x, x), which doubles the cost. */
+__device__ __forceinline__ double rs_fmax(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double rs_fmin(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float rs_fmax(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ float rs_fmin(float a, float b) { return __builtin_fminf(a, b); }
 __device__ __forceinline__ double rs_fabs(double x) { return __builtin_fabs(x); }
 __device__ __forceinline__ float rs_fabs(float x) { return __builtin_fabsf(x); }
 

@@ -148,9 +148,15 @@ def test_chunked_coupling_with_failing_points(replay, monkeypatch):
     f2["tair"][17, 5] = -200.0            # before the window
     for q in (25, 26, 27, 28, 29, 30):    # at the index behind the window end (1-based ci + 1)
         f2["tair"][q, ci] = -200.0
+    # AT the window end (1-based ci): the step still runs and Coupling_control still decides
+    # (CheckEndCoupling does not look at simulation_failed), then the loop exits - no rewind, the
+    # rows behind the window stay -9999.0 (a lane that parked there would leave them unwritten)
+    for q in range(33, 49):
+        f2["tair"][q, ci - 1] = -200.0
     ora, _, _ = oh.run_oracle(_kind(), f2, s, p, ls)
     whole, _ = device.run_points(f2, s, p, ls)
     parts, _ = device.run_points(f2, s, p, ls, chunk=128)
     for q in oh.F64_OUT:
         assert np.array_equal(whole[q], ora[q]), q
         assert np.array_equal(parts[q], ora[q]), q
+    assert (ora["tsurf"][33:49, ci:] == -9999.0).all() and (ora["tsurf"][33:49, ci - 1] != -9999.0).all()

@@ -8,7 +8,7 @@ import pytest
 
 import driver_helpers as dh
 import oracle_helpers as oh
-from roadsurf_amd import abi, driver
+from roadsurf_amd import abi, driver, lib
 
 pytestmark = pytest.mark.gpu
 M = -9999.9
@@ -229,6 +229,27 @@ def test_shared_axis_chunked_coupling_in_plan_order(monkeypatch):
         assert np.array_equal(g["status"], o["status"]), env
         for k in driver.OUT_FIELDS:
             assert _same_bits(g[k], o[k]), (env, k, int((g[k] != o[k]).sum()))
+
+
+def test_spread_coupling_windows_are_cut_to_the_window_budget(monkeypatch):
+    """Chunked coupling sizes its replay block from the tile's couplingIndexI values: a station whose
+    observations stopped early stretches the block, and with it the forcing windows.  A tile whose
+    windows would exceed ROADSURF_HIP_WINDOW_BUDGET_MB is cut in halves (down to 4 096 points) and
+    started again; the results do not change."""
+    n = 9000
+    src, L, t0, tf = dh.scenario(n, hours=6, seed=43, obs_hours=4)
+    s = _settings(L, use_relaxation=1, use_coupling=1, coupling_minutes=30, outputStep=10)
+    p = abi.default_parameters()
+    o = dh.oracle_run(_kind(True), src, s, p, t0, tf)
+    ci = np.array([o["local"][q].couplingIndexI for q in range(n)])[o["status"] == 0]
+    assert ci.max() - ci.min() > 100          # the replay block is much longer than a window
+    monkeypatch.setenv("ROADSURF_HIP_CHUNK_STEPS", "64")
+    monkeypatch.setenv("ROADSURF_HIP_WINDOW_BUDGET_MB", "40")
+    g = driver.run(src, s, p, t0, tf, device=0)
+    assert np.array_equal(g["status"], o["status"])
+    for k in driver.OUT_FIELDS:
+        assert _same_bits(g[k], o[k]), (k, int((g[k] != o[k]).sum()))
+    assert lib.load().rs_driver_last_tiles() >= 3   # 9 000 points: 4 096 + 4 096 + the rest
 
 
 def test_identical_per_point_axes_equal_the_shared_axis(monkeypatch):
