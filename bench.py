@@ -110,7 +110,9 @@ def main() -> None:
     ap.add_argument("--chunk", type=int, default=0,
                     help="time indices per step-kernel launch; 0 = auto: 120 for >= 750 000 points on "
                          "the GPU, 240 for smaller shards (measured, tools/exp_small.sh)")
-    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 register profile, 2 LDS profile")
+    ap.add_argument("--variant", type=int, default=0,
+                    help="0 auto (by shard size: 3 below 200 000 points on the GPU, else 1), 1 register "
+                         "profile, 2 LDS profile, 3 two wavefronts per 64 points")
     ap.add_argument("--seed", type=int, default=20240110)
     ap.add_argument("--f32", action="store_true",
                     help="BASELINE config 5 flavour: fp32 state/forcing/outputs/arithmetic "
@@ -131,6 +133,11 @@ def main() -> None:
                          "0 = auto: 4 from 200 000 points on the GPU, 2 from 100 000, else 1")
     ap.add_argument("--no-natural-leg", action="store_true",
                     help="skip the second timed leg (natural order) that gives natural_order_value")
+    ap.add_argument("--checksum", action="store_true",
+                    help="after the timed legs run ONE more untimed pass and report config.checksum: the "
+                         "order-independent wrap-around sum of the bit patterns of all six outputs of every "
+                         "point and index, summed over the ranks (what tests/test_hip_config4.py compares "
+                         "between a one-rank and a two-rank launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16384)
     args = ap.parse_args()
@@ -174,6 +181,10 @@ def main() -> None:
     K = args.plans_per_gpu if args.plans_per_gpu > 0 else (4 if n >= 200_000 else 2 if n >= 100_000 else 1)
     if args.chunk <= 0:
         args.chunk = 120 if n >= 750_000 else 240
+    if args.variant == 0 and not args.f32:
+        # measured (tools/r3_duo.sh): two plans of <= 100 000 points run faster with two wavefronts per
+        # 64 points; with four plans in flight one point per lane fills the chip
+        args.variant = 3 if n < 200_000 else 1
     plans, offsets = [], []
     for j in range(K):
         off_j, n_j = sharding.strong_shard(n, K, j)
@@ -246,6 +257,32 @@ def main() -> None:
     if cluster and not args.no_natural_leg:
         natural = timed_leg(False)
     nfail = sum(pl.failed_count() for pl in plans)
+    checksum = None
+    if args.checksum:
+        itype = torch.int32 if args.f32 else torch.int64
+        acc = torch.zeros((), dtype=torch.int64, device=dev)
+        for pl, o in zip(plans, offsets):
+            run = workload.SyntheticRun(pl, args.seed, args.hours, args.chunk, point_offset=o,
+                                        plan_order=cluster, f32=args.f32, forecast=args.sort_key == "forecast",
+                                        forecast_alpha=args.forecast_alpha, forecast_mode=args.forecast_mode)
+
+            def on_launch(c, t0, ns, run=run, pl=pl):
+                with torch.cuda.stream(pl.stream):
+                    for k in device.OUT_FIELDS:
+                        acc.add_(run.out.tensors[k][:ns, :pl.npoints].view(itype).sum(dtype=torch.int64))
+            torch.cuda.synchronize(dev)
+            run.run_pass(on_launch)
+            torch.cuda.synchronize(dev)
+            del run
+        total = acc.cpu()
+        if world > 1:
+            if dist.get_backend() == "nccl":
+                t = acc.clone()
+                dist.all_reduce(t)  # SUM of int64 wraps around like the per-rank sums
+                total = t.cpu()
+            else:
+                dist.all_reduce(total)
+        checksum = int(total.item())
 
     units_per_pass_job = total_points * simlen          # whole job, all ranks
     units_per_pass_rank = n * simlen
@@ -292,6 +329,7 @@ def main() -> None:
                 "kernel_variant": args.variant,
                 "parallelism": f"points sharded over {world} GPU(s) ({scaling} scaling), no collectives",
                 "failed_points": int(nfail),
+                "checksum": checksum,
             },
             "roofline": {
                 "bound": "hbm",

@@ -450,11 +450,14 @@ int64_t rs_hip_div_special_count(RsPlan *plan);
  * square root), IEEE result, bare result}; out = host double[64][4] */
 int rs_hip_div_samples(RsPlan *plan, double *out);
 
-/* Kernel flavour: 0 auto (1 for the LEAN feature set with NLayers == 15, else 2), 1 register
- * profile, 2 LDS profile,
- * 3 register profile with the boundary-layer iteration tail compacted over the workgroup
- * (an experiment that executes 12 % fewer instructions and is slower, with or without plan
- * order: DESIGN.md 6).  All flavours return the same bits. */
+/* Kernel flavour: 0 auto, 1 register profile (NLayers == 15), 2 LDS profile (any NLayers),
+ * 3 two wavefronts per 64 points - one steps the surface (forcing, boundary layer, layers 1-2,
+ * storages), the other the layers below, meeting once per time step: the flavour for launches too
+ * small to fill the chip with one point per lane (LEAN feature set, NLayers == 15, windows under
+ * 4 GiB per stream; any other launch of such a plan runs as 0).  0 picks 3 for launches of at most
+ * ROADSURF_HIP_DUO_MAX points (environment; the default is the measured break-even), else 1 for
+ * NLayers == 15, else 2.  + 10 * W: compile-time bound of W = 2..4 waves per SIMD for flavours 1
+ * and 2 (tuning).  All flavours return the same bits. */
 int rs_hip_set_variant(RsPlan *plan, int32_t variant);
 
 /* ---- plan order: load balancing by regime ----------------------------------------------

@@ -195,7 +195,7 @@ RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints, const RsConstants *c
   pl->stream = (hipStream_t)stream;
   if (const char *ev = getenv("ROADSURF_HIP_VARIANT")) { /* tuning: default flavour of new plans */
     const int v = atoi(ev);
-    if (v >= 0 && v % 10 <= 2 && v / 10 <= 4 &&
+    if (v >= 0 && v % 10 <= 3 && v / 10 <= 4 && !(v % 10 == RS_VARIANT_DUO && v / 10 != 0) &&
         !(v % 10 == RS_VARIANT_REG && consts->NLayers != 15))
       pl->variant = v;
   }
@@ -389,11 +389,13 @@ int rs_hip_set_history_score(RsPlan *pl, int32_t on) {
 }
 
 int rs_hip_set_variant(RsPlan *pl, int32_t variant) {
-  if (!pl || variant < 0 || variant % 10 > 2 || variant / 10 > 4)
+  if (!pl || variant < 0 || variant % 10 > 3 || variant / 10 > 4)
     return set_err("rs_hip_set_variant: bad arguments");
   if (variant % 10 == RS_VARIANT_REG && pl->c.NLayers != 15)
     return set_err("register-profile kernel is built for NLayers == 15 only (got %d)",
                    pl->c.NLayers);
+  if (variant % 10 == RS_VARIANT_DUO && variant / 10 != 0)
+    return set_err("the two-wavefront flavour takes no waves-per-SIMD bound");
   pl->variant = variant;
   return 0;
 }
@@ -533,6 +535,7 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
   a.cpl_nlist = 0;
   a.cpl_stop = 0;
   a.out_index = nullptr;
+  a.duo_roles = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (pl->timing) {
     if (pl->ev_used + 2 > pl->ev.size()) {

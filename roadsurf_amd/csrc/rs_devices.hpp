@@ -10,6 +10,8 @@
  *   ROADSURF_HIP_DEVICES   comma-separated device indices ("0,1,2,3"; a device may be listed more
  *                          than once: that many concurrent plans on it), or "all" (default)
  *   ROADSURF_HIP_DEVICE    one device (kept from round 1; ROADSURF_HIP_DEVICES wins)
+ *   LOCAL_RANK             with neither of the two set: a rank-local process (one process per GPU)
+ *                          uses device LOCAL_RANK modulo the visible devices, not the whole node
  *   ROADSURF_HIP_PLANS_PER_DEVICE  when the list is not given explicitly, every device appears this
  *                          many times (default 4): four blocks per device run on four host threads
  *                          and four streams, so that one block's PCIe copies and host-side
@@ -57,6 +59,11 @@ inline std::vector<int> device_list() {
     if (const char *one = getenv("ROADSURF_HIP_DEVICE")) {
       const int d = atoi(one);
       if (d >= 0 && d < ndev) { lo = d; hi = d + 1; }
+    } else if (const char *lr = getenv("LOCAL_RANK")) {
+      /* one process per GPU (torch.distributed.run and friends): a rank that sees the whole node
+       * keeps to its own device instead of spreading over - and oversubscribing - all of them */
+      const int d = atoi(lr);
+      if (d >= 0) { lo = d % ndev; hi = lo + 1; }
     }
   }
   int per = 4;

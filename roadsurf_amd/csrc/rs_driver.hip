@@ -1041,7 +1041,10 @@ int rs_driver_last_tiles(void) { return g_last_tiles; }
 int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputParameters *params,
                   LocalParameters *local, const RsDriverOutput *out, int32_t device) {
   if (!in || in->n_points < 1) return fail_msg("rs_driver_run: bad arguments", -1);
-  if (device >= 0) return driver_run_range(in, st, params, local, out, device, 0, in->n_points);
+  if (device >= 0) {
+    rsu::g_last_fanout = 1;
+    return driver_run_range(in, st, params, local, out, device, 0, in->n_points);
+  }
   const std::vector<rsu::Shard> shards = rsu::make_shards(in->n_points, rsu::device_list());
   return rsu::fan_out(shards, [&](const rsu::Shard &sh, int) {
     return driver_run_range(in, st, params, local, out, sh.device, sh.off, sh.off + sh.cnt);

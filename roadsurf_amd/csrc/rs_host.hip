@@ -95,9 +95,11 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
     return -1;
   }
   const int host_threads = rsu::host_threads(omp_get_num_procs());
-  if (device >= 0)
+  if (device >= 0) {
+    rsu::g_last_fanout = 1;
     return run_batch_on_device(n, outPointers, inPointers, consts, localParam, tbottom, extras, device,
                                host_threads);
+  }
   /* fan out: one contiguous block of points per device, one host thread + stream + plan each */
   const std::vector<rsu::Shard> shards = rsu::make_shards(n, rsu::device_list());
   return rsu::fan_out(shards, [&](const rsu::Shard &sh, int nshards) {

@@ -6,7 +6,15 @@
 
 #define RS_BLOCK 256
 
-enum { RS_VARIANT_AUTO = 0, RS_VARIANT_REG = 1, RS_VARIANT_LDS = 2 };
+enum { RS_VARIANT_AUTO = 0, RS_VARIANT_REG = 1, RS_VARIANT_LDS = 2, RS_VARIANT_DUO = 3 };
+/* AUTO takes the two-wavefronts-per-64-points flavour for launches of at most this many points:
+ * 1 024 wavefronts, a quarter of the chip's slots (measured, tools/r3_duo.sh: two plans of 62 500
+ * points 1.13e10 against 1.06e10 point-timesteps/s with one point per lane; four such plans in
+ * flight at once are better off with one point per lane - a caller that runs that many sets the
+ * flavour itself, as bench.py does) */
+#ifndef RS_DUO_MAX_POINTS
+#define RS_DUO_MAX_POINTS 65536
+#endif
 
 namespace rs {
 
@@ -35,6 +43,7 @@ struct StepArgs {
    * (NULL: column s).  With the plan order as index the (decimated) outputs land in point order
    * whatever order the slots are in (rs_hip_set_output_by_point). */
   const int32_t *out_index;
+  int32_t duo_roles; /* step_kernel_duo: how the two roles are dealt to the wavefronts (launcher) */
 };
 
 struct InitArgs {

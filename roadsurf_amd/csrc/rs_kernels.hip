@@ -1071,6 +1071,174 @@ __global__ void __launch_bounds__(kBlock, WPE) step_kernel_lds(const StepArgs a)
   a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
 }
 
+/* ---- two wavefronts per 64 points: the flavour for small shards --------------------------------
+ * A launch of one point per lane needs ~260 000 points to put four wavefronts on every SIMD; the
+ * per-GPU shard of BASELINE config 4 (1 M points over 8 GPUs) has 125 000: under two waves per
+ * SIMD, each of which must issue its ~2 300 instructions per time step one after the other, with
+ * nothing to hide its waits behind.  Here a workgroup is TWO wavefronts that share 64 points:
+ *   wave 0, "surface": everything of a time step that forms the serial chain - forcing, checks,
+ *           precipitation, boundary layer, radiation, layers 1-2, melting, storages, outputs;
+ *   wave 1, "ground":  layers 3..N of the explicit profile update (src/BalanceModel.f90:112-128),
+ *           which only read the OLD temperatures of their neighbours.
+ * They meet once per time step: the surface wave publishes its new Tmp(2), the ground wave its
+ * new Tmp(3) (two LDS words per point, double-buffered, one s_barrier).  The serial chain of a
+ * step shrinks from ~1 460 to ~1 020 vector instructions and the shard occupies twice as many
+ * wave slots.  Same arithmetic in the same order per point: same bits (layer_step is the one
+ * function both flavours call).  LEAN feature set, NLayers = 15, 32-bit window offsets. */
+struct DuoMail {
+  double v[2][2][64]; /* [buffer][0: Tmp(2) from the surface wave, 1: Tmp(3) from the ground wave][lane] */
+};
+
+/* LDS writes done, then the workgroup barrier.  Not __syncthreads(): that also waits for the global
+ * memory counter, i.e. for the six output stores of the step and the prefetched forcing loads. */
+__device__ __forceinline__ void duo_meet() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NL, bool SCORE>
+__device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, const StepArgs &a) {
+  KernArgs ka = kernargs();
+  const uint32_t lane = threadIdx.x & 63u;
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  const int64_t p = row0 + lane;
+  const bool live = p < a.npoints; /* a dead lane still walks to every barrier */
+  RegProfile<2> T;
+  Scalars s;
+  {
+    RegProfile<NL> all;
+    if (live) {
+      load_state<false>(a.state, a.np_pad, p, all, s);
+    } else {
+      for (int j = 1; j <= NL; ++j) all.set(j, 0.0);
+      s = Scalars();
+      s.failed = true;
+    }
+    T.set(1, all.get(1));
+    T.set(2, all.get(2));
+  }
+  mail.v[0][0][lane] = T.get(2);
+  duo_meet();
+  const int32_t nsteps = ka->nsteps, t0 = ka->t0;
+  int32_t score = 0; /* scheduling hint of rs_hip_recluster, as in time_loop */
+  Forcing nxt = load_forcing<false, true>(ka, row0, lane, 0);
+  for (int32_t kv = 0; kv < nsteps; ++kv) {
+    asm volatile("" : "+s"(ka));
+    const ConstsAS &c = consts_of(ka);
+    const int32_t k = __builtin_amdgcn_readfirstlane(kv);
+    const int32_t i = t0 + k;
+    const Forcing f = nxt;
+    int64_t orow = 0;
+    const bool owrite = output_row<true>(ka, i, orow);
+    const double t3 = mail.v[k & 1][1][lane]; /* Tmp(3) as the last step left it */
+    if (!s.failed) {
+      double tair = f.tair, vz = f.vz, rhz = f.rhz;
+      if (i == 1 && vz < R4(0.4)) vz = R4(0.4); /* src/Initialization.f90:121-123 */
+      const double prec_ts = RS_DIVC(f.prec, 3600.0, r_3600) * c.DTSecs;
+      if (i < c.SimLen) {
+        Forcing chk = f;
+        chk.vz = vz;
+        if (check_values(c, chk, s.tsurf, false)) {
+          s.failed = true;
+          ka->state[(int64_t)RS_ST_FAILED * ka->np_pad + row0 + lane] = (double)i;
+        }
+      }
+      s.tnw1 = T.get(1);
+      s.tnw2 = T.get(2);
+      const Fluxes fx =
+          model_step_fluxes<SCORE>(c, mt, s, tair, vz, rhz, prec_ts, f.sw, f.lw, f.phase, f.hour);
+      if (SCORE) {
+        score += (fx.trips & 63) - 5;
+        if ((fx.trips & 64) && k >= nsteps - RS_REGIME_WINDOW) score |= 1 << 30;
+      }
+      if (k + 1 < nsteps) nxt = load_forcing<false, true>(ka, row0, lane, k + 1);
+      /* layers 1-2 with Tmp(3) where a two-layer column has its lower boundary */
+      model_step_ground<RegProfile<2>, RegProfile<2>, false>(c, s, T, t3, tair, fx, f.depth);
+      if (owrite) store_outputs<false, true>(ka, orow, row0, lane, s, true);
+    } else {
+      if (k + 1 < nsteps) nxt = load_forcing<false, true>(ka, row0, lane, k + 1);
+      if (owrite && live) store_outputs<false, true>(ka, orow, row0, lane, s, false);
+    }
+    mail.v[(k & 1) ^ 1][0][lane] = T.get(2);
+    duo_meet();
+  }
+  if (live) {
+    double *st = a.state;
+    const int64_t np = a.np_pad;
+    st[(int64_t)(RS_ST_TMP0 + 0) * np + p] = T.get(1);
+    st[(int64_t)(RS_ST_TMP0 + 1) * np + p] = T.get(2);
+    st[(int64_t)RS_ST_TNW1 * np + p] = s.tnw1;
+    st[(int64_t)RS_ST_TNW2 * np + p] = s.tnw2;
+    st[(int64_t)RS_ST_TSURF * np + p] = s.tsurf;
+    st[(int64_t)RS_ST_WAT * np + p] = s.wat;
+    st[(int64_t)RS_ST_SNOW * np + p] = s.snow;
+    st[(int64_t)RS_ST_ICE * np + p] = s.ice;
+    st[(int64_t)RS_ST_ICE2 * np + p] = s.ice2;
+    st[(int64_t)RS_ST_DEP * np + p] = s.dep;
+    st[(int64_t)RS_ST_Q2MELT * np + p] = s.q2melt;
+    st[(int64_t)RS_ST_T4MELT * np + p] = s.t4melt;
+    st[(int64_t)RS_ST_ALBEDO * np + p] = s.albedo;
+    st[(int64_t)RS_ST_VERYCOLD * np + p] = s.verycold ? 1.0 : 0.0;
+    if (SCORE) st[(int64_t)RS_ST_BLSCORE * np + p] = bl_score_key(score, s);
+  }
+}
+
+template <int NL>
+__device__ __forceinline__ void duo_ground(DuoMail &mail, const StepArgs &a) {
+  KernArgs ka = kernargs();
+  const uint32_t lane = threadIdx.x & 63u;
+  const int64_t p = (int64_t)blockIdx.x * 64 + lane;
+  const bool live = p < a.npoints;
+  double Tg[NL - 2]; /* Tmp(3..NL) */
+#pragma unroll
+  for (int j = 3; j <= NL; ++j) Tg[j - 3] = live ? a.state[(int64_t)(RS_ST_TMP0 + j - 1) * a.np_pad + p] : 0.0;
+  const double tbot = live ? ka->pp.tbottom[p] : 0.0;
+  mail.v[0][1][lane] = Tg[0];
+  duo_meet();
+  const int32_t nsteps = ka->nsteps;
+  for (int32_t kv = 0; kv < nsteps; ++kv) {
+    asm volatile("" : "+s"(ka));
+    const ConstsAS &c = consts_of(ka);
+    const int32_t k = __builtin_amdgcn_readfirstlane(kv);
+    const double t2 = mail.v[k & 1][0][lane]; /* Tmp(2) as the last step left it (melting included) */
+    double Gprev = c.condDZ[2] * (Tg[0] - t2); /* G(2), the expression layer 2 itself evaluates */
+#pragma unroll
+    for (int j = 3; j <= NL; ++j) {
+      const double tj = Tg[j - 3];
+      const double tnext = (j == NL) ? tbot : Tg[j - 2];
+      Tg[j - 3] = layer_step(c, j, tj, tj, tnext, Gprev, nullptr);
+    }
+    mail.v[(k & 1) ^ 1][1][lane] = Tg[0];
+    duo_meet();
+  }
+  if (live) {
+#pragma unroll
+    for (int j = 3; j <= NL; ++j) a.state[(int64_t)(RS_ST_TMP0 + j - 1) * a.np_pad + p] = Tg[j - 3];
+  }
+}
+
+template <int NL, bool SCORE>
+__global__ void __launch_bounds__(128, 4) step_kernel_duo(const StepArgs a) {
+  __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
+  __shared__ DuoMail mail;
+  __shared__ uint32_t swap_roles;
+  const MathTab mt = fill_math_tables(math_lds);
+  /* Which wavefront steps the surface?  The surface wave issues twice the instructions of the ground
+   * wave, and the dispatcher hands the waves of two-wave workgroups to the SIMDs of a CU in turn:
+   * wave 0 always to SIMD 0 or 2, wave 1 to SIMD 1 or 3.  With fixed roles two SIMDs of every CU
+   * would carry all the surface waves (measured: 67 % of the rate with balanced roles).  The wave
+   * slot a workgroup gets on its SIMD counts the workgroups that came before it there: its parity
+   * alternates the roles, so every SIMD hosts both kinds. */
+  if (threadIdx.x == 0) {
+    const uint32_t hw_id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4); /* HW_ID.wave_id */
+    /* duo_roles (ROADSURF_HIP_DUO_ROLES, experiments): 0 slot parity, 1 fixed, 2 by workgroup index */
+    swap_roles = a.duo_roles == 1 ? 0u : a.duo_roles == 2 ? ((blockIdx.x >> 1) & 1u) : (hw_id & 1u);
+  }
+  __syncthreads();
+  /* no early return: both wavefronts walk to every barrier, lanes beyond npoints are dead weight */
+  const bool first = threadIdx.x < 64;
+  const bool swapped = __builtin_amdgcn_readfirstlane((int32_t)swap_roles) != 0;
+  if (first != swapped) duo_surface<NL, SCORE>(mt, mail, a);
+  else duo_ground<NL>(mail, a);
+}
+
 /* FULL feature set + sky view in lock step, LDS profile (any NLayers). */
 __global__ void __launch_bounds__(kBlock, 3) step_kernel_sky(const StepArgs a) {
   extern __shared__ double lds[]; /* [NLayers][kBlock] */
@@ -1535,21 +1703,39 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
   /* variant = flavour + 10 * waves-per-SIMD bound (0 = default for the flavour) */
   int wpe = variant / 10;
   variant %= 10;
-  if (variant == RS_VARIANT_AUTO) variant = (NL == 15) ? RS_VARIANT_REG : RS_VARIANT_LDS;
+  const bool auto_variant = variant == RS_VARIANT_AUTO;
+  if (auto_variant) variant = (NL == 15) ? RS_VARIANT_REG : RS_VARIANT_LDS;
   /* measured (tools/bench_driver_path.py relax, 1 M points, one plan): the FULL feature set in the
    * register flavour at 3 waves/SIMD (168 VGPRs) 0.745 s, at 2 waves 0.80 s, at 4 waves (130 spilled
    * VGPRs) 0.87 s; with the profile in LDS 0.86 s (3 waves) / 0.88 s (4 waves).  LEAN: registers,
    * 4 waves */
+  /* 32-bit window offsets (WinOff) where every stream of both windows spans < 4 GiB */
+  static const bool addr64 = getenv("ROADSURF_HIP_ADDR64") != nullptr; /* A/B switch */
+  const int64_t out_rows = ((int64_t)a.t0 + a.nsteps - 2) / a.o.decimate - a.o.row0 + 1;
+  const bool a32 = (uint64_t)a.f.t_stride * (uint64_t)a.nsteps < (1ull << 29) &&
+                   (uint64_t)a.o.t_stride * (uint64_t)(out_rows > 0 ? out_rows : 1) < (1ull << 29) &&
+                   !addr64;
+  /* small shards: two wavefronts per 64 points (step_kernel_duo).  Measured on MI355X
+   * (tools/r3_eval.sh): faster than one point per lane below ROADSURF_HIP_DUO_MAX points per launch */
+  const char *edm = getenv("ROADSURF_HIP_DUO_MAX"); /* read per launch: the tests switch it */
+  const int64_t duo_max = edm ? atoll(edm) : RS_DUO_MAX_POINTS;
+  const bool duo_ok = !full && NL == 15 && a32;
+  if (variant == RS_VARIANT_DUO && !duo_ok) { /* not this launch: as AUTO */
+    variant = (NL == 15) ? RS_VARIANT_REG : RS_VARIANT_LDS;
+    wpe = 0;
+  } else if (variant == RS_VARIANT_DUO || (auto_variant && wpe == 0 && duo_ok && a.npoints <= duo_max)) {
+    const dim3 gd((unsigned)((a.npoints + 63) / 64));
+    const char *er = getenv("ROADSURF_HIP_DUO_ROLES");
+    rs::StepArgs b = a;
+    b.duo_roles = er ? atoi(er) : 0;
+    if (score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true>), gd, dim3(128), 0, stream, b);
+    else hipLaunchKernelGGL((rs::step_kernel_duo<15, false>), gd, dim3(128), 0, stream, b);
+    return hipGetLastError();
+  }
   if (variant == RS_VARIANT_REG) {
     if (NL != 15) return hipErrorInvalidValue;
     if (wpe == 0) wpe = full ? 3 : 4;
     if (wpe < 2 || wpe > 4) return hipErrorInvalidValue;
-    /* 32-bit window offsets (WinOff) where every stream of both windows spans < 4 GiB */
-    static const bool addr64 = getenv("ROADSURF_HIP_ADDR64") != nullptr; /* A/B switch */
-    const int64_t out_rows = ((int64_t)a.t0 + a.nsteps - 2) / a.o.decimate - a.o.row0 + 1;
-    const bool a32 = (uint64_t)a.f.t_stride * (uint64_t)a.nsteps < (1ull << 29) &&
-                     (uint64_t)a.o.t_stride * (uint64_t)(out_rows > 0 ? out_rows : 1) < (1ull << 29) &&
-                     !addr64;
     /* the history score is only kept off in the default flavours (LEAN at 4 waves, FULL at 3) */
     const bool sc = score || wpe != (full ? 3 : 4);
 #define RS_REG(F, W, S, A)                                                              \

@@ -80,7 +80,8 @@ class OutputWindow:
 
     @classmethod
     def empty(cls, nrows: int, np_pad: int, device, decimate: int = 1, dtype=torch.float64):
-        t = {n: torch.empty((nrows, np_pad), dtype=dtype, device=device) for n in OUT_FIELDS}
+        # rows the simulation never saves read -9999.0, as in the reference (OutputData.cpp:5-13)
+        t = {n: torch.full((nrows, np_pad), -9999.0, dtype=dtype, device=device) for n in OUT_FIELDS}
         return cls(nrows, np_pad, t, decimate)
 
     def struct(self, row0: int) -> lib.RsOutputs:

@@ -1,0 +1,129 @@
+"""GPU: BASELINE config 4 - 1 000 000 points sharded over the 8 GPUs of a node - exercised with the
+product on the ONE GPU a test box has.
+
+The partition is the reference driver's worker pool turned inside out
+(/root/reference/examples/example1/src/roadrunner.cpp:423-501: `jobs` threads each take the next
+point): contiguous blocks of points, one per GPU, no term of the model couples two points, so no
+data crosses between blocks.  Two ways to run it, both tested here:
+
+  * inside the library: rs_driver_run / runsimulation_batch cut their points over
+    ROADSURF_HIP_DEVICES - "0,0,0,0,0,0,0,0" makes the eight blocks of 125 000 points of config 4
+    on one device, each with its own host thread, stream, windows and plans;
+  * one process per GPU: bench.py under torch.distributed.run (what the driver launches for the
+    scaling curve) - started here as a fresh child process with two ranks that share the device.
+
+(The device-resident form - eight SyntheticRun plans at their global offsets, half of them with the
+two-wavefront flavour bench.py picks at that shard size - is part of
+tests/test_hip_golden_and_scale.py::test_full_size_properties_1M_points_48h, which holds the
+single-plan checksum they must add up to.)"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import driver_helpers as dh
+import oracle_helpers as oh
+from roadsurf_amd import abi, driver, lib
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _raw_series(n, hours, seed):
+    """Hourly forecast (-1 h .. hours+1 h) and 10-minute observations for the first 6 h: the raw
+    series of tools/bench_driver_path.py, cheap enough to make for a million points."""
+    rs = np.random.RandomState(seed)
+    start = dh.START
+
+    def series(nt, dt, lo, hi, amp, period=86400.0):
+        base = rs.uniform(lo, hi, (n, 1))
+        ph = rs.uniform(0, 2 * np.pi, (n, 1))
+        t = np.arange(nt)[None, :] * dt
+        return base + amp * np.sin(2 * np.pi * t / period + ph)
+
+    nt_fc = hours + 3
+    fc_t = start - 3600 + np.arange(nt_fc, dtype=np.int64) * 3600
+    tair = series(nt_fc, 3600, -12, 6, 4.0)
+    fc = dict(tair=tair, tdew=tair - rs.uniform(0.5, 4, (n, 1)),
+              vz=np.abs(series(nt_fc, 3600, 1, 8, 2.0, 43200.0)) + 0.2,
+              prec=np.where(rs.rand(n, nt_fc) < 0.1, rs.uniform(0, 2, (n, nt_fc)), 0.0),
+              sw=np.maximum(0.0, series(nt_fc, 3600, -50, 150, 200.0)), lw=series(nt_fc, 3600, 230, 320, 15.0))
+    obs_h = 6
+    nt_ob = obs_h * 6 + 1
+    ob_t = start + np.arange(nt_ob, dtype=np.int64) * 600
+    ob = dict(tair=series(nt_ob, 600, -12, 6, 1.0), rhz=np.clip(series(nt_ob, 600, 70, 95, 5.0), 5, 100),
+              vz=np.abs(series(nt_ob, 600, 1, 8, 1.0)) + 0.2, tsurfobs=series(nt_ob, 600, -10, 4, 1.0))
+    return [driver.RawSource(fc_t, fc, False), driver.RawSource(ob_t, ob, True)], start, start + obs_h * 3600
+
+
+def _slice(src, lo, hi):
+    return [driver.RawSource(x.times, {k: np.ascontiguousarray(v[lo:hi]) for k, v in x.fields.items()},
+                             x.is_observation) for x in src]
+
+
+def test_one_million_points_in_eight_blocks_inside_the_library(monkeypatch):
+    """rs_driver_run over ROADSURF_HIP_DEVICES = eight entries: 1 M points as the eight blocks of
+    125 000 of config 4.  Every output of every point equals the single-device call's (bit for bit),
+    and sampled blocks - the first 64 points of the first, a middle and the last block - equal the
+    reference run on their raw series."""
+    n, hours = 1_000_000, 12
+    L = hours * 120 + 1
+    src, t0, tf = _raw_series(n, hours, seed=4)
+    s = abi.default_settings(L)
+    s.use_relaxation = 1
+    p = abi.default_parameters()
+    one = driver.run(src, s, p, t0, tf, device=0)
+    assert int((one["status"] == 0).sum()) == n
+    monkeypatch.setenv("ROADSURF_HIP_DEVICES", "0,0,0,0,0,0,0,0")
+    monkeypatch.setenv("ROADSURF_HIP_PLANS_PER_DEVICE", "1")
+    eight = driver.run(src, s, p, t0, tf, device=-1)
+    assert lib.load().rs_last_fanout() == 8
+    for k in driver.OUT_FIELDS:
+        assert np.array_equal(one[k].view(np.int64), eight[k].view(np.int64)), k
+        # the wrap-around checksum of checksums a rank-wise run would report
+        blocks = [eight[k][j * 125_000:(j + 1) * 125_000].view(np.int64).sum(dtype=np.int64) for j in range(8)]
+        assert np.sum(np.array(blocks, np.int64), dtype=np.int64) == one[k].view(np.int64).sum(dtype=np.int64), k
+    assert np.array_equal(one["status"], eight["status"])
+    kind = "ref" if oh.have_ref() else "port"
+    for b in (0, 4 * 125_000, 7 * 125_000 + 124_936):
+        o = dh.oracle_run(kind, _slice(src, b, b + 64), s, p, t0, tf)
+        for k in driver.OUT_FIELDS:
+            assert np.array_equal(eight[k][b:b + 64].view(np.int64), o[k].view(np.int64)), (k, b)
+
+
+def _bench(nproc, extra, port):
+    """bench.py as the driver starts it: a fresh child process (never an exec of this one, which has
+    touched the GPU), `nproc` ranks; returns the parsed JSON line of rank 0."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    args = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-natural-leg", "--checksum",
+            "--total-points", "200000"] + extra
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + args
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_of_bench_py_equal_one_rank():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 --total-points 200000`:
+    two ranks, each with its block of 100 000 points at its global offset (they share the one GPU of
+    the box; the control plane is gloo then), against the one-rank run of the same 200 000 points:
+    the wrap-around checksum over every output of every point and index is the same."""
+    one = _bench(1, [], 0)
+    two = _bench(2, [], 29600 + os.getpid() % 1000)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["scaling"] == "strong" and two["config"]["points_per_gpu"] == 100_000
+    assert one["config"]["failed_points"] == 0 and two["config"]["failed_points"] == 0
+    assert one["config"]["checksum"] is not None
+    assert one["config"]["checksum"] == two["config"]["checksum"]
+    assert two["value"] > 0 and two["ms_per_step"] > 0

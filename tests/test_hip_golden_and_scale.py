@@ -27,7 +27,7 @@ def test_golden_scenarios_on_gpu():
     f = gh.expand_knots(K, L, SPK)
     s = abi.default_settings(L); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
     idx = z["out_index"]
-    for variant in (1, 2):
+    for variant in (1, 2, 3):
         res, nfail = device.run_points(f, s, p, l, variant=variant)
         assert nfail == 1
         for k in oh.F64_OUT:
@@ -129,6 +129,57 @@ def _synthetic_pass(run, sample_points, itype=None):
             mins, maxs)
 
 
+def _interleaved_plans(K, chunk, variants, n, s, p, seed, hours, cols, c_want, samp_want, dev):
+    """n points as K plans (contiguous blocks at their global offsets, sharding.strong_shard) on K
+    streams whose launches interleave, in plan order: the K wrap-around checksums must add up to the
+    single plan's and the sampled points - found in whichever plan holds them, through that plan's
+    order rows - must carry the same bits."""
+    import torch
+    from roadsurf_amd import device, sharding, workload
+    L = hours * SPK + 1
+    plans, runs, offs = [], [], []
+    for j in range(K):
+        off, cnt = sharding.strong_shard(n, K, j)
+        pl = device.Plan(cnt, s, p, dev.index, stream=torch.cuda.Stream(dev))
+        if variants[j]:
+            pl.set_variant(variants[j])
+        plans.append(pl); offs.append(off)
+        runs.append(workload.SyntheticRun(pl, seed, hours, chunk, point_offset=off, plan_order=True))
+    sums = [torch.zeros((), dtype=torch.int64, device=dev) for _ in range(K)]
+    got = {k: np.full((L, len(cols)), np.nan) for k in device.OUT_FIELDS}
+    pending = []
+
+    def hook(j):
+        run_j, off, cnt = runs[j], offs[j], plans[j].npoints
+        mine = [(q, c - off) for q, c in enumerate(cols) if off <= c < off + cnt]
+        local = torch.as_tensor([c for _, c in mine], device=dev, dtype=torch.long)
+
+        def on_launch(c, t0, ns):
+            with torch.cuda.stream(plans[j].stream):
+                slots = run_j.slots_of(c, local) if len(mine) else None
+                for k in device.OUT_FIELDS:
+                    o = run_j.out.tensors[k][:ns, :cnt]
+                    sums[j] += o.view(torch.int64).sum()
+                    if len(mine):
+                        pending.append((k, t0, ns, [q for q, _ in mine], o[:, slots].clone()))
+        return on_launch
+
+    its = [r.iter_pass(hook(j)) for j, r in enumerate(runs)]
+    while its:
+        its = [it for it in its if next(it, None) is not None]
+    torch.cuda.synchronize()
+    assert (sum(int(x.item()) for x in sums) - c_want) % (1 << 64) == 0, f"{K} plans: checksum"   # wrap-around sums
+    for k, t0, ns, qs, block in pending:
+        got[k][t0 - 1:t0 - 1 + ns, qs] = block.cpu().numpy()
+    for k in device.OUT_FIELDS:
+        assert np.array_equal(got[k], samp_want[k]), (f"{K} interleaved plans", k)
+    assert sum(pl.failed_count() for pl in plans) == 0
+    del runs
+    for pl in plans:
+        pl.close()
+    torch.cuda.empty_cache()
+
+
 def test_full_size_properties_1M_points_48h():
     """BASELINE config 3 at its size, in BOTH orders bench.py times: natural order, and plan order
     (slots re-sorted after every launch, windows generated in slot order, order rows kept)."""
@@ -177,46 +228,12 @@ def test_full_size_properties_1M_points_48h():
     # interleave (one plan's window expansion and re-sort under another's step kernel).  Same
     # points, same values: the four checksums add up to the single plan's, the sampled blocks -
     # found in whichever plan holds them, through that plan's order rows - carry the same bits
-    from roadsurf_amd import sharding
-    K = 4
-    plans, runs, offs = [], [], []
-    for j in range(K):
-        off, cnt = sharding.strong_shard(n, K, j)
-        pl = device.Plan(cnt, s, p, 0, stream=torch.cuda.Stream(plan.device))
-        plans.append(pl); offs.append(off)
-        runs.append(workload.SyntheticRun(pl, seed, hours, 120, point_offset=off, plan_order=True))
-    sums = [torch.zeros((), dtype=torch.int64, device=plan.device) for _ in range(K)]
-    got = {k: np.full((L, len(cols)), np.nan) for k in device.OUT_FIELDS}
-    pending = []
-
-    def hook(j):
-        run_j, off, cnt = runs[j], offs[j], plans[j].npoints
-        mine = [(q, c - off) for q, c in enumerate(cols) if off <= c < off + cnt]
-        local = torch.as_tensor([c for _, c in mine], device=plan.device, dtype=torch.long)
-
-        def on_launch(c, t0, ns):
-            with torch.cuda.stream(plans[j].stream):
-                slots = run_j.slots_of(c, local) if len(mine) else None
-                for k in device.OUT_FIELDS:
-                    o = run_j.out.tensors[k][:ns, :cnt]
-                    sums[j] += o.view(torch.int64).sum()
-                    if len(mine):
-                        pending.append((k, t0, ns, [q for q, _ in mine], o[:, slots].clone()))
-        return on_launch
-
-    its = [r.iter_pass(hook(j)) for j, r in enumerate(runs)]
-    while its:
-        its = [it for it in its if next(it, None) is not None]
-    torch.cuda.synchronize()
-    assert (sum(int(x.item()) for x in sums) - c1) % (1 << 64) == 0   # wrap-around sums
-    for k, t0, ns, qs, block in pending:
-        got[k][t0 - 1:t0 - 1 + ns, qs] = block.cpu().numpy()
-    for k in device.OUT_FIELDS:
-        assert np.array_equal(got[k], samp1[k]), ("four interleaved plans", k)
-    assert sum(pl.failed_count() for pl in plans) == 0
-    del runs
-    for pl in plans:
-        pl.close()
+    _interleaved_plans(4, 120, [0] * 4, n, s, p, seed, hours, cols, c1, samp1, plan.device)
+    # BASELINE config 4's partition on the hardware at hand: the EIGHT blocks of 125 000 points the
+    # eight ranks of a node would hold, at their global offsets, as eight plans on this one GPU -
+    # four of them stepped by the two-wavefront flavour (what bench.py picks at that shard size),
+    # four with one point per lane
+    _interleaved_plans(8, 240, [3, 1] * 4, n, s, p, seed, hours, cols, c1, samp1, plan.device)
     # shard independence + reference spot check: re-run each sampled block as its own tiny batch
     l = abi.default_local(); l.InitLenI = 1
     for bi, b in enumerate(blocks):

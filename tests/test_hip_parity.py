@@ -46,7 +46,7 @@ def _compare(res, ora, tag):
     return worst
 
 
-@pytest.mark.parametrize("variant", [1, 2], ids=["reg", "lds"])
+@pytest.mark.parametrize("variant", [1, 2, 3], ids=["reg", "lds", "duo"])
 def test_lean_48h_vs_oracle(variant):
     from roadsurf_amd import device
     n, L = 512, 5761
@@ -60,7 +60,7 @@ def test_lean_48h_vs_oracle(variant):
     assert ora["snow"].max() > 0.5 and ora["ice"].max() > 0.5 and ora["deposit"].max() > 0.1
 
 
-@pytest.mark.parametrize("variant", [1, 2], ids=["reg", "lds"])
+@pytest.mark.parametrize("variant", [1, 2, 3], ids=["reg", "lds", "duo"])
 def test_chunked_equals_whole(variant):
     """Time-chunked stepping (state parked in HBM between launches) is bit-identical
     to one launch over the whole series."""

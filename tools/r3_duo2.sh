@@ -1,0 +1,28 @@
+#!/usr/bin/env bash
+# two-wavefront flavour: how the roles are dealt to the wavefronts, by shard size and plans
+set -e
+OUT=gpurun_out/r3_duo2
+mkdir -p $OUT
+export TMPDIR=/tmp
+ROADSURF_HIP_DUO_MAX=1000000000 timeout -k 10 600 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "lean or chunked" > $OUT/tests.log 2>&1 || { tail -30 $OUT/tests.log; exit 1; }
+tail -2 $OUT/tests.log
+run() { # name, bench args
+  local name=$1; shift
+  timeout -k 10 300 python bench.py --no-cpu-baseline --no-natural-leg "$@" > $OUT/$name.json 2> $OUT/$name.err || { tail -5 $OUT/$name.err; exit 1; }
+  python - <<PY
+import json
+d=json.load(open("$OUT/$name.json")); r=d["roofline"]
+print("$name value %.4e ms/pass %.1f kernel-only %.4e avg launch %.2f ms conc %.2f"%(d["value"],d["ms_per_step"],r["step_kernel_only_value"],r["avg_launch_ms"],r["concurrent_launches"]), flush=True)
+PY
+}
+for R in 0 1 2; do
+  export ROADSURF_HIP_DUO_ROLES=$R
+  run n125k_v3_r$R --total-points 125000 --steps 5 --variant 3
+  run n125k_v3_k1_r$R --total-points 125000 --steps 5 --variant 3 --plans-per-gpu 1
+  run n250k_v3_r$R --total-points 250000 --steps 5 --variant 3
+done
+unset ROADSURF_HIP_DUO_ROLES
+run n125k_v1 --total-points 125000 --steps 5 --variant 1
+run n250k_v1 --total-points 250000 --steps 5 --variant 1
+run n250k_v3_k2 --total-points 250000 --steps 5 --variant 3 --plans-per-gpu 2
+run n500k_v3 --total-points 500000 --steps 5 --variant 3

@@ -22,8 +22,8 @@ PY
 run n1m --steps 5
 run n250k --total-points 250000 --steps 10
 run n125k --total-points 125000 --steps 10
-if [[ " $* " != *" nopmc "* ]]; then
 G="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES"
+if [[ " $* " != *" nopmc "* ]]; then
 for N in 1000000 125000; do
   rocprofv3 --kernel-trace --pmc $G --output-format csv -d $OUT/pmc_$N -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-natural-leg --total-points $N > $OUT/pmc_bench_$N.json 2> $OUT/pmc_err_$N.txt || { tail -20 $OUT/pmc_err_$N.txt; echo "pmc $N failed"; continue; }
   python3 - <<PY
@@ -39,3 +39,25 @@ PY
   rm -rf $OUT/pmc_$N
 done
 fi
+# A/B: environment switches given as ab:VAR=VALUE ... -> bench + counters at 1 M with each
+for arg in "$@"; do
+  case $arg in ab:*)
+    kv=${arg#ab:}
+    export "$kv"
+    run n1m_${kv%%=*} --steps 3
+    N=1000000
+    rocprofv3 --kernel-trace --pmc $G --output-format csv -d $OUT/pmc_ab -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-natural-leg --total-points $N > $OUT/pmc_bench_ab.json 2> $OUT/pmc_err_ab.txt || { tail -20 $OUT/pmc_err_ab.txt; }
+    python3 - <<PY
+import csv,glob,collections
+acc=collections.defaultdict(float)
+for fn in glob.glob("$OUT/pmc_ab/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(fn)):
+        if "step_kernel" not in row["Kernel_Name"]: continue
+        acc[row["Counter_Name"]]+=float(row["Counter_Value"])
+ws=$N/64.0*5761
+print("$kv N=$N per wave-step:", {k: round(v/ws,1) for k,v in sorted(acc.items()) if k!="SQ_WAVES"}, flush=True)
+PY
+    rm -rf $OUT/pmc_ab
+    unset "${kv%%=*}"
+  ;; esac
+done
