@@ -39,7 +39,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 ALGO_BYTES_PER_UNIT = 100.0    # 52 B read + 48 B written per point-timestep
-TRAFFIC_FILE = "profiles/r02_traffic.json"  # committed PMC summary the roofline's `traffic` is read from
+TRAFFIC_FILE = "profiles/r03_traffic.json"  # committed PMC summary the roofline's `traffic` is read from
+TRAFFIC_FILE_F32 = "profiles/r03_f32_traffic.json"
 
 
 def effective_cpus() -> int:
@@ -83,17 +84,65 @@ def cpu_baseline(sample_points: int, simlen: int, seed: int):
     }
 
 
-def measured_traffic(points: int, chunk: int, plans: int):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
-    (TRAFFIC_FILE), valid for the configuration it was collected on."""
-    path = os.path.join(ROOT, TRAFFIC_FILE)
+def measured_traffic(points: int, chunk: int, plans: int, f32: bool):
+    """HBM bytes per launch of the dominant kernel and the counter-derived figures from the committed
+    rocprofv3 PMC summary - only if it was collected on THIS configuration and from THESE kernel
+    sources (the summary is stamped with roadsurf_amd.provenance.csrc_sha16() when it is made; a
+    summary that predates the last kernel change is not reported)."""
+    from roadsurf_amd import provenance
+
+    name = TRAFFIC_FILE_F32 if f32 else TRAFFIC_FILE
     try:
-        t = json.load(open(path))
+        t = json.load(open(os.path.join(ROOT, name)))
     except (OSError, ValueError):
-        return None, None
+        return None, None, name, "no committed counter summary"
     if t.get("points") != points or t.get("chunk_steps") != chunk or t.get("plans_per_gpu") != plans:
-        return None, None
-    return t.get("traffic_bytes_per_launch"), t.get("derived")
+        return None, None, name, "counter summary was collected on another configuration"
+    if t.get("csrc_sha16") != provenance.csrc_sha16():
+        return None, None, name, "counter summary predates the kernel sources of this run"
+    return t.get("traffic_bytes_per_launch"), t.get("derived"), name, None
+
+
+class ClockSampler:
+    """Engine clock of the GPU while the timed passes run, read from sysfs every 50 ms (best effort:
+    None where the driver does not expose it)."""
+
+    def __init__(self, dev_index: int):
+        import glob
+        import threading
+
+        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.path = self.paths[dev_index] if dev_index < len(self.paths) else None
+        self.samples, self._stop = [], threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        try:
+            for ln in open(self.path):
+                if "*" in ln:
+                    return float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except (OSError, ValueError, IndexError, TypeError):
+            pass
+        return None
+
+    def _run(self):
+        while not self._stop.wait(0.05):
+            v = self._read()
+            if v:
+                self.samples.append(v)
+
+    def __enter__(self):
+        if self.path:
+            self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self.path:
+            self._t.join(1.0)
+
+    def mean_mhz(self):
+        return sum(self.samples) / len(self.samples) if self.samples else None
 
 
 def main() -> None:
@@ -133,6 +182,10 @@ def main() -> None:
                          "0 = auto: 4 from 200 000 points on the GPU, 2 from 100 000, else 1")
     ap.add_argument("--no-natural-leg", action="store_true",
                     help="skip the second timed leg (natural order) that gives natural_order_value")
+    ap.add_argument("--full", action="store_true",
+                    help="the FULL feature set instead of the BASELINE workload's LEAN one: Tdew / TsurfObs / "
+                         "depth streams present, a 6-hour initialization phase and relaxation behind it (what "
+                         "an operational run uses; reported as config.feature_set)")
     ap.add_argument("--checksum", action="store_true",
                     help="after the timed legs run ONE more untimed pass and report config.checksum: the "
                          "order-independent wrap-around sum of the bit patterns of all six outputs of every "
@@ -175,13 +228,18 @@ def main() -> None:
         offset, n = sharding.strong_shard(total_points, world, rank)
     simlen = args.hours * workload.SPK + 1  # examples/example1/src/InputSettings.cpp:98
     settings = abi.default_settings(simlen)
+    if args.full:
+        settings.use_relaxation = 1
     params = abi.default_parameters()
     # measured on MI355X (tools/exp_plans.sh, tools/exp_small.sh): 4 plans from 200 000
     # points, 2 from 100 000; launches of 120 indices for a full GPU, 240 for small shards
     K = args.plans_per_gpu if args.plans_per_gpu > 0 else (4 if n >= 200_000 else 2 if n >= 100_000 else 1)
     if args.chunk <= 0:
         args.chunk = 120 if n >= 750_000 else 240
-    if args.variant == 0 and not args.f32:
+    if args.full and n >= 750_000:  # measured (tools/r3_full3.sh): three plans, launches of 240 indices
+        K = args.plans_per_gpu if args.plans_per_gpu > 0 else 3
+        args.chunk = 240
+    if args.variant == 0 and not args.f32 and not args.full:
         # measured (tools/r3_duo.sh): two plans of <= 100 000 points run faster with two wavefronts per
         # 64 points; with four plans in flight one point per lane fills the chip
         args.variant = 3 if n < 200_000 else 1
@@ -209,7 +267,8 @@ def main() -> None:
         runs = [workload.SyntheticRun(pl, args.seed, args.hours, args.chunk, point_offset=o,
                                       plan_order=plan_order, f32=args.f32,
                                       forecast=args.sort_key == "forecast",
-                                      forecast_alpha=args.forecast_alpha, forecast_mode=args.forecast_mode)
+                                      forecast_alpha=args.forecast_alpha, forecast_mode=args.forecast_mode,
+                                      full=args.full)
                 for pl, o in zip(plans, offsets)]
         run = runs[0]
 
@@ -227,10 +286,12 @@ def main() -> None:
         ref.record(torch.cuda.current_stream(dev))
         torch.cuda.synchronize(dev)
         t_start = time.perf_counter()
-        for _ in range(args.steps):
-            one_pass()
-        fence()
+        with ClockSampler(dev_index) as clk:
+            for _ in range(args.steps):
+                one_pass()
+            fence()
         elapsed = time.perf_counter() - t_start
+        sclk.append(clk.mean_mhz())
         elapsed = sharding.max_over_ranks(
             elapsed, dist if world > 1 else None,
             dev if (world > 1 and dist.get_backend() == "nccl") else None)
@@ -252,6 +313,7 @@ def main() -> None:
         return elapsed, step_ms, nlaunch, chunk, busy_ms
 
     cluster = bool(args.cluster)
+    sclk = []  # mean engine clock of each timed leg (MHz), None where not readable
     elapsed, step_ms, nlaunch, chunk, busy_ms = timed_leg(cluster)
     natural = None
     if cluster and not args.no_natural_leg:
@@ -264,7 +326,8 @@ def main() -> None:
         for pl, o in zip(plans, offsets):
             run = workload.SyntheticRun(pl, args.seed, args.hours, args.chunk, point_offset=o,
                                         plan_order=cluster, f32=args.f32, forecast=args.sort_key == "forecast",
-                                        forecast_alpha=args.forecast_alpha, forecast_mode=args.forecast_mode)
+                                        forecast_alpha=args.forecast_alpha, forecast_mode=args.forecast_mode,
+                                        full=args.full)
 
             def on_launch(c, t0, ns, run=run, pl=pl):
                 with torch.cuda.stream(pl.stream):
@@ -298,7 +361,18 @@ def main() -> None:
     achieved = algo_bytes * units_per_pass_rank * args.steps / (busy_ms / 1e3) / 1e9
     concurrency = step_ms / busy_ms
 
-    traffic, valu = (None, None) if args.f32 else measured_traffic(n, chunk, K)
+    traffic, valu, traffic_file, traffic_note = measured_traffic(n, chunk, K, args.f32)
+    if args.full:
+        traffic, valu, traffic_note = None, None, "counter summaries are kept for the LEAN feature set only"
+
+    # the binding roofline, from this run: vector-issue time of one pass (SQ_ACTIVE_INST_VALU of the
+    # matching counter summary, x4 cycles, over the chip's 1 024 SIMDs) at the clock sampled DURING the
+    # timed passes, against the measured pass time
+    valu_issue_frac = clock_mhz = None
+    if valu and valu.get("valu_active_quadcycles_per_pass"):
+        clock_mhz = sclk[0] or 2400.0
+        issue_s = valu["valu_active_quadcycles_per_pass"] * 4.0 / 1024.0 / (clock_mhz * 1e6)
+        valu_issue_frac = issue_s / (elapsed / args.steps)
     if rank == 0:
         line = {
             "metric": "point_timesteps_per_s",
@@ -315,12 +389,14 @@ def main() -> None:
             "data": "synthetic",
             "config": {
                 "workload": f"{total_points} synthetic points x {args.hours} h (SimLen {simlen}, DTSecs 30, "
-                            f"NLayers 15), {'fp32' if args.f32 else 'fp64'}, outputs every time index, "
+                            f"NLayers 15), {'fp32' if args.f32 else 'fp64'}, {'FULL' if args.full else 'LEAN'} feature set, outputs every time index, "
                             f"attributable to points"
                             + (" (per-launch order rows kept inside the timed region)" if cluster else ""),
                 "total_points": total_points,
                 "points_per_gpu": n,
                 "plans_per_gpu": K,
+                "feature_set": "FULL (optional streams, 6 h initialization phase, relaxation)" if args.full else "LEAN",
+
                 "simlen": simlen,
                 "chunk_steps": chunk,
                 "plan_order": cluster,
@@ -339,14 +415,16 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
+                "traffic_source": traffic_file + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
                                   "mean per launch, averaged over the launches of a pass like "
-                                  "avg_launch_ms)" if traffic else None,
+                                  "avg_launch_ms; stamped with the hash of the kernel sources)" if traffic else None,
+                "traffic_note": traffic_note,
                 "valu": valu,
-                # measured pass time against the vector-issue time of its step launches (PMC figure of
-                # the committed profile, at the 2.4 GHz peak clock; the chip holds ~2.23 GHz here)
-                "valu_issue_frac": (valu["valu_issue_ms_per_pass_at_2.4GHz"] / (elapsed / args.steps * 1e3)
-                                    if valu and "valu_issue_ms_per_pass_at_2.4GHz" in valu else None),
+                "valu_issue_frac": valu_issue_frac,
+                "valu_issue_clock_mhz": clock_mhz,
+                "valu_issue_clock_source": (None if valu_issue_frac is None else
+                                            "sysfs pp_dpm_sclk sampled during the timed passes" if sclk[0]
+                                            else "not readable on this box: the 2.4 GHz peak clock assumed"),
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "launches": nlaunch,
                 "units_per_launch": units_per_launch,

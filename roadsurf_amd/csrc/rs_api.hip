@@ -59,6 +59,7 @@ struct RsPlan {
   int variant = RS_VARIANT_AUTO;
   /* the plan's constants on the device (no table of slots: any number of plans may be alive) */
   void *consts_dev = nullptr;   /* RsConstantsDev (rs_consts_dev.h) */
+  double *relax_tab = nullptr;  /* RsConstantsDev::relax_tab */
   void *consts32_dev = nullptr; /* RsConstantsF, allocated by rs_hip_set_precision(32) */
   rs::Writeback wb{nullptr, nullptr, nullptr, 0};
   /* coupling rounds: scratch for the list of points that replay their window */
@@ -195,7 +196,7 @@ RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints, const RsConstants *c
   pl->stream = (hipStream_t)stream;
   if (const char *ev = getenv("ROADSURF_HIP_VARIANT")) { /* tuning: default flavour of new plans */
     const int v = atoi(ev);
-    if (v >= 0 && v % 10 <= 3 && v / 10 <= 4 && !(v % 10 == RS_VARIANT_DUO && v / 10 != 0) &&
+    if (v >= 0 && v % 10 <= 4 && v / 10 <= 4 && !(v % 10 >= RS_VARIANT_DUO && v / 10 != 0) &&
         !(v % 10 == RS_VARIANT_REG && consts->NLayers != 15))
       pl->variant = v;
   }
@@ -210,7 +211,17 @@ RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints, const RsConstants *c
   (void)hipMemsetAsync(pl->state, 0, bytes, pl->stream);
   RsConstantsDev cd;
   rs_consts_dev_fill(pl->c, cd);
-  hipError_t ce = hipMalloc(&pl->consts_dev, sizeof(RsConstantsDev));
+  hipError_t ce = hipSuccess;
+  {
+    const std::vector<double> tab = rs_relax_table(pl->c);
+    if (!tab.empty()) {
+      ce = hipMalloc(&pl->relax_tab, tab.size() * sizeof(double));
+      if (ce == hipSuccess)
+        ce = hipMemcpy(pl->relax_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
+      cd.relax_tab = pl->relax_tab;
+    }
+  }
+  if (ce == hipSuccess) ce = hipMalloc(&pl->consts_dev, sizeof(RsConstantsDev));
   if (ce == hipSuccess)
     ce = hipMemcpyAsync(pl->consts_dev, &cd, sizeof(RsConstantsDev), hipMemcpyHostToDevice, pl->stream);
   if (ce == hipSuccess) ce = hipStreamSynchronize(pl->stream); /* cd is stack scratch */
@@ -225,6 +236,7 @@ RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints, const RsConstants *c
   if (ce != hipSuccess) {
     set_err("rs_hip_plan_create: upload of the constants failed: %s", hipGetErrorString(ce));
     if (pl->consts_dev) (void)hipFree(pl->consts_dev);
+    if (pl->relax_tab) (void)hipFree(pl->relax_tab);
     (void)hipFree(pl->state);
     (void)hipFree(pl->counter);
     delete pl;
@@ -239,6 +251,7 @@ void rs_hip_plan_destroy(RsPlan *pl) {
   (void)hipStreamSynchronize(pl->stream);
   for (hipEvent_t e : pl->ev) (void)hipEventDestroy(e);
   if (pl->consts_dev) (void)hipFree(pl->consts_dev);
+  if (pl->relax_tab) (void)hipFree(pl->relax_tab);
   if (pl->consts32_dev) (void)hipFree(pl->consts32_dev);
   (void)hipFree(pl->state);
   (void)hipFree(pl->counter);
@@ -389,13 +402,13 @@ int rs_hip_set_history_score(RsPlan *pl, int32_t on) {
 }
 
 int rs_hip_set_variant(RsPlan *pl, int32_t variant) {
-  if (!pl || variant < 0 || variant % 10 > 3 || variant / 10 > 4)
+  if (!pl || variant < 0 || variant % 10 > 4 || variant / 10 > 4)
     return set_err("rs_hip_set_variant: bad arguments");
   if (variant % 10 == RS_VARIANT_REG && pl->c.NLayers != 15)
     return set_err("register-profile kernel is built for NLayers == 15 only (got %d)",
                    pl->c.NLayers);
-  if (variant % 10 == RS_VARIANT_DUO && variant / 10 != 0)
-    return set_err("the two-wavefront flavour takes no waves-per-SIMD bound");
+  if (variant % 10 >= RS_VARIANT_DUO && variant / 10 != 0)
+    return set_err("flavours 3 and 4 take no waves-per-SIMD bound");
   pl->variant = variant;
   return 0;
 }

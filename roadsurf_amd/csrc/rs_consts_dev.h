@@ -19,6 +19,13 @@ struct RsConstantsDev : RsConstants {
   /* CheckValues' bounds (src/InputOutput.f90:45-84; REAL(4) literals): 100, -0.1, -90, 120, -1,
    * 4000, 1000, 500 - in the order check_values reads them */
   double chk[8];
+  /* relax_tab[d] = exp(-(DTSecs*d)/14400), d = 0..SimLen: the relaxation factor
+   * exp(-(DTSecs*i - DTSecs*InitLenI)/(4*3600)) of src/Relaxation.f90:34-37 for i - InitLenI = d.
+   * Device pointer, or NULL where the argument is not a function of the difference alone (a time
+   * step that is not an integer: DTSecs*i then rounds) or relaxation is off.  Filled by
+   * rs_hip_plan_create with the host's exp - glibc's, whose bits rs_exp reproduces
+   * (tests/test_hip_math.py), and IEEE division, which rs_div reproduces. */
+  const double *relax_tab;
 };
 
 static inline void rs_consts_dev_fill(const RsConstants &c, RsConstantsDev &d) {
@@ -35,6 +42,7 @@ static inline void rs_consts_dev_fill(const RsConstants &c, RsConstantsDev &d) {
   d.r_logCond = 1.0 / c.logCond;
   const float chk[8] = {100.0f, -0.1f, -90.0f, 120.0f, -1.0f, 4000.0f, 1000.0f, 500.0f};
   for (int i = 0; i < 8; ++i) d.chk[i] = (double)chk[i];
+  d.relax_tab = nullptr;
   d.bareFastOk = (c.MaxWatmms >= 0.0 && c.MaxSnowmms >= 0.0 && c.MaxIcemms >= 0.0 && c.MaxDepmms >= 0.0) ? 1 : 0;
   if (getenv("ROADSURF_HIP_NO_BARE_FAST")) d.bareFastOk = 0; /* A/B switch: same bits either way */
 }
@@ -63,4 +71,17 @@ static inline const char *rs_consts_domain_error(const RsConstants &c) {
     if (!(c.ZDpth[j + 1] - c.ZDpth[j] > lo)) return "layer grid (ZDpth)";
   }
   return nullptr;
+}
+
+/* The relaxation table of RsConstantsDev::relax_tab on the host, or empty where it does not apply. */
+#include <cmath>
+#include <vector>
+static inline std::vector<double> rs_relax_table(const RsConstants &c) {
+  std::vector<double> t;
+  const double dt = c.DTSecs;
+  if (!c.use_relaxation || !(dt == std::floor(dt)) || !(dt * ((double)c.SimLen + 1.0) < 9.0e15)) return t;
+  const double den = (double)(4.f * 3600.f);
+  t.resize((size_t)c.SimLen + 1);
+  for (int32_t d = 0; d <= c.SimLen; ++d) t[(size_t)d] = std::exp(-((dt * d) - (dt * 0)) / den);
+  return t;
 }

@@ -6,7 +6,7 @@
 
 #define RS_BLOCK 256
 
-enum { RS_VARIANT_AUTO = 0, RS_VARIANT_REG = 1, RS_VARIANT_LDS = 2, RS_VARIANT_DUO = 3 };
+enum { RS_VARIANT_AUTO = 0, RS_VARIANT_REG = 1, RS_VARIANT_LDS = 2, RS_VARIANT_DUO = 3, RS_VARIANT_HYBRID = 4 };
 /* AUTO takes the two-wavefronts-per-64-points flavour for launches of at most this many points:
  * 1 024 wavefronts, a quarter of the chip's slots (measured, tools/r3_duo.sh: two plans of 62 500
  * points 1.13e10 against 1.06e10 point-timesteps/s with one point per lane; four such plans in

@@ -69,6 +69,25 @@ struct RegProfile {
   }
 };
 
+/* The upper NREG layers in registers, the rest in LDS columns: what lets the FULL feature set (more
+ * live values than the LEAN one) keep four waves per SIMD without scratch spills.  Layer indices are
+ * compile-time constants after unrolling, so the split costs no selects. */
+template <int NL, int NREG>
+struct HybridProfile {
+  double v[NREG];
+  double *col; /* &lds[threadIdx.x]; layer NREG + 1 + r is col[r * kBlock] */
+  __device__ __forceinline__ constexpr int nlayers() const { return NL; }
+  __device__ __forceinline__ double get(int j) const { return j <= NREG ? v[j - 1] : col[(j - NREG - 1) * kBlock]; }
+  __device__ __forceinline__ void set(int j, double x) {
+    if (j <= NREG) v[j - 1] = x;
+    else col[(j - NREG - 1) * kBlock] = x;
+  }
+  __device__ __forceinline__ void pin() {
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) asm volatile("" : "+v"(v[j]));
+  }
+};
+
 struct LdsProfile {
   double *col; /* &lds[threadIdx.x]; layer stride = kBlock doubles */
   int n;
@@ -106,7 +125,9 @@ __device__ __forceinline__ void load_state(const double *__restrict__ st, int64_
   }
 }
 
-template <bool FULL, class Prof>
+/* ANCHORS: the relaxation anchors are part of the Scalars (the general coupled kernel); the
+ * lock-step loop writes them to the state block at the index that sets them and carries differences */
+template <bool FULL, class Prof, bool ANCHORS = false>
 __device__ __forceinline__ void store_state(double *__restrict__ st, int64_t np, int64_t p,
                                             const Prof &T, const Scalars &s) {
   const int N = T.nlayers();
@@ -125,7 +146,7 @@ __device__ __forceinline__ void store_state(double *__restrict__ st, int64_t np,
   st[(int64_t)RS_ST_ALBEDO * np + p] = s.albedo;
   st[(int64_t)RS_ST_VERYCOLD * np + p] = s.verycold ? 1.0 : 0.0;
   /* RS_ST_FAILED is written where the failure is detected (the index it happened at) */
-  if (FULL) {
+  if (FULL && ANCHORS) {
     st[(int64_t)RS_ST_TAIR_END * np + p] = s.tair_end;
     st[(int64_t)RS_ST_VZ_END * np + p] = s.vz_end;
     st[(int64_t)RS_ST_RH_END * np + p] = s.rh_end;
@@ -479,16 +500,26 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
   }
   int32_t initlen = 0;
   bool relax = false;
-  double tairR = 0, vzR = 0, rhR = 0;
+  /* RelaxationOperations (src/Relaxation.f90:34-43) only ever uses target - anchor: the three
+   * differences are what the loop carries (the targets are read again at the one index that sets
+   * the anchors, the anchors go to the state block there and then) */
+  double relax_dt = 0, relax_dv = 0, relax_dr = 0;
+  auto relax_targets = [&](double &tairR, double &vzR, double &rhR) {
+    /* setInputParam, src/InputOutput.f90:19-26: targets pass through REAL(4) */
+    tairR = (double)(float)(ka->pp.tair_relax + row0)[lane];
+    vzR = (double)(float)(ka->pp.vz_relax + row0)[lane];
+    rhR = (double)(float)(ka->pp.rh_relax + row0)[lane];
+  };
   if (FULL) {
     initlen = ka->pp.initlen ? (ka->pp.initlen + row0)[lane] : 0;
     if (consts_of(ka).use_relaxation && ka->pp.tair_relax) {
-      /* setInputParam, src/InputOutput.f90:19-26: targets pass through REAL(4) */
-      tairR = (double)(float)(ka->pp.tair_relax + row0)[lane];
-      vzR = (double)(float)(ka->pp.vz_relax + row0)[lane];
-      rhR = (double)(float)(ka->pp.rh_relax + row0)[lane];
+      double tairR, vzR, rhR;
+      relax_targets(tairR, vzR, rhR);
       relax = !(tairR < R4(-100.0) || tairR > R4(100.0) || vzR < R4(0.0) || vzR > R4(100.0) ||
                 rhR < R4(0.0) || rhR > 110);
+      relax_dt = tairR - s.tair_end;
+      relax_dv = vzR - s.vz_end;
+      relax_dr = rhR - s.rh_end;
     }
   }
 
@@ -554,6 +585,11 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
       continue;
     }
     double tair = f.tair, vz = f.vz, rhz = f.rhz;
+    /* TmpNw(1:2) as CalcHCapHCond will see them (src/BalanceModel.f90:215): the values the last step
+     * left - Tmp = TmpNw at its end (:60-62) - whatever observation forcing does to Tmp(1:2) below
+     * (src/InputOutput.f90:122-124 does not touch TmpNw) */
+    s.tnw1 = T.get(1);
+    s.tnw2 = T.get(2);
     /* src/Initialization.f90:121-123: VZ(1) is raised to 0.4 in the input array */
     if (i == 1 && vz < R4(0.4)) vz = R4(0.4);
     const double prec_ts = RS_DIVC(f.prec, 3600.0, r_3600) * c.DTSecs; /* src/InputOutput.f90:111,186 */
@@ -665,17 +701,33 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
         }
         /* RelaxationOperations, src/Relaxation.f90:10-47 */
         if (relax) {
-          if (i == initlen) {
-            s.tair_end = tair;
-            s.vz_end = vz;
-            s.rh_end = rhz;
+          if (i == initlen) { /* the anchors: once per point */
+            double tairR, vzR, rhR;
+            relax_targets(tairR, vzR, rhR);
+            relax_dt = tairR - tair;
+            relax_dv = vzR - vz;
+            relax_dr = rhR - rhz;
+            double *st = ka->state;
+            const int64_t np = ka->np_pad, p = row0 + lane;
+            st[(int64_t)RS_ST_TAIR_END * np + p] = tair;
+            st[(int64_t)RS_ST_VZ_END * np + p] = vz;
+            st[(int64_t)RS_ST_RH_END * np + p] = rhz;
           }
           if (i > initlen) {
-            const double den = (double)(4.f * 3600.f);
-            const double e = rs_exp(mt, rs_div(-((c.DTSecs * i) - (c.DTSecs * initlen)), den));
-            tair = tair - (tairR - s.tair_end) * e;
-            vz = vz - (vzR - s.vz_end) * e;
-            rhz = rhz - (rhR - s.rh_end) * e;
+            /* exp(-(DT*i - DT*InitLenI)/14400): for an integral time step the argument is a function
+             * of i - InitLenI alone and the plan holds the table (rs_consts_dev.h, host libm = the
+             * bits rs_exp returns); otherwise evaluated here */
+            double e;
+            const uint32_t d = (uint32_t)(i - initlen);
+            if (c.relax_tab && d <= (uint32_t)c.SimLen) {
+              e = ((const double *)c.relax_tab)[d];
+            } else {
+              const double den = (double)(4.f * 3600.f);
+              e = rs_exp(mt, rs_div(-((c.DTSecs * i) - (c.DTSecs * initlen)), den));
+            }
+            tair = tair - relax_dt * e;
+            vz = vz - relax_dv * e;
+            rhz = rhz - relax_dr * e;
             if (rhz > R4(100.)) rhz = R4(100.0);
           }
         }
@@ -699,10 +751,6 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
       }
     }
     if (CPL) cp.last_tsurf_obs = cpl_lastobs;
-    if (!FULL) { /* TmpNw(1:2) == Tmp(1:2) whenever observation forcing cannot act */
-      s.tnw1 = T.get(1);
-      s.tnw2 = T.get(2);
-    }
     double sw_in = f.sw, lw_in = f.lw;
     if (SKY && sky_on) {
       /* the reference runs this between PrecipitationToStorage and BalanceModelOneStep
@@ -1054,6 +1102,29 @@ __global__ void __launch_bounds__(kBlock, WPE) step_kernel_reg(const StepArgs a)
   if (SCORE) a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
 }
 
+/* FULL feature set, NLayers = 15, four waves per SIMD: layers 1..RS_HYBRID_REG in registers, the
+ * rest in LDS (HybridProfile). */
+#ifndef RS_HYBRID_REG
+#define RS_HYBRID_REG 7
+#endif
+template <bool SCORE, bool A32>
+__global__ void __launch_bounds__(kBlock, 4) step_kernel_hybrid(const StepArgs a) {
+  __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
+  __shared__ double prof_lds[(15 - RS_HYBRID_REG) * kBlock];
+  const MathTab mt = fill_math_tables(math_lds);
+  __syncthreads();
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= a.npoints) return; /* no barriers below: each lane owns its column */
+  HybridProfile<15, RS_HYBRID_REG> T;
+  T.col = prof_lds + threadIdx.x;
+  Scalars s;
+  int32_t score = 0;
+  load_state<true>(a.state, a.np_pad, p, T, s);
+  time_loop<true, HybridProfile<15, RS_HYBRID_REG>, false, SCORE, false, false, A32>(mt, T, s, score);
+  store_state<true>(a.state, a.np_pad, p, T, s);
+  if (SCORE) a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
+}
+
 template <bool FULL, int WPE>
 __global__ void __launch_bounds__(kBlock, WPE) step_kernel_lds(const StepArgs a) {
   extern __shared__ double lds[]; /* [NLayers][kBlock] */
@@ -1307,7 +1378,7 @@ __global__ void __launch_bounds__(kBlock, RS_CPL_WAVES) step_kernel_coupled(cons
   load_state<true>(a.state, a.np_pad, p, T, s);
   load_coupling(a.state, a.np_pad, p, q);
   time_loop_coupled(mt, T, s, q, a.state, a.np_pad, p);
-  store_state<true>(a.state, a.np_pad, p, T, s);
+  store_state<true, LdsProfile, true>(a.state, a.np_pad, p, T, s);
   store_coupling(a.state, a.np_pad, p, q);
 }
 
@@ -1704,7 +1775,10 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
   int wpe = variant / 10;
   variant %= 10;
   const bool auto_variant = variant == RS_VARIANT_AUTO;
-  if (auto_variant) variant = (NL == 15) ? RS_VARIANT_REG : RS_VARIANT_LDS;
+  /* measured (tools/r3_full2.sh, 1 M points): FULL feature set - layers 8-15 in LDS at 4 waves/SIMD
+   * 1.36e10, all in registers at 3 waves/SIMD (167 VGPRs) 1.34e10, at 4 waves (14 doubles spilled)
+   * 1.23e10, all in LDS 1.28e10.  LEAN: registers, 4 waves */
+  if (auto_variant) variant = (NL != 15) ? RS_VARIANT_LDS : full ? RS_VARIANT_HYBRID : RS_VARIANT_REG;
   /* measured (tools/bench_driver_path.py relax, 1 M points, one plan): the FULL feature set in the
    * register flavour at 3 waves/SIMD (168 VGPRs) 0.745 s, at 2 waves 0.80 s, at 4 waves (130 spilled
    * VGPRs) 0.87 s; with the profile in LDS 0.86 s (3 waves) / 0.88 s (4 waves).  LEAN: registers,
@@ -1732,18 +1806,30 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
     else hipLaunchKernelGGL((rs::step_kernel_duo<15, false>), gd, dim3(128), 0, stream, b);
     return hipGetLastError();
   }
+  if (variant == RS_VARIANT_HYBRID && (NL != 15 || !full)) { /* not this launch: as AUTO */
+    variant = (NL == 15) ? RS_VARIANT_REG : RS_VARIANT_LDS;
+    wpe = 0;
+  }
+  if (variant == RS_VARIANT_HYBRID) {
+#define RS_HYB(S, A) \
+  if (score == S && a32 == A) hipLaunchKernelGGL((rs::step_kernel_hybrid<S, A>), g, b, 0, stream, a);
+    RS_HYB(false, false) RS_HYB(false, true) RS_HYB(true, false) RS_HYB(true, true)
+#undef RS_HYB
+    return hipGetLastError();
+  }
   if (variant == RS_VARIANT_REG) {
     if (NL != 15) return hipErrorInvalidValue;
     if (wpe == 0) wpe = full ? 3 : 4;
     if (wpe < 2 || wpe > 4) return hipErrorInvalidValue;
-    /* the history score is only kept off in the default flavours (LEAN at 4 waves, FULL at 3) */
-    const bool sc = score || wpe != (full ? 3 : 4);
+    /* instances without the history score: LEAN at 4 waves, FULL at 3 and 4 */
+    const bool sc = score || !(wpe == 4 || (full && wpe == 3));
 #define RS_REG(F, W, S, A)                                                              \
   if (full == F && wpe == W && sc == S && a32 == A)                                      \
     hipLaunchKernelGGL((rs::step_kernel_reg<15, F, W, S, A>), g, b, 0, stream, a);
 #define RS_REG_A(F, W, S) RS_REG(F, W, S, false) RS_REG(F, W, S, true)
     RS_REG_A(false, 2, true) RS_REG_A(false, 3, true) RS_REG_A(false, 4, true) RS_REG_A(false, 4, false)
     RS_REG_A(true, 2, true) RS_REG_A(true, 3, true) RS_REG_A(true, 4, true) RS_REG_A(true, 3, false)
+    RS_REG_A(true, 4, false)
 #undef RS_REG_A
 #undef RS_REG
   } else {

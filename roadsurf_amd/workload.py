@@ -24,7 +24,8 @@ SPK = 120  # 3600 s / DTSecs 30 s: time indices per hourly knot
 class SyntheticRun:
     def __init__(self, plan: device.Plan, seed: int, hours: int, chunk: int, point_offset: int = 0,
                  plan_order: bool = True, f32: bool = False, year_month_day=(2024, 1, 10),
-                 forecast: bool = True, forecast_alpha: float = 0.5, forecast_mode: int = 3124):
+                 forecast: bool = True, forecast_alpha: float = 0.5, forecast_mode: int = 3124,
+                 full: bool = False, initlen: int = 720):
         self.plan, self.seed, self.hours = plan, seed, hours
         self.simlen = hours * SPK + 1  # examples/example1/src/InputSettings.cpp:98
         self.chunk = min(chunk, self.simlen)
@@ -35,11 +36,22 @@ class SyntheticRun:
         plan.set_history_score(not (plan_order and forecast))  # nobody reads it then
         dev, npad = plan.device, plan.np_pad
         wdtype = torch.float32 if f32 else torch.float64
-        self.win = device.ForcingWindow.empty(self.chunk, npad, dev, optional=(), dtype=wdtype)
+        # full: the FULL feature set as an operational run has it - Tdew, TsurfObs and depth streams
+        # present, an initialization phase of `initlen` indices and (if the plan's settings say so)
+        # relaxation towards per-point targets behind it.  The per-point parameters are the same for
+        # every point here, so the plan order does not have to move them.
+        self.full = full
+        opt = ("tdew", "tsurfobs", "depth") if full else ()
+        self.win = device.ForcingWindow.empty(self.chunk, npad, dev, optional=opt, dtype=wdtype)
         self.out = device.OutputWindow.empty(self.chunk, npad, dev, dtype=wdtype)
         # index-1 window for the init kernel: needs TsurfObs(1)
         self.win0 = device.ForcingWindow.empty(1, npad, dev, optional=("tsurfobs",), dtype=wdtype)
-        self.pp = plan.point_params(plan.uniform_tbottom(*year_month_day))
+        if full:
+            il = torch.full((npad,), int(initlen), dtype=torch.int32, device=dev)
+            rel = [torch.full((npad,), v, dtype=torch.float64, device=dev) for v in (-3.0, 2.5, 85.0)]
+            self.pp = plan.point_params(plan.uniform_tbottom(*year_month_day), il, *rel)
+        else:
+            self.pp = plan.point_params(plan.uniform_tbottom(*year_month_day))
         self.starts = list(range(1, self.simlen + 1, self.chunk))
         self.spec = None
         self.knots = None
