@@ -103,46 +103,39 @@ def measured_traffic(points: int, chunk: int, plans: int, f32: bool):
     return t.get("traffic_bytes_per_launch"), t.get("derived"), name, None
 
 
-class ClockSampler:
-    """Engine clock of the GPU while the timed passes run, read from sysfs every 50 ms (best effort:
-    None where the driver does not expose it)."""
+class ClockProbe:
+    """Engine clock of the GPU while the timed passes run: rs_hip_clock_probe kernels (one wavefront
+    that reads the shader-clock counter and the constant 100 MHz counter about 0.2 ms apart) enqueued
+    on a side stream after every pass, i.e. beside the step kernels of the next one.  MHz = 100 x
+    shader ticks / 100 MHz ticks, averaged over the probes; None if the two counters run in step (a
+    chip whose shader counter is the constant clock)."""
 
-    def __init__(self, dev_index: int):
-        import glob
-        import threading
+    def __init__(self, torch, dev, dev_index: int, nprobes: int):
+        from roadsurf_amd import lib as rslib
 
-        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        self.path = self.paths[dev_index] if dev_index < len(self.paths) else None
-        self.samples, self._stop = [], threading.Event()
-        self._t = threading.Thread(target=self._run, daemon=True)
+        self.torch, self.dev_index = torch, dev_index
+        self.L = rslib.load()
+        self.stream = torch.cuda.Stream(dev)
+        self.buf = torch.zeros((max(nprobes, 1), 2), dtype=torch.int64, device=dev)
+        self.n = 0
 
-    def _read(self):
-        try:
-            for ln in open(self.path):
-                if "*" in ln:
-                    return float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
-        except (OSError, ValueError, IndexError, TypeError):
-            pass
-        return None
+    def probe(self) -> None:
+        if self.n < self.buf.shape[0]:
+            import ctypes as C
 
-    def _run(self):
-        while not self._stop.wait(0.05):
-            v = self._read()
-            if v:
-                self.samples.append(v)
-
-    def __enter__(self):
-        if self.path:
-            self._t.start()
-        return self
-
-    def __exit__(self, *a):
-        self._stop.set()
-        if self.path:
-            self._t.join(1.0)
+            self.L.rs_hip_clock_probe(self.dev_index, C.c_void_p(self.buf[self.n].data_ptr()), 200,
+                                      C.c_void_p(self.stream.cuda_stream))
+            self.n += 1
 
     def mean_mhz(self):
-        return sum(self.samples) / len(self.samples) if self.samples else None
+        self.stream.synchronize()
+        b = self.buf[:self.n].cpu().numpy()
+        ok = [(c, r) for c, r in b if r > 0 and c > 0]
+        if not ok:
+            return None
+        mhz = [100.0 * c / r for c, r in ok]
+        m = sum(mhz) / len(mhz)
+        return None if abs(m - 100.0) < 1.0 else m
 
 
 def main() -> None:
@@ -285,11 +278,12 @@ def main() -> None:
         ref = torch.cuda.Event(enable_timing=True)
         ref.record(torch.cuda.current_stream(dev))
         torch.cuda.synchronize(dev)
+        clk = ClockProbe(torch, dev, dev_index, args.steps)
         t_start = time.perf_counter()
-        with ClockSampler(dev_index) as clk:
-            for _ in range(args.steps):
-                one_pass()
-            fence()
+        for _ in range(args.steps):
+            one_pass()
+            clk.probe()  # runs beside the launches still in flight
+        fence()
         elapsed = time.perf_counter() - t_start
         sclk.append(clk.mean_mhz())
         elapsed = sharding.max_over_ranks(
@@ -423,7 +417,7 @@ def main() -> None:
                 "valu_issue_frac": valu_issue_frac,
                 "valu_issue_clock_mhz": clock_mhz,
                 "valu_issue_clock_source": (None if valu_issue_frac is None else
-                                            "sysfs pp_dpm_sclk sampled during the timed passes" if sclk[0]
+                                            "rs_hip_clock_probe: shader-clock / 100 MHz counter ratio, beside the timed passes" if sclk[0]
                                             else "not readable on this box: the 2.4 GHz peak clock assumed"),
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "launches": nlaunch,

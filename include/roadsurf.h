@@ -380,6 +380,11 @@ int rs_hip_state_download(RsPlan *plan, double *host, size_t bytes);
 int rs_hip_state_upload(RsPlan *plan, const double *host, size_t bytes);
 /* Number of points with the sticky failure flag set (src/InputOutput.f90:66). */
 int64_t rs_hip_failed_count(RsPlan *plan);
+/* Measurement aid: one wavefront that reads the shader-clock counter and the constant 100 MHz
+ * counter about spin_us microseconds apart and leaves the two deltas in out[0], out[1] (device
+ * memory, 2 x uint64).  Enqueued on a side stream beside the step kernels it tells the engine clock
+ * the chip holds under that load: MHz = 100 * out[0] / out[1].  Asynchronous on `stream`. */
+int rs_hip_clock_probe(int32_t device, void *out, uint32_t spin_us, void *stream);
 /* Per point (host int32[npoints], in local point order whatever the plan order is): 0, or the
  * 1-based time index at which CheckValues raised simulation_failed - the step of that index was
  * still taken and saved, later outputs read -9999.0 (examples/example1/src/Simulation.f90:58,

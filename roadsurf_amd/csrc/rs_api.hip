@@ -18,6 +18,7 @@
 
 #include "../../include/roadsurf.h"
 #include "rs_kernels.h"
+#include <cstdint>
 #include "rs_consts_dev.h"
 #include "rs_state.h"
 
@@ -60,6 +61,7 @@ struct RsPlan {
   /* the plan's constants on the device (no table of slots: any number of plans may be alive) */
   void *consts_dev = nullptr;   /* RsConstantsDev (rs_consts_dev.h) */
   double *relax_tab = nullptr;  /* RsConstantsDev::relax_tab */
+  double *cpl_tab = nullptr;    /* RsConstantsDev::cpl_tab */
   void *consts32_dev = nullptr; /* RsConstantsF, allocated by rs_hip_set_precision(32) */
   rs::Writeback wb{nullptr, nullptr, nullptr, 0};
   /* coupling rounds: scratch for the list of points that replay their window */
@@ -220,6 +222,13 @@ RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints, const RsConstants *c
         ce = hipMemcpy(pl->relax_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
       cd.relax_tab = pl->relax_tab;
     }
+    const std::vector<double> ctab = rs_cpl_table(pl->c);
+    if (ce == hipSuccess && !ctab.empty()) {
+      ce = hipMalloc(&pl->cpl_tab, ctab.size() * sizeof(double));
+      if (ce == hipSuccess)
+        ce = hipMemcpy(pl->cpl_tab, ctab.data(), ctab.size() * sizeof(double), hipMemcpyHostToDevice);
+      cd.cpl_tab = pl->cpl_tab;
+    }
   }
   if (ce == hipSuccess) ce = hipMalloc(&pl->consts_dev, sizeof(RsConstantsDev));
   if (ce == hipSuccess)
@@ -237,6 +246,7 @@ RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints, const RsConstants *c
     set_err("rs_hip_plan_create: upload of the constants failed: %s", hipGetErrorString(ce));
     if (pl->consts_dev) (void)hipFree(pl->consts_dev);
     if (pl->relax_tab) (void)hipFree(pl->relax_tab);
+    if (pl->cpl_tab) (void)hipFree(pl->cpl_tab);
     (void)hipFree(pl->state);
     (void)hipFree(pl->counter);
     delete pl;
@@ -252,6 +262,7 @@ void rs_hip_plan_destroy(RsPlan *pl) {
   for (hipEvent_t e : pl->ev) (void)hipEventDestroy(e);
   if (pl->consts_dev) (void)hipFree(pl->consts_dev);
   if (pl->relax_tab) (void)hipFree(pl->relax_tab);
+  if (pl->cpl_tab) (void)hipFree(pl->cpl_tab);
   if (pl->consts32_dev) (void)hipFree(pl->consts32_dev);
   (void)hipFree(pl->state);
   (void)hipFree(pl->counter);
@@ -480,6 +491,15 @@ static int cpl_replay_rounds(RsPlan *pl, rs::StepArgs a, bool lockstep = false) 
     else
       HIP_OK(rs_launch_step_coupled(a, pl->c.NLayers, pl->stream));
     pl->cpl_rounds_last = round + 1;
+    if (round == 63) { /* Coupling_control gives up after 25 passes: a point still listed now never will */
+      HIP_OK(rs_cpl_select_again(pl->state, pl->np_pad, pl->npoints, pl->cpl_flags, pl->cpl_list,
+                                 pl->cpl_count, pl->cpl_tmp, pl->cpl_tmp_bytes, pl->stream));
+      HIP_OK(hipMemcpyAsync(&n_again, pl->cpl_count, sizeof(n_again), hipMemcpyDeviceToHost, pl->stream));
+      HIP_OK(hipStreamSynchronize(pl->stream));
+      if (n_again != 0)
+        return set_err("coupling replays: %d points still ask for a replay after 64 rounds - the window "
+                       "passed does not cover their coupling windows", n_again);
+    }
   }
   return 0;
 }
@@ -654,6 +674,30 @@ int rs_hip_cpl_replay(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const 
     if (strcmp(e, "lockstep") == 0) lockstep = true;
   }
   if ((int64_t)t0 + nsteps - 1 >= pl->c.SimLen || pp->sky_view) lockstep = false;
+  {
+    /* the window must cover [couplingStartI, couplingEndI + 1] of every point that replays: the rewind
+     * reads the forcing of the index behind the window end (CheckValues, Simulation.f90:59-66), and a
+     * point whose window start lies before t0 would never step */
+    if (!pl->cpl_list) { /* scratch of the rounds (allocated here so that cpl_count exists) */
+      HIP_OK(hipMalloc(&pl->cpl_flags, (size_t)2 * pl->np_pad * sizeof(int32_t)));
+      HIP_OK(hipMalloc(&pl->cpl_list, (size_t)pl->np_pad * sizeof(int32_t)));
+      HIP_OK(hipMalloc(&pl->cpl_count, sizeof(int32_t)));
+      pl->cpl_tmp_bytes = rs_cpl_select_scratch_bytes(pl->npoints);
+      HIP_OK(hipMalloc(&pl->cpl_tmp, pl->cpl_tmp_bytes ? pl->cpl_tmp_bytes : 8));
+    }
+    int32_t b[2] = {INT32_MAX, 0};
+    HIP_OK(hipMemcpyAsync(pl->cpl_flags, b, sizeof(b), hipMemcpyHostToDevice, pl->stream));
+    HIP_OK(rs_launch_cpl_window_bounds(a, pl->cpl_flags, pl->stream));
+    HIP_OK(hipMemcpyAsync(b, pl->cpl_flags, sizeof(b), hipMemcpyDeviceToHost, pl->stream));
+    HIP_OK(hipStreamSynchronize(pl->stream));
+    if (b[1] > 0) {
+      const int32_t need_hi = b[1] + 1 < pl->c.SimLen ? b[1] + 1 : pl->c.SimLen;
+      if (b[0] < t0 || need_hi > t0 + nsteps - 1)
+        return set_err("rs_hip_cpl_replay: the window [%d,%d] does not cover the coupling windows of the "
+                       "points that replay, [%d,%d] (window start to the index behind the window end)",
+                       t0, t0 + nsteps - 1, b[0], need_hi);
+    }
+  }
   if (cpl_replay_rounds(pl, a, lockstep)) return -1;
   if (rounds) *rounds = pl->cpl_rounds_last;
   return 0;
@@ -713,6 +757,14 @@ int rs_hip_state_upload(RsPlan *pl, const double *host, size_t bytes) {
   HIP_OK(hipSetDevice(pl->device));
   HIP_OK(hipMemcpyAsync(pl->state, host, bytes, hipMemcpyHostToDevice, pl->stream));
   HIP_OK(hipStreamSynchronize(pl->stream));
+  return 0;
+}
+
+/* out (device, 2 x uint64): see rs_launch_clock_probe; asynchronous on `stream` */
+int rs_hip_clock_probe(int32_t device, void *out, uint32_t spin_us, void *stream) {
+  if (!out) return set_err("rs_hip_clock_probe: null output");
+  HIP_OK(hipSetDevice(device));
+  HIP_OK(rs_launch_clock_probe(static_cast<uint64_t *>(out), spin_us, (hipStream_t)stream));
   return 0;
 }
 

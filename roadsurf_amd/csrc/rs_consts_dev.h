@@ -26,6 +26,10 @@ struct RsConstantsDev : RsConstants {
    * rs_hip_plan_create with the host's exp - glibc's, whose bits rs_exp reproduces
    * (tests/test_hip_math.py), and IEEE division, which rs_div reproduces. */
   const double *relax_tab;
+  /* cpl_tab[d] = exp(-(DTSecs*d)/couplingEffectReduction): the decay of the radiation corrections
+   * behind a coupling window, exp(-(DTSecs*i - DTSecs*couplingEndI)/reduction) of
+   * src/Coupling.f90:80-88, for i - couplingEndI = d.  Same conditions as relax_tab. */
+  const double *cpl_tab;
 };
 
 static inline void rs_consts_dev_fill(const RsConstants &c, RsConstantsDev &d) {
@@ -43,6 +47,7 @@ static inline void rs_consts_dev_fill(const RsConstants &c, RsConstantsDev &d) {
   const float chk[8] = {100.0f, -0.1f, -90.0f, 120.0f, -1.0f, 4000.0f, 1000.0f, 500.0f};
   for (int i = 0; i < 8; ++i) d.chk[i] = (double)chk[i];
   d.relax_tab = nullptr;
+  d.cpl_tab = nullptr;
   d.bareFastOk = (c.MaxWatmms >= 0.0 && c.MaxSnowmms >= 0.0 && c.MaxIcemms >= 0.0 && c.MaxDepmms >= 0.0) ? 1 : 0;
   if (getenv("ROADSURF_HIP_NO_BARE_FAST")) d.bareFastOk = 0; /* A/B switch: same bits either way */
 }
@@ -76,12 +81,18 @@ static inline const char *rs_consts_domain_error(const RsConstants &c) {
 /* The relaxation table of RsConstantsDev::relax_tab on the host, or empty where it does not apply. */
 #include <cmath>
 #include <vector>
-static inline std::vector<double> rs_relax_table(const RsConstants &c) {
+static inline std::vector<double> rs_decay_table(const RsConstants &c, bool on, double den) {
   std::vector<double> t;
   const double dt = c.DTSecs;
-  if (!c.use_relaxation || !(dt == std::floor(dt)) || !(dt * ((double)c.SimLen + 1.0) < 9.0e15)) return t;
-  const double den = (double)(4.f * 3600.f);
+  if (!on || !(dt == std::floor(dt)) || !(dt * ((double)c.SimLen + 1.0) < 9.0e15)) return t;
   t.resize((size_t)c.SimLen + 1);
   for (int32_t d = 0; d <= c.SimLen; ++d) t[(size_t)d] = std::exp(-((dt * d) - (dt * 0)) / den);
   return t;
+}
+static inline std::vector<double> rs_relax_table(const RsConstants &c) {
+  return rs_decay_table(c, c.use_relaxation != 0, (double)(4.f * 3600.f));
+}
+static inline std::vector<double> rs_cpl_table(const RsConstants &c) {
+  return rs_decay_table(c, c.use_coupling != 0 && c.cplReduction > 1e-30 && c.cplReduction < 1e30,
+                        c.cplReduction);
 }

@@ -94,6 +94,8 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
 hipError_t rs_launch_step_cpl_replay(const rs::StepArgs &a, int NL, hipStream_t stream);
 hipError_t rs_launch_step_coupled(const rs::StepArgs &a, int NL, hipStream_t stream);
 hipError_t rs_launch_step_cpl(const rs::StepArgs &a, int NL, hipStream_t stream);
+/* out[2] (device): min couplingStartI / max couplingEndI over the points that ask for a replay */
+hipError_t rs_launch_cpl_window_bounds(const rs::StepArgs &a, int32_t *out, hipStream_t stream);
 /* list of the points whose coupling asks for another replay (start_coupling_again): list[0..*count) */
 size_t rs_cpl_select_scratch_bytes(int64_t npoints);
 hipError_t rs_cpl_select_again(const double *state, int64_t np_pad, int64_t npoints, int32_t *flags,
@@ -103,6 +105,8 @@ hipError_t rs_launch_step_sky(const rs::StepArgs &a, int NL, hipStream_t stream)
 hipError_t rs_launch_init(const rs::InitArgs &a, hipStream_t stream);
 hipError_t rs_launch_knots(const rs::KnotArgs &a, int32_t nknots, hipStream_t stream);
 hipError_t rs_launch_expand(const rs::ExpandArgs &a, int32_t nintervals, hipStream_t stream);
+/* out[0] = shader-clock ticks, out[1] = 100 MHz ticks over the same ~spin_us microseconds */
+hipError_t rs_launch_clock_probe(uint64_t *out, uint32_t spin_us, hipStream_t stream);
 hipError_t rs_launch_count_failed(const double *st, int64_t np_pad, int64_t npoints,
                                   unsigned long long *out, hipStream_t stream);
 

@@ -30,6 +30,9 @@
 #ifndef RS_CPL_WAVES
 #define RS_CPL_WAVES 2 /* waves per SIMD the general (per-lane time index) kernel is compiled for */
 #endif
+#ifndef RS_CPL_PROFILE_DEFAULT
+#define RS_CPL_PROFILE_DEFAULT 3 /* profile of the lock-step coupling kernels: see rs_launch_step_cpl */
+#endif
 #ifndef RS_REGIME_WINDOW
 #define RS_REGIME_WINDOW 30 /* indices at the end of a launch that define a point's regime
                                (rs_hip_recluster; 8 ... 90 measured equal) */
@@ -453,6 +456,14 @@ struct GlobalProfile {
 
 __device__ __forceinline__ Forcing gather_forcing(KernArgs ka, int64_t p, int32_t i, int32_t t0);
 
+/* exp(-(DT*i - DT*couplingEndI)/couplingEffectReduction), src/Coupling.f90:80-88: from the plan's
+ * table where the argument is a function of i - couplingEndI alone (rs_consts_dev.h), else here */
+__device__ __forceinline__ double cpl_decay(const ConstsAS &c, const MathTab &mt, int32_t i, int32_t ce) {
+  const uint32_t d = (uint32_t)(i - ce);
+  if (c.cpl_tab && d <= (uint32_t)c.SimLen) return ((const double *)c.cpl_tab)[d];
+  return rs_exp(mt, rs_div(-((c.DTSecs * i) - (c.DTSecs * ce)), c.cplReduction));
+}
+
 /* The time loop of runsimulation (examples/example1/src/Simulation.f90:57-115)
  * for one point over absolute indices [t0, t0+nsteps). */
 /* SKY: sky view / local horizons (src/ModRadiation.f90, examples/example1/src/Simulation.f90:
@@ -674,7 +685,7 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
           /* SW/LWRadCof = 1, SW/LW_correction = 0: what the registers hold before the window end */
         }
         if (i > cpl_ce) {
-          const double e = rs_exp(mt, rs_div(-((c.DTSecs * i) - (c.DTSecs * cpl_ce)), c.cplReduction));
+          const double e = cpl_decay(c, mt, i, cpl_ce);
           cp.sw_cof = R4(1.0) + cpl_swcorr * e;
           cp.lw_cof = R4(1.0) + cpl_lwcorr * e;
         }
@@ -741,7 +752,7 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
         const int32_t j = c.SimLen - 1;
         cp.in_phase = (j >= cpl_cs && j <= cpl_ce);
         if (j > cpl_ce) {
-          const double e = rs_exp(mt, rs_div(-((c.DTSecs * j) - (c.DTSecs * cpl_ce)), c.cplReduction));
+          const double e = cpl_decay(c, mt, j, cpl_ce);
           cp.sw_cof = R4(1.0) + cpl_swcorr * e;
           cp.lw_cof = R4(1.0) + cpl_lwcorr * e;
         } else if (j >= cpl_cs) { /* the window reaches the end of the series: as the last pass left them */
@@ -980,7 +991,7 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Sc
           }
         }
         if (i > q.ce) {
-          const double e = rs_exp(mt, rs_div(-((c.DTSecs * i) - (c.DTSecs * q.ce)), c.cplReduction));
+          const double e = cpl_decay(c, mt, i, q.ce);
           q.swcof = R4(1.0) + q.swcorr * e;
           q.lwcof = R4(1.0) + q.lwcorr * e;
         }
@@ -1345,6 +1356,44 @@ __global__ void __launch_bounds__(kBlock, 3) step_kernel_cpl(const StepArgs a) {
   a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s); /* parked lanes: cheap */
 }
 
+/* The same two kernels for NLayers = 15 with the hybrid profile (layers 1-RS_HYBRID_REG in
+ * registers, the rest in LDS) at W waves per SIMD. */
+template <int W>
+__global__ void __launch_bounds__(kBlock, W) step_kernel_cpl_h(const StepArgs a) {
+  __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
+  __shared__ double prof_lds[(15 - RS_HYBRID_REG) * kBlock];
+  const MathTab mt = fill_math_tables(math_lds);
+  __syncthreads();
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= a.npoints) return;
+  HybridProfile<15, RS_HYBRID_REG> T;
+  T.col = prof_lds + threadIdx.x;
+  Scalars s;
+  int32_t score = 0;
+  load_state<true>(a.state, a.np_pad, p, T, s);
+  time_loop<true, HybridProfile<15, RS_HYBRID_REG>, false, true, true>(mt, T, s, score);
+  store_state<true>(a.state, a.np_pad, p, T, s);
+  a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
+}
+
+template <int W>
+__global__ void __launch_bounds__(kBlock, W) step_kernel_cpl_replay_h(const StepArgs a) {
+  __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
+  __shared__ double prof_lds[(15 - RS_HYBRID_REG) * kBlock];
+  const MathTab mt = fill_math_tables(math_lds);
+  __syncthreads();
+  const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (g >= (int64_t)a.cpl_nlist) return;
+  const int64_t p = (int64_t)a.cpl_list[g];
+  HybridProfile<15, RS_HYBRID_REG> T;
+  T.col = prof_lds + threadIdx.x;
+  Scalars s;
+  int32_t score = 0;
+  load_state<true>(a.state, a.np_pad, p, T, s);
+  time_loop<true, HybridProfile<15, RS_HYBRID_REG>, false, false, true, true>(mt, T, s, score, (uint32_t)p);
+  store_state<true>(a.state, a.np_pad, p, T, s);
+}
+
 /* One replay round in lock step over the compacted list (time_loop<REPLAY>). */
 __global__ void __launch_bounds__(kBlock, 3) step_kernel_cpl_replay(const StepArgs a) {
   extern __shared__ double lds[]; /* [NLayers][kBlock] */
@@ -1603,6 +1652,39 @@ __global__ void __launch_bounds__(kBlock) count_failed_kernel(const double *st, 
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
 }
 
+/* Engine clock as the shader sees it: one wavefront reads the shader-clock counter (s_memtime) and
+ * the constant 100 MHz counter (s_memrealtime) `spin_us` apart; out[0..1] = the two deltas.  Enqueued
+ * beside the step kernels, it measures the clock the chip holds UNDER that load (bench.py). */
+__global__ void __launch_bounds__(64) clock_probe_kernel(uint64_t *out, uint32_t spin_us) {
+  const uint64_t c0 = __builtin_readcyclecounter();
+  const uint64_t r0 = __builtin_amdgcn_s_memrealtime();
+  uint64_t r1 = r0;
+  while (r1 - r0 < (uint64_t)spin_us * 100ull) {
+    __builtin_amdgcn_s_sleep(32);
+    r1 = __builtin_amdgcn_s_memrealtime();
+  }
+  const uint64_t c1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) {
+    out[0] = c1 - c0;
+    out[1] = r1 - r0;
+  }
+}
+
+/* Coupling windows of the points that ask for a replay (start_coupling_again): out[0] = min
+ * couplingStartI, out[1] = max couplingEndI (initialised by the caller to INT_MAX / 0).  What
+ * rs_hip_cpl_replay checks the caller's window against. */
+__global__ void __launch_bounds__(kBlock) cpl_window_bounds_kernel(const StepArgs a, int32_t *out) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= a.npoints) return;
+  const ConstsAS &c = consts_of(&a);
+  if ((((int32_t)a.state[(int64_t)RS_ST_CPL_FLAGS * a.np_pad + p]) & 1) == 0) return;
+  const int32_t cidx = a.pp.coupling_index[p];
+  if (a.pp.coupling_tsurf[p] < -100 || cidx < 1) return;
+  const int32_t cs = ((double)cidx <= c.cplLenR) ? 1 : cidx - c.cplLenI;
+  atomicMin(&out[0], cs);
+  atomicMax(&out[1], cidx);
+}
+
 /* Sort key of rs_hip_recluster_forecast (include/roadsurf.h): CalcBLCondAndLE's fixed point
  * (src/BoundaryLayer.f90:64-96) run at the preview times of the NEXT window, with the carried
  * surface temperature moved along with the air temperature.  A predictor: single precision,
@@ -1746,17 +1828,34 @@ hipError_t rs_launch_step_sky(const rs::StepArgs &a, int NL, hipStream_t stream)
   return hipGetLastError();
 }
 
+/* ROADSURF_HIP_CPL_PROFILE (tuning): 0 LDS profile at 3 waves/SIMD (any NLayers), 3 / 4 hybrid
+ * profile at that many waves (NLayers = 15) */
+static int cpl_profile_mode(int NL) {
+  const char *e = getenv("ROADSURF_HIP_CPL_PROFILE");
+  const int m = e ? atoi(e) : RS_CPL_PROFILE_DEFAULT;
+  return (NL == 15 && (m == 3 || m == 4)) ? m : 0;
+}
+
 hipError_t rs_launch_step_cpl(const rs::StepArgs &a, int NL, hipStream_t stream) {
-  /* LDS profile: a register-profile instance of this loop was measured twice as slow (spills) */
+  /* measured (tools/r3_cpl.sh, rs_driver_run with coupling, 1 M points): hybrid profile at 3 waves/SIMD
+   * 7.75e9, LDS profile at 3 waves 7.0e9, hybrid at 4 waves (spills) 6.6e9; a profile wholly in
+   * registers was twice as slow (spills) */
+  const int m = cpl_profile_mode(NL);
   const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
-  hipLaunchKernelGGL(rs::step_kernel_cpl, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
+  if (m == 4) hipLaunchKernelGGL((rs::step_kernel_cpl_h<4>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
+  else if (m == 3) hipLaunchKernelGGL((rs::step_kernel_cpl_h<3>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
+  else hipLaunchKernelGGL(rs::step_kernel_cpl, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
   return hipGetLastError();
 }
 
 hipError_t rs_launch_step_cpl_replay(const rs::StepArgs &a, int NL, hipStream_t stream) {
   if (!a.cpl_list || a.cpl_nlist < 1) return hipSuccess;
+  const int m = cpl_profile_mode(NL);
   const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
-  hipLaunchKernelGGL(rs::step_kernel_cpl_replay, grid_for(a.cpl_nlist), dim3(RS_BLOCK), lds, stream, a);
+  const dim3 g = grid_for(a.cpl_nlist);
+  if (m == 4) hipLaunchKernelGGL((rs::step_kernel_cpl_replay_h<4>), g, dim3(RS_BLOCK), 0, stream, a);
+  else if (m == 3) hipLaunchKernelGGL((rs::step_kernel_cpl_replay_h<3>), g, dim3(RS_BLOCK), 0, stream, a);
+  else hipLaunchKernelGGL(rs::step_kernel_cpl_replay, g, dim3(RS_BLOCK), lds, stream, a);
   return hipGetLastError();
 }
 
@@ -1870,6 +1969,16 @@ hipError_t rs_launch_expand(const rs::ExpandArgs &a, int32_t nintervals, hipStre
                        dim3(RS_BLOCK), 0, stream, a);
   RS_EXPAND(0) RS_EXPAND(1) RS_EXPAND(2) RS_EXPAND(3) RS_EXPAND(4) RS_EXPAND(5) RS_EXPAND(6) RS_EXPAND(7)
 #undef RS_EXPAND
+  return hipGetLastError();
+}
+
+hipError_t rs_launch_clock_probe(uint64_t *out, uint32_t spin_us, hipStream_t stream) {
+  hipLaunchKernelGGL(rs::clock_probe_kernel, dim3(1), dim3(64), 0, stream, out, spin_us);
+  return hipGetLastError();
+}
+
+hipError_t rs_launch_cpl_window_bounds(const rs::StepArgs &a, int32_t *out, hipStream_t stream) {
+  hipLaunchKernelGGL(rs::cpl_window_bounds_kernel, grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a, out);
   return hipGetLastError();
 }
 

@@ -443,6 +443,32 @@ contains
                                   c_null_ptr)
    end subroutine runsimulation_batch
 
+   !> The six calendar arrays of a point's time axis.
+   subroutine axis_of(ip, nt, yy, mm, dd, hh, mi, ss)
+      type(InputPointers), intent(in) :: ip
+      integer, intent(in) :: nt
+      integer(c_int), pointer, intent(out) :: yy(:), mm(:), dd(:), hh(:), mi(:), ss(:)
+      call c_f_pointer(ip%c_year, yy, [nt]); call c_f_pointer(ip%c_month, mm, [nt])
+      call c_f_pointer(ip%c_day, dd, [nt]); call c_f_pointer(ip%c_hour, hh, [nt])
+      call c_f_pointer(ip%c_minute, mi, [nt]); call c_f_pointer(ip%c_second, ss, [nt])
+   end subroutine axis_of
+
+   !> Do two points carry the same time axis (same arrays, or equal values)?
+   logical function same_axis(a, b, nt)
+      type(InputPointers), intent(in) :: a, b
+      integer, intent(in) :: nt
+      integer(c_int), pointer :: y1(:), m1(:), d1(:), h1(:), i1(:), s1(:)
+      integer(c_int), pointer :: y2(:), m2(:), d2(:), h2(:), i2(:), s2(:)
+      same_axis = .true.
+      if (c_associated(a%c_year, b%c_year) .and. c_associated(a%c_month, b%c_month) .and. &
+          c_associated(a%c_day, b%c_day) .and. c_associated(a%c_hour, b%c_hour) .and. &
+          c_associated(a%c_minute, b%c_minute) .and. c_associated(a%c_second, b%c_second)) return
+      call axis_of(a, nt, y1, m1, d1, h1, i1, s1)
+      call axis_of(b, nt, y2, m2, d2, h2, i2, s2)
+      same_axis = all(y1 == y2) .and. all(m1 == m2) .and. all(d1 == d2) .and. all(h1 == h2) .and. &
+                  all(i1 == i2) .and. all(s1 == s2)
+   end function same_axis
+
    !> Same; first_failed (int32[n] or NULL) receives per point 0 or the 1-based time index at which
    !! CheckValues failed it.  ROADSURF_HIP_WRITEBACK=1: the reference's in-place edits of the input
    !! arrays (SW_dir clamp, sky-view SW/SW_dir/LW) are written back to the caller.
@@ -462,15 +488,23 @@ contains
       type(RsConstants) :: consts
       type(RsHostExtras) :: extras
       real(c_double), allocatable, target :: tbottom(:), sun(:, :), slat(:), clat(:), lrad(:)
-      integer(c_int), pointer :: yy(:), mm(:), dd(:), hh(:), mi(:), ss(:), other(:)
+      integer(c_int), pointer :: yy(:), mm(:), dd(:), hh(:), mi(:), ss(:)
       logical :: any_sky
-      integer :: k, nt
+      integer :: k, nt, g, m, ngroups
       real(c_double), pointer :: vz(:)
       integer :: p
       integer(c_int) :: rc
+      integer, allocatable :: group(:), rep(:), gidx(:)
+      type(InputPointers), allocatable :: gi(:)
+      type(OutputPointers), allocatable :: go(:)
+      type(LocalParameters), allocatable :: gl(:)
+      real(c_double), allocatable, target :: gtb(:), gslat(:), gclat(:), glrad(:)
+      integer(c_int), allocatable, target :: gff(:)
+      integer(c_int), pointer :: ff_all(:)
 
       status = 0
       any_sky = .false.
+      call rs_host_set_error(c_null_char)   ! rs_last_error() is empty unless THIS call fails
       if (n < 1) return
       call rs_build_constants(inSettings, inputParam, consts, rc)
       if (rc /= 0) then
@@ -507,37 +541,72 @@ contains
          if (envv(1:1) /= '0') extras%writeback = 1
       end if
       if (any_sky) then
-         ! the solar quantities that depend on time only are computed here, on the host, for
-         ! the time axis of point 1; the device path needs that axis to be shared by all points
+         ! The solar quantities that depend on time only (src/SunPosition.f90:196-260 and :70-125)
+         ! are computed here, on the host, per DISTINCT time axis of the batch: the reference takes
+         ! the Julian day from each point's own year(i)..second(i).  Points that share an axis - all
+         ! of them in the reference driver's batches - form one group and one device call.
          nt = inSettings%SimLen
-         call c_f_pointer(inPointers(1)%c_year, yy, [nt]); call c_f_pointer(inPointers(1)%c_month, mm, [nt])
-         call c_f_pointer(inPointers(1)%c_day, dd, [nt]); call c_f_pointer(inPointers(1)%c_hour, hh, [nt])
-         call c_f_pointer(inPointers(1)%c_minute, mi, [nt]); call c_f_pointer(inPointers(1)%c_second, ss, [nt])
-         do p = 2, n
-            do k = 1, 6
-               select case (k)
-               case (1); call c_f_pointer(inPointers(p)%c_year, other, [nt]); if (any(other /= yy)) rc = -1
-               case (2); call c_f_pointer(inPointers(p)%c_month, other, [nt]); if (any(other /= mm)) rc = -1
-               case (3); call c_f_pointer(inPointers(p)%c_day, other, [nt]); if (any(other /= dd)) rc = -1
-               case (4); call c_f_pointer(inPointers(p)%c_hour, other, [nt]); if (any(other /= hh)) rc = -1
-               case (5); call c_f_pointer(inPointers(p)%c_minute, other, [nt]); if (any(other /= mi)) rc = -1
-               case (6); call c_f_pointer(inPointers(p)%c_second, other, [nt]); if (any(other /= ss)) rc = -1
-               end select
+         allocate (group(n), rep(n))
+         ngroups = 0
+         do p = 1, n
+            group(p) = 0
+            do g = 1, ngroups
+               if (same_axis(inPointers(p), inPointers(rep(g)), nt)) then
+                  group(p) = g
+                  exit
+               end if
             end do
-            if (rc /= 0) then
-               call fail('runsimulation_batch: sky view needs one time axis shared by all points of the batch', status, -5)
-               return
+            if (group(p) == 0) then
+               ngroups = ngroups + 1
+               rep(ngroups) = p
+               group(p) = ngroups
             end if
          end do
          allocate (sun(4, nt), slat(n), clat(n), lrad(n))
-         call rs_sun_table(int(nt, c_int), yy, mm, dd, hh, mi, ss, sun)
          call rs_point_geometry(n, localParam, slat, clat, lrad)
-         extras%sun = c_loc(sun); extras%sin_lat = c_loc(slat); extras%cos_lat = c_loc(clat)
-         extras%lon_rad = c_loc(lrad)
+         if (ngroups == 1) then
+            call axis_of(inPointers(1), nt, yy, mm, dd, hh, mi, ss)
+            call rs_sun_table(int(nt, c_int), yy, mm, dd, hh, mi, ss, sun)
+            extras%sun = c_loc(sun); extras%sin_lat = c_loc(slat); extras%cos_lat = c_loc(clat)
+            extras%lon_rad = c_loc(lrad)
+            rc = rs_host_run_batch(n, outPointers, inPointers, consts, localParam, tbottom, extras, &
+                                   rs_host_default_device())
+            if (rc /= 0) status = rc
+         else
+            if (c_associated(first_failed)) call c_f_pointer(first_failed, ff_all, [n])
+            do g = 1, ngroups
+               m = count(group == g)
+               allocate (gi(m), go(m), gl(m), gtb(m), gslat(m), gclat(m), glrad(m), gff(m), gidx(m))
+               k = 0
+               do p = 1, n
+                  if (group(p) /= g) cycle
+                  k = k + 1
+                  gidx(k) = p
+                  gi(k) = inPointers(p); go(k) = outPointers(p); gl(k) = localParam(p)
+                  gtb(k) = tbottom(p); gslat(k) = slat(p); gclat(k) = clat(p); glrad(k) = lrad(p)
+               end do
+               call axis_of(inPointers(rep(g)), nt, yy, mm, dd, hh, mi, ss)
+               call rs_sun_table(int(nt, c_int), yy, mm, dd, hh, mi, ss, sun)
+               extras%sun = c_loc(sun); extras%sin_lat = c_loc(gslat); extras%cos_lat = c_loc(gclat)
+               extras%lon_rad = c_loc(glrad)
+               extras%first_failed = c_null_ptr
+               if (c_associated(first_failed)) extras%first_failed = c_loc(gff)
+               rc = rs_host_run_batch(int(m, c_int), go, gi, consts, gl, gtb, extras, rs_host_default_device())
+               if (rc /= 0 .and. status == 0) status = rc
+               if (c_associated(first_failed)) then
+                  do k = 1, m
+                     ff_all(gidx(k)) = gff(k)
+                  end do
+               end if
+               deallocate (gi, go, gl, gtb, gslat, gclat, glrad, gff, gidx)
+            end do
+         end if
+         deallocate (group, rep)
+      else
+         rc = rs_host_run_batch(n, outPointers, inPointers, consts, localParam, tbottom, extras, &
+                                rs_host_default_device())
+         if (rc /= 0) status = rc
       end if
-      rc = rs_host_run_batch(n, outPointers, inPointers, consts, localParam, tbottom, extras, &
-                             rs_host_default_device())
-      if (rc /= 0) status = rc
       deallocate (tbottom)
    end subroutine runsimulation_batch_ex
 

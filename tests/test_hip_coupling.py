@@ -160,3 +160,38 @@ def test_chunked_coupling_with_failing_points(replay, monkeypatch):
         assert np.array_equal(whole[q], ora[q]), q
         assert np.array_equal(parts[q], ora[q]), q
     assert (ora["tsurf"][33:49, ci:] == -9999.0).all() and (ora["tsurf"][33:49, ci - 1] != -9999.0).all()
+
+
+def test_replay_window_that_misses_a_coupling_window_is_refused():
+    """rs_hip_cpl_replay checks the caller's window against the coupling windows of the points that ask
+    for a replay: the rewind reads the forcing of the index behind the window end, and a point whose
+    window start lies before the window would never step.  (In-tree callers compute the block from
+    the points' couplingIndexI; this is the guard of the public entry.)"""
+    import torch
+    from roadsurf_amd import device
+    n, L = 256, 121
+    s = abi.default_settings(L); s.use_coupling = 1
+    p = abi.default_parameters()
+    plan = device.Plan(n, s, p, 0)
+    dev, npad = plan.device, plan.np_pad
+    win = device.ForcingWindow.empty(L, npad, dev)
+    for k, v in (("tair", -2.0), ("tdew", -4.0), ("vz", 3.0), ("rhz", 80.0), ("prec", 0.0), ("sw", 0.0),
+                 ("lw", 250.0), ("tsurfobs", -9999.9), ("depth", -9999.9)):
+        win.tensors[k].fill_(v)
+    win.tensors["precphase"].fill_(-9999)
+    win.tensors["hour"].fill_(12)
+    win.tensors["tsurfobs"][0].fill_(-2.0)
+    out = device.OutputWindow.empty(L, npad, dev)
+    ci = torch.full((npad,), 50, dtype=torch.int32, device=dev)
+    ct = torch.full((npad,), 4.0, dtype=torch.float64, device=dev)   # far from what the model reaches
+    il = torch.ones((npad,), dtype=torch.int32, device=dev)
+    pp = plan.point_params(plan.uniform_tbottom(2024, 1, 10), il, None, None, None, ci, ct)
+    plan.init_state(win, pp)
+    plan.step_cpl(win, out, pp, 1, 60, window_row=0, out_row0=0)   # every point parks behind index 50
+    with pytest.raises(RuntimeError, match="does not cover"):
+        plan.cpl_replay(win, out, pp, 30, 31, window_row=29, out_row0=0)   # window starts behind couplingStartI = 1
+    with pytest.raises(RuntimeError, match="does not cover"):
+        plan.cpl_replay(win, out, pp, 1, 50, window_row=0, out_row0=0)     # ends at the window end, not behind it
+    rounds = plan.cpl_replay(win, out, pp, 1, 51, window_row=0, out_row0=0)
+    assert rounds is None or rounds >= 1
+    plan.close()

@@ -173,3 +173,51 @@ def test_writeback_of_the_sw_dir_clamp_without_sky_view(monkeypatch):
     # the same numbers from the reference's outputs: the first index it left at -9999.0
     first_missing = np.where((ora["tsurf"] == -9999.0).any(1), (ora["tsurf"] == -9999.0).argmax(1), 0)
     assert np.array_equal(ff, first_missing.astype(np.int32))
+
+
+def test_sky_view_with_two_time_axes_in_one_batch():
+    """The reference takes the solar position from each point's OWN year(i)..second(i)
+    (src/SunPosition.f90:196-260): a batch may mix points whose series start on different dates.
+    runsimulation_batch_ex groups the points by time axis (one sun table and one device call per
+    distinct axis; axes given as separate but equal arrays count as one): winter and midsummer
+    points interleaved in one batch equal the reference run of each group on its own axis, the
+    failure indices included."""
+    L_ = lib.load()
+    n, SL = 192, 1441
+    f, ls = _sky_case(n, SL, 31, summer=False)
+    axis_w = {k: f[k] for k in oh.I32_AXIS}
+    axis_s = oh.time_axis(SL, 30.0, (2024, 6, 20, 3, 0, 0))
+    summer = (np.arange(n) % 3 == 1)           # interleaved: the groups are not contiguous
+    f["tair"][5, 700] = 150.0                    # one failing point in each group
+    f["tair"][7, 900] = -150.0
+    assert not summer[5] and summer[7]
+    s = abi.default_settings(SL); p = abi.default_parameters()
+    kind = "ref" if oh.have_ref() else "port"
+    want = {k: np.full((n, SL), np.nan) for k in oh.F64_OUT}
+    for grp, axis in ((~summer, axis_w), (summer, axis_s)):
+        idx = np.nonzero(grp)[0]
+        g = {k: (np.ascontiguousarray(v[idx]) if isinstance(v, np.ndarray) and v.ndim == 2 and v.shape[0] == n else v)
+             for k, v in f.items()}
+        g.update(axis)
+        o, _, _ = oh.run_oracle(kind, g, s, p, [ls[i] for i in idx])
+        for k in oh.F64_OUT:
+            want[k][idx] = o[k]
+    out = {k: np.full((n, SL), np.nan) for k in oh.F64_OUT}
+    g = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in f.items()}
+    ips, ops, keep = _batch_arrays(g, out, n)
+    # every summer point gets its OWN copy of the summer axis (equal values, different arrays)
+    axes = []
+    for pt in np.nonzero(summer)[0]:
+        own = {k: np.ascontiguousarray(v.copy()) for k, v in axis_s.items()}
+        axes.append(own)
+        for k in oh.I32_AXIS:
+            setattr(ips[pt], "c_" + k, own[k].ctypes.data_as(abi.c_int32_p))
+    larr = (abi.LocalParameters * n)(*ls)
+    st = C.c_int32(99)
+    ff = np.full(n, -1, np.int32)
+    L_.runsimulation_batch_ex(n, ops, ips, C.byref(s), C.byref(p), larr, C.byref(st),
+                              ff.ctypes.data_as(abi.c_int32_p))
+    assert st.value == 0, lib.last_error()
+    for k in oh.F64_OUT:
+        assert np.array_equal(out[k], want[k]), k
+    assert ff[5] == 701 and ff[7] == 901 and (np.delete(ff, [5, 7]) == 0).all()
