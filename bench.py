@@ -363,7 +363,9 @@ def main() -> None:
     # matching counter summary, x4 cycles, over the chip's 1 024 SIMDs) at the clock sampled DURING the
     # timed passes, against the measured pass time
     valu_issue_frac = clock_mhz = None
-    if valu and valu.get("valu_active_quadcycles_per_pass"):
+    if valu and valu.get("valu_active_quadcycles_per_pass") and not args.f32:
+        # (fp64 only: a wave64 fp64 instruction holds its SIMD for four cycles; fp32 instructions issue
+        # at twice that rate and the counter does not tell the two apart)
         clock_mhz = sclk[0] or 2400.0
         issue_s = valu["valu_active_quadcycles_per_pass"] * 4.0 / 1024.0 / (clock_mhz * 1e6)
         valu_issue_frac = issue_s / (elapsed / args.steps)

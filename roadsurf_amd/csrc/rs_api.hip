@@ -568,7 +568,6 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
   a.cpl_nlist = 0;
   a.cpl_stop = 0;
   a.out_index = nullptr;
-  a.duo_roles = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (pl->timing) {
     if (pl->ev_used + 2 > pl->ev.size()) {

@@ -43,7 +43,6 @@ struct StepArgs {
    * (NULL: column s).  With the plan order as index the (decimated) outputs land in point order
    * whatever order the slots are in (rs_hip_set_output_by_point). */
   const int32_t *out_index;
-  int32_t duo_roles; /* step_kernel_duo: how the two roles are dealt to the wavefronts (launcher) */
 };
 
 struct InitArgs {

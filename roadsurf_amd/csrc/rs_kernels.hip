@@ -1300,24 +1300,13 @@ template <int NL, bool SCORE>
 __global__ void __launch_bounds__(128, 4) step_kernel_duo(const StepArgs a) {
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
   __shared__ DuoMail mail;
-  __shared__ uint32_t swap_roles;
   const MathTab mt = fill_math_tables(math_lds);
-  /* Which wavefront steps the surface?  The surface wave issues twice the instructions of the ground
-   * wave, and the dispatcher hands the waves of two-wave workgroups to the SIMDs of a CU in turn:
-   * wave 0 always to SIMD 0 or 2, wave 1 to SIMD 1 or 3.  With fixed roles two SIMDs of every CU
-   * would carry all the surface waves (measured: 67 % of the rate with balanced roles).  The wave
-   * slot a workgroup gets on its SIMD counts the workgroups that came before it there: its parity
-   * alternates the roles, so every SIMD hosts both kinds. */
-  if (threadIdx.x == 0) {
-    const uint32_t hw_id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4); /* HW_ID.wave_id */
-    /* duo_roles (ROADSURF_HIP_DUO_ROLES, experiments): 0 slot parity, 1 fixed, 2 by workgroup index */
-    swap_roles = a.duo_roles == 1 ? 0u : a.duo_roles == 2 ? ((blockIdx.x >> 1) & 1u) : (hw_id & 1u);
-  }
   __syncthreads();
-  /* no early return: both wavefronts walk to every barrier, lanes beyond npoints are dead weight */
-  const bool first = threadIdx.x < 64;
-  const bool swapped = __builtin_amdgcn_readfirstlane((int32_t)swap_roles) != 0;
-  if (first != swapped) duo_surface<NL, SCORE>(mt, mail, a);
+  /* no early return: both wavefronts walk to every barrier, lanes beyond npoints are dead weight.
+   * (Dealing the roles by the parity of the hardware wave slot or of the workgroup index, so that every
+   * SIMD hosts both kinds, was measured: 1.08e10 and 1.13e10 against 1.12e10 with fixed roles at
+   * 125 000 points - nothing to gain.) */
+  if (threadIdx.x < 64) duo_surface<NL, SCORE>(mt, mail, a);
   else duo_ground<NL>(mail, a);
 }
 
@@ -1898,11 +1887,8 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
     wpe = 0;
   } else if (variant == RS_VARIANT_DUO || (auto_variant && wpe == 0 && duo_ok && a.npoints <= duo_max)) {
     const dim3 gd((unsigned)((a.npoints + 63) / 64));
-    const char *er = getenv("ROADSURF_HIP_DUO_ROLES");
-    rs::StepArgs b = a;
-    b.duo_roles = er ? atoi(er) : 0;
-    if (score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true>), gd, dim3(128), 0, stream, b);
-    else hipLaunchKernelGGL((rs::step_kernel_duo<15, false>), gd, dim3(128), 0, stream, b);
+    if (score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true>), gd, dim3(128), 0, stream, a);
+    else hipLaunchKernelGGL((rs::step_kernel_duo<15, false>), gd, dim3(128), 0, stream, a);
     return hipGetLastError();
   }
   if (variant == RS_VARIANT_HYBRID && (NL != 15 || !full)) { /* not this launch: as AUTO */
