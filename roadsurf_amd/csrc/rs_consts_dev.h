@@ -16,6 +16,8 @@ struct RsConstantsDev : RsConstants {
   /* 1: a bare, dry road stays bare whatever the limits say (road_condition's fast path,
    * rs_physics_body.inc): no upper storage limit is negative */
   int32_t bareFastOk;
+  /* 1: an index without precipitation leaves the storages alone (fluxes_pre's shortcut): MinPrecmm >= 0 */
+  int32_t precFastOk;
   /* CheckValues' bounds (src/InputOutput.f90:45-84; REAL(4) literals): 100, -0.1, -90, 120, -1,
    * 4000, 1000, 500 - in the order check_values reads them */
   double chk[8];
@@ -49,7 +51,8 @@ static inline void rs_consts_dev_fill(const RsConstants &c, RsConstantsDev &d) {
   d.relax_tab = nullptr;
   d.cpl_tab = nullptr;
   d.bareFastOk = (c.MaxWatmms >= 0.0 && c.MaxSnowmms >= 0.0 && c.MaxIcemms >= 0.0 && c.MaxDepmms >= 0.0) ? 1 : 0;
-  if (getenv("ROADSURF_HIP_NO_BARE_FAST")) d.bareFastOk = 0; /* A/B switch: same bits either way */
+  d.precFastOk = (c.MinPrecmm >= 0.0) ? 1 : 0;
+  if (getenv("ROADSURF_HIP_NO_BARE_FAST")) d.bareFastOk = d.precFastOk = 0; /* A/B switch: same bits either way */
 }
 
 /* Operand domain the bare division/sqrt sequences of rs_math.hpp rely on, as far as it is set by

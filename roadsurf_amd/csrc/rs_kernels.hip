@@ -569,6 +569,18 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
   /* REPLAY: SWRadCof / LWRadCof of the window being replayed, and "TmpNw is the stale profile" */
   double r_swcof = R4(1.0), r_lwcof = R4(1.0);
   bool stale_now = false;
+  /* A failed point's rows read -9999.0 from behind the index that failed it (the reference's loop has
+   * exited: src/Initialization.f90:404-411).  Without coupling they are written HERE - the rest of the
+   * window when the failure is detected, the whole window for a point that arrives failed - and not by
+   * a second store site in the time loop: the compiler merges two store sites of a loop into one and
+   * pays for it with ~25 register moves on every step of every lane. */
+  auto blank_rows = [&](int32_t i_from) {
+    for (int32_t ii = i_from; ii < t0 + nsteps; ++ii) {
+      int64_t r;
+      if (output_row<false>(ka, ii, r)) store_outputs<false, false>(ka, r, row0, lane, s, false);
+    }
+  };
+  if (!CPL && s.failed) blank_rows(t0);
   Forcing nxt = load_forcing<FULL, A32>(ka, row0, lane, 0);
   for (int32_t kv = 0; kv < nsteps; ++kv) {
     asm volatile("" : "+s"(ka));
@@ -589,10 +601,11 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
     }
     if (CPL) next_i = i + 1;
     if (s.failed) { /* loop has exited in the reference: outputs stay -9999.0 */
-      if (k + 1 < nsteps) nxt = load_forcing<FULL, A32>(ka, row0, lane, k + 1);
+      /* (no forcing is fetched for a failed point: it never steps again, and a second fetch site would
+       * be merged with the one in the middle of the step at the price of moves at the loop's end) */
       /* a point that fails in the middle of a replay keeps, up to its window end, what the earlier
        * passes saved there (src/InputOutput.f90:151-165 only ever overwrites) */
-      if (owrite && (!REPLAY || i > cpl_ce)) store_outputs<CPL, A32>(ka, orow, row0, lane, s, false);
+      if (CPL && owrite && (!REPLAY || i > cpl_ce)) store_outputs<CPL, A32>(ka, orow, row0, lane, s, false);
       continue;
     }
     double tair = f.tair, vz = f.vz, rhz = f.rhz;
@@ -807,6 +820,7 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
       model_step_ground<Prof, Prof, FULL>(c, s, T, tbot, tair, fx, f.depth, cp);
     }
     if (owrite) store_outputs<CPL, A32>(ka, orow, row0, lane, s, true);
+    if (!CPL && s.failed) blank_rows(i + 1); /* failed at this index: its own row is saved, the rest is not */
     if (CPL && cpl_on && i < c.SimLen && i == cpl_ce) {
       /* CheckEndCoupling + CouplingOperations2, src/Coupling.f90:98-141 (Coupling_failed is
        * .false. before the first decision) */
@@ -1199,6 +1213,13 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
   mail.v[0][0][lane] = T.get(2);
   duo_meet();
   const int32_t nsteps = ka->nsteps, t0 = ka->t0;
+  auto blank_rows = [&](int32_t i_from) { /* as in time_loop */
+    for (int32_t ii = i_from; ii < t0 + nsteps; ++ii) {
+      int64_t r;
+      if (output_row<false>(ka, ii, r)) store_outputs<false, false>(ka, r, row0, lane, s, false);
+    }
+  };
+  if (live && s.failed) blank_rows(t0);
   int32_t score = 0; /* scheduling hint of rs_hip_recluster, as in time_loop */
   Forcing nxt = load_forcing<false, true>(ka, row0, lane, 0);
   for (int32_t kv = 0; kv < nsteps; ++kv) {
@@ -1234,9 +1255,7 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
       /* layers 1-2 with Tmp(3) where a two-layer column has its lower boundary */
       model_step_ground<RegProfile<2>, RegProfile<2>, false>(c, s, T, t3, tair, fx, f.depth);
       if (owrite) store_outputs<false, true>(ka, orow, row0, lane, s, true);
-    } else {
-      if (k + 1 < nsteps) nxt = load_forcing<false, true>(ka, row0, lane, k + 1);
-      if (owrite && live) store_outputs<false, true>(ka, orow, row0, lane, s, false);
+      if (s.failed) blank_rows(i + 1);
     }
     mail.v[(k & 1) ^ 1][0][lane] = T.get(2);
     duo_meet();

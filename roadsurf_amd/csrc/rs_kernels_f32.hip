@@ -26,6 +26,7 @@
 #define RS_BL_GUARD 0
 #define RS_MELTDEN (c.WatMHeat * c.WatDens)
 #define RS_CHK(c, i, lit) (lit)
+#define RS_PREC_FAST(c) ((c).MinPrecmm >= 0.f)
 #define RS_BARE_FAST(c) ((c).MaxWatmms >= 0.f && (c).MaxSnowmms >= 0.f && (c).MaxIcemms >= 0.f && (c).MaxDepmms >= 0.f)
 namespace rs32 {
 using rs::MathTab;

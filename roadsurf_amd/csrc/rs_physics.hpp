@@ -40,6 +40,7 @@
 #define RS_BL_GUARD 1
 #define RS_MELTDEN c.meltDen /* WatMHeat*WatDens, the same IEEE product formed once on the host */
 #define RS_BARE_FAST(c) ((c).bareFastOk != 0) /* rs_consts_dev.h */
+#define RS_PREC_FAST(c) ((c).precFastOk != 0)
 #define RS_CHK(c, i, lit) ((c).chk[i])         /* rs_consts_dev.h: CheckValues' bounds */
 #define R4(x) ((double)(x##f))
 #include "rs_physics_body.inc"
@@ -49,6 +50,7 @@
 #undef RS_BL_GUARD
 #undef RS_MELTDEN
 #undef RS_BARE_FAST
+#undef RS_PREC_FAST
 #undef RS_CHK
 
 namespace rs {
