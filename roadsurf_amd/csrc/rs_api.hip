@@ -19,6 +19,7 @@
 #include "../../include/roadsurf.h"
 #include "rs_kernels.h"
 #include <cstdint>
+#include <algorithm>
 #include "rs_consts_dev.h"
 #include "rs_state.h"
 
@@ -300,7 +301,8 @@ static int recluster_buffers(RsPlan *pl) {
     HIP_OK(hipMalloc(&pl->state_alt, state_bytes));
     HIP_OK(hipMalloc(&pl->order_alt, pl->np_pad * sizeof(int32_t)));
     HIP_OK(hipMalloc(&pl->sort_keys, (size_t)4 * pl->np_pad * sizeof(uint32_t)));
-    pl->sort_tmp_bytes = rs_cluster_scratch_bytes(pl->npoints);
+    pl->sort_tmp_bytes = std::max(rs_cluster_scratch_bytes(pl->npoints),
+                                  rs_cluster_count_scratch_bytes(pl->npoints, 12));
     HIP_OK(hipMalloc(&pl->sort_tmp, pl->sort_tmp_bytes ? pl->sort_tmp_bytes : 8));
   }
   return 0;
@@ -334,9 +336,18 @@ int rs_hip_recluster_forecast(RsPlan *pl, const RsPreview *pv) {
   a.pv = *pv;
   a.keys = pl->sort_keys;
   a.slots = pl->sort_keys + 2 * pl->np_pad;
+  /* a key of at most 12 bits is sorted by the plan's own counting pass (3 kernels), a longer one by
+   * the library (ROADSURF_HIP_LIBRARY_SORT=1 forces the library: A/B) */
+  const int bits = rs_forecast_key_bits(pv->mode);
+  const bool lib_sort = getenv("ROADSURF_HIP_LIBRARY_SORT") != nullptr; /* read per call: the tests switch it */
+  a.compact = (bits >= 1 && bits <= 12 && !lib_sort) ? 1 : 0;
   HIP_OK(rs_launch_forecast_keys(a, pl->stream));
-  HIP_OK(rs_cluster_sort_keys(pl->np_pad, pl->npoints, pl->sort_keys, pl->sort_tmp, pl->sort_tmp_bytes,
-                              pl->stream));
+  if (a.compact)
+    HIP_OK(rs_cluster_count_sort(pl->np_pad, pl->npoints, bits, pl->sort_keys, pl->sort_tmp,
+                                 pl->sort_tmp_bytes, pl->stream));
+  else
+    HIP_OK(rs_cluster_sort_keys(pl->np_pad, pl->npoints, pl->sort_keys, pl->sort_tmp, pl->sort_tmp_bytes,
+                                pl->stream));
   return recluster_apply(pl);
 }
 

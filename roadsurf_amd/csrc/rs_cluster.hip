@@ -109,6 +109,159 @@ hipError_t rs_cluster_sort(const double *state, bool f32, int64_t np_pad, int64_
                                             KEY_BITS, stream);
 }
 
+/* ---- the plan's own sort: one stable counting pass -----------------------------------------
+ * The forecast key of the default field set is short - something on the road (1 bit), unstable
+ * previews and table-path previews (2 bits each for the two or three previews of a window), predicted
+ * extra passes saturating at 31 (5 bits), storage class (2 bits): 12 bits - so ONE counting pass
+ * sorts it, in four small kernels instead of the 17 of the library's merge sort:
+ *   cs_hist     a histogram per tile of CS_TILE keys (LDS atomics): H[tile][bin]
+ *   cs_binscan  one lane per bin: exclusive prefix of its counts over the tiles, in place, and the
+ *               bin's total (every access a coalesced row of H)
+ *   cs_base     exclusive scan of the totals: where every bin starts
+ *   cs_scatter  one wavefront per tile: start of (bin, tile) = the bin's start + its tile prefix;
+ *               then it walks its keys in order, and the rank of a key among the equal keys of
+ *               its 64 is a popcount of ballots - equal keys keep their order (stable, deterministic:
+ *               no atomic decides a position, no workgroup waits for another)
+ * perm_out[new slot] = old slot, as the library sort's value output. */
+namespace {
+constexpr int CS_TILE = 1024;
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t u = (uint32_t)__shfl_up((int)v, off, 64);
+    if (lane >= (uint32_t)off) v += u;
+  }
+  return v;
+}
+
+__global__ void __launch_bounds__(256) cs_hist_kernel(const uint32_t *__restrict__ keys, int64_t n,
+                                                      int nbins, int ntiles, uint32_t *__restrict__ H) {
+  extern __shared__ uint32_t cs_h[];
+  for (int b = threadIdx.x; b < nbins; b += 256) cs_h[b] = 0u;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * CS_TILE;
+  for (int i = threadIdx.x; i < CS_TILE; i += 256) {
+    const int64_t idx = base + i;
+    if (idx < n) atomicAdd(&cs_h[keys[idx] & (uint32_t)(nbins - 1)], 1u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nbins; b += 256) H[(int64_t)blockIdx.x * nbins + b] = cs_h[b];
+}
+
+/* one lane per bin: walks the tiles in order (coalesced rows of H[tile][bin]), leaves the bin's
+ * exclusive prefix over the tiles in place and its total in T[bin] */
+__global__ void __launch_bounds__(64) cs_binscan_kernel(uint32_t *H, uint32_t *T, int nbins, int ntiles) {
+  const int bin = (int)blockIdx.x * 64 + (int)threadIdx.x;
+  if (bin >= nbins) return;
+  uint32_t run = 0u;
+#pragma unroll 8
+  for (int t = 0; t < ntiles; ++t) {
+    const uint32_t v = H[(int64_t)t * nbins + bin];
+    H[(int64_t)t * nbins + bin] = run;
+    run += v;
+  }
+  T[bin] = run;
+}
+
+/* T[0..nbins) -> exclusive scan in place: where every bin starts in the output.  One workgroup. */
+__global__ void __launch_bounds__(1024) cs_base_kernel(uint32_t *T, int nbins) {
+  __shared__ uint32_t wsum[16];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const int per = (nbins + 1023) / 1024; /* consecutive bins per thread */
+  const int b0 = (int)threadIdx.x * per;
+  uint32_t local = 0u;
+  for (int b = b0; b < b0 + per && b < nbins; ++b) local += T[b];
+  const uint32_t incl = wave_incl_scan(local, lane);
+  if (lane == 63u) wsum[wave] = incl;
+  __syncthreads();
+  uint32_t before = 0u;
+  for (uint32_t w = 0; w < wave; ++w) before += wsum[w];
+  uint32_t run = before + incl - local;
+  for (int b = b0; b < b0 + per && b < nbins; ++b) {
+    const uint32_t v = T[b];
+    T[b] = run;
+    run += v;
+  }
+}
+
+__global__ void __launch_bounds__(64) cs_scatter_kernel(const uint32_t *__restrict__ keys, int64_t n,
+                                                        int nbits, int ntiles,
+                                                        const uint32_t *__restrict__ H,
+                                                        const uint32_t *__restrict__ T,
+                                                        uint32_t *__restrict__ perm_out) {
+  extern __shared__ uint32_t cs_cur[];
+  const int nbins = 1 << nbits;
+  const uint32_t lane = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * CS_TILE;
+  /* where every bin starts for this tile: the bin's start (cs_base) + its prefix over the tiles before
+   * this one (cs_binscan); coalesced rows */
+  for (int b = (int)lane; b < nbins; b += 64) cs_cur[b] = T[b] + H[(int64_t)blockIdx.x * nbins + b];
+  __syncthreads();
+  /* the keys of CS_BATCH rounds are fetched together (a load per round would put 64 memory round trips
+   * behind one another), but no more: the kernel has to fit beside the step kernels' wavefronts, which
+   * leave few vector registers free on a SIMD (64 keys in registers: 193 VGPRs, 0.5 ms per sort) */
+  constexpr int CS_BATCH = 8;
+  for (int r0 = 0; r0 < CS_TILE / 64; r0 += CS_BATCH) {
+    if (base + (int64_t)r0 * 64 >= n) break; /* uniform: behind the last key */
+    uint32_t kreg[CS_BATCH];
+#pragma unroll
+    for (int q = 0; q < CS_BATCH; ++q) {
+      const int64_t idx = base + (int64_t)(r0 + q) * 64 + lane;
+      kreg[q] = idx < n ? (keys[idx] & (uint32_t)(nbins - 1)) : 0u;
+    }
+#pragma unroll
+  for (int q = 0; q < CS_BATCH; ++q) {
+    const int64_t idx = base + (int64_t)(r0 + q) * 64 + lane;
+    const bool valid = idx < n;
+    const uint32_t key = kreg[q];
+    unsigned long long same = __ballot(valid);
+    for (int bit = 0; bit < nbits; ++bit) {
+      const bool one = (key >> bit) & 1u;
+      const unsigned long long b = __ballot(one);
+      same &= one ? b : ~b;
+    }
+    const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+    uint32_t start = 0u;
+    if (valid) {
+      start = cs_cur[key];
+      perm_out[start + rank] = (uint32_t)idx;
+    }
+    /* every lane has read its cursor before the first of its group moves it: the workgroup is ONE
+     * wavefront, whose LDS accesses execute in program order - a scheduling fence for the compiler is
+     * all it takes (a __syncthreads() here also waits for the scattered store above: 64 memory round
+     * trips per tile, measured 0.5 ms per sort) */
+    __builtin_amdgcn_wave_barrier();
+    if (valid && rank == 0u) cs_cur[key] = start + (uint32_t)__popcll(same);
+    __builtin_amdgcn_wave_barrier();
+  }
+  }
+}
+}  // namespace
+
+size_t rs_cluster_count_scratch_bytes(int64_t npoints, int nbits) {
+  const int64_t ntiles = (npoints + CS_TILE - 1) / CS_TILE;
+  return ((size_t)(1 << nbits) * (size_t)ntiles + (size_t)(1 << nbits)) * sizeof(uint32_t);
+}
+
+/* keys in scratch[0..npoints) (values < 2^nbits), permutation out to scratch + 3*np_pad */
+hipError_t rs_cluster_count_sort(int64_t np_pad, int64_t npoints, int nbits, uint32_t *scratch, void *tmp,
+                                 size_t tmp_bytes, hipStream_t stream) {
+  if (nbits < 1 || nbits > 12 || tmp_bytes < rs_cluster_count_scratch_bytes(npoints, nbits))
+    return hipErrorInvalidValue;
+  const int nbins = 1 << nbits;
+  const int ntiles = (int)((npoints + CS_TILE - 1) / CS_TILE);
+  uint32_t *H = static_cast<uint32_t *>(tmp);
+  uint32_t *T = H + (size_t)nbins * ntiles;
+  hipLaunchKernelGGL(cs_hist_kernel, dim3(ntiles), dim3(256), nbins * sizeof(uint32_t), stream, scratch,
+                     npoints, nbins, ntiles, H);
+  hipLaunchKernelGGL(cs_binscan_kernel, dim3((nbins + 63) / 64), dim3(64), 0, stream, H, T, nbins, ntiles);
+  hipLaunchKernelGGL(cs_base_kernel, dim3(1), dim3(1024), 0, stream, T, nbins);
+  hipLaunchKernelGGL(cs_scatter_kernel, dim3(ntiles), dim3(64), nbins * sizeof(uint32_t), stream, scratch,
+                     npoints, nbits, ntiles, H, T, scratch + 3 * np_pad);
+  return hipGetLastError();
+}
+
 hipError_t rs_cluster_sort_keys(int64_t np_pad, int64_t npoints, uint32_t *scratch, void *tmp,
                                 size_t tmp_bytes, hipStream_t stream) {
   uint32_t *kin = scratch, *kout = scratch + np_pad, *sin = scratch + 2 * np_pad,

@@ -1400,7 +1400,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
       }
       pv.tair_now = pv.tair[0];
       pv.alpha = 0.5;
-      pv.mode = 3124;
+      pv.mode = 37865; /* 12 bits: the plan's own counting sort (rs_cluster.hip) */
       if (rs_hip_recluster_forecast(pg.p, &pv) != 0) return -14;
       return gather_params();
     };

@@ -60,6 +60,8 @@ struct ForecastArgs {
   int64_t npoints, np_pad;
   RsPreview pv;
   uint32_t *keys, *slots;
+  int32_t compact; /* 1: the key is stored right-aligned in its own bits (counting sort), 0: left-aligned
+                      in RS_SORT_KEY_BITS (library sort) */
 };
 
 struct KnotArgs {
@@ -120,6 +122,12 @@ hipError_t rs_cluster_sort(const double *state, bool f32, int64_t np_pad, int64_
 /* same with keys/slots already in scratch[0..np_pad) / scratch[2*np_pad..) */
 hipError_t rs_cluster_sort_keys(int64_t np_pad, int64_t npoints, uint32_t *scratch, void *tmp,
                                 size_t tmp_bytes, hipStream_t stream);
+/* the plan's own stable counting sort for keys of at most 12 bits (rs_cluster.hip) */
+size_t rs_cluster_count_scratch_bytes(int64_t npoints, int nbits);
+hipError_t rs_cluster_count_sort(int64_t np_pad, int64_t npoints, int nbits, uint32_t *scratch, void *tmp,
+                                 size_t tmp_bytes, hipStream_t stream);
+/* significant bits of the forecast key for a field list (RsPreview::mode) */
+int rs_forecast_key_bits(int32_t mode);
 hipError_t rs_cluster_apply(const double *state_src, double *state_dst, bool f32,
                             const int32_t *order_src, int32_t *order_dst, const uint32_t *perm,
                             int64_t np_pad, int64_t npoints, int nlayers, int cpl_rows,

@@ -1777,11 +1777,19 @@ __global__ void __launch_bounds__(kBlock) forecast_key_kernel(const ForecastArgs
     else if (d == 3) { key = (key << 1) | (uint32_t)cover; bits += 1; }
     else if (d == 4) { key = (key << 12) | (uint32_t)extra; bits += 12; }
     else if (d == 5) { key = (key << 2) | (uint32_t)sclass; bits += 2; }
+    /* compact forms: extra passes saturating at 31 (5 bits), the two preview counts at 3 (2 bits) */
+    else if (d == 6) { key = (key << 5) | (uint32_t)(extra > 31 ? 31 : extra); bits += 5; }
+    else if (d == 7) { key = (key << 2) | (uint32_t)(unst > 3 ? 3 : unst); bits += 2; }
+    else if (d == 8) { key = (key << 2) | (uint32_t)(farc > 3 ? 3 : farc); bits += 2; }
   }
-  if (bits < RS_SORT_KEY_BITS) key <<= (RS_SORT_KEY_BITS - bits); /* left-aligned in the sorted bits */
-  else key >>= (bits - RS_SORT_KEY_BITS);
   /* descending: the expensive points get the low slots (longest job first, rs_cluster.hip) */
-  a.keys[s] = ((1u << RS_SORT_KEY_BITS) - 1u) - key;
+  if (a.compact) { /* right-aligned in its own bits: the plan's counting sort */
+    a.keys[s] = ((1u << bits) - 1u) - key;
+  } else {
+    if (bits < RS_SORT_KEY_BITS) key <<= (RS_SORT_KEY_BITS - bits); /* left-aligned in the sorted bits */
+    else key >>= (bits - RS_SORT_KEY_BITS);
+    a.keys[s] = ((1u << RS_SORT_KEY_BITS) - 1u) - key;
+  }
   a.slots[s] = (uint32_t)s;
 }
 
@@ -1823,6 +1831,17 @@ hipError_t rs_upload_math_tables(hipStream_t stream) {
   if (e != hipSuccess) return e;
   return hipMemcpyToSymbolAsync(HIP_SYMBOL(rs::c_gl_log_tab), rs_gl_log_tab, sizeof(rs_gl_log_tab), 0,
                                 hipMemcpyHostToDevice, stream);
+}
+
+/* the same field widths as forecast_key_kernel */
+int rs_forecast_key_bits(int32_t m) {
+  m = (m == 0) ? 14 : (m == 1) ? 124 : (m == 2) ? 134 : (m == 3) ? 1234 : m;
+  int bits = 0;
+  for (; m > 0; m /= 10) {
+    const int d = m % 10;
+    bits += d == 1 ? 4 : d == 2 ? 4 : d == 3 ? 1 : d == 4 ? 12 : d == 5 ? 2 : d == 6 ? 5 : d == 7 ? 2 : d == 8 ? 2 : 0;
+  }
+  return bits;
 }
 
 hipError_t rs_launch_forecast_keys(const rs::ForecastArgs &a, hipStream_t stream) {

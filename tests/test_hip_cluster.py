@@ -182,3 +182,34 @@ def test_forecast_recluster_is_a_value_neutral_permutation():
     with pytest.raises(RuntimeError, match="history score"):
         plan.recluster()
     plan.close()
+
+
+@pytest.mark.parametrize("n", [1000, 70_001])
+def test_the_plans_own_sort_equals_the_library_sort(n, monkeypatch):
+    """A forecast key of at most 12 bits (the default field set) is sorted by the plan's own stable
+    counting pass - per-tile histograms, one scan, a scatter that ranks equal keys by ballot - instead
+    of the library's merge sort.  Both are stable, so every launch must see the SAME slot order with
+    either (ROADSURF_HIP_LIBRARY_SORT=1 forces the library), whatever the batch size does to the tiles
+    of 1 024 keys (1 000 points: one partial tile; 70 001: 69 tiles, the last with 369 keys)."""
+    import torch
+    from roadsurf_amd import abi, device, workload
+    hours = 4
+    L = hours * 120 + 1
+    s = abi.default_settings(L); p = abi.default_parameters()
+    rows = {}
+    for tag, env in (("own", None), ("library", "1")):
+        if env:
+            monkeypatch.setenv("ROADSURF_HIP_LIBRARY_SORT", env)
+        plan = device.Plan(n, s, p, 0)
+        run = workload.SyntheticRun(plan, 5, hours, 60, plan_order=True, forecast=True)
+        assert run.forecast_mode == workload.DEFAULT_FORECAST_MODE
+        run.run_pass()
+        plan.sync()
+        rows[tag] = run.orders[:, :n].cpu().numpy().copy()
+        cs = plan.failed_count()
+        assert cs == 0
+        plan.close()
+    assert (rows["own"][0] == np.arange(n)).all() and (rows["own"][-1] != np.arange(n)).any()
+    assert np.array_equal(rows["own"], rows["library"])
+    for r in rows["own"]:
+        assert np.array_equal(np.sort(r), np.arange(n))
