@@ -60,6 +60,7 @@ __device__ __forceinline__ const ConstsAS &consts_of(Args a) {
 template <int NL>
 struct RegProfile {
   double v[NL];
+  static constexpr bool kUnrolled = true; /* the layer count is a compile-time constant */
   __device__ __forceinline__ constexpr int nlayers() const { return NL; }
   __device__ __forceinline__ double get(int j) const { return v[j - 1]; }
   __device__ __forceinline__ void set(int j, double x) { v[j - 1] = x; }
@@ -79,6 +80,7 @@ template <int NL, int NREG>
 struct HybridProfile {
   double v[NREG];
   double *col; /* &lds[threadIdx.x]; layer NREG + 1 + r is col[r * kBlock] */
+  static constexpr bool kUnrolled = true; /* the layer count is a compile-time constant */
   __device__ __forceinline__ constexpr int nlayers() const { return NL; }
   __device__ __forceinline__ double get(int j) const { return j <= NREG ? v[j - 1] : col[(j - NREG - 1) * kBlock]; }
   __device__ __forceinline__ void set(int j, double x) {
@@ -94,6 +96,7 @@ struct HybridProfile {
 struct LdsProfile {
   double *col; /* &lds[threadIdx.x]; layer stride = kBlock doubles */
   int n;
+  static constexpr bool kUnrolled = false;
   __device__ __forceinline__ int nlayers() const { return n; }
   __device__ __forceinline__ double get(int j) const { return col[(j - 1) * kBlock]; }
   __device__ __forceinline__ void set(int j, double x) { col[(j - 1) * kBlock] = x; }

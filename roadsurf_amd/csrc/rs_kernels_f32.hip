@@ -57,6 +57,7 @@ __device__ __forceinline__ const ConstsAS &consts_of(Args a) {
 template <int NL>
 struct RegProfile {
   float v[NL];
+  static constexpr bool kUnrolled = true; /* the layer count is a compile-time constant */
   __device__ __forceinline__ constexpr int nlayers() const { return NL; }
   __device__ __forceinline__ float get(int j) const { return v[j - 1]; }
   __device__ __forceinline__ void set(int j, float x) { v[j - 1] = x; }
@@ -65,6 +66,7 @@ struct RegProfile {
 struct LdsProfile {
   float *col;
   int n;
+  static constexpr bool kUnrolled = false;
   __device__ __forceinline__ int nlayers() const { return n; }
   __device__ __forceinline__ float get(int j) const { return col[(j - 1) * kBlock]; }
   __device__ __forceinline__ void set(int j, float x) { col[(j - 1) * kBlock] = x; }
