@@ -419,6 +419,13 @@ int rs_hip_synth_knots(RsPlan *plan, const RsSynthSpec *spec, double *knots,
 int rs_hip_expand_forcing(RsPlan *plan, const RsSynthSpec *spec,
                           const double *knots, int32_t k0, int32_t nknots,
                           const RsForcing *f, int32_t t0, int32_t nsteps);
+/* Same with the knot buffer in POINT order (generated once, spec->order NULL) and the window produced
+ * in the plan's current SLOT order: column p of the window is interpolated from knot column
+ * rs_hip_plan_order()[p].  What a plan that is re-sorted between launches uses instead of
+ * regenerating the knots in slot order for every window. */
+int rs_hip_expand_forcing_ordered(RsPlan *plan, const RsSynthSpec *spec,
+                                  const double *knots, int32_t k0, int32_t nknots,
+                                  const RsForcing *f, int32_t t0, int32_t nsteps);
 
 /* Same, enqueued on another HIP stream (hipStream_t) than the plan's: lets a caller
  * overlap the HBM-bound expansion of window c+1 with the VALU-bound stepping of
@@ -513,6 +520,9 @@ typedef struct RsPreview {
   int32_t mode;                          /* key fields in priority order as decimal digits: 1 unstable
                                             previews, 2 table-path previews, 3 cover, 4 predicted extra
                                             passes (e.g. 1234); 0..3 = 14, 124, 134, 1234 */
+  const int32_t *index;                  /* NULL: the preview rows are in SLOT order; else row element
+                                            index[slot] belongs to that slot (rows kept in point order,
+                                            index = rs_hip_plan_order(): no regeneration after a re-sort) */
 } RsPreview;
 int rs_hip_recluster_forecast(RsPlan *plan, const RsPreview *preview);
 /* A plan that is only ever sorted by forecast can tell the step kernels not to keep the history
@@ -660,7 +670,7 @@ int rs_driver_expand(const RsDriverInput *in, const InputSettings *settings,
                      LocalParameters *local, double *merged, int32_t *status,
                      int32_t *missing_index, int32_t device);
 
-#define RS_ABI_VERSION 2 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index) */
+#define RS_ABI_VERSION 3 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles */
 int rs_abi_version(void);
 /* sizeof of the boundary structs as the C side / the Fortran side see them
  * (0 InputPointers, 1 OutputPointers, 2 InputSettings, 3 InputParameters,

@@ -871,9 +871,9 @@ int rs_hip_synth_knots(RsPlan *pl, const RsSynthSpec *spec, double *knots, int32
   return 0;
 }
 
-int rs_hip_expand_forcing_on(RsPlan *pl, const RsSynthSpec *spec, const double *knots, int32_t k0,
-                             int32_t nknots, const RsForcing *f, int32_t t0, int32_t nsteps,
-                             void *stream) {
+static int expand_forcing(RsPlan *pl, const RsSynthSpec *spec, const double *knots, int32_t k0,
+                          int32_t nknots, const RsForcing *f, int32_t t0, int32_t nsteps, void *stream,
+                          const int32_t *gather) {
   if (!pl || !spec || !knots || !f) return set_err("rs_hip_expand_forcing: bad arguments");
   if (check_forcing(pl, f, "rs_hip_expand_forcing")) return -1;
   if (nsteps < 1 || nsteps > 65535 || t0 < 1)
@@ -900,6 +900,7 @@ int rs_hip_expand_forcing_on(RsPlan *pl, const RsSynthSpec *spec, const double *
   a.kfirst = kfirst;
   a.nsteps = nsteps;
   a.r_spk = 1.0 / (double)spk;
+  a.gather = gather;
   if (pl->f32) {
     if (f->depth || f->tdew) return set_err("rs_hip_expand_forcing: fp32 windows carry no Tdew/depth");
     HIP_OK(rs32_launch_expand(a, (t0 + nsteps - 2) / spk - kfirst + 1, (hipStream_t)stream));
@@ -909,10 +910,24 @@ int rs_hip_expand_forcing_on(RsPlan *pl, const RsSynthSpec *spec, const double *
   return 0;
 }
 
+int rs_hip_expand_forcing_on(RsPlan *pl, const RsSynthSpec *spec, const double *knots, int32_t k0,
+                             int32_t nknots, const RsForcing *f, int32_t t0, int32_t nsteps,
+                             void *stream) {
+  return expand_forcing(pl, spec, knots, k0, nknots, f, t0, nsteps, stream, nullptr);
+}
+
 int rs_hip_expand_forcing(RsPlan *pl, const RsSynthSpec *spec, const double *knots, int32_t k0,
                           int32_t nknots, const RsForcing *f, int32_t t0, int32_t nsteps) {
   if (!pl) return set_err("rs_hip_expand_forcing: bad arguments");
-  return rs_hip_expand_forcing_on(pl, spec, knots, k0, nknots, f, t0, nsteps, pl->stream);
+  return expand_forcing(pl, spec, knots, k0, nknots, f, t0, nsteps, pl->stream, nullptr);
+}
+
+int rs_hip_expand_forcing_ordered(RsPlan *pl, const RsSynthSpec *spec, const double *knots, int32_t k0,
+                                  int32_t nknots, const RsForcing *f, int32_t t0, int32_t nsteps) {
+  if (!pl) return set_err("rs_hip_expand_forcing_ordered: bad arguments");
+  const int32_t *order = rs_hip_plan_order(pl);
+  if (!order) return -1;
+  return expand_forcing(pl, spec, knots, k0, nknots, f, t0, nsteps, pl->stream, order);
 }
 
 } /* extern "C" */

@@ -78,6 +78,7 @@ struct ExpandArgs {
   int32_t k0, t0, spk, start_hour;
   int32_t kfirst, nsteps;
   double r_spk; /* RN(1 / spk): the interpolation's division has a uniform denominator (rs_div_u) */
+  const int32_t *gather; /* NULL, or: the knots of window column p are knot column gather[p] */
 };
 
 }  // namespace rs

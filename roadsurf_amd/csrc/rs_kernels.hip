@@ -1562,7 +1562,8 @@ __global__ void __launch_bounds__(kBlock) expand_kernel(const ExpandArgs a) {
   if (tlo < a.t0 - 1) tlo = a.t0 - 1;
   if (thi > a.t0 - 1 + a.nsteps) thi = a.t0 - 1 + a.nsteps;
   if (tlo >= thi) return;
-  const double *ka = a.knots + ((int64_t)(k - a.k0) * RS_KNOT_FIELDS) * a.np_pad + p;
+  const int64_t kcol = a.gather ? (int64_t)a.gather[p] : p; /* knots kept in point order: gather */
+  const double *ka = a.knots + ((int64_t)(k - a.k0) * RS_KNOT_FIELDS) * a.np_pad + kcol;
   const double *kb = ka + (int64_t)RS_KNOT_FIELDS * a.np_pad;
   const bool need_b = (thi - 1) > k * a.spk; /* some r > 0 in range */
   double v0[7], dv[7];
@@ -1715,12 +1716,13 @@ __global__ void __launch_bounds__(kBlock) forecast_key_kernel(const ForecastArgs
   const int32_t cover = (has_snow || has_ice || has_wet) ? 1 : 0;
   /* which storage branches the point will take (src/Storage.f90): snow is the longest chain */
   const int32_t sclass = has_snow ? 3 : has_ice ? 2 : has_wet ? 1 : 0;
-  const double ta_now = a.pv.tair_now[s];
+  const int64_t pq = a.pv.index ? (int64_t)a.pv.index[s] : s; /* preview rows in point order */
+  const double ta_now = a.pv.tair_now[pq];
   const double stab_num = -c.VK_Const * c.ZRefT * c.Grav;
   int32_t unst = 0, farc = 0, extra = 0;
   for (int q = 0; q < a.pv.n; ++q) {
-    const double ta = a.pv.tair[q][s];
-    double vz = a.pv.vz[q][s];
+    const double ta = a.pv.tair[q][pq];
+    double vz = a.pv.vz[q][pq];
     const double hour = (double)a.pv.hour[q];
     const double calm = (hour >= c.NightOn || hour <= c.NightOff) ? c.CalmLimNgt : c.CalmLimDay;
     if (vz < calm) vz = calm;

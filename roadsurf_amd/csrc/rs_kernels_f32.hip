@@ -210,7 +210,8 @@ __global__ void __launch_bounds__(kBlock) expand_kernel_f32(const rs::ExpandArgs
   if (tlo < a.t0 - 1) tlo = a.t0 - 1;
   if (thi > a.t0 - 1 + a.nsteps) thi = a.t0 - 1 + a.nsteps;
   if (tlo >= thi) return;
-  const double *ka = a.knots + ((int64_t)(k - a.k0) * RS_KNOT_FIELDS) * a.np_pad + p;
+  const int64_t kcol = a.gather ? (int64_t)a.gather[p] : p;
+  const double *ka = a.knots + ((int64_t)(k - a.k0) * RS_KNOT_FIELDS) * a.np_pad + kcol;
   const double *kb = ka + (int64_t)RS_KNOT_FIELDS * a.np_pad;
   const bool need_b = (thi - 1) > k * a.spk;
   double v0[7], dv[7];

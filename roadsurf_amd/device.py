@@ -276,10 +276,12 @@ class Plan:
         lib.check(self.L.rs_hip_plan_reset_order(self._h), "rs_hip_plan_reset_order")
 
     def recluster_forecast(self, tair_rows, vz_rows, hours, tair_now, alpha: float = 0.5,
-                           mode: int = 1) -> None:
+                           mode: int = 1, point_order: bool = False) -> None:
         """Sort the slots by a forecast of the next launch (rs_hip_recluster_forecast): rows are
-        tensors [np_pad] in the CURRENT slot order at the preview times, hours the hour of day."""
+        tensors [np_pad] at the preview times, hours the hour of day.  Rows in the CURRENT slot order,
+        or - ``point_order`` - in point order, read through the plan's order row."""
         pv = lib.RsPreview()
+        pv.index = self.L.rs_hip_plan_order(self._h) if point_order else None
         pv.n = len(tair_rows)
         for q, (ta, vz, h) in enumerate(zip(tair_rows, vz_rows, hours)):
             pv.tair[q] = ta.data_ptr(); pv.vz[q] = vz.data_ptr(); pv.hour[q] = int(h)
@@ -306,6 +308,14 @@ class Plan:
         lib.check(self.L.rs_hip_expand_forcing(self._h, C.byref(spec), C.c_void_p(knots.data_ptr()),
                                                k0, nknots, C.byref(f), t0, nsteps),
                   "rs_hip_expand_forcing")
+
+    def expand_ordered(self, spec, knots: torch.Tensor, window: ForcingWindow, t0: int, nsteps: int) -> None:
+        """Knots [nknots][9][np_pad] in POINT order (all of the series, knot 0 first) -> the window in
+        the plan's current slot order (rs_hip_expand_forcing_ordered)."""
+        f = window.struct(0)
+        lib.check(self.L.rs_hip_expand_forcing_ordered(self._h, C.byref(spec), C.c_void_p(knots.data_ptr()),
+                                                       0, knots.shape[0], C.byref(f), t0, nsteps),
+                  "rs_hip_expand_forcing_ordered")
 
     def expand(self, spec, knots, window: ForcingWindow, t0: int, nsteps: int,
                stream: torch.cuda.Stream | None = None) -> None:

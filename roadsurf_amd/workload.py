@@ -58,17 +58,16 @@ class SyntheticRun:
         else:
             self.pp = plan.point_params(plan.uniform_tbottom(*year_month_day))
         self.starts = list(range(1, self.simlen + 1, self.chunk))
-        self.spec = None
-        self.knots = None
-        if plan_order:
-            # knots are generated per window in the current slot order (130x smaller than the window)
-            self.spec = lib.RsSynthSpec(seed, point_offset, SPK, 0)
-            self.kbuf = torch.empty((self.chunk // SPK + 3, 9, npad), dtype=torch.float64, device=dev)
-            self.orders = torch.empty((len(self.starts), npad), dtype=torch.int32, device=dev)
-        else:
-            self.spec, self.knots = plan.synth_knots(seed, hours + 2, point_offset=point_offset,
-                                                     steps_per_knot=SPK)
-            self.orders = None
+        # the hourly knots of every point (what an NWP source delivers): resident in HBM in POINT order,
+        # made once.  In plan order the windows are produced in the current SLOT order by reading the
+        # knots through the plan's order row (rs_hip_expand_forcing_ordered), and the re-sort's previews
+        # are knot rows read the same way - nothing is regenerated after a re-sort (round 2 regenerated
+        # the window's and the previews' knots in slot order for every launch: 0.7 ms per launch cycle of
+        # 250 000 points beside the step kernels)
+        self.spec, self.knots = plan.synth_knots(seed, hours + 2, point_offset=point_offset,
+                                                 steps_per_knot=SPK)
+        self.orders = (torch.empty((len(self.starts), npad), dtype=torch.int32, device=dev)
+                       if plan_order else None)
 
     def run_pass(self, on_launch=None) -> None:
         """Enqueue one pass on the plan's stream.  ``on_launch(c, t0, ns)`` is called after launch
@@ -82,18 +81,14 @@ class SyntheticRun:
         plan, spec = self.plan, self.spec
         if self.plan_order:
             plan.reset_order()
-            plan.synth_knots_range(spec, self.kbuf, 0, 2, ordered=True)
-            plan.expand_range(spec, self.kbuf, 0, 2, self.win0, 1, 1)
+            plan.expand_ordered(spec, self.knots, self.win0, 1, 1)
         else:
             plan.expand(spec, self.knots, self.win0, 1, 1)
         plan.init_state(self.win0, self.pp)
         for c, t0 in enumerate(self.starts):
             ns = min(self.chunk, self.simlen - t0 + 1)
             if self.plan_order:
-                k0 = (t0 - 1) // SPK
-                nk = (t0 + ns - 2) // SPK + 1 - k0 + 1
-                plan.synth_knots_range(spec, self.kbuf, k0, nk, ordered=True)
-                plan.expand_range(spec, self.kbuf, k0, nk, self.win, t0, ns)
+                plan.expand_ordered(spec, self.knots, self.win, t0, ns)
             else:
                 plan.expand(spec, self.knots, self.win, t0, ns)
             plan.step(self.win, self.out, self.pp, t0, ns, out_row0=t0 - 1)
@@ -114,17 +109,18 @@ class SyntheticRun:
         if not self.forecast:
             plan.recluster()
             return
-        # previews = the hourly knots that fall into the next window, generated in the CURRENT
-        # order; field 0 is Tair, field 2 is VZ (rs_synth.h); the window starts on a knot when
-        # chunk is a multiple of SPK, else the nearest earlier knot stands in for "now"
+        # previews = the hourly knots that fall into the next window, rows of the resident knot block
+        # (point order, read through the order row); field 0 is Tair, field 2 is VZ (rs_synth.h); the
+        # window starts on a knot when chunk is a multiple of SPK, else the nearest earlier knot stands
+        # in for "now"
         ns = min(self.chunk, self.simlen - t_next + 1)
         k0 = (t_next - 1) // SPK
         k1 = (t_next + ns - 2) // SPK + 1
         nk = min(k1 - k0 + 1, 8)
-        plan.synth_knots_range(self.spec, self.kbuf, k0, nk, ordered=True)
         hours = [(self.spec.start_hour + k0 + q) % 24 for q in range(nk)]
-        plan.recluster_forecast([self.kbuf[q, 0] for q in range(nk)], [self.kbuf[q, 2] for q in range(nk)],
-                                hours, self.kbuf[0, 0], self.forecast_alpha, self.forecast_mode)
+        kn = self.knots
+        plan.recluster_forecast([kn[k0 + q, 0] for q in range(nk)], [kn[k0 + q, 2] for q in range(nk)],
+                                hours, kn[k0, 0], self.forecast_alpha, self.forecast_mode, point_order=True)
 
     def slots_of(self, c: int, points: torch.Tensor) -> torch.Tensor:
         """Columns of launch ``c``'s output window that hold the given local points."""
