@@ -150,8 +150,8 @@ def main() -> None:
     ap.add_argument("--points", type=int, default=None, help="points per GPU (implies --scaling weak)")
     ap.add_argument("--hours", type=int, default=48)
     ap.add_argument("--chunk", type=int, default=0,
-                    help="time indices per step-kernel launch; 0 = auto: 120 for >= 750 000 points on "
-                         "the GPU, 240 for smaller shards (measured, tools/exp_small.sh)")
+                    help="time indices per step-kernel launch; 0 = auto: 120 for >= 400 000 points on "
+                         "the GPU, 240 for smaller shards (measured, tools/r3_small2.sh)")
     ap.add_argument("--variant", type=int, default=0,
                     help="0 auto (by shard size: 3 below 200 000 points on the GPU, else 1), 1 register "
                          "profile, 2 LDS profile, 3 two wavefronts per 64 points")
@@ -229,7 +229,7 @@ def main() -> None:
     # points, 2 from 100 000; launches of 120 indices for a full GPU, 240 for small shards
     K = args.plans_per_gpu if args.plans_per_gpu > 0 else (4 if n >= 200_000 else 2 if n >= 100_000 else 1)
     if args.chunk <= 0:
-        args.chunk = 120 if n >= 750_000 else 240
+        args.chunk = 120 if n >= 400_000 else 240  # measured: tools/r3_small2.sh
     if args.full and n >= 750_000:  # measured (tools/r3_full3.sh): three plans, launches of 240 indices
         K = args.plans_per_gpu if args.plans_per_gpu > 0 else 3
         args.chunk = 240
