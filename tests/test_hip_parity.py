@@ -74,6 +74,28 @@ def test_chunked_equals_whole(variant):
         assert np.array_equal(whole[k], parts[k]), k
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3], ids=["reg", "lds", "duo"])
+def test_failed_points_in_every_flavour(variant):
+    """CheckValues failures (src/InputOutput.f90:45-84) at the first index, inside a launch, at a launch
+    boundary and at the last checked index, in the first and in the second half of a wavefront's
+    columns and in the ragged last workgroup: the failing index keeps its row, the rows behind it read
+    -9999.0, the point's neighbours are untouched, launch by launch (chunk 97) as in one launch."""
+    from roadsurf_amd import device
+    n, L = 300, 721
+    f = oh.synth_forcing(n, L, seed=31)
+    bad = {0: 0, 5: 96, 70: 97, 131: 350, 200: 98, 257: 719, 299: 193, 64: 194, 190: 1}
+    for pt, idx in bad.items():
+        f["tair"][pt, idx] = 250.0
+    s = abi.default_settings(L); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
+    ora, _, _ = oh.run_oracle(_oracle_kind(), f, s, p, l)
+    for chunk in (0, 97):
+        res, nfail = device.run_points(f, s, p, l, variant=variant, chunk=chunk)
+        assert nfail == len(bad)
+        _compare(res, ora, f"failed-{variant}-{chunk}")
+    for pt, idx in bad.items():
+        assert (ora["tsurf"][pt, idx + 1:] == -9999.0).all() and ora["tsurf"][pt, idx] != -9999.0
+
+
 @pytest.mark.parametrize("variant", [1, 2], ids=["reg", "lds"])
 def test_full_variant_features(variant):
     """Init-phase observation forcing, relaxation, output depth, failures."""
