@@ -123,12 +123,21 @@ __device__ __forceinline__ void div_check_note(double q, double f, double a = 0.
   }
 }
 
+/* v_rcp_f64 is good to 2^-24.4 (measured over 4e9 mantissas, tools/rcp_accuracy.hip): one Newton
+ * step leaves 2^-48.6, so the compiler's expansion takes two (error e^4).  One third-order step
+ * r(1 + e + e^2) leaves e^3 = 2^-73 - as far below the rounding of r as e^4 is - in three
+ * instructions instead of four.  (-DRS_DIV_TWO_NEWTON: the two-step form.) */
 __device__ __forceinline__ double div_bare(double a, double b) {
   double r = __builtin_amdgcn_rcp(b);
   double e = __builtin_fma(-b, r, 1.0);
+#ifdef RS_DIV_TWO_NEWTON
   r = __builtin_fma(r, e, r);
   e = __builtin_fma(-b, r, 1.0);
   r = __builtin_fma(r, e, r);
+#else
+  e = __builtin_fma(e, e, e);
+  r = __builtin_fma(r, e, r);
+#endif
   const double q = a * r;
   const double rem = __builtin_fma(-b, q, a);
   return __builtin_fma(rem, r, q);
