@@ -346,8 +346,10 @@ int rs_hip_step(RsPlan *plan, const RsForcing *f, const RsOutputs *o,
  *                      ask for a replay, until none does (`rounds` = how many, <= 25).
  * A point only ever steps the index it is due for (it remembers it), so the caller then simply
  * continues - or, if the points' windows end at different indices, re-issues - the chunks from
- * min(couplingEndI) + 1 on: points that are ahead wait.  No sky view here (that combination goes
- * through rs_hip_step).  Outputs of replayed indices are overwritten, as in the reference. */
+ * min(couplingEndI) + 1 on: points that are ahead wait.  Sky view (RsPointParams::sky_view with
+ * sin_lat, cos_lat, lon_rad, RsForcing::sw_dir, lw_net and sun rows of the window) is honoured by both
+ * calls; the write-back of rs_hip_set_writeback is not (it follows whole-series windows: rs_hip_step).
+ * Outputs of replayed indices are overwritten, as in the reference. */
 /* With plan order (rs_hip_recluster) AND coupling: rs_hip_step_cpl / rs_hip_cpl_replay can write
  * the outputs of slot s into column order[s] of the output window, i.e. in POINT order whatever
  * the slots' order is (a replay rewrites rows of earlier launches, so a per-launch buffer in slot

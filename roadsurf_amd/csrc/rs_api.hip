@@ -637,7 +637,14 @@ static int cpl_args(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const Rs
     return set_err("%s: tbottom, coupling_index and coupling_tsurf are required", who);
   if (!pl->c.use_coupling) return set_err("%s: the plan's settings have use_coupling = 0", who);
   if (pl->f32) return set_err("%s: coupling needs the fp64 flavour", who);
-  if (pp->sky_view) return set_err("%s: sky view with coupling runs through rs_hip_step (whole series)", who);
+  if (pp->sky_view) {
+    if (!pp->sin_lat || !pp->cos_lat || !pp->lon_rad || !f->sw_dir || !f->lw_net || !f->sun)
+      return set_err("%s: sky view needs sin_lat, cos_lat, lon_rad, sw_dir, lw_net and sun", who);
+    if (f->hour_pstride) return set_err("%s: sky view needs a time axis shared by all points", who);
+    if (pl->wb.sw_dir)
+      return set_err("%s: the write-back of the sky-view edits follows whole-series windows: use "
+                     "rs_hip_step", who);
+  }
   if (pl->c.use_relaxation && pp->tair_relax && (!pp->vz_relax || !pp->rh_relax || !pp->initlen))
     return set_err("%s: relaxation needs tair_relax, vz_relax, rh_relax and initlen", who);
   if (!o || !o->tsurf || !o->snow || !o->water || !o->ice || !o->deposit || !o->ice2)
@@ -683,7 +690,7 @@ int rs_hip_cpl_replay(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const 
     if (strcmp(e, "general") == 0) lockstep = false;
     if (strcmp(e, "lockstep") == 0) lockstep = true;
   }
-  if ((int64_t)t0 + nsteps - 1 >= pl->c.SimLen || pp->sky_view) lockstep = false;
+  if ((int64_t)t0 + nsteps - 1 >= pl->c.SimLen) lockstep = false;
   {
     /* the window must cover [couplingStartI, couplingEndI + 1] of every point that replays: the rewind
      * reads the forcing of the index behind the window end (CheckValues, Simulation.f90:59-66), and a

@@ -1093,10 +1093,11 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
   /* Tile of points: large enough to fill the chip (256 CUs x 4 workgroups of 256 points is
    * 262144 points per round).  With coupling the windows hold the whole series (a point
    * replays its coupling window), so the tile follows from a 64 GB window budget. */
-  /* Coupling without sky view runs time-chunked too (rs_hip_step_cpl / rs_hip_cpl_replay): lock-step
+  /* Coupling runs time-chunked too (rs_hip_step_cpl / rs_hip_cpl_replay): lock-step
    * chunks that park a point behind its coupling window, replay rounds over a window-sized block,
-   * lock-step chunks again.  Coupling WITH sky view keeps the whole series in one window. */
-  const bool cpl_chunked = coupled && !skyview && !getenv("ROADSURF_HIP_CPL_WHOLE");
+   * lock-step chunks again - with sky view too (in natural order: the per-point geometry is not
+   * gathered into a plan order). */
+  const bool cpl_chunked = coupled && !getenv("ROADSURF_HIP_CPL_WHOLE");
   int64_t Pdef = 524288;
   if (coupled && !cpl_chunked) {
     Pdef = (int64_t)(64e9 / ((double)L * NFLD * sizeof(double)));

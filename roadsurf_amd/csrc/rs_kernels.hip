@@ -495,7 +495,6 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
   static_assert(FULL || !SKY, "sky view belongs to the FULL feature set");
   static_assert(FULL || !CPL, "coupling belongs to the FULL feature set");
   static_assert(CPL || !REPLAY, "replays belong to coupling");
-  static_assert(!(REPLAY && SKY), "sky view with coupling runs in the general kernel");
   KernArgs ka = kernargs();
   const uint32_t lane = REPLAY ? point : threadIdx.x;
   const int64_t row0 = REPLAY ? 0 : (int64_t)blockIdx.x * kBlock; /* first point of this workgroup */
@@ -642,8 +641,15 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
         if (check_values(c, chk, s.tsurf, FULL && ka->f.tdew != nullptr)) fail_at(i);
       }
       if (SKY) {
-        if (sky_on && (sw_dir < R4(-0.1) || sw_dir > R4(4000.0) || lw_net < R4(-1000.0) ||
-                       lw_net > R4(1000.0)))
+        if (REPLAY && i == cpl_cs) {
+          /* the rewind: CheckValues has just seen the index behind the window end (above) */
+          if (sky_on) {
+            const int64_t off = (int64_t)(cpl_ce + 1 - t0) * ka->f.t_stride + row0 + lane;
+            const double sd = ka->f.sw_dir[off], ln = ka->f.lw_net[off];
+            if (sd < R4(-0.1) || sd > R4(4000.0) || ln < R4(-1000.0) || ln > R4(1000.0)) fail_at(cpl_ce + 1);
+          }
+        } else if (sky_on && (sw_dir < R4(-0.1) || sw_dir > R4(4000.0) || lw_net < R4(-1000.0) ||
+                              lw_net > R4(1000.0)))
           fail_at(i);                           /* src/InputOutput.f90:68-74 */
         if (sw_dir > f.sw) sw_dir = f.sw;       /* :75-77 */
       }
@@ -673,9 +679,9 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
             T.set(j, st[(int64_t)(RS_ST_CPL_SAVE_TMP0 + j - 1) * np + p]);
           }
           stale_now = true;
-          /* short-wave scaling by day, long-wave by night (:68-76; no sky view here) */
+          /* short-wave scaling by day, long-wave by night - and always with sky view (:68-76) */
           const double radcoeff = st[(int64_t)RS_ST_CPL_RADCOEFF * np + p];
-          if (f.sw > f.lw) {
+          if (f.sw > f.lw && !(SKY && sky_on)) {
             r_swcof = radcoeff;
             r_lwcof = R4(1.0);
           } else {
@@ -1350,7 +1356,11 @@ __global__ void __launch_bounds__(kBlock, 3) step_kernel_sky(const StepArgs a) {
 }
 
 /* FULL feature set + coupling in lock step (time_loop<CPL>): everything of a coupled run except
- * the replays.  LDS profile (any NLayers). */
+ * the replays.  LDS profile (any NLayers).  SKY: with the sky-view radiation of the points that have
+ * one (src/ModRadiation.f90:7-73) - the forcing windows are read-only here, so what the reference
+ * saves and restores of SW / SW_dir / LW around a window (src/Coupling.f90:204-208,249-253) is simply
+ * the window as it stands. */
+template <bool SKY>
 __global__ void __launch_bounds__(kBlock, 3) step_kernel_cpl(const StepArgs a) {
   extern __shared__ double lds[]; /* [NLayers][kBlock] */
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
@@ -1362,7 +1372,7 @@ __global__ void __launch_bounds__(kBlock, 3) step_kernel_cpl(const StepArgs a) {
   Scalars s;
   int32_t score = 0;
   load_state<true>(a.state, a.np_pad, p, T, s);
-  time_loop<true, LdsProfile, false, true, true>(mt, T, s, score);
+  time_loop<true, LdsProfile, SKY, true, true>(mt, T, s, score);
   store_state<true>(a.state, a.np_pad, p, T, s);
   a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s); /* parked lanes: cheap */
 }
@@ -1406,6 +1416,7 @@ __global__ void __launch_bounds__(kBlock, W) step_kernel_cpl_replay_h(const Step
 }
 
 /* One replay round in lock step over the compacted list (time_loop<REPLAY>). */
+template <bool SKY>
 __global__ void __launch_bounds__(kBlock, 3) step_kernel_cpl_replay(const StepArgs a) {
   extern __shared__ double lds[]; /* [NLayers][kBlock] */
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
@@ -1418,7 +1429,7 @@ __global__ void __launch_bounds__(kBlock, 3) step_kernel_cpl_replay(const StepAr
   Scalars s;
   int32_t score = 0;
   load_state<true>(a.state, a.np_pad, p, T, s);
-  time_loop<true, LdsProfile, false, false, true, true>(mt, T, s, score, (uint32_t)p);
+  time_loop<true, LdsProfile, SKY, false, true, true>(mt, T, s, score, (uint32_t)p);
   store_state<true>(a.state, a.np_pad, p, T, s);
 }
 
@@ -1874,9 +1885,10 @@ hipError_t rs_launch_step_cpl(const rs::StepArgs &a, int NL, hipStream_t stream)
    * registers was twice as slow (spills) */
   const int m = cpl_profile_mode(NL);
   const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
-  if (m == 4) hipLaunchKernelGGL((rs::step_kernel_cpl_h<4>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
+  if (a.pp.sky_view) hipLaunchKernelGGL(rs::step_kernel_cpl<true>, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
+  else if (m == 4) hipLaunchKernelGGL((rs::step_kernel_cpl_h<4>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
   else if (m == 3) hipLaunchKernelGGL((rs::step_kernel_cpl_h<3>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
-  else hipLaunchKernelGGL(rs::step_kernel_cpl, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
+  else hipLaunchKernelGGL(rs::step_kernel_cpl<false>, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
   return hipGetLastError();
 }
 
@@ -1885,9 +1897,10 @@ hipError_t rs_launch_step_cpl_replay(const rs::StepArgs &a, int NL, hipStream_t 
   const int m = cpl_profile_mode(NL);
   const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
   const dim3 g = grid_for(a.cpl_nlist);
-  if (m == 4) hipLaunchKernelGGL((rs::step_kernel_cpl_replay_h<4>), g, dim3(RS_BLOCK), 0, stream, a);
+  if (a.pp.sky_view) hipLaunchKernelGGL(rs::step_kernel_cpl_replay<true>, g, dim3(RS_BLOCK), lds, stream, a);
+  else if (m == 4) hipLaunchKernelGGL((rs::step_kernel_cpl_replay_h<4>), g, dim3(RS_BLOCK), 0, stream, a);
   else if (m == 3) hipLaunchKernelGGL((rs::step_kernel_cpl_replay_h<3>), g, dim3(RS_BLOCK), 0, stream, a);
-  else hipLaunchKernelGGL(rs::step_kernel_cpl_replay, g, dim3(RS_BLOCK), lds, stream, a);
+  else hipLaunchKernelGGL(rs::step_kernel_cpl_replay<false>, g, dim3(RS_BLOCK), lds, stream, a);
   return hipGetLastError();
 }
 

@@ -411,7 +411,7 @@ def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputPara
         pp = plan.point_params(tb)
     out = OutputWindow.empty(L, npad, dev)
     plan.init_state(win, pp)
-    if coupled and chunk and not sky_on:
+    if coupled and chunk:
         # time-chunked coupling: lock-step chunks up to the last coupling-window end, the replay
         # rounds over the window block, then the chunks from the first window end on (points whose
         # window ends later wait there; include/roadsurf.h, rs_hip_step_cpl)

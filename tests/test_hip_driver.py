@@ -87,16 +87,19 @@ def test_read_input_edge_cases_match_checker():
             _compare_read_input(g, o, 3)
 
 
-@pytest.mark.parametrize("mode", ["plain", "relaxation", "coupling", "skyview"])
-def test_run_matches_checker_bitwise(mode):
+@pytest.mark.parametrize("mode", ["plain", "relaxation", "coupling", "skyview", "skyview_coupling"])
+def test_run_matches_checker_bitwise(mode, monkeypatch):
     n = 384
     src, L, t0, tf = dh.scenario(n, hours=12, seed=23)
     kw = {"plain": dict(), "relaxation": dict(use_relaxation=1),
-          "coupling": dict(use_relaxation=1, use_coupling=1), "skyview": dict(use_relaxation=1)}[mode]
+          "coupling": dict(use_relaxation=1, use_coupling=1), "skyview": dict(use_relaxation=1),
+          "skyview_coupling": dict(use_relaxation=1, use_coupling=1)}[mode]
+    if mode == "skyview_coupling":  # launch boundaries inside the coupling windows
+        monkeypatch.setenv("ROADSURF_HIP_CHUNK_STEPS", "97")
     s = _settings(L, outputStep=20, **kw)
     p = abi.default_parameters()
     local, hz = None, None
-    if mode == "skyview":
+    if mode.startswith("skyview"):
         rs = np.random.RandomState(3)
         local = []
         for i in range(n):
@@ -106,7 +109,7 @@ def test_run_matches_checker_bitwise(mode):
             local.append(lp)
         hz = rs.uniform(0, 25, (n, 360))
     g = driver.run(src, s, p, t0, tf, local=local, horizons=hz)
-    o = dh.oracle_run(_kind(mode == "coupling"), src, s, p, t0, tf, local=local, horizons=hz)
+    o = dh.oracle_run(_kind(mode.endswith("coupling")), src, s, p, t0, tf, local=local, horizons=hz)
     assert g["step"] == o["step"] == 40
     assert np.array_equal(g["status"], o["status"])
     assert np.array_equal(g["missing_index"], o["missing_index"])
@@ -119,8 +122,8 @@ def test_run_matches_checker_bitwise(mode):
     for q in range(n):
         for f in LP_FIELDS:
             assert getattr(g["local"][q], f) == getattr(o["local"][q], f), (q, f)
-    if mode == "coupling":
-        base = driver.run(src, _settings(L, outputStep=20, use_relaxation=1), p, t0, tf)
+    if mode.endswith("coupling"):
+        base = driver.run(src, _settings(L, outputStep=20, use_relaxation=1), p, t0, tf, local=local, horizons=hz)
         moved = (np.abs(base["tsurf"] - g["tsurf"]).max(1) > 1e-3)[~rejected].sum()
         assert moved > (~rejected).sum() // 2     # coupling really acts
 

@@ -78,6 +78,35 @@ def test_sky_view_with_coupling_and_c_abi():
         assert np.array_equal(out[k], ora[k]), k
 
 
+@pytest.mark.parametrize("chunk", [97, 400])
+def test_sky_view_with_coupling_time_chunked(chunk):
+    """Sky view and coupling together through the lock-step kernels (rs_hip_step_cpl + the replay rounds
+    of rs_hip_cpl_replay, time_loop<SKY, CPL>): coupling windows that end at different indices, points
+    with and without a sky view, launch boundaries inside the windows - against the reference."""
+    from roadsurf_amd import device
+    n, SL = 200, 1441
+    f, ls = _sky_case(n, SL, 11, summer=True)
+    p = abi.default_parameters()
+    base, _, _ = oh.run_oracle("port", f, abi.default_settings(SL), p, ls)
+    rs = np.random.RandomState(3)
+    for i, li in enumerate(ls):
+        ce = int(rs.choice([700, 900, 905]))
+        li.couplingIndexI = ce; li.InitLenI = ce
+        li.couplingTsurf = float(base["tsurf"][i, ce - 1] + rs.choice([0.0, 1.0, -2.0, 5.0]))
+    f["tsurfobs"][:, :] = base["tsurf"] + 0.2
+    s = abi.default_settings(SL); s.use_coupling = 1
+    kind = "ref_cpl" if os.path.exists(oh.REF_CPL_SO) else "port"
+    ora, _, _ = oh.run_oracle(kind, f, s, p, ls)
+    whole, _ = device.run_points(f, s, p, ls)
+    parts, _ = device.run_points(f, s, p, ls, chunk=chunk)
+    for k in oh.F64_OUT:
+        assert np.array_equal(whole[k], ora[k]), k
+        assert np.array_equal(parts[k], ora[k]), k
+    off = abi.default_settings(SL)
+    plain, _, _ = oh.run_oracle("port", f, off, p, ls)
+    assert np.abs(plain["tsurf"] - ora["tsurf"]).max() > 0.3  # coupling really acts on this case
+
+
 def _batch_arrays(g, out, n):
     ips = (abi.InputPointers * n)(); ops = (abi.OutputPointers * n)(); keep = []
     for pt in range(n):

@@ -1,6 +1,6 @@
 """Rate of the raw-series boundary (rs_driver_run): hourly forecast + 10-minute observations in,
 hourly outputs back, everything else on the GPU.  PCIe-inclusive, host arrays pageable.
-usage: python tools/bench_driver_path.py [n_points] [hours] [mode: plain|relax|coupling|skyview]"""
+usage: python tools/bench_driver_path.py [n_points] [hours] [mode: plain|relax|coupling|skyview|skycoupling]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
@@ -32,14 +32,14 @@ ob = dict(tair=series(nt_ob, 600, -12, 6, 1.0), rhz=np.clip(series(nt_ob, 600, 7
           vz=np.abs(series(nt_ob, 600, 1, 8, 1.0)) + 0.2, tsurfobs=series(nt_ob, 600, -10, 4, 1.0))
 src = [driver.RawSource(fc_t, fc, False), driver.RawSource(ob_t, ob, True)]
 s = abi.default_settings(L)
-s.use_relaxation = 1 if mode in ("relax", "coupling", "skyview") else 0
-s.use_coupling = 1 if mode == "coupling" else 0
+s.use_relaxation = 1 if mode in ("relax", "coupling", "skyview", "skycoupling") else 0
+s.use_coupling = 1 if mode in ("coupling", "skycoupling") else 0
 p = abi.default_parameters()
 cal = driver.calendar(START, L, 30)
 raw_bytes = sum(a.nbytes for d in (fc, ob) for a in d.values())
 local = driver._locals(n, None)
 hz = None
-if mode == "skyview":
+if mode in ("skyview", "skycoupling"):
     fc["sw_dir"] = 0.6 * fc["sw"]
     fc["lw_net"] = np.full_like(fc["lw"], -40.0)
     sv = rs.uniform(0.3, 1.0, n)
