@@ -33,6 +33,9 @@
 #ifndef RS_CPL_PROFILE_DEFAULT
 #define RS_CPL_PROFILE_DEFAULT 3 /* profile of the lock-step coupling kernels: see rs_launch_step_cpl */
 #endif
+#ifndef RS_SKY_PROFILE_DEFAULT
+#define RS_SKY_PROFILE_DEFAULT 4 /* profile of the lock-step sky-view kernel: see rs_launch_step_sky */
+#endif
 #ifndef RS_REGIME_WINDOW
 #define RS_REGIME_WINDOW 30 /* indices at the end of a launch that define a point's regime
                                (rs_hip_recluster; 8 ... 90 measured equal) */
@@ -1355,6 +1358,25 @@ __global__ void __launch_bounds__(kBlock, 3) step_kernel_sky(const StepArgs a) {
   a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
 }
 
+/* The same for NLayers = 15 with the hybrid profile at W waves per SIMD (rs_launch_step_sky). */
+template <int W>
+__global__ void __launch_bounds__(kBlock, W) step_kernel_sky_h(const StepArgs a) {
+  __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
+  __shared__ double prof_lds[(15 - RS_HYBRID_REG) * kBlock];
+  const MathTab mt = fill_math_tables(math_lds);
+  __syncthreads();
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= a.npoints) return;
+  HybridProfile<15, RS_HYBRID_REG> T;
+  T.col = prof_lds + threadIdx.x;
+  Scalars s;
+  int32_t score = 0;
+  load_state<true>(a.state, a.np_pad, p, T, s);
+  time_loop<true, HybridProfile<15, RS_HYBRID_REG>, true>(mt, T, s, score);
+  store_state<true>(a.state, a.np_pad, p, T, s);
+  a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
+}
+
 /* FULL feature set + coupling in lock step (time_loop<CPL>): everything of a coupled run except
  * the replays.  LDS profile (any NLayers).  SKY: with the sky-view radiation of the points that have
  * one (src/ModRadiation.f90:7-73) - the forcing windows are read-only here, so what the reference
@@ -1867,7 +1889,14 @@ hipError_t rs_launch_forecast_keys(const rs::ForecastArgs &a, hipStream_t stream
 
 hipError_t rs_launch_step_sky(const rs::StepArgs &a, int NL, hipStream_t stream) {
   const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
-  hipLaunchKernelGGL(rs::step_kernel_sky, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
+  /* ROADSURF_HIP_SKY_PROFILE (tuning): 0 LDS profile at 3 waves/SIMD (any NLayers), 3 / 4 hybrid profile
+   * at that many waves (NLayers = 15).  Measured (rs_driver_run, sky view, 262 144 points in four blocks):
+   * 6.9e9 / 7.1e9 / 7.4e9 */
+  const char *e = getenv("ROADSURF_HIP_SKY_PROFILE");
+  const int m = (NL == 15) ? (e ? atoi(e) : RS_SKY_PROFILE_DEFAULT) : 0;
+  if (m == 4) hipLaunchKernelGGL((rs::step_kernel_sky_h<4>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
+  else if (m == 3) hipLaunchKernelGGL((rs::step_kernel_sky_h<3>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
+  else hipLaunchKernelGGL(rs::step_kernel_sky, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
   return hipGetLastError();
 }
 
