@@ -56,7 +56,6 @@ struct RsPlan {
   int32_t *order = nullptr, *order_alt = nullptr;
   double *state_alt = nullptr;
   void *sort_tmp = nullptr;
-  uint32_t *sort_ticket = nullptr;
   size_t sort_tmp_bytes = 0;
   uint32_t *sort_keys = nullptr; /* [4][np_pad]: keys in/out, slots in/out */
   int variant = RS_VARIANT_AUTO;
@@ -272,7 +271,6 @@ void rs_hip_plan_destroy(RsPlan *pl) {
   if (pl->order_alt) (void)hipFree(pl->order_alt);
   if (pl->state_alt) (void)hipFree(pl->state_alt);
   if (pl->sort_tmp) (void)hipFree(pl->sort_tmp);
-  if (pl->sort_ticket) (void)hipFree(pl->sort_ticket);
   if (pl->sort_keys) (void)hipFree(pl->sort_keys);
   if (pl->cpl_flags) (void)hipFree(pl->cpl_flags);
   if (pl->cpl_list) (void)hipFree(pl->cpl_list);
@@ -306,9 +304,6 @@ static int recluster_buffers(RsPlan *pl) {
     pl->sort_tmp_bytes = std::max(rs_cluster_scratch_bytes(pl->npoints),
                                   rs_cluster_count_scratch_bytes(pl->npoints, 12));
     HIP_OK(hipMalloc(&pl->sort_tmp, pl->sort_tmp_bytes ? pl->sort_tmp_bytes : 8));
-    /* the counting sort's ticket counter: starts at zero, the kernel that uses it leaves it at zero */
-    HIP_OK(hipMalloc(&pl->sort_ticket, 8));
-    HIP_OK(hipMemsetAsync(pl->sort_ticket, 0, 8, pl->stream));
   }
   return 0;
 }
@@ -349,7 +344,7 @@ int rs_hip_recluster_forecast(RsPlan *pl, const RsPreview *pv) {
   HIP_OK(rs_launch_forecast_keys(a, pl->stream));
   if (a.compact)
     HIP_OK(rs_cluster_count_sort(pl->np_pad, pl->npoints, bits, pl->sort_keys, pl->sort_tmp,
-                                 pl->sort_tmp_bytes, pl->sort_ticket, pl->stream));
+                                 pl->sort_tmp_bytes, pl->stream));
   else
     HIP_OK(rs_cluster_sort_keys(pl->np_pad, pl->npoints, pl->sort_keys, pl->sort_tmp, pl->sort_tmp_bytes,
                                 pl->stream));

@@ -116,9 +116,9 @@ hipError_t rs_cluster_sort(const double *state, bool f32, int64_t np_pad, int64_
  * sorts it, in three small kernels instead of the 17 of the library's merge sort:
  *   cs_hist     a histogram per tile of CS_TILE keys (LDS atomics): H[tile][bin]
  *   cs_binscan  one lane per bin: exclusive prefix of its counts over the tiles, in place, and the
- *               bin's total (every access a coalesced row of H); the last workgroup to finish scans
- *               the totals: where every bin starts
- *   cs_scatter  one wavefront per tile: start of (bin, tile) = the bin's start + its tile prefix;
+ *               bin's total (every access a coalesced row of H)
+ *   cs_scatter  one wavefront per tile: scans the bins' totals (where every bin starts), start of
+ *               (bin, tile) = the bin's start + its tile prefix;
  *               then it walks its keys in order, and the rank of a key among the equal keys of
  *               its 64 is a popcount of ballots - equal keys keep their order (stable, deterministic:
  *               no atomic decides a position, no workgroup waits for another)
@@ -150,41 +150,18 @@ __global__ void __launch_bounds__(256) cs_hist_kernel(const uint32_t *__restrict
 }
 
 /* one lane per bin: walks the tiles in order (coalesced rows of H[tile][bin]), leaves the bin's
- * exclusive prefix over the tiles in place and its total in T[bin].  The workgroup that finishes last
- * (a ticket counter behind a fence; nobody waits for anybody) turns the totals into the bins' starts:
- * the exclusive scan of T, 64 consecutive bins per lane - what a kernel of its own did before. */
-__global__ void __launch_bounds__(64) cs_binscan_kernel(uint32_t *H, uint32_t *T, int nbins, int ntiles,
-                                                        uint32_t *ticket) {
-  const uint32_t lane = threadIdx.x;
-  const int bin = (int)blockIdx.x * 64 + (int)lane;
-  if (bin < nbins) {
-    uint32_t run = 0u;
+ * exclusive prefix over the tiles in place and its total in T[bin] */
+__global__ void __launch_bounds__(64) cs_binscan_kernel(uint32_t *H, uint32_t *T, int nbins, int ntiles) {
+  const int bin = (int)blockIdx.x * 64 + (int)threadIdx.x;
+  if (bin >= nbins) return;
+  uint32_t run = 0u;
 #pragma unroll 8
-    for (int t = 0; t < ntiles; ++t) {
-      const uint32_t v = H[(int64_t)t * nbins + bin];
-      H[(int64_t)t * nbins + bin] = run;
-      run += v;
-    }
-    T[bin] = run;
-  }
-  __threadfence();
-  uint32_t mine = 0u;
-  if (lane == 0u) mine = atomicAdd(ticket, 1u);
-  mine = (uint32_t)__shfl((int)mine, 0, 64);
-  if (mine != gridDim.x - 1u) return;
-  __threadfence();
-  volatile uint32_t *Tv = T; /* the other workgroups' totals: not through this CU's caches */
-  const int per = (nbins + 63) / 64;
-  const int b0 = (int)lane * per;
-  uint32_t local = 0u;
-  for (int b = b0; b < b0 + per && b < nbins; ++b) local += Tv[b];
-  uint32_t run = wave_incl_scan(local, lane) - local;
-  for (int b = b0; b < b0 + per && b < nbins; ++b) {
-    const uint32_t v = Tv[b];
-    Tv[b] = run;
+  for (int t = 0; t < ntiles; ++t) {
+    const uint32_t v = H[(int64_t)t * nbins + bin];
+    H[(int64_t)t * nbins + bin] = run;
     run += v;
   }
-  if (lane == 0u) *ticket = 0u; /* ready for the next sort on this stream */
+  T[bin] = run;
 }
 
 __global__ void __launch_bounds__(64) cs_scatter_kernel(const uint32_t *__restrict__ keys, int64_t n,
@@ -196,9 +173,20 @@ __global__ void __launch_bounds__(64) cs_scatter_kernel(const uint32_t *__restri
   const int nbins = 1 << nbits;
   const uint32_t lane = threadIdx.x;
   const int64_t base = (int64_t)blockIdx.x * CS_TILE;
-  /* where every bin starts for this tile: the bin's start (cs_binscan's last workgroup) + its prefix over the tiles before
-   * this one (cs_binscan); coalesced rows */
-  for (int b = (int)lane; b < nbins; b += 64) cs_cur[b] = T[b] + H[(int64_t)blockIdx.x * nbins + b];
+  /* where every bin starts for this tile: the bin's start - the exclusive scan of the bins' totals,
+   * which every wavefront forms for itself, a row of 64 bins at a time (64 independent coalesced loads,
+   * a wavefront scan per row and the carry of the rows before: cheaper than a launch of its own, and no
+   * workgroup waits for another) - plus its prefix over the tiles before this one (cs_binscan) */
+  {
+    uint32_t carry = 0u;
+    for (int r = 0; r < nbins; r += 64) {
+      const int b = r + (int)lane;
+      const uint32_t t = b < nbins ? T[b] : 0u;
+      const uint32_t incl = wave_incl_scan(t, lane);
+      if (b < nbins) cs_cur[b] = carry + incl - t + H[(int64_t)blockIdx.x * nbins + b];
+      carry += (uint32_t)__shfl((int)incl, 63, 64);
+    }
+  }
   __syncthreads();
   /* the keys of CS_BATCH rounds are fetched together (a load per round would put 64 memory round trips
    * behind one another), but no more: the kernel has to fit beside the step kernels' wavefronts, which
@@ -248,8 +236,8 @@ size_t rs_cluster_count_scratch_bytes(int64_t npoints, int nbits) {
 
 /* keys in scratch[0..npoints) (values < 2^nbits), permutation out to scratch + 3*np_pad */
 hipError_t rs_cluster_count_sort(int64_t np_pad, int64_t npoints, int nbits, uint32_t *scratch, void *tmp,
-                                 size_t tmp_bytes, uint32_t *ticket, hipStream_t stream) {
-  if (nbits < 1 || nbits > 12 || tmp_bytes < rs_cluster_count_scratch_bytes(npoints, nbits) || !ticket)
+                                 size_t tmp_bytes, hipStream_t stream) {
+  if (nbits < 1 || nbits > 12 || tmp_bytes < rs_cluster_count_scratch_bytes(npoints, nbits))
     return hipErrorInvalidValue;
   const int nbins = 1 << nbits;
   const int ntiles = (int)((npoints + CS_TILE - 1) / CS_TILE);
@@ -257,10 +245,7 @@ hipError_t rs_cluster_count_sort(int64_t np_pad, int64_t npoints, int nbits, uin
   uint32_t *T = H + (size_t)nbins * ntiles;
   hipLaunchKernelGGL(cs_hist_kernel, dim3(ntiles), dim3(256), nbins * sizeof(uint32_t), stream, scratch,
                      npoints, nbins, ntiles, H);
-  /* ticket: one zeroed word of the plan's own (not in tmp, which the library sort scribbles over),
-   * reset by the kernel itself */
-  hipLaunchKernelGGL(cs_binscan_kernel, dim3((nbins + 63) / 64), dim3(64), 0, stream, H, T, nbins, ntiles,
-                     ticket);
+  hipLaunchKernelGGL(cs_binscan_kernel, dim3((nbins + 63) / 64), dim3(64), 0, stream, H, T, nbins, ntiles);
   hipLaunchKernelGGL(cs_scatter_kernel, dim3(ntiles), dim3(64), nbins * sizeof(uint32_t), stream, scratch,
                      npoints, nbits, ntiles, H, T, scratch + 3 * np_pad);
   return hipGetLastError();

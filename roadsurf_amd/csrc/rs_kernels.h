@@ -126,7 +126,7 @@ hipError_t rs_cluster_sort_keys(int64_t np_pad, int64_t npoints, uint32_t *scrat
 /* the plan's own stable counting sort for keys of at most 12 bits (rs_cluster.hip) */
 size_t rs_cluster_count_scratch_bytes(int64_t npoints, int nbits);
 hipError_t rs_cluster_count_sort(int64_t np_pad, int64_t npoints, int nbits, uint32_t *scratch, void *tmp,
-                                 size_t tmp_bytes, uint32_t *ticket, hipStream_t stream);
+                                 size_t tmp_bytes, hipStream_t stream);
 /* significant bits of the forecast key for a field list (RsPreview::mode) */
 int rs_forecast_key_bits(int32_t mode);
 hipError_t rs_cluster_apply(const double *state_src, double *state_dst, bool f32,
