@@ -152,6 +152,8 @@ def main() -> None:
     ap.add_argument("--chunk", type=int, default=0,
                     help="time indices per step-kernel launch; 0 = auto: 120 for >= 400 000 points on "
                          "the GPU, 240 for smaller shards (measured, tools/r3_small2.sh)")
+    ap.add_argument("--control", choices=["gloo", "nccl"], default="gloo",
+                    help="backend of the barriers / MAX / checksum SUM between ranks (no data-path collective)")
     ap.add_argument("--variant", type=int, default=0,
                     help="0 auto (by shard size: 3 below 200 000 points on the GPU, else 1), 1 register "
                          "profile, 2 LDS profile, 3 two wavefronts per 64 points")
@@ -205,11 +207,16 @@ def main() -> None:
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
-        if ndev >= world:
-            dist.init_process_group("nccl", device_id=dev)  # RCCL; used for barrier + MAX only
-        else:  # rehearsal: more ranks than GPUs on this box -> ranks share cards, gloo for control
-            print(f"[bench] {world} ranks on {ndev} GPU(s): sharing devices, gloo control plane",
-                  file=sys.stderr)
+        # The data path has no collective (points are independent: SURVEY.md 8e); what the ranks
+        # exchange is the control plane of this script - the barriers around the timed region, the MAX
+        # of the elapsed times, the SUM of the checksums.  gloo by default: it is what the two-rank test
+        # exercises (tests/test_hip_config4.py) and it cannot fail on the GPU side; --control nccl
+        # runs the same three calls over RCCL.
+        if args.control == "nccl" and ndev >= world:
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            if ndev < world:  # rehearsal: more ranks than GPUs on this box -> ranks share cards
+                print(f"[bench] {world} ranks on {ndev} GPU(s): sharing devices", file=sys.stderr)
             dist.init_process_group("gloo")
 
     scaling = args.scaling or ("weak" if args.points is not None else "strong")
