@@ -437,7 +437,8 @@ int rs_hip_expand_forcing_on(RsPlan *plan, const RsSynthSpec *spec,
                              const RsForcing *f, int32_t t0, int32_t nsteps,
                              void *stream);
 
-/* Test hook: y[i] = device exp (fn 0) / log (fn 1) of x[i], device pointers
+/* Test hook: y[i] = device exp (fn 0) / log (fn 1) / bare square root (fn 3) of x[i], or the bare
+ * division x[i] / x[n + i] (fn 2; x holds 2n values); device pointers
  * (roadsurf_amd/csrc/rs_math.hpp; tests/test_hip_math.py). */
 int rs_hip_test_math(RsPlan *plan, int32_t fn, int64_t n, const double *x, double *y);
 

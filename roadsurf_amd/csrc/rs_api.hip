@@ -856,7 +856,7 @@ int rs_hip_division_mode(void) {
 }
 
 int rs_hip_test_math(RsPlan *pl, int32_t fn, int64_t n, const double *x, double *y) {
-  if (!pl || !x || !y || n < 1 || fn < 0 || fn > 1) return set_err("rs_hip_test_math: bad arguments");
+  if (!pl || !x || !y || n < 1 || fn < 0 || fn > 3) return set_err("rs_hip_test_math: bad arguments");
   HIP_OK(hipSetDevice(pl->device));
   HIP_OK(rs_launch_math_test(fn, n, x, y, pl->stream));
   return 0;

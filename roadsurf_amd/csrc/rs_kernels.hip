@@ -1638,7 +1638,8 @@ __global__ void __launch_bounds__(kBlock) expand_kernel(const ExpandArgs a) {
       ((int32_t *)a.f.hour)[t - (a.t0 - 1)] = rs_sy_hour(t + 1, a.spk, a.start_hour);
 }
 
-/* Unit-test kernel for rs_exp / rs_log (tests/test_hip_math.py). fn: 0 exp, 1 log. */
+/* Unit-test kernel for rs_math.hpp (tests/test_hip_math.py). fn: 0 exp, 1 log, 2 the bare division
+ * x[i] / x[n + i], 3 the bare square root. */
 __global__ void __launch_bounds__(kBlock) math_test_kernel(int fn, int64_t n, const double *x,
                                                            double *y) {
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
@@ -1646,7 +1647,9 @@ __global__ void __launch_bounds__(kBlock) math_test_kernel(int fn, int64_t n, co
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  y[i] = fn == 0 ? rs_exp(mt, x[i]) : rs_log(mt, x[i]);
+  if (fn == 2) y[i] = rs_div(x[i], x[n + i]);
+  else if (fn == 3) y[i] = rs_sqrt(x[i]);
+  else y[i] = fn == 0 ? rs_exp(mt, x[i]) : rs_log(mt, x[i]);
 }
 
 /* Tdew <-> RH completion of a raw series, examples/example1/src/JsonSource.cpp:288-295 with
