@@ -1401,7 +1401,7 @@ __global__ void __launch_bounds__(kBlock, 3) step_kernel_cpl(const StepArgs a) {
 
 /* The same two kernels for NLayers = 15 with the hybrid profile (layers 1-RS_HYBRID_REG in
  * registers, the rest in LDS) at W waves per SIMD. */
-template <int W>
+template <int W, bool SKY = false>
 __global__ void __launch_bounds__(kBlock, W) step_kernel_cpl_h(const StepArgs a) {
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
   __shared__ double prof_lds[(15 - RS_HYBRID_REG) * kBlock];
@@ -1414,12 +1414,12 @@ __global__ void __launch_bounds__(kBlock, W) step_kernel_cpl_h(const StepArgs a)
   Scalars s;
   int32_t score = 0;
   load_state<true>(a.state, a.np_pad, p, T, s);
-  time_loop<true, HybridProfile<15, RS_HYBRID_REG>, false, true, true>(mt, T, s, score);
+  time_loop<true, HybridProfile<15, RS_HYBRID_REG>, SKY, true, true>(mt, T, s, score);
   store_state<true>(a.state, a.np_pad, p, T, s);
   a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
 }
 
-template <int W>
+template <int W, bool SKY = false>
 __global__ void __launch_bounds__(kBlock, W) step_kernel_cpl_replay_h(const StepArgs a) {
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
   __shared__ double prof_lds[(15 - RS_HYBRID_REG) * kBlock];
@@ -1433,7 +1433,7 @@ __global__ void __launch_bounds__(kBlock, W) step_kernel_cpl_replay_h(const Step
   Scalars s;
   int32_t score = 0;
   load_state<true>(a.state, a.np_pad, p, T, s);
-  time_loop<true, HybridProfile<15, RS_HYBRID_REG>, false, false, true, true>(mt, T, s, score, (uint32_t)p);
+  time_loop<true, HybridProfile<15, RS_HYBRID_REG>, SKY, false, true, true>(mt, T, s, score, (uint32_t)p);
   store_state<true>(a.state, a.np_pad, p, T, s);
 }
 
@@ -1917,7 +1917,8 @@ hipError_t rs_launch_step_cpl(const rs::StepArgs &a, int NL, hipStream_t stream)
    * registers was twice as slow (spills) */
   const int m = cpl_profile_mode(NL);
   const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
-  if (a.pp.sky_view) hipLaunchKernelGGL(rs::step_kernel_cpl<true>, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
+  if (a.pp.sky_view && m != 0) hipLaunchKernelGGL((rs::step_kernel_cpl_h<3, true>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
+  else if (a.pp.sky_view) hipLaunchKernelGGL(rs::step_kernel_cpl<true>, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
   else if (m == 4) hipLaunchKernelGGL((rs::step_kernel_cpl_h<4>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
   else if (m == 3) hipLaunchKernelGGL((rs::step_kernel_cpl_h<3>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
   else hipLaunchKernelGGL(rs::step_kernel_cpl<false>, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
@@ -1929,7 +1930,8 @@ hipError_t rs_launch_step_cpl_replay(const rs::StepArgs &a, int NL, hipStream_t 
   const int m = cpl_profile_mode(NL);
   const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
   const dim3 g = grid_for(a.cpl_nlist);
-  if (a.pp.sky_view) hipLaunchKernelGGL(rs::step_kernel_cpl_replay<true>, g, dim3(RS_BLOCK), lds, stream, a);
+  if (a.pp.sky_view && m != 0) hipLaunchKernelGGL((rs::step_kernel_cpl_replay_h<3, true>), g, dim3(RS_BLOCK), 0, stream, a);
+  else if (a.pp.sky_view) hipLaunchKernelGGL(rs::step_kernel_cpl_replay<true>, g, dim3(RS_BLOCK), lds, stream, a);
   else if (m == 4) hipLaunchKernelGGL((rs::step_kernel_cpl_replay_h<4>), g, dim3(RS_BLOCK), 0, stream, a);
   else if (m == 3) hipLaunchKernelGGL((rs::step_kernel_cpl_replay_h<3>), g, dim3(RS_BLOCK), 0, stream, a);
   else hipLaunchKernelGGL(rs::step_kernel_cpl_replay<false>, g, dim3(RS_BLOCK), lds, stream, a);
