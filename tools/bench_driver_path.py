@@ -1,6 +1,6 @@
 """Rate of the raw-series boundary (rs_driver_run): hourly forecast + 10-minute observations in,
 hourly outputs back, everything else on the GPU.  PCIe-inclusive, host arrays pageable.
-usage: python tools/bench_driver_path.py [n_points] [hours] [mode: plain|relax|coupling|skyview|skycoupling]"""
+usage: python tools/bench_driver_path.py [n_points] [hours] [mode: plain|relax|coupling|skyview|skycoupling] [tsurfOutputDepth]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
@@ -34,6 +34,8 @@ src = [driver.RawSource(fc_t, fc, False), driver.RawSource(ob_t, ob, True)]
 s = abi.default_settings(L)
 s.use_relaxation = 1 if mode in ("relax", "coupling", "skyview", "skycoupling") else 0
 s.use_coupling = 1 if mode in ("coupling", "skycoupling") else 0
+if len(sys.argv) > 4:  # TsurfAve at this depth below the surface instead of the top layers' mean
+    s.tsurfOutputDepth = float(sys.argv[4])
 p = abi.default_parameters()
 cal = driver.calendar(START, L, 30)
 raw_bytes = sum(a.nbytes for d in (fc, ob) for a in d.values())
