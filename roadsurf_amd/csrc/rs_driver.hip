@@ -509,18 +509,6 @@ __global__ void __launch_bounds__(RS_BLOCK) gather_params_kernel(
   }
 }
 
-/* rows of a [rows][stride] table of per-point values into slot order: dst[r][s] = src[r][order[s]]
- * (the sky-view geometry, 4 rows, and the local horizons, 360 rows) */
-__global__ void __launch_bounds__(RS_BLOCK) gather_rows_kernel(const int32_t *__restrict__ order,
-                                                               int64_t npoints, int64_t stride,
-                                                               const double *__restrict__ src,
-                                                               double *__restrict__ dst) {
-  const int64_t s = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
-  if (s >= npoints) return;
-  const int64_t r = blockIdx.y;
-  dst[r * stride + s] = src[r * stride + (int64_t)order[s]];
-}
-
 /* output rows of one launch, written in slot order, into the natural-order result */
 __global__ void __launch_bounds__(RS_BLOCK) unpermute_rows_kernel(
     const int32_t *__restrict__ order, int64_t npoints, const double *__restrict__ chunk_out,
@@ -1177,7 +1165,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     pt.lap(2);
 
     /* per-point parameters */
-    Dev d_tb, d_geo, d_hz, d_hzpt, d_geo_s, d_hz_s;
+    Dev d_tb, d_geo, d_hz, d_hzpt;
     HOK(d_tb.alloc(mp * sizeof(double)));
     hipLaunchKernelGGL(fill_f64_kernel, grid1(mp), dim3(RS_BLOCK), 0, stream, d_tb.as<double>(), mp,
                        tbottom);
@@ -1294,10 +1282,9 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
      * column (rs_hip_set_output_by_point).  Measured at 1 M points, four plans: 0.90 s against
      * 0.96 s in natural order with the history key (-12 % vector instructions in the lock-step
      * kernel), see DESIGN.md 6 for the forecast key.  ROADSURF_HIP_CLUSTER=0 switches the order
-     * off.  With sky view the per-point geometry and the 360 horizon columns are gathered into the
-     * slot order as well (gather_rows_kernel: 2.9 KB per point and re-sort, a few ms per run). */
+     * off.  Not for sky view with coupling (general kernel over the whole series: no sort key). */
     const char *ec = getenv("ROADSURF_HIP_CLUSTER");
-    const bool cluster = (!coupled || cpl_chunked) && TC < L && !(ec && atoi(ec) == 0);
+    const bool cluster = (!coupled || cpl_chunked) && !skyview && TC < L && !(ec && atoi(ec) == 0);
     const int rows_c = TC / step + 2; /* output rows one launch can produce */
     Dev d_outc, d_pp_s;
     RsOutputs oc = oo;
@@ -1320,17 +1307,6 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
         pps.coupling_index = reinterpret_cast<int32_t *>(pd + 4 * mp) + mp;
       }
       HOK(hipMemsetAsync(d_pp_s.p, 0, (size_t)mp * (2 * sizeof(int32_t) + 4 * sizeof(double)), stream));
-      if (skyview) { /* the geometry and the horizon columns travel with the slot too */
-        HOK(d_geo_s.alloc((size_t)4 * mp * sizeof(double)));
-        HOK(d_hz_s.alloc((size_t)360 * mp * sizeof(double)));
-        HOK(hipMemcpyAsync(d_geo_s.p, d_geo.p, (size_t)4 * mp * sizeof(double), hipMemcpyDeviceToDevice, stream));
-        HOK(hipMemcpyAsync(d_hz_s.p, d_hz.p, (size_t)360 * mp * sizeof(double), hipMemcpyDeviceToDevice, stream));
-        pps.sky_view = d_geo_s.as<double>();
-        pps.sin_lat = d_geo_s.as<double>() + mp;
-        pps.cos_lat = d_geo_s.as<double>() + 2 * mp;
-        pps.lon_rad = d_geo_s.as<double>() + 3 * mp;
-        pps.horizons = d_hz_s.as<double>();
-      }
     }
     /* per-point parameters into the plan's current slot order */
     auto gather_params = [&]() -> int {
@@ -1345,15 +1321,6 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
                          coupled ? pp.coupling_tsurf : nullptr,
                          coupled ? const_cast<double *>(pps.coupling_tsurf) : nullptr);
       HOK(hipGetLastError());
-      if (skyview) {
-        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((m + RS_BLOCK - 1) / RS_BLOCK), 4), dim3(RS_BLOCK),
-                           0, stream, ea.order, (int64_t)m, (int64_t)mp, (const double *)d_geo.as<double>(),
-                           d_geo_s.as<double>());
-        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((m + RS_BLOCK - 1) / RS_BLOCK), 360),
-                           dim3(RS_BLOCK), 0, stream, ea.order, (int64_t)m, (int64_t)mp,
-                           (const double *)d_hz.as<double>(), d_hz_s.as<double>());
-        HOK(hipGetLastError());
-      }
       return 0;
     };
     if (cluster)
