@@ -4,7 +4,7 @@ set -e
 export TMPDIR=/tmp
 OUT=gpurun_out/r3_cpl_trace
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 tools/bench_driver_path.py 1000000 48 coupling > $OUT/bench.log 2> $OUT/trace.err || { tail -20 $OUT/trace.err; exit 1; }
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 tools/bench_driver_path.py 1000000 48 ${MODE:-coupling} > $OUT/bench.log 2> $OUT/trace.err || { tail -20 $OUT/trace.err; exit 1; }
 grep "rep " $OUT/bench.log
 python3 - <<'PY'
 import csv, glob, collections
