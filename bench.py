@@ -24,6 +24,11 @@ data-path collective; the only collectives are the timing barrier and the MAX
 over ranks.  Default is STRONG scaling (BASELINE config 4: --total-points 1 000 000
 sharded over the GPUs); `--points N` gives every GPU N points (weak scaling).
 
+The default run (N = 1) adds short extra legs under the same clock, reported as extra keys of the
+one JSON line: `full_feature_value` (the FULL feature set on the same points) and
+`driver_path_{relax,coupling,sky}_value` (rs_driver_run from raw series in host arrays, PCIe
+inclusive); `--no-extra-legs` skips them.
+
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -187,6 +192,12 @@ def main() -> None:
                          "order-independent wrap-around sum of the bit patterns of all six outputs of every "
                          "point and index, summed over the ranks (what tests/test_hip_config4.py compares "
                          "between a one-rank and a two-rank launch)")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the short extra legs of the default run (N = 1, fp64, LEAN headline only): the FULL "
+                         "feature set on the same synthetic points (full_feature_value) and the driver data path "
+                         "rs_driver_run with relaxation / coupling / sky view (driver_path_*_value)")
+    ap.add_argument("--extra-points", type=int, default=262144,
+                    help="points of the driver-path legs (host arrays in, hourly outputs back: PCIe inclusive)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16384)
     args = ap.parse_args()
@@ -244,18 +255,22 @@ def main() -> None:
         # measured (tools/r3_duo.sh): two plans of <= 100 000 points run faster with two wavefronts per
         # 64 points; with four plans in flight one point per lane fills the chip
         args.variant = 3 if n < 200_000 else 1
-    plans, offsets = [], []
-    for j in range(K):
-        off_j, n_j = sharding.strong_shard(n, K, j)
-        st = torch.cuda.current_stream(dev) if K == 1 else torch.cuda.Stream(dev)
-        pl = device.Plan(n_j, settings, params, dev_index, stream=st)
-        if args.variant:
-            pl.set_variant(args.variant)
-        if args.f32:
-            pl.set_precision(32)
-        plans.append(pl)
-        offsets.append(offset + off_j)
-    plan = plans[0]
+    def make_plans(K, settings, variant):
+        plans, offsets = [], []
+        for j in range(K):
+            off_j, n_j = sharding.strong_shard(n, K, j)
+            st = torch.cuda.current_stream(dev) if K == 1 else torch.cuda.Stream(dev)
+            pl = device.Plan(n_j, settings, params, dev_index, stream=st)
+            if variant:
+                pl.set_variant(variant)
+            if args.f32:
+                pl.set_precision(32)
+            plans.append(pl)
+            offsets.append(offset + off_j)
+        return plans, offsets
+
+    plans, offsets = make_plans(K, settings, args.variant)
+    plans_main, offsets_main = plans, offsets
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -263,13 +278,20 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed_leg(plan_order: bool):
+    def timed_leg(plan_order: bool, plans=None, offsets=None, chunk_steps=None, full=None, steps=None,
+                  warmup=None):
         """W untimed + exactly K timed passes, barrier + synchronize on both sides, MAX over ranks."""
-        runs = [workload.SyntheticRun(pl, args.seed, args.hours, args.chunk, point_offset=o,
+        plans = plans_main if plans is None else plans
+        offsets = offsets_main if offsets is None else offsets
+        chunk_steps = args.chunk if chunk_steps is None else chunk_steps
+        full = args.full if full is None else full
+        steps = args.steps if steps is None else steps
+        warmup = args.warmup if warmup is None else warmup
+        runs = [workload.SyntheticRun(pl, args.seed, args.hours, chunk_steps, point_offset=o,
                                       plan_order=plan_order, f32=args.f32,
                                       forecast=args.sort_key == "forecast",
                                       forecast_alpha=args.forecast_alpha, forecast_mode=args.forecast_mode,
-                                      full=args.full)
+                                      full=full)
                 for pl, o in zip(plans, offsets)]
         run = runs[0]
 
@@ -278,7 +300,7 @@ def main() -> None:
             while its:  # launch c of every plan, then launch c+1 ...
                 its = [it for it in its if next(it, None) is not None]
 
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             one_pass()
         fence()
         for pl in plans:
@@ -286,9 +308,9 @@ def main() -> None:
         ref = torch.cuda.Event(enable_timing=True)
         ref.record(torch.cuda.current_stream(dev))
         torch.cuda.synchronize(dev)
-        clk = ClockProbe(torch, dev, dev_index, args.steps)
+        clk = ClockProbe(torch, dev, dev_index, steps)
         t_start = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             one_pass()
             clk.probe()  # runs beside the launches still in flight
         fence()
@@ -352,6 +374,59 @@ def main() -> None:
     units_per_pass_job = total_points * simlen          # whole job, all ranks
     units_per_pass_rank = n * simlen
     value = units_per_pass_job * args.steps / elapsed
+
+    # ---- extra legs of the default run: the rows behind the headline, under the same clock ----------
+    # (N = 1, fp64, LEAN headline only; each a few seconds; --no-extra-legs skips them)
+    extra = {}
+    if world == 1 and not (args.no_extra_legs or args.f32 or args.full) and cluster:
+        t_x = time.perf_counter()
+        # (1) the FULL feature set (Tdew / TsurfObs / depth streams, 6 h initialization phase, relaxation
+        # behind it) on the same synthetic points: what `bench.py --full` reports as its headline
+        s_full = abi.default_settings(simlen)
+        s_full.use_relaxation = 1
+        Kf, chunk_f = (3, 240) if n >= 750_000 else (K, args.chunk)  # measured: tools/r3_full3.sh
+        fplans, foffs = make_plans(Kf, s_full, 0)
+        f_steps = 2
+        f_elapsed, _, f_nl, f_chunk, f_busy = timed_leg(True, fplans, foffs, chunk_f, True, steps=f_steps, warmup=1)
+        extra["full_feature"] = {
+            "value": units_per_pass_job * f_steps / f_elapsed, "unit": "point-timesteps/s",
+            "ms_per_step": f_elapsed / f_steps * 1e3, "steps": f_steps, "warmup": 1,
+            "step_kernel_only_value": units_per_pass_rank * f_steps / (f_busy / 1e3),
+            "config": {"workload": f"{total_points} synthetic points x {args.hours} h (SimLen {simlen}), fp64, FULL "
+                                   "feature set (optional streams, 6 h initialization phase, relaxation), outputs "
+                                   "every time index, inputs resident in HBM",
+                       "plans_per_gpu": Kf, "chunk_steps": f_chunk, "plan_order": True, "launches": f_nl},
+        }
+        for pl in fplans:
+            pl.close()
+        del fplans
+        torch.cuda.empty_cache()
+        # (2) the driver data path: raw hourly forecast + 10-minute observations in HOST arrays ->
+        # rs_driver_run -> hourly outputs back in host arrays (PCIe inclusive: a whole-call rate, never
+        # comparable with `value`, whose inputs are resident in HBM)
+        from roadsurf_amd import driver_workload
+
+        if not (os.environ.get("ROADSURF_HIP_DEVICES") or os.environ.get("ROADSURF_HIP_DEVICE")):
+            os.environ["ROADSURF_HIP_DEVICE"] = str(dev_index)  # the library's fan-out stays on THIS GPU
+        dw = driver_workload.DriverWorkload(args.extra_points, args.hours, unique=65536)
+        for mode in ("relax", "coupling", "skyview"):
+            best, times, r = dw.time_calls(mode, reps=2, warm=1, device=-1)
+            extra["driver_path_" + ("sky" if mode == "skyview" else mode)] = {
+                "value": dw.n * dw.simlen / best, "unit": "point-timesteps/s", "seconds_per_call": best,
+                "calls_timed": len(times), "calls_warm": 1, "points_ok": int((r["status"] == 0).sum()),
+                "config": {"workload": f"rs_driver_run: {dw.n} points x {args.hours} h (SimLen {dw.simlen}) from raw series "
+                                       f"in pageable host arrays (hourly forecast + 10-minute observations over the "
+                                       f"first {driver_workload.OBS_HOURS} h), interpolation / overlay / Tdew<->RH / "
+                                       f"simulation / hourly decimation on the GPU, outputs back in host arrays; "
+                                       f"mode {mode}: relaxation"
+                                       + (", coupling" if mode == "coupling" else "")
+                                       + (", per-point sky view and local horizons" if mode == "skyview" else ""),
+                           "pcie_inclusive": True, "raw_input_bytes": dw.raw_bytes(mode),
+                           "blocks_per_device": int(os.environ.get("ROADSURF_HIP_PLANS_PER_DEVICE", "4"))},
+            }
+            del r
+        del dw
+        extra["seconds"] = time.perf_counter() - t_x
     # dominant kernel: step kernel, HIP events on its own stream around every launch (this rank).
     # achieved = algorithmic bytes of the launches / time the device spent in them.  With one plan
     # that is bytes per launch / average launch duration; with K plans on K streams the launches
@@ -406,6 +481,8 @@ def main() -> None:
                 "plan_order": cluster,
                 "sort_key": args.sort_key if cluster else None,
                 "order_rows_kept": cluster,
+                "inputs_resident": "hourly knots of every point, made once before the timed region (since round "
+                                   "3; round 2 regenerated the windows' and previews' knots inside it)",
                 "kernel_variant": args.variant,
                 "parallelism": f"points sharded over {world} GPU(s) ({scaling} scaling), no collectives",
                 "failed_points": int(nfail),
@@ -443,6 +520,11 @@ def main() -> None:
                         "is reported as the contract asks, the binding roofline is vector-ALU issue",
             },
         }
+        for k, v in extra.items():
+            if isinstance(v, dict):
+                line[k + "_value"] = v["value"]
+        if extra:
+            line["extra_legs"] = extra
         if natural is not None:
             n_elapsed, n_step_ms, n_nlaunch, _, n_busy = natural
             line["natural_order_value"] = units_per_pass_job * args.steps / n_elapsed

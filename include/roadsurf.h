@@ -385,7 +385,8 @@ int64_t rs_hip_failed_count(RsPlan *plan);
 /* Measurement aid: one wavefront that reads the shader-clock counter and the constant 100 MHz
  * counter about spin_us microseconds apart and leaves the two deltas in out[0], out[1] (device
  * memory, 2 x uint64).  Enqueued on a side stream beside the step kernels it tells the engine clock
- * the chip holds under that load: MHz = 100 * out[0] / out[1].  Asynchronous on `stream`. */
+ * the chip holds under that load: MHz = 100 * out[0] / out[1].  Asynchronous on `stream`.  spin_us is
+ * clamped to 10 ms and the wait is bounded: out[1] = 0 means the 100 MHz counter did not advance. */
 int rs_hip_clock_probe(int32_t device, void *out, uint32_t spin_us, void *stream);
 /* Per point (host int32[npoints], in local point order whatever the plan order is): 0, or the
  * 1-based time index at which CheckValues raised simulation_failed - the step of that index was

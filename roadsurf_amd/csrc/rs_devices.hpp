@@ -30,6 +30,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <cstdio>
 #include <vector>
 
 extern "C" const char *rs_last_error(void);
@@ -61,9 +62,20 @@ inline std::vector<int> device_list() {
       if (d >= 0 && d < ndev) { lo = d; hi = d + 1; }
     } else if (const char *lr = getenv("LOCAL_RANK")) {
       /* one process per GPU (torch.distributed.run and friends): a rank that sees the whole node
-       * keeps to its own device instead of spreading over - and oversubscribing - all of them */
+       * keeps to its own device instead of spreading over - and oversubscribing - all of them.
+       * Only where there ARE several local ranks: a lone process that a launcher happened to start
+       * with LOCAL_RANK=0 (Slurm, torchrun --nproc-per-node 1, a notebook kernel) keeps the fan-out */
+      const char *lws = getenv("LOCAL_WORLD_SIZE");
+      const char *ws = lws ? lws : getenv("WORLD_SIZE");
       const int d = atoi(lr);
-      if (d >= 0) { lo = d % ndev; hi = lo + 1; }
+      if (d >= 0 && ws && atoi(ws) > 1) {
+        lo = d % ndev;
+        hi = lo + 1;
+        static std::atomic<bool> said{false};
+        if (ndev > 1 && !said.exchange(true))
+          fprintf(stderr, "roadsurf_hip: LOCAL_RANK=%d of %s local ranks: this process keeps to device %d "
+                          "(ROADSURF_HIP_DEVICES overrides)\n", d, ws, lo);
+      }
     }
   }
   int per = 4;

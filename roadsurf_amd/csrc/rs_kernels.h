@@ -107,7 +107,9 @@ hipError_t rs_launch_step_sky(const rs::StepArgs &a, int NL, hipStream_t stream)
 hipError_t rs_launch_init(const rs::InitArgs &a, hipStream_t stream);
 hipError_t rs_launch_knots(const rs::KnotArgs &a, int32_t nknots, hipStream_t stream);
 hipError_t rs_launch_expand(const rs::ExpandArgs &a, int32_t nintervals, hipStream_t stream);
-/* out[0] = shader-clock ticks, out[1] = 100 MHz ticks over the same ~spin_us microseconds */
+/* out[0] = shader-clock ticks, out[1] = 100 MHz ticks over the same ~spin_us microseconds (spin_us is
+ * clamped to RS_CLOCK_PROBE_MAX_US; out[1] = 0 if the 100 MHz counter did not advance) */
+#define RS_CLOCK_PROBE_MAX_US 10000u
 hipError_t rs_launch_clock_probe(uint64_t *out, uint32_t spin_us, hipStream_t stream);
 hipError_t rs_launch_count_failed(const double *st, int64_t np_pad, int64_t npoints,
                                   unsigned long long *out, hipStream_t stream);

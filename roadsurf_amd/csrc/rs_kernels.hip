@@ -1133,10 +1133,19 @@ __global__ void __launch_bounds__(kBlock, WPE) step_kernel_reg(const StepArgs a)
   RegProfile<NL> T;
   Scalars s;
   int32_t score = 0;
+#ifdef RS_WAVE_TIMING /* tools/wave_times.py: when each wavefront of a launch starts and ends (100 MHz ticks) */
+  const uint64_t wt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   load_state<FULL>(a.state, a.np_pad, p, T, s);
   time_loop<FULL, RegProfile<NL>, false, SCORE, false, false, A32>(mt, T, s, score);
   store_state<FULL>(a.state, a.np_pad, p, T, s);
   if (SCORE) a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
+#ifdef RS_WAVE_TIMING
+  if (!FULL) {
+    a.state[(int64_t)RS_ST_VZ_END * a.np_pad + p] = (double)(wt0 & 0xffffffffffffull);
+    a.state[(int64_t)RS_ST_RH_END * a.np_pad + p] = (double)(__builtin_amdgcn_s_memrealtime() & 0xffffffffffffull);
+  }
+#endif
 }
 
 /* FULL feature set, NLayers = 15, four waves per SIMD: layers 1..RS_HYBRID_REG in registers, the
@@ -1195,6 +1204,8 @@ __global__ void __launch_bounds__(kBlock, WPE) step_kernel_lds(const StepArgs a)
  * function both flavours call).  LEAN feature set, NLayers = 15, 32-bit window offsets. */
 struct DuoMail {
   double v[2][2][64]; /* [buffer][0: Tmp(2) from the surface wave, 1: Tmp(3) from the ground wave][lane] */
+  uint32_t failed[64]; /* sticky, set by the surface wave: the point's loop has exited (the ground wave
+                          then leaves Tmp(3..N) alone, as the one-point-per-lane flavours do) */
 };
 
 /* LDS writes done, then the workgroup barrier.  Not __syncthreads(): that also waits for the global
@@ -1223,6 +1234,7 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
     T.set(2, all.get(2));
   }
   mail.v[0][0][lane] = T.get(2);
+  mail.failed[lane] = s.failed ? 1u : 0u; /* arrives failed (or a dead lane): frozen from the first index */
   duo_meet();
   const int32_t nsteps = ka->nsteps, t0 = ka->t0;
   auto blank_rows = [&](int32_t i_from) { /* as in time_loop */
@@ -1233,7 +1245,10 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
   };
   if (live && s.failed) blank_rows(t0);
   int32_t score = 0; /* scheduling hint of rs_hip_recluster, as in time_loop */
-  Forcing nxt = load_forcing<false, true>(ka, row0, lane, 0);
+  /* the windows need only span npoints columns (t_stride >= npoints): a lane beyond them fetches nothing
+   * (the one-point-per-lane flavours return before they load; here the lane walks on to the barriers) */
+  Forcing nxt = Forcing();
+  if (live) nxt = load_forcing<false, true>(ka, row0, lane, 0);
   for (int32_t kv = 0; kv < nsteps; ++kv) {
     asm volatile("" : "+s"(ka));
     const ConstsAS &c = consts_of(ka);
@@ -1253,6 +1268,7 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
         if (check_values(c, chk, s.tsurf, false)) {
           s.failed = true;
           ka->state[(int64_t)RS_ST_FAILED * ka->np_pad + row0 + lane] = (double)i;
+          mail.failed[lane] = 1u; /* this index still steps (the ground wave is in it already); the next does not */
         }
       }
       s.tnw1 = T.get(1);
@@ -1311,12 +1327,16 @@ __device__ __forceinline__ void duo_ground(DuoMail &mail, const StepArgs &a) {
     const ConstsAS &c = consts_of(ka);
     const int32_t k = __builtin_amdgcn_readfirstlane(kv);
     const double t2 = mail.v[k & 1][0][lane]; /* Tmp(2) as the last step left it (melting included) */
-    double Gprev = c.condDZ[2] * (Tg[0] - t2); /* G(2), the expression layer 2 itself evaluates */
+    /* a failed point takes no further step in any flavour: its Tmp(3..N) stay as the failing index left
+     * them (the flag was raised before the barrier that ended that index) */
+    if (!mail.failed[lane]) {
+      double Gprev = c.condDZ[2] * (Tg[0] - t2); /* G(2), the expression layer 2 itself evaluates */
 #pragma unroll
-    for (int j = 3; j <= NL; ++j) {
-      const double tj = Tg[j - 3];
-      const double tnext = (j == NL) ? tbot : Tg[j - 2];
-      Tg[j - 3] = layer_step(c, j, tj, tj, tnext, Gprev, nullptr);
+      for (int j = 3; j <= NL; ++j) {
+        const double tj = Tg[j - 3];
+        const double tnext = (j == NL) ? tbot : Tg[j - 2];
+        Tg[j - 3] = layer_step(c, j, tj, tj, tnext, Gprev, nullptr);
+      }
     }
     mail.v[(k & 1) ^ 1][1][lane] = Tg[0];
     duo_meet();
@@ -1707,14 +1727,22 @@ __global__ void __launch_bounds__(64) clock_probe_kernel(uint64_t *out, uint32_t
   const uint64_t c0 = __builtin_readcyclecounter();
   const uint64_t r0 = __builtin_amdgcn_s_memrealtime();
   uint64_t r1 = r0;
-  while (r1 - r0 < (uint64_t)spin_us * 100ull) {
+  /* bounded: at most RS_CLOCK_PROBE_MAX_US (the launcher clamps spin_us) and at most 1 << 16 naps of
+   * ~0.9 us - on a part whose real-time counter stands still the wave leaves with out[1] = 0, which
+   * bench.py reads as "clock not readable" */
+  bool ok = false;
+  for (int it = 0; it < (1 << 16); ++it) {
+    if (r1 - r0 >= (uint64_t)spin_us * 100ull) {
+      ok = true;
+      break;
+    }
     __builtin_amdgcn_s_sleep(32);
     r1 = __builtin_amdgcn_s_memrealtime();
   }
   const uint64_t c1 = __builtin_readcyclecounter();
   if (threadIdx.x == 0) {
     out[0] = c1 - c0;
-    out[1] = r1 - r0;
+    out[1] = ok ? r1 - r0 : 0;
   }
 }
 
@@ -2049,6 +2077,7 @@ hipError_t rs_launch_expand(const rs::ExpandArgs &a, int32_t nintervals, hipStre
 }
 
 hipError_t rs_launch_clock_probe(uint64_t *out, uint32_t spin_us, hipStream_t stream) {
+  if (spin_us > RS_CLOCK_PROBE_MAX_US) spin_us = RS_CLOCK_PROBE_MAX_US; /* a probe, not a way to park a wave */
   hipLaunchKernelGGL(rs::clock_probe_kernel, dim3(1), dim3(64), 0, stream, out, spin_us);
   return hipGetLastError();
 }

@@ -221,3 +221,75 @@ def test_output_decimation_matches_driver_semantics():
         got = out.tensors[q][:, :n].T.cpu().numpy()
         assert np.array_equal(got, full[q][:, ::k]), q
     plan.close()
+
+
+def _stepwise(f, s, p, n, variant, chunks, t_stride):
+    """Step host arrays through the device API with windows whose row stride is `t_stride` columns
+    (>= n: include/roadsurf.h only asks for that), in launches of the given lengths; returns the
+    outputs [n, L] and the carried state block."""
+    import torch
+    from roadsurf_amd import device
+    L = s.SimLen
+    plan = device.Plan(n, s, p, 0)
+    plan.set_variant(variant)
+    dev = plan.device
+
+    def rows(a, dtype):
+        t = torch.zeros((L, t_stride), dtype=dtype, device=dev)
+        t[:, :n] = torch.from_numpy(np.ascontiguousarray(a)).to(dev).T
+        return t
+    tens = {k: rows(f[k], torch.float64) for k in ("tair", "vz", "rhz", "prec", "sw", "lw", "tsurfobs")}
+    tens["tdew"] = tens["depth"] = None
+    tens["precphase"] = rows(f["precphase"], torch.int32)
+    tens["hour"] = torch.from_numpy(np.ascontiguousarray(f["hour"])).to(dev)
+    win = device.ForcingWindow(L, t_stride, tens)
+    out = device.OutputWindow.empty(L, t_stride, dev)
+    pp = plan.point_params(plan.uniform_tbottom(int(f["year"][0]), int(f["month"][0]), int(f["day"][0])))
+    plan.init_state(win, pp)
+    t0 = 1
+    for ns in chunks:
+        plan.step(win, out, pp, t0, ns, window_row=t0 - 1, out_row0=0)
+        t0 += ns
+    assert t0 == L + 1
+    plan.sync()
+    res = {k: out.tensors[k][:, :n].T.contiguous().cpu().numpy() for k in device.OUT_FIELDS}
+    st = plan.state().numpy().copy()
+    plan.close()
+    return res, st
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3], ids=["reg", "lds", "duo"])
+def test_unpadded_window_stride_and_one_index_launch(variant):
+    """Windows that span exactly npoints columns (npoints not a multiple of the wavefront width) and a
+    series that ends in a launch of ONE index, SimLen = k * 120 + 1 as the reference driver makes them
+    (examples/example1/src/InputSettings.cpp:98): lanes beyond npoints must not touch the windows."""
+    n, L = 203, 241
+    f = oh.synth_forcing(n, L, seed=404)
+    s = abi.default_settings(L); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
+    ora, _, _ = oh.run_oracle(_oracle_kind(), f, s, p, l)
+    res, _ = _stepwise(f, s, p, n, variant, [120, 120, 1], t_stride=n)
+    _compare(res, ora, f"unpadded-{variant}")
+
+
+def test_state_of_failed_points_is_the_same_in_every_flavour():
+    """A point that fails CheckValues takes the step of that index and none after it
+    (examples/example1/src/Simulation.f90:58): the carried profile rs_hip_state_download returns for it
+    is the one that index left, whichever kernel flavour stepped it (the two-wavefront flavour's ground
+    wave used to go on integrating Tmp(3..N) behind the failure)."""
+    n, L = 200, 361
+    f = oh.synth_forcing(n, L, seed=58)
+    for pt, idx in {3: 0, 70: 100, 131: 119, 150: 120, 199: 300}.items():
+        f["tair"][pt, idx] = 250.0
+    s = abi.default_settings(L); p = abi.default_parameters()
+    states = {}
+    for variant in (1, 2, 3):
+        _, st = _stepwise(f, s, p, n, variant, [120, 120, 121], t_stride=256)
+        states[variant] = st[:, :n]
+    NL = s.NLayers
+    failed = states[1][abi.RS_MAX_LAYERS + 12] != 0  # RS_ST_FAILED
+    assert failed.sum() == 5
+    for v in (2, 3):
+        for row in range(NL):
+            assert np.array_equal(states[1][row], states[v][row]), (v, row)
+        for row in range(abi.RS_MAX_LAYERS, abi.RS_MAX_LAYERS + 13):
+            assert np.array_equal(states[1][row], states[v][row]), (v, row)
