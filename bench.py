@@ -196,7 +196,7 @@ def main() -> None:
                     help="skip the short extra legs of the default run (N = 1, fp64, LEAN headline only): the FULL "
                          "feature set on the same synthetic points (full_feature_value) and the driver data path "
                          "rs_driver_run with relaxation / coupling / sky view (driver_path_*_value)")
-    ap.add_argument("--extra-points", type=int, default=262144,
+    ap.add_argument("--extra-points", type=int, default=1_000_000,
                     help="points of the driver-path legs (host arrays in, hourly outputs back: PCIe inclusive)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16384)

@@ -301,6 +301,12 @@ typedef struct RsPointParams {
   const double *sky_view, *sin_lat, *cos_lat, *lon_rad;
   const double *horizons;
   double albedo_surroundings; /* InputParameters.Albedo_surroundings */
+  /* Column of `horizons` that belongs to slot s: horizons[deg * npoints_padded + horizon_index[s]].
+   * NULL = column s.  What a caller that re-sorts the plan's slots (rs_hip_recluster*) passes instead
+   * of a re-ordered copy of the 2.9 KB-per-point table: the scalars above are gathered into slot
+   * order, the table stays where it is and the kernels read it through this row (the plan's own
+   * order row, rs_hip_plan_order, is exactly that). */
+  const int32_t *horizon_index;
 } RsPointParams;
 
 const char *rs_last_error(void);
@@ -674,7 +680,7 @@ int rs_driver_expand(const RsDriverInput *in, const InputSettings *settings,
                      LocalParameters *local, double *merged, int32_t *status,
                      int32_t *missing_index, int32_t device);
 
-#define RS_ABI_VERSION 3 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles */
+#define RS_ABI_VERSION 4 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles; 4: RsPointParams::horizon_index */
 int rs_abi_version(void);
 /* sizeof of the boundary structs as the C side / the Fortran side see them
  * (0 InputPointers, 1 OutputPointers, 2 InputSettings, 3 InputParameters,

@@ -18,6 +18,7 @@
 
 #include "../../include/roadsurf.h"
 #include "rs_kernels.h"
+#include "rs_devutil.hpp"
 #include <cstdint>
 #include <algorithm>
 #include "rs_consts_dev.h"
@@ -74,10 +75,30 @@ struct RsPlan {
   bool cpl_windows_closed = false; /* rs_hip_coupling_windows_closed: re-sorts leave the saved state */
   bool history_score = true; /* the step kernels leave the sort key of rs_hip_recluster */
   bool f32 = false; /* single-precision flavour: windows and state hold floats */
+  std::vector<void *> owned; /* hipMalloc-ed pieces (plan_malloc): what rs_hip_plan_destroy frees */
   std::vector<hipEvent_t> ev; /* start/stop pairs */
   size_t ev_used = 0;
   bool timing = false;
 };
+
+/* Device memory of a plan: out of the calling thread's arena where one is installed (rs_devutil.hpp:
+ * the workers of rs_driver_run create and destroy a plan per tile), else hipMalloc, kept in
+ * RsPlan::owned for rs_hip_plan_destroy. */
+template <class T>
+static hipError_t plan_malloc(RsPlan *pl, T **p, size_t bytes) {
+  if (rsu::Arena *a = rsu::tls_arena())
+    if (void *q = a->take(bytes ? bytes : 8)) {
+      *p = static_cast<T *>(q);
+      return hipSuccess;
+    }
+  void *q = nullptr;
+  const hipError_t e = hipMalloc(&q, bytes ? bytes : 8);
+  if (e == hipSuccess) {
+    pl->owned.push_back(q);
+    *p = static_cast<T *>(q);
+  }
+  return e;
+}
 
 extern "C" {
 
@@ -204,10 +225,10 @@ RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints, const RsConstants *c
       pl->variant = v;
   }
   const size_t bytes = (size_t)RS_NSTATE * pl->np_pad * sizeof(double);
-  if (hipMalloc(&pl->state, bytes) != hipSuccess ||
-      hipMalloc(&pl->counter, sizeof(unsigned long long)) != hipSuccess) {
+  if (plan_malloc(pl, &pl->state, bytes) != hipSuccess ||
+      plan_malloc(pl, &pl->counter, sizeof(unsigned long long)) != hipSuccess) {
     set_err("rs_hip_plan_create: hipMalloc of %zu state bytes failed", bytes);
-    if (pl->state) (void)hipFree(pl->state);
+    for (void *q : pl->owned) (void)hipFree(q);
     delete pl;
     return nullptr;
   }
@@ -218,20 +239,20 @@ RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints, const RsConstants *c
   {
     const std::vector<double> tab = rs_relax_table(pl->c);
     if (!tab.empty()) {
-      ce = hipMalloc(&pl->relax_tab, tab.size() * sizeof(double));
+      ce = plan_malloc(pl, &pl->relax_tab, tab.size() * sizeof(double));
       if (ce == hipSuccess)
         ce = hipMemcpy(pl->relax_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
       cd.relax_tab = pl->relax_tab;
     }
     const std::vector<double> ctab = rs_cpl_table(pl->c);
     if (ce == hipSuccess && !ctab.empty()) {
-      ce = hipMalloc(&pl->cpl_tab, ctab.size() * sizeof(double));
+      ce = plan_malloc(pl, &pl->cpl_tab, ctab.size() * sizeof(double));
       if (ce == hipSuccess)
         ce = hipMemcpy(pl->cpl_tab, ctab.data(), ctab.size() * sizeof(double), hipMemcpyHostToDevice);
       cd.cpl_tab = pl->cpl_tab;
     }
   }
-  if (ce == hipSuccess) ce = hipMalloc(&pl->consts_dev, sizeof(RsConstantsDev));
+  if (ce == hipSuccess) ce = plan_malloc(pl, &pl->consts_dev, sizeof(RsConstantsDev));
   if (ce == hipSuccess)
     ce = hipMemcpyAsync(pl->consts_dev, &cd, sizeof(RsConstantsDev), hipMemcpyHostToDevice, pl->stream);
   if (ce == hipSuccess) ce = hipStreamSynchronize(pl->stream); /* cd is stack scratch */
@@ -245,11 +266,7 @@ RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints, const RsConstants *c
   }
   if (ce != hipSuccess) {
     set_err("rs_hip_plan_create: upload of the constants failed: %s", hipGetErrorString(ce));
-    if (pl->consts_dev) (void)hipFree(pl->consts_dev);
-    if (pl->relax_tab) (void)hipFree(pl->relax_tab);
-    if (pl->cpl_tab) (void)hipFree(pl->cpl_tab);
-    (void)hipFree(pl->state);
-    (void)hipFree(pl->counter);
+    for (void *q : pl->owned) (void)hipFree(q);
     delete pl;
     return nullptr;
   }
@@ -261,21 +278,7 @@ void rs_hip_plan_destroy(RsPlan *pl) {
   (void)hipSetDevice(pl->device);
   (void)hipStreamSynchronize(pl->stream);
   for (hipEvent_t e : pl->ev) (void)hipEventDestroy(e);
-  if (pl->consts_dev) (void)hipFree(pl->consts_dev);
-  if (pl->relax_tab) (void)hipFree(pl->relax_tab);
-  if (pl->cpl_tab) (void)hipFree(pl->cpl_tab);
-  if (pl->consts32_dev) (void)hipFree(pl->consts32_dev);
-  (void)hipFree(pl->state);
-  (void)hipFree(pl->counter);
-  if (pl->order) (void)hipFree(pl->order);
-  if (pl->order_alt) (void)hipFree(pl->order_alt);
-  if (pl->state_alt) (void)hipFree(pl->state_alt);
-  if (pl->sort_tmp) (void)hipFree(pl->sort_tmp);
-  if (pl->sort_keys) (void)hipFree(pl->sort_keys);
-  if (pl->cpl_flags) (void)hipFree(pl->cpl_flags);
-  if (pl->cpl_list) (void)hipFree(pl->cpl_list);
-  if (pl->cpl_count) (void)hipFree(pl->cpl_count);
-  if (pl->cpl_tmp) (void)hipFree(pl->cpl_tmp);
+  for (void *q : pl->owned) (void)hipFree(q); /* pieces of a worker's arena are the worker's to reclaim */
   delete pl;
 }
 
@@ -286,7 +289,7 @@ const int32_t *rs_hip_plan_order(RsPlan *pl) {
   }
   if (!pl->order) {
     if (hipSetDevice(pl->device) != hipSuccess ||
-        hipMalloc(&pl->order, pl->np_pad * sizeof(int32_t)) != hipSuccess ||
+        plan_malloc(pl, &pl->order, pl->np_pad * sizeof(int32_t)) != hipSuccess ||
         rs_cluster_identity(pl->order, pl->np_pad, pl->stream) != hipSuccess) {
       set_err("rs_hip_plan_order: allocation failed");
       return nullptr;
@@ -298,12 +301,12 @@ const int32_t *rs_hip_plan_order(RsPlan *pl) {
 static int recluster_buffers(RsPlan *pl) {
   const size_t state_bytes = (size_t)RS_NSTATE * pl->np_pad * sizeof(double);
   if (!pl->state_alt) {
-    HIP_OK(hipMalloc(&pl->state_alt, state_bytes));
-    HIP_OK(hipMalloc(&pl->order_alt, pl->np_pad * sizeof(int32_t)));
-    HIP_OK(hipMalloc(&pl->sort_keys, (size_t)4 * pl->np_pad * sizeof(uint32_t)));
+    HIP_OK(plan_malloc(pl, &pl->state_alt, state_bytes));
+    HIP_OK(plan_malloc(pl, &pl->order_alt, pl->np_pad * sizeof(int32_t)));
+    HIP_OK(plan_malloc(pl, &pl->sort_keys, (size_t)4 * pl->np_pad * sizeof(uint32_t)));
     pl->sort_tmp_bytes = std::max(rs_cluster_scratch_bytes(pl->npoints),
                                   rs_cluster_count_scratch_bytes(pl->npoints, 12));
-    HIP_OK(hipMalloc(&pl->sort_tmp, pl->sort_tmp_bytes ? pl->sort_tmp_bytes : 8));
+    HIP_OK(plan_malloc(pl, &pl->sort_tmp, pl->sort_tmp_bytes ? pl->sort_tmp_bytes : 8));
   }
   return 0;
 }
@@ -390,7 +393,7 @@ int rs_hip_set_precision(RsPlan *pl, int32_t bits) {
   if (!pl || (bits != 32 && bits != 64)) return set_err("rs_hip_set_precision: bits must be 32 or 64");
   HIP_OK(hipSetDevice(pl->device));
   if (bits == 32) {
-    if (!pl->consts32_dev) HIP_OK(hipMalloc(&pl->consts32_dev, rs32_constants_bytes()));
+    if (!pl->consts32_dev) HIP_OK(plan_malloc(pl, &pl->consts32_dev, rs32_constants_bytes()));
     HIP_OK(rs32_upload_constants(pl->consts32_dev, &pl->c, pl->stream));
   }
   pl->f32 = (bits == 32);
@@ -477,11 +480,11 @@ int rs_hip_init_state(RsPlan *pl, const RsForcing *f, const RsPointParams *pp) {
  * kernel, which carries a time index per lane. */
 static int cpl_replay_rounds(RsPlan *pl, rs::StepArgs a, bool lockstep = false) {
   if (!pl->cpl_list) {
-    HIP_OK(hipMalloc(&pl->cpl_flags, (size_t)2 * pl->np_pad * sizeof(int32_t)));
-    HIP_OK(hipMalloc(&pl->cpl_list, (size_t)pl->np_pad * sizeof(int32_t)));
-    HIP_OK(hipMalloc(&pl->cpl_count, sizeof(int32_t)));
+    HIP_OK(plan_malloc(pl, &pl->cpl_flags, (size_t)2 * pl->np_pad * sizeof(int32_t)));
+    HIP_OK(plan_malloc(pl, &pl->cpl_list, (size_t)pl->np_pad * sizeof(int32_t)));
+    HIP_OK(plan_malloc(pl, &pl->cpl_count, sizeof(int32_t)));
     pl->cpl_tmp_bytes = rs_cpl_select_scratch_bytes(pl->npoints);
-    HIP_OK(hipMalloc(&pl->cpl_tmp, pl->cpl_tmp_bytes ? pl->cpl_tmp_bytes : 8));
+    HIP_OK(plan_malloc(pl, &pl->cpl_tmp, pl->cpl_tmp_bytes ? pl->cpl_tmp_bytes : 8));
   }
   a.cpl_stop = 1;
   pl->cpl_rounds_last = 0;
@@ -696,11 +699,11 @@ int rs_hip_cpl_replay(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const 
      * reads the forcing of the index behind the window end (CheckValues, Simulation.f90:59-66), and a
      * point whose window start lies before t0 would never step */
     if (!pl->cpl_list) { /* scratch of the rounds (allocated here so that cpl_count exists) */
-      HIP_OK(hipMalloc(&pl->cpl_flags, (size_t)2 * pl->np_pad * sizeof(int32_t)));
-      HIP_OK(hipMalloc(&pl->cpl_list, (size_t)pl->np_pad * sizeof(int32_t)));
-      HIP_OK(hipMalloc(&pl->cpl_count, sizeof(int32_t)));
+      HIP_OK(plan_malloc(pl, &pl->cpl_flags, (size_t)2 * pl->np_pad * sizeof(int32_t)));
+      HIP_OK(plan_malloc(pl, &pl->cpl_list, (size_t)pl->np_pad * sizeof(int32_t)));
+      HIP_OK(plan_malloc(pl, &pl->cpl_count, sizeof(int32_t)));
       pl->cpl_tmp_bytes = rs_cpl_select_scratch_bytes(pl->npoints);
-      HIP_OK(hipMalloc(&pl->cpl_tmp, pl->cpl_tmp_bytes ? pl->cpl_tmp_bytes : 8));
+      HIP_OK(plan_malloc(pl, &pl->cpl_tmp, pl->cpl_tmp_bytes ? pl->cpl_tmp_bytes : 8));
     }
     int32_t b[2] = {INT32_MAX, 0};
     HIP_OK(hipMemcpyAsync(pl->cpl_flags, b, sizeof(b), hipMemcpyHostToDevice, pl->stream));

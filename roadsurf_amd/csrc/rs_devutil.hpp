@@ -37,18 +37,47 @@ inline hipError_t transpose(const T *src, T *dst, int rows, int cols, int64_t ld
   return hipGetLastError();
 }
 
+/* A bump allocator over one device block that a worker keeps across calls (rs_driver.hip): while a
+ * thread has one installed (tls_arena), Dev::alloc carves its buffers out of it instead of calling
+ * hipMalloc - two dozen allocations and, worse, as many hipFree per tile, each of which waits for the
+ * whole device (every other worker's kernels included).  A request that does not fit falls back to
+ * hipMalloc, so nothing depends on the size estimate.  The owner rewinds the arena when the buffers of
+ * a tile are dead (after a stream synchronisation). */
+struct Arena {
+  char *base = nullptr;
+  size_t cap = 0, off = 0;
+  void *take(size_t n) {
+    const size_t a = (off + 255) & ~(size_t)255;
+    if (!base || a + n > cap) return nullptr;
+    off = a + n;
+    return base + a;
+  }
+};
+inline Arena *&tls_arena() {
+  static thread_local Arena *a = nullptr;
+  return a;
+}
+
 struct Dev {
   void *p = nullptr;
+  bool owned = true; /* false: a piece of the thread's arena */
   Dev() = default;
   Dev(const Dev &) = delete;
   Dev &operator=(const Dev &) = delete;
   ~Dev() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
     p = nullptr;
+    owned = true;
   }
   hipError_t alloc(size_t n) {
     release();
+    if (Arena *a = tls_arena())
+      if (void *q = a->take(n ? n : 8)) {
+        p = q;
+        owned = false;
+        return hipSuccess;
+      }
     return hipMalloc(&p, n ? n : 8);
   }
   template <typename T>

@@ -38,6 +38,7 @@
 
 #include "../../include/roadsurf.h"
 #include "rs_devutil.hpp"
+#include "rs_state.h"
 #include "rs_devices.hpp"
 #include "rs_kernels.h"
 
@@ -495,7 +496,8 @@ __global__ void __launch_bounds__(RS_BLOCK) gather_params_kernel(
     const int32_t *__restrict__ order, int64_t npoints, const int32_t *initlen_p, int32_t *initlen_s,
     const double *tair_p, double *tair_s, const double *vz_p, double *vz_s, const double *rh_p,
     double *rh_s, const int32_t *cidx_p = nullptr, int32_t *cidx_s = nullptr,
-    const double *ctsurf_p = nullptr, double *ctsurf_s = nullptr) {
+    const double *ctsurf_p = nullptr, double *ctsurf_s = nullptr,
+    const double *geo_p = nullptr, double *geo_s = nullptr, int64_t geo_stride = 0) {
   const int64_t s = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
   if (s >= npoints) return;
   const int64_t p = order[s];
@@ -507,6 +509,9 @@ __global__ void __launch_bounds__(RS_BLOCK) gather_params_kernel(
     cidx_s[s] = cidx_p[p];
     ctsurf_s[s] = ctsurf_p[p];
   }
+  if (geo_s) /* sky view factor, sin/cos of the latitude, longitude: four scalars; the 360-column horizon
+                table stays in point order and is read through the order row (RsPointParams::horizon_index) */
+    for (int q = 0; q < 4; ++q) geo_s[q * geo_stride + s] = geo_p[q * geo_stride + p];
 }
 
 /* output rows of one launch, written in slot order, into the natural-order result */
@@ -798,21 +803,65 @@ int decide_tile(const Common &c, const InputSettings *st, const TileRaw &T, Tile
 }
 
 /* Copy the decisions back into the caller's LocalParameters / status arrays the way
- * read_input leaves them. */
-int report_tile(const Common &c, const InputSettings *st, const TileDecisions &D, int64_t p0, int m,
-                LocalParameters *local, int32_t *status, int32_t *missing_index,
-                hipStream_t stream) {
-  std::vector<int32_t> hs(m), hm(m), hi(m), hc(m);
-  std::vector<double> tr(m), vr(m), rr(m), ct(m);
-  HOK(hipMemcpyAsync(hs.data(), D.status.p, m * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-  HOK(hipMemcpyAsync(hm.data(), D.missing_index.p, m * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-  HOK(hipMemcpyAsync(hi.data(), D.initlen.p, m * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-  HOK(hipMemcpyAsync(hc.data(), D.cpl_index.p, m * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-  HOK(hipMemcpyAsync(tr.data(), D.tair_relax.p, m * sizeof(double), hipMemcpyDeviceToHost, stream));
-  HOK(hipMemcpyAsync(vr.data(), D.vz_relax.p, m * sizeof(double), hipMemcpyDeviceToHost, stream));
-  HOK(hipMemcpyAsync(rr.data(), D.rh_relax.p, m * sizeof(double), hipMemcpyDeviceToHost, stream));
-  HOK(hipMemcpyAsync(ct.data(), D.cpl_tsurf.p, m * sizeof(double), hipMemcpyDeviceToHost, stream));
-  HOK(hipStreamSynchronize(stream));
+ * read_input leaves them.  In two halves: `issue` enqueues the device-to-host copies (into page-locked
+ * memory the worker thread keeps) behind the decision kernels and returns; `finish` waits for them and
+ * writes the caller's arrays.  A run without coupling finishes after it has enqueued the whole
+ * simulation - nothing on the host needs the decisions before - so the time loop starts without
+ * waiting for the upload and the scan to drain. */
+struct TileReport {
+  int m = 0;
+  int64_t p0 = 0;
+  hipEvent_t ev = nullptr;
+  char *h = nullptr; /* [4][m] int32 status, missing_index, initlen, cpl_index; [4][m] double relax x 3, cpl_tsurf */
+  bool pending = false;
+  ~TileReport() {
+    if (ev) (void)hipEventDestroy(ev);
+  }
+};
+
+inline char *report_staging(size_t bytes) {
+  static thread_local rsu::Pinned buf;
+  static thread_local size_t cap = 0;
+  if (cap < bytes) {
+    if (buf.p) (void)hipHostFree(buf.p);
+    buf.p = nullptr;
+    cap = 0;
+    if (buf.alloc(bytes) != hipSuccess) return nullptr;
+    cap = bytes;
+  }
+  return static_cast<char *>(buf.p);
+}
+
+int report_issue(const TileDecisions &D, int64_t p0, int m, TileReport &R, hipStream_t stream) {
+  R.m = m;
+  R.p0 = p0;
+  R.h = report_staging((size_t)m * (4 * sizeof(int32_t) + 4 * sizeof(double)));
+  if (!R.h) return fail_msg("rs_driver_run: no page-locked memory for the decisions", -10);
+  int32_t *hi = reinterpret_cast<int32_t *>(R.h);
+  double *hd = reinterpret_cast<double *>(R.h + (size_t)4 * m * sizeof(int32_t));
+  const void *si[4] = {D.status.p, D.missing_index.p, D.initlen.p, D.cpl_index.p};
+  const void *sd[4] = {D.tair_relax.p, D.vz_relax.p, D.rh_relax.p, D.cpl_tsurf.p};
+  for (int k = 0; k < 4; ++k) {
+    HOK(hipMemcpyAsync(hi + (size_t)k * m, si[k], (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    HOK(hipMemcpyAsync(hd + (size_t)k * m, sd[k], (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream));
+  }
+  if (!R.ev) HOK(hipEventCreateWithFlags(&R.ev, hipEventDisableTiming));
+  HOK(hipEventRecord(R.ev, stream));
+  R.pending = true;
+  return 0;
+}
+
+int report_finish(const Common &c, const InputSettings *st, TileReport &R, LocalParameters *local,
+                  int32_t *status, int32_t *missing_index) {
+  if (!R.pending) return 0;
+  HOK(hipEventSynchronize(R.ev));
+  R.pending = false;
+  const int m = R.m;
+  const int64_t p0 = R.p0;
+  const int32_t *hs = reinterpret_cast<const int32_t *>(R.h), *hm = hs + m, *hi = hs + 2 * (size_t)m,
+                *hc = hs + 3 * (size_t)m;
+  const double *tr = reinterpret_cast<const double *>(R.h + (size_t)4 * m * sizeof(int32_t)), *vr = tr + m,
+               *rr = tr + 2 * (size_t)m, *ct = tr + 3 * (size_t)m;
   for (int p = 0; p < m; ++p) {
     if (status) status[p0 + p] = hs[p];
     if (missing_index) missing_index[p0 + p] = hm[p];
@@ -832,6 +881,14 @@ int report_tile(const Common &c, const InputSettings *st, const TileDecisions &D
     }
   }
   return 0;
+}
+
+int report_tile(const Common &c, const InputSettings *st, const TileDecisions &D, int64_t p0, int m,
+                LocalParameters *local, int32_t *status, int32_t *missing_index,
+                hipStream_t stream) {
+  TileReport R;
+  if (int rc = report_issue(D, p0, m, R, stream)) return rc;
+  return report_finish(c, st, R, local, status, missing_index);
 }
 
 int check_device(int32_t device) {
@@ -882,7 +939,8 @@ struct WindowCache {
   void *p[WINCACHE_SLOTS] = {};
   size_t bytes[WINCACHE_SLOTS] = {};
   bool busy[WINCACHE_SLOTS] = {};
-} g_wincache[64]; /* per device: the fan-out of rs_driver_run has several workers on each */
+} g_wincache[64], /* per device: the fan-out of rs_driver_run has several workers on each */
+    g_arenacache[64]; /* the same for the workers' arenas (rs_devutil.hpp): every other buffer of a tile */
 
 struct WindowLease {
   void *p = nullptr;
@@ -890,9 +948,10 @@ struct WindowLease {
   hipStream_t stream = nullptr; /* the stream whose kernels use the block */
   ~WindowLease() { release(); }
   int device = 0, slot = -1;
+  WindowCache *cache = g_wincache;
   hipError_t acquire(size_t bytes, int dev) {
     device = dev & 63;
-    WindowCache &c = g_wincache[device];
+    WindowCache &c = cache[device];
     std::lock_guard<std::mutex> lk(c.m);
     /* a free slot that is large enough, else a free slot to (re)allocate */
     int pick = -1;
@@ -932,8 +991,8 @@ struct WindowLease {
      * stream is still alive here) */
     if (stream) (void)hipStreamSynchronize(stream);
     if (cached) {
-      std::lock_guard<std::mutex> lk(g_wincache[device].m);
-      g_wincache[device].busy[slot] = false;
+      std::lock_guard<std::mutex> lk(cache[device].m);
+      cache[device].busy[slot] = false;
     } else {
       (void)hipFree(p);
     }
@@ -1013,12 +1072,12 @@ int rs_driver_expand(const RsDriverInput *in, const InputSettings *st, LocalPara
 }
 
 void rs_driver_release_cache(void) {
-  for (int d = 0; d < 64; ++d) {
-    WindowCache &c = g_wincache[d];
+  for (int d = 0; d < 128; ++d) {
+    WindowCache &c = d < 64 ? g_wincache[d] : g_arenacache[d - 64];
     std::lock_guard<std::mutex> lk(c.m);
     for (int k = 0; k < WINCACHE_SLOTS; ++k) {
       if (c.busy[k] || !c.p[k]) continue;
-      if (hipSetDevice(d) != hipSuccess) break;
+      if (hipSetDevice(d & 63) != hipSuccess) break;
       (void)hipFree(c.p[k]);
       c.p[k] = nullptr;
       c.bytes[k] = 0;
@@ -1106,6 +1165,45 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
   const int P = (int)std::min<int64_t>(pend - pbeg, ep ? std::max(1, atoi(ep)) : Pdef);
   const int TC = (coupled && !cpl_chunked) ? L : std::min(L, et ? std::max(1, atoi(et)) : 256);
 
+  /* Every buffer of a tile other than the forcing windows comes out of one block this worker keeps
+   * across calls (rs_devutil.hpp: Arena): no hipMalloc / hipFree inside the tile loop.  The size is
+   * an estimate from the tile's shape; what does not fit is allocated the old way. */
+  WindowLease arena_lease;
+  arena_lease.stream = stream;
+  arena_lease.cache = g_arenacache;
+  rsu::Arena arena;
+  struct ArenaScope {
+    rsu::Arena *prev;
+    explicit ArenaScope(rsu::Arena *a) : prev(rsu::tls_arena()) { rsu::tls_arena() = a; }
+    ~ArenaScope() { rsu::tls_arena() = prev; }
+  };
+  if (!getenv("ROADSURF_HIP_NO_ARENA")) {
+    const size_t mpx = ((size_t)P + RS_BLOCK - 1) / RS_BLOCK * RS_BLOCK;
+    size_t raw = 0, maxnt = 1;
+    for (int k = 0; k < c.nsrc; ++k) {
+      const size_t nt = (size_t)std::max(in->sources[k].n_times, 1);
+      maxnt = std::max(maxnt, nt);
+      raw += nt * mpx * 8 * (NFLD + 1) + (size_t)L * sizeof(PlanStep) + 3 * mpx * 8;
+    }
+    const int step_e = std::max(1, (int)((double)(st->outputStep * 60) / st->DTSecs));
+    const size_t n_out_e = ((size_t)L + step_e - 1) / step_e;
+    const size_t rows_e = cpl_chunked ? (size_t)std::max(TC, std::min(L, c.cplLen + 2)) : (size_t)TC;
+    size_t need = raw + (size_t)P * maxnt * 8            /* raw series + landing buffer */
+                  + mpx * 160                            /* decisions, bottom temperature, slot-order copies */
+                  + mpx * rows_e * 4                     /* PrecPhase window */
+                  + 7 * mpx * n_out_e * 8                /* outputs + their point-major copy */
+                  + 6 * mpx * ((size_t)TC / step_e + 2) * 8 /* one launch's rows in slot order */
+                  + 6 * mpx * 8 + (size_t)L * 40;        /* previews, hour, sun */
+    if (skyview) need += 2 * (size_t)360 * mpx * 8 + 8 * mpx * 8;
+    need += mpx * ((size_t)2 * RS_NSTATE * 8 + 64) + ((size_t)16 << 20); /* the tile's plan: two state blocks, order rows, sort scratch */
+    need += need / 16 + ((size_t)64 << 10) * 64; /* alignment of ~60 pieces, slack */
+    if (arena_lease.acquire(need, device) == hipSuccess) {
+      arena.base = static_cast<char *>(arena_lease.p);
+      arena.cap = need;
+    }
+  }
+  ArenaScope arena_scope(arena.base ? &arena : nullptr);
+
   /* shared axes */
   Dev d_hour, d_sun;
   HOK(d_hour.alloc((size_t)L * sizeof(int32_t)));
@@ -1145,8 +1243,10 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
   const size_t win_budget = eb ? (size_t)std::max(1, atoi(eb)) << 20 : (size_t)24 << 30;
   int Pcur = P;
   g_last_tiles = 0;
+  const size_t arena_mark = arena.off; /* the shared axes stay; a tile's buffers go when it is done */
   for (int64_t p0 = pbeg, m_done = 0; p0 < pend; p0 += m_done) {
     m_done = 0; /* a tile that has to be cut is started again at the same p0 */
+    arena.off = arena_mark; /* the last tile's buffers are gone (same stream: what still runs there runs first) */
     const int m = (int)std::min<int64_t>(Pcur, pend - p0);
     PlanGuard pg;
     pg.p = rs_hip_plan_create(device, m, &consts, stream);
@@ -1161,7 +1261,11 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     pt.lap(1);
     TileDecisions D;
     if (int rc = decide_tile(c, st, T, D, stream)) return rc;
-    if (int rc = report_tile(c, st, D, p0, m, local, out->status, out->missing_index, stream)) return rc;
+    TileReport rep;
+    if (int rc = report_issue(D, p0, m, rep, stream)) return rc;
+    /* chunked coupling sizes its replay block from the decisions (below): it needs them now */
+    if (cpl_chunked || pt.on)
+      if (int rc = report_finish(c, st, rep, local, out->status, out->missing_index)) return rc;
     pt.lap(2);
 
     /* per-point parameters */
@@ -1282,13 +1386,24 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
      * column (rs_hip_set_output_by_point).  Measured at 1 M points, four plans: 0.90 s against
      * 0.96 s in natural order with the history key (-12 % vector instructions in the lock-step
      * kernel), see DESIGN.md 6 for the forecast key.  ROADSURF_HIP_CLUSTER=0 switches the order
-     * off.  Not for sky view with coupling (general kernel over the whole series: no sort key). */
+     * off.  Sky view (round 4): the four geometry scalars are gathered like the other per-point
+     * parameters, the local-horizon table is read through the order row. */
     const char *ec = getenv("ROADSURF_HIP_CLUSTER");
-    const bool cluster = (!coupled || cpl_chunked) && !skyview && TC < L && !(ec && atoi(ec) == 0);
+    const bool cluster = (!coupled || cpl_chunked) && TC < L && !(ec && atoi(ec) == 0);
     const int rows_c = TC / step + 2; /* output rows one launch can produce */
-    Dev d_outc, d_pp_s;
+    Dev d_outc, d_pp_s, d_geo_s;
     RsOutputs oc = oo;
     RsPointParams pps = pp;
+    if (cluster && skyview) { /* the four geometry scalars in slot order (padding: sky view 1.0 = off) */
+      HOK(d_geo_s.alloc((size_t)4 * mp * sizeof(double)));
+      hipLaunchKernelGGL(fill_f64_kernel, grid1((int64_t)(4 * mp)), dim3(RS_BLOCK), 0, stream,
+                         d_geo_s.as<double>(), (int64_t)(4 * mp), 1.0);
+      HOK(hipGetLastError());
+      pps.sky_view = d_geo_s.as<double>();
+      pps.sin_lat = d_geo_s.as<double>() + mp;
+      pps.cos_lat = d_geo_s.as<double>() + 2 * mp;
+      pps.lon_rad = d_geo_s.as<double>() + 3 * mp;
+    }
     if (cluster) {
       HOK(d_outc.alloc((size_t)6 * rows_c * mp * sizeof(double)));
       double *cb = d_outc.as<double>();
@@ -1319,8 +1434,10 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
                          coupled ? pp.coupling_index : nullptr,
                          coupled ? const_cast<int32_t *>(pps.coupling_index) : nullptr,
                          coupled ? pp.coupling_tsurf : nullptr,
-                         coupled ? const_cast<double *>(pps.coupling_tsurf) : nullptr);
+                         coupled ? const_cast<double *>(pps.coupling_tsurf) : nullptr,
+                         skyview ? pp.sky_view : nullptr, skyview ? d_geo_s.as<double>() : nullptr, (int64_t)mp);
       HOK(hipGetLastError());
+      if (skyview) pps.horizon_index = ea.order; /* slot -> column of the horizon table */
       return 0;
     };
     if (cluster)
@@ -1472,6 +1589,8 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
       if (t0 + len <= L)
         if (int rc = resort_for(t0 + len, std::min(TC, L - (t0 + len) + 1))) return rc;
     }
+    /* everything is enqueued: the decisions go to the caller's arrays while the device works */
+    if (int rc = report_finish(c, st, rep, local, out->status, out->missing_index)) return rc;
     pt.lap(4);
     hipLaunchKernelGGL(blank_rejected_kernel, grid1(m), dim3(RS_BLOCK), 0, stream, ob, (int64_t)mp,
                        (int32_t)n_out, (int64_t)m, (const int32_t *)D.status.as<int32_t>());
@@ -1488,8 +1607,10 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     d_phase.release();
     d_outc.release();
     d_pp_s.release();
+    d_geo_s.release();
     d_out.release();
     d_outpt.release();
+    d_prev.release();
     pt.lap(7);
     m_done = m;
     ++g_last_tiles;

@@ -505,6 +505,7 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
   const double tbot = (ka->pp.tbottom + row0)[lane];
   double skyv = R4(1.0), sinlat = 0, coslat = 0, lonrad = 0;
   bool sky_on = false;
+  uint32_t hcol = 0; /* the point's column of the local-horizon table (RsPointParams::horizon_index) */
   if (SKY) {
     skyv = (ka->pp.sky_view + row0)[lane];
     sky_on = (skyv < R4(1.0) && skyv > R4(-0.01));
@@ -513,6 +514,7 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
       coslat = (ka->pp.cos_lat + row0)[lane];
       lonrad = (ka->pp.lon_rad + row0)[lane];
     }
+    hcol = ka->pp.horizon_index ? (uint32_t)(ka->pp.horizon_index + row0)[lane] : (uint32_t)row0 + lane;
   }
   int32_t initlen = 0;
   bool relax = false;
@@ -793,7 +795,7 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
        * (Simulation.f90:151-162); the two do not share data, so the order is free */
       if (!sky_view_radiation(ka->f.sun + (int64_t)k * 4, sinlat, coslat, lonrad, skyv,
                               ka->pp.albedo_surroundings,
-                              ka->pp.horizons ? ka->pp.horizons + row0 + lane : nullptr, ka->np_pad,
+                              ka->pp.horizons ? ka->pp.horizons + hcol : nullptr, ka->np_pad,
                               sw_in, sw_dir, lw_in, lw_net))
         fail_at(i); /* the reference would `stop` the process here */
     }
@@ -1063,8 +1065,10 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Sc
        * (Simulation.f90:151-162); the two do not share data, so the order is free */
       if (!sky_view_radiation(ka->f.sun + (int64_t)(i - t0) * 4, sinlat, coslat, lonrad, skyv,
                               ka->pp.albedo_surroundings,
-                              ka->pp.horizons ? ka->pp.horizons + p : nullptr, np, sw_in, sw_dir,
-                              lw_in, lw_net))
+                              ka->pp.horizons
+                                  ? ka->pp.horizons + (ka->pp.horizon_index ? (int64_t)ka->pp.horizon_index[p] : p)
+                                  : nullptr,
+                              np, sw_in, sw_dir, lw_in, lw_net))
         fail_at(i); /* the reference would `stop` the process here */
     }
     if (ka->wb.sw_dir) { /* in-place input edits of the reference; a replay overwrites them */

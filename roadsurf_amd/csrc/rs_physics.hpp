@@ -69,6 +69,17 @@ __device__ __forceinline__ bool sky_view_radiation(const double *sun, double sin
                                                    int64_t hstride, double &sw, double &sw_dir,
                                                    double &lw, double lw_net) {
   const double pi = 3.141592653589793; /* 4*atan(1.0_8) */
+  /* In the dark - global and direct short wave both +0.0 - the position of the sun cannot show:
+   * above the horizon the reference forms SW_dir * shadow_fac = +0, SW_ref = a*0 + a*0, dif_SW =
+   * sv*0 + (1-sv)*SW_ref and SW = dif_SW + SW_dir, which is +0.0 again for any finite albedo of the
+   * surroundings (a sum of zeros of both signs is +0), below it nothing is touched; and SunPosition's
+   * `stop` needs |cos| >= 1.001, out of reach of sines and cosines of finite angles.  So a lane in the
+   * dark goes straight to the long-wave line: two cos, two acos and a division less per step for every
+   * night-time index. */
+  if (rs_is_pos_zero(sw) && rs_is_pos_zero(sw_dir) && __builtin_fabs(albedo_surr) < __builtin_inf()) {
+    lw = sky_view * lw + (R4(1.0) - sky_view) * (-(lw_net - lw));
+    return true;
+  }
   const double ra = sun[0], stG = sun[1], sin_decl = sun[2], cos_decl = sun[3];
   const double cos_dec_lat = cos_decl * cos_lat;
   const double sin_dec_lat = sin_decl * sin_lat;

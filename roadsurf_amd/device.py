@@ -142,6 +142,7 @@ class Plan:
             pp.sky_view = _ptr(sky["sky_view"]); pp.sin_lat = _ptr(sky["sin_lat"])
             pp.cos_lat = _ptr(sky["cos_lat"]); pp.lon_rad = _ptr(sky["lon_rad"])
             pp.horizons = _ptr(sky.get("horizons"))
+            pp.horizon_index = _ptr(sky.get("horizon_index"))  # int32[np_pad]: column of slot s (plan order)
             pp.albedo_surroundings = float(self.params.Albedo_surroundings)
             keep = keep + (sky,)
         self._pp_keep = keep

@@ -21,20 +21,35 @@ OBS_HOURS = 6
 MODES = ("plain", "relax", "coupling", "skyview", "skycoupling")
 
 
+def _pin(a: np.ndarray) -> np.ndarray:
+    """A copy of `a` in page-locked host memory (what a C++ caller gets from hipHostMalloc): copies
+    from and to it are DMA transfers the runtime does not have to stage."""
+    import torch
+
+    t = torch.from_numpy(np.ascontiguousarray(a)).pin_memory()
+    b = t.numpy()
+    _PINNED_KEEP.append(t)
+    return b
+
+
+_PINNED_KEEP: list = []
+
+
 class DriverWorkload:
     """Inputs of one batch.  ``unique``: the series are generated for that many points and tiled up
     to ``n`` (bounds the host time spent making inputs; the regimes inside a tile are what a batch
     of that size has)."""
 
-    def __init__(self, n: int, hours: int = 48, seed: int = 1, unique: int | None = None):
-        self.n, self.hours = n, hours
+    def __init__(self, n: int, hours: int = 48, seed: int = 1, unique: int | None = None, pinned: bool = False):
+        self.n, self.hours, self.pinned = n, hours, pinned
         self.simlen = hours * 120 + 1
         u = n if unique is None else min(unique, n)
         rs = np.random.RandomState(seed)
         reps = -(-n // u)
 
         def tile(a):
-            return np.ascontiguousarray(np.tile(a, (reps, 1))[:n]) if u < n else a
+            a = np.ascontiguousarray(np.tile(a, (reps, 1))[:n]) if u < n else a
+            return _pin(a) if pinned else a
 
         def series(nt, dt, lo, hi, amp, period=86400.0):
             base = rs.uniform(lo, hi, (u, 1))
@@ -64,7 +79,7 @@ class DriverWorkload:
 
     def horizons(self) -> np.ndarray:
         if self._hz is None:
-            self._hz = self._tile(self._hz_unique)
+            self._hz = self._tile(self._hz_unique)  # (pinned with the rest if the workload is)
         return self._hz
 
     def sources(self, mode: str):
@@ -72,6 +87,8 @@ class DriverWorkload:
         if mode in ("skyview", "skycoupling"):
             fc["sw_dir"] = 0.6 * fc["sw"]
             fc["lw_net"] = np.full_like(fc["lw"], -40.0)
+            if self.pinned:
+                fc["sw_dir"], fc["lw_net"] = _pin(fc["sw_dir"]), _pin(fc["lw_net"])
         return [driver.RawSource(self.fc_t, fc, False), driver.RawSource(self.ob_t, self.ob, True)]
 
     def settings(self, mode: str, tsurf_output_depth: float | None = None) -> abi.InputSettings:
@@ -110,6 +127,11 @@ class DriverWorkload:
         loc = self.local(mode)
         hz = self.horizons() if mode in ("skyview", "skycoupling") else None
         r, times = None, []
+        if self.pinned:  # result arrays in page-locked memory too
+            step, n_out = driver.output_rows(s)
+            r = {k: _pin(np.full((self.n, n_out), np.nan)) for k in driver.OUT_FIELDS}
+            r["status"] = np.empty(self.n, np.int32)
+            r["missing_index"] = np.empty(self.n, np.int32)
         for rep in range(warm + reps):
             t0 = time.perf_counter()
             r = driver.run(src, s, p, START, START + OBS_HOURS * 3600, cal=self.cal, local=loc, horizons=hz,
