@@ -23,6 +23,7 @@
  */
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <atomic>
 #include <cstdint>
 #include <cstdlib>
@@ -110,8 +111,24 @@ inline std::vector<Shard> make_shards(int64_t n, const std::vector<int> &devs) {
     s.push_back(Shard{d, 0, n});
     return s;
   }
-  const int64_t base = n / k, rem = n % k;
+  /* ROADSURF_HIP_FIRST_BLOCK_PCT (tuning): the first block's share of an even share, in percent -
+   * its upload is the one no other block's kernels hide */
+  int64_t first = -1;
+  if (const char *e = getenv("ROADSURF_HIP_FIRST_BLOCK_PCT"))
+    if (k > 1 && atoi(e) >= 1 && atoi(e) < 100) first = std::max<int64_t>(min_shard, n / k * atoi(e) / 100);
   int64_t off = 0;
+  if (first > 0 && first < n) {
+    s.push_back(Shard{devs[0], 0, first});
+    off = first;
+    const int64_t base = (n - first) / (k - 1), rem = (n - first) % (k - 1);
+    for (int64_t i = 1; i < k; ++i) {
+      const int64_t cnt = base + (i - 1 < rem ? 1 : 0);
+      s.push_back(Shard{devs[(size_t)i], off, cnt});
+      off += cnt;
+    }
+    return s;
+  }
+  const int64_t base = n / k, rem = n % k;
   for (int64_t i = 0; i < k; ++i) {
     const int64_t cnt = base + (i < rem ? 1 : 0);
     s.push_back(Shard{devs[(size_t)i], off, cnt});

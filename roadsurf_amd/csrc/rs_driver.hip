@@ -347,6 +347,112 @@ __global__ void __launch_bounds__(RS_BLOCK) scan_raw_kernel(const ScanArgs A) {
   }
 }
 
+/* Shared time axes: a SEGMENT is a run of simulation indices over which every source keeps its
+ * (kind, rawPos).  Whether a source supplies a value is then the same at every index of the run:
+ * K_COPY: raw[rawPos] > threshold; K_INTERP: both ends > threshold - the interpolated value lies
+ * between them (the weight num/den is at most 1 - 1/den, so the rounded increment is smaller in
+ * magnitude than the rounded difference of the ends) and passes GetWeather's own test with them.
+ * That holds for finite ends; a run with a non-finite end above the threshold is walked index by
+ * index like the general scan.  ~250 segments instead of SimLen = 5 761 indices per point and
+ * variable: the scan was 18 ms of a block's 35 ms before its first time step. */
+struct ScanSeg {
+  int32_t i0, i1; /* [i0, i1) */
+  int32_t kind[RS_MAX_SOURCES], rp[RS_MAX_SOURCES];
+};
+
+__device__ __forceinline__ bool rs_finite(double x) { return __builtin_fabs(x) < __builtin_inf(); }
+
+/* merged value at one index, shared axes (walk_field's body for a single i) */
+__device__ __forceinline__ double merged_one(const SrcSet &S, int fld, int64_t p, int32_t i, uint32_t &mask) {
+  const double thr = threshold(fld);
+  double v = miss_r();
+  mask = 0;
+  for (int s = 0; s < S.nsrc; ++s) {
+    const double *x = S.src[s].fld[fld];
+    if (!x) continue;
+    const PlanStep st = plan_at(S.src[s].plan, i);
+    if (st.kind == K_NONE) continue;
+    const double a = x[(int64_t)st.rp * S.np_pad + p], b = x[(int64_t)(st.rp + 1) * S.np_pad + p];
+    double vs;
+    if (source_value(st, a, b, thr, vs)) {
+      v = vs;
+      mask |= 1u << s;
+    }
+  }
+  return v;
+}
+
+__global__ void __launch_bounds__(RS_BLOCK) scan_seg_kernel(const ScanArgs A, const ScanSeg *segs, int32_t nseg) {
+  const int64_t p = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
+  if (p >= A.S.npoints) return;
+  const int y = blockIdx.y;
+  const int L = A.S.simlen;
+  const int fld = (y == 0) ? R_TAIR : (y == 1) ? R_RHZ : (y == 2) ? R_PREC : (y == 3) ? R_SW
+                : (y == 4) ? R_LW : (y == 5) ? R_VZ : R_OBS;
+  const double thr = threshold(fld);
+  uint32_t obsmask = 0;
+  for (int s = 0; s < A.S.nsrc; ++s)
+    if (A.S.src[s].is_obs) obsmask |= 1u << s;
+  const double *xs[RS_MAX_SOURCES];
+#pragma unroll
+  for (int s = 0; s < RS_MAX_SOURCES; ++s) xs[s] = (s < A.S.nsrc) ? A.S.src[s].fld[fld] : nullptr;
+  const int64_t np_pad = A.S.np_pad;
+  int32_t first = L, last = -1, ci = -1;
+  const ScanSeg __attribute__((address_space(4))) *sg = (const ScanSeg __attribute__((address_space(4))) *)segs;
+  for (int32_t k = 0; k < nseg; ++k) {
+    const int32_t i0 = sg[k].i0, i1 = sg[k].i1;
+    uint32_t mask = 0;
+    bool slow = false;
+#pragma unroll
+    for (int s = 0; s < RS_MAX_SOURCES; ++s) {
+      if (s >= A.S.nsrc || !xs[s]) continue;
+      const int32_t kind = sg[k].kind[s], rp = sg[k].rp[s];
+      if (kind == K_NONE) continue;
+      const double a = xs[s][(int64_t)rp * np_pad + p];
+      if (kind == K_COPY) {
+        if (a > thr) mask |= 1u << s;
+      } else {
+        const double b = xs[s][(int64_t)(rp + 1) * np_pad + p];
+        if (a > thr && b > thr) {
+          mask |= 1u << s;
+          if (!rs_finite(a) || !rs_finite(b)) slow = true;
+        }
+      }
+    }
+    if (slow) { /* an infinite end: index by index, as the general scan does */
+      for (int32_t i = i0; i < i1; ++i) {
+        uint32_t mi;
+        const double v = merged_one(A.S, fld, p, i, mi);
+        if (y < 6) {
+          if (first == L && is_missing(v)) first = i;
+          if (mi & obsmask) last = i + 1;
+        } else if (!(is_missing(v) || v < -100)) {
+          ci = i;
+        }
+      }
+      continue;
+    }
+    if (y < 6) {
+      if (first == L && mask == 0) first = i0; /* nobody supplies a value: the merged series is missing */
+      if (mask & obsmask) last = i1;           /* (the run's last index) + 1 */
+    } else if (mask != 0) {
+      ci = i1 - 1; /* a supplied value is > -100: roadrunner.cpp:256-261 takes it */
+    }
+  }
+  if (y < 6) {
+    A.first_missing[(int64_t)y * np_pad + p] = first;
+    if (y == 0) A.last_obs[p] = last;
+  } else {
+    double ct = miss_r();
+    if (ci >= 0) {
+      uint32_t mi;
+      ct = merged_one(A.S, R_OBS, p, ci, mi);
+    }
+    A.cpl_i[p] = ci;
+    A.cpl_t[p] = ct;
+  }
+}
+
 struct FinalArgs {
   SrcSet S;
   const int32_t *first_missing, *last_obs, *cpl_i;
@@ -620,6 +726,7 @@ struct Common {
   int default_initlen = 0, cplLen = 0;
   std::vector<int64_t> simtime;
   std::vector<std::vector<PlanStep>> plans;
+  std::vector<ScanSeg> segs; /* shared axes only (scan_seg_kernel); empty: some source has per-point axes */
 };
 
 int prepare(const RsDriverInput *in, const InputSettings *st, Common &c) {
@@ -654,6 +761,26 @@ int prepare(const RsDriverInput *in, const InputSettings *st, Common &c) {
       build_plan(rs.times, rs.n_times, c.simtime, c.plans[s]);
     }
   }
+  bool any_pp = false;
+  for (int s = 0; s < c.nsrc; ++s) any_pp = any_pp || (in->sources[s].times_per_point && in->sources[s].n_times > 0);
+  c.segs.clear();
+  if (!any_pp && !getenv("ROADSURF_HIP_SCAN_FULL")) {
+    for (int i = 0; i < c.L; ++i) {
+      ScanSeg g{};
+      g.i0 = i;
+      g.i1 = i + 1;
+      for (int s = 0; s < RS_MAX_SOURCES; ++s) {
+        g.kind[s] = s < c.nsrc ? c.plans[s][i].kind : K_NONE;
+        g.rp[s] = s < c.nsrc ? c.plans[s][i].rp : 0;
+      }
+      bool same = !c.segs.empty();
+      if (same)
+        for (int s = 0; s < RS_MAX_SOURCES; ++s)
+          same = same && c.segs.back().kind[s] == g.kind[s] && (g.kind[s] == K_NONE || c.segs.back().rp[s] == g.rp[s]);
+      if (same) c.segs.back().i1 = i + 1;
+      else c.segs.push_back(g);
+    }
+  }
   return 0;
 }
 
@@ -663,21 +790,68 @@ struct TileRaw {
   Dev ptimes[RS_MAX_SOURCES], plen[RS_MAX_SOURCES], prp[RS_MAX_SOURCES];
   Dev fld[RS_MAX_SOURCES][NFLD];
   bool any_pp = false;
-  Dev stage; /* [m][n_times] landing buffer for the H2D copy */
+  Dev stage; /* landing block of the H2D copies */
+  Dev segs;  /* Common::segs */
   SrcSet S{};
 };
 
-int upload_tile(const RsDriverInput *in, const Common &c, int64_t p0, int m, int64_t mp,
-                TileRaw &T, hipStream_t stream) {
+/* The tile's raw series onto the device, in two halves.  `upload_copies` lands every host array of the
+ * tile - point-major rows [m][n_times], as the caller holds them - in ONE landing block with back-to-
+ * back copies and waits for them: that is the part that owns the PCIe link, and the part the workers of
+ * a device take in turns (rs_devices.hpp: copy_gate).  `upload_finish` turns the rows into the
+ * [n_times][mp] columns the kernels read (LDS-tiled transposes), completes Tdew / RH and positions the
+ * per-point walks - device work on the worker's own stream, beside the next worker's copies.  (Round 3
+ * had one landing buffer per field, so copy and transpose alternated inside the gate and the blocks of a
+ * call started ~38 ms apart; the copies alone take less than half of that.) */
+struct TileLanding {
+  size_t off[RS_MAX_SOURCES][NFLD + 1] = {}; /* byte offset of (source, field) in the landing block; NFLD: the times */
+  bool has[RS_MAX_SOURCES][NFLD + 1] = {};
+};
+
+int upload_copies(const RsDriverInput *in, const Common &c, int64_t p0, int m, int64_t mp,
+                  TileRaw &T, TileLanding &Ld, hipStream_t stream) {
+  size_t total = 0;
+  for (int s = 0; s < c.nsrc; ++s) {
+    const RsRawSource &rs = in->sources[s];
+    if (rs.n_times < 1) continue;
+    const size_t piece = ((size_t)m * rs.n_times * sizeof(double) + 255) & ~(size_t)255;
+    if (rs.times_per_point) {
+      Ld.off[s][NFLD] = total;
+      Ld.has[s][NFLD] = true;
+      total += piece;
+    }
+    for (int f = 0; f < NFLD; ++f)
+      if (raw_field(rs, f)) {
+        Ld.off[s][f] = total;
+        Ld.has[s][f] = true;
+        total += piece;
+      }
+  }
+  HOK(T.stage.alloc(total));
+  char *base = T.stage.as<char>();
+  for (int s = 0; s < c.nsrc; ++s) {
+    const RsRawSource &rs = in->sources[s];
+    if (Ld.has[s][NFLD])
+      HOK(hipMemcpyAsync(base + Ld.off[s][NFLD], rs.times + (size_t)p0 * rs.n_times,
+                         (size_t)m * rs.n_times * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+    for (int f = 0; f < NFLD; ++f)
+      if (Ld.has[s][f])
+        HOK(hipMemcpyAsync(base + Ld.off[s][f], raw_field(rs, f) + (size_t)p0 * rs.n_times,
+                           (size_t)m * rs.n_times * sizeof(double), hipMemcpyHostToDevice, stream));
+  }
+  (void)mp;
+  return 0;
+}
+
+int upload_finish(const RsDriverInput *in, const Common &c, int64_t p0, int m, int64_t mp,
+                  TileRaw &T, const TileLanding &Ld, hipStream_t stream) {
   T.S.nsrc = c.nsrc;
   T.S.simlen = c.L;
   T.S.np_pad = mp;
   T.S.npoints = m;
   T.S.sim0 = in->start_time;
   T.S.dt = c.DT;
-  int maxnt = 1;
-  for (int s = 0; s < c.nsrc; ++s) maxnt = std::max(maxnt, in->sources[s].n_times);
-  HOK(T.stage.alloc((size_t)m * maxnt * sizeof(double)));
+  const char *base = T.stage.as<char>();
   for (int s = 0; s < c.nsrc; ++s) {
     const RsRawSource &rs = in->sources[s];
     SrcDev &d = T.S.src[s];
@@ -690,10 +864,8 @@ int upload_tile(const RsDriverInput *in, const Common &c, int64_t p0, int m, int
     if (rs.times_per_point && rs.n_times > 0) {
       /* per-point axes: times [m][n_times] -> [n_times][mp], lengths, walk positions */
       HOK(T.ptimes[s].alloc((size_t)rs.n_times * mp * sizeof(int64_t)));
-      HOK(hipMemcpyAsync(T.stage.p, rs.times + (size_t)p0 * rs.n_times,
-                         (size_t)m * rs.n_times * sizeof(int64_t), hipMemcpyHostToDevice, stream));
-      HOK(transpose((const int64_t *)T.stage.p, T.ptimes[s].as<int64_t>(), m, rs.n_times, rs.n_times,
-                    mp, stream));
+      HOK(transpose(reinterpret_cast<const int64_t *>(base + Ld.off[s][NFLD]), T.ptimes[s].as<int64_t>(), m,
+                    rs.n_times, rs.n_times, mp, stream));
       HOK(T.plen[s].alloc(mp * sizeof(int32_t)));
       if (rs.lengths) {
         HOK(hipMemsetAsync(T.plen[s].p, 0, mp * sizeof(int32_t), stream));
@@ -716,7 +888,7 @@ int upload_tile(const RsDriverInput *in, const Common &c, int64_t p0, int m, int
       d.plan = T.plan[s].as<PlanStep>();
     }
     for (int f = 0; f < NFLD; ++f) {
-      const double *h = raw_field(rs, f);
+      const bool h = Ld.has[s][f];
       d.fld[f] = nullptr;
       /* Tdew and RH can be completed from each other: both exist if either does */
       const bool derived = (f == R_TDEW && rs.rhz && rs.tair) || (f == R_RHZ && rs.tdew && rs.tair);
@@ -725,9 +897,8 @@ int upload_tile(const RsDriverInput *in, const Common &c, int64_t p0, int m, int
       HOK(T.fld[s][f].alloc(ne * sizeof(double)));
       double *dst = T.fld[s][f].as<double>();
       if (h) {
-        HOK(hipMemcpyAsync(T.stage.p, h + (size_t)p0 * rs.n_times,
-                           (size_t)m * rs.n_times * sizeof(double), hipMemcpyHostToDevice, stream));
-        HOK(transpose(T.stage.as<double>(), dst, m, rs.n_times, rs.n_times, mp, stream));
+        HOK(transpose(reinterpret_cast<const double *>(base + Ld.off[s][f]), dst, m, rs.n_times, rs.n_times,
+                      mp, stream));
       } else {
         hipLaunchKernelGGL(fill_f64_kernel, grid1((int64_t)ne), dim3(RS_BLOCK), 0, stream, dst,
                            (int64_t)ne, -9999.9);
@@ -745,7 +916,18 @@ int upload_tile(const RsDriverInput *in, const Common &c, int64_t p0, int m, int
     hipLaunchKernelGGL(pp_init_kernel, grid1(mp), dim3(RS_BLOCK), 0, stream, T.S);
     HOK(hipGetLastError());
   }
+  if (!c.segs.empty()) {
+    HOK(T.segs.alloc(c.segs.size() * sizeof(ScanSeg)));
+    HOK(hipMemcpyAsync(T.segs.p, c.segs.data(), c.segs.size() * sizeof(ScanSeg), hipMemcpyHostToDevice, stream));
+  }
   return 0;
+}
+
+int upload_tile(const RsDriverInput *in, const Common &c, int64_t p0, int m, int64_t mp,
+                TileRaw &T, hipStream_t stream) {
+  TileLanding Ld;
+  if (int rc = upload_copies(in, c, p0, m, mp, T, Ld, stream)) return rc;
+  return upload_finish(in, c, p0, m, mp, T, Ld, stream);
 }
 
 /* Per-point decisions of read_input for one tile (device arrays, [mp]). */
@@ -774,6 +956,9 @@ int decide_tile(const Common &c, const InputSettings *st, const TileRaw &T, Tile
   if (T.any_pp)
     hipLaunchKernelGGL(scan_raw_kernel<true>, dim3((unsigned)(mp / RS_BLOCK), 7), dim3(RS_BLOCK), 0,
                        stream, sa);
+  else if (!c.segs.empty() && T.segs.p)
+    hipLaunchKernelGGL(scan_seg_kernel, dim3((unsigned)(mp / RS_BLOCK), 7), dim3(RS_BLOCK), 0, stream, sa,
+                       (const ScanSeg *)T.segs.as<ScanSeg>(), (int32_t)c.segs.size());
   else
     hipLaunchKernelGGL(scan_raw_kernel<false>, dim3((unsigned)(mp / RS_BLOCK), 7), dim3(RS_BLOCK), 0,
                        stream, sa);
@@ -1179,16 +1364,15 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
   };
   if (!getenv("ROADSURF_HIP_NO_ARENA")) {
     const size_t mpx = ((size_t)P + RS_BLOCK - 1) / RS_BLOCK * RS_BLOCK;
-    size_t raw = 0, maxnt = 1;
+    size_t raw = 0;
     for (int k = 0; k < c.nsrc; ++k) {
       const size_t nt = (size_t)std::max(in->sources[k].n_times, 1);
-      maxnt = std::max(maxnt, nt);
       raw += nt * mpx * 8 * (NFLD + 1) + (size_t)L * sizeof(PlanStep) + 3 * mpx * 8;
     }
     const int step_e = std::max(1, (int)((double)(st->outputStep * 60) / st->DTSecs));
     const size_t n_out_e = ((size_t)L + step_e - 1) / step_e;
     const size_t rows_e = cpl_chunked ? (size_t)std::max(TC, std::min(L, c.cplLen + 2)) : (size_t)TC;
-    size_t need = raw + (size_t)P * maxnt * 8            /* raw series + landing buffer */
+    size_t need = 2 * raw                                /* raw series + their landing block */
                   + mpx * 160                            /* decisions, bottom temperature, slot-order copies */
                   + mpx * rows_e * 4                     /* PrecPhase window */
                   + 7 * mpx * n_out_e * 8                /* outputs + their point-major copy */
@@ -1253,11 +1437,19 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     if (!pg.p) return -11;
     const int64_t mp = rs_hip_plan_npoints_padded(pg.p);
     TileRaw T;
+    TileLanding landing;
     {
+      const double tg0 = PhaseTimer::now();
       std::lock_guard<std::mutex> turn(rsu::copy_gate(device)); /* rs_devices.hpp: uploads take turns */
-      if (int rc = upload_tile(in, c, p0, m, mp, T, stream)) return rc;
+      const double tg1 = PhaseTimer::now();
+      if (int rc = upload_copies(in, c, p0, m, mp, T, landing, stream)) return rc;
+      const double tg2 = PhaseTimer::now();
       HOK(hipStreamSynchronize(stream));
+      if (pt.on)
+        fprintf(stderr, "rs_driver_run upload: waited %.1f ms for the link, issued the copies in %.1f ms, "
+                        "drained in %.1f ms\n", 1e3 * (tg1 - tg0), 1e3 * (tg2 - tg1), 1e3 * (PhaseTimer::now() - tg2));
     }
+    if (int rc = upload_finish(in, c, p0, m, mp, T, landing, stream)) return rc;
     pt.lap(1);
     TileDecisions D;
     if (int rc = decide_tile(c, st, T, D, stream)) return rc;

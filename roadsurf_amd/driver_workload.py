@@ -119,7 +119,7 @@ class DriverWorkload:
         return b
 
     def time_calls(self, mode: str, reps: int = 3, warm: int = 1, device: int = -1,
-                   tsurf_output_depth: float | None = None, verbose: bool = False):
+                   tsurf_output_depth: float | None = None, verbose: bool = False, pause: float = 0.0):
         """``warm`` untimed calls (the first one allocates), then ``reps`` timed ones.
         Returns (best seconds, all timed seconds, last result).  device -1: the library's own fan-out
         (ROADSURF_HIP_DEVICES / ROADSURF_HIP_PLANS_PER_DEVICE)."""
@@ -133,6 +133,8 @@ class DriverWorkload:
             r["status"] = np.empty(self.n, np.int32)
             r["missing_index"] = np.empty(self.n, np.int32)
         for rep in range(warm + reps):
+            if pause and rep:
+                time.sleep(pause)  # (profiling: lets a kernel trace tell the calls apart)
             t0 = time.perf_counter()
             r = driver.run(src, s, p, START, START + OBS_HOURS * 3600, cal=self.cal, local=loc, horizons=hz,
                            device=device, out=r)

@@ -59,6 +59,26 @@ def test_read_input_matches_checker_bitwise():
     assert (m["tsurfobs"] > -100).any() and (m["tsurfobs"] < -9000).any()
 
 
+def test_segment_scan_equals_the_index_by_index_scan(monkeypatch):
+    """Shared time axes: the decisions come from a scan over the runs of constant (kind, rawPos)
+    (scan_seg_kernel); ROADSURF_HIP_SCAN_FULL=1 walks every simulation index like the per-point-axis
+    path.  Same decisions - also with an infinite raw value, above every threshold but poisonous to the
+    interpolation (the runs that touch it are walked index by index)."""
+    n = 600
+    src, L, t0, tf = dh.scenario(n, hours=12, seed=19)
+    src[0].fields["tair"][7, 3] = np.inf
+    src[0].fields["sw"][9, 5] = np.inf
+    src[1].fields["tair"][11, 2] = np.inf
+    s = _settings(L, use_relaxation=1, use_coupling=1)
+    fast = driver.read_input(src, s, t0, tf)
+    monkeypatch.setenv("ROADSURF_HIP_SCAN_FULL", "1")
+    full = driver.read_input(src, s, t0, tf)
+    monkeypatch.delenv("ROADSURF_HIP_SCAN_FULL")
+    _compare_read_input(fast, full, n)
+    o = dh.oracle_read_input(src, s, t0, tf)
+    _compare_read_input(fast, o, n)
+
+
 def test_read_input_edge_cases_match_checker():
     t0 = dh.START
 

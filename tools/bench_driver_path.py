@@ -14,6 +14,6 @@ unique = int(os.environ["BENCH_UNIQUE"]) if "BENCH_UNIQUE" in os.environ else No
 w = driver_workload.DriverWorkload(n, hours, unique=unique, pinned=bool(int(os.environ.get("BENCH_PINNED", "0"))))
 best, times, r = w.time_calls(mode, reps=int(os.environ.get("BENCH_REPS", "3")), warm=1,
                               device=int(os.environ.get("BENCH_DEVICE", "-1")), tsurf_output_depth=depth,
-                              verbose=True)
+                              verbose=True, pause=float(os.environ.get("BENCH_PAUSE_S", "0")))
 print(f"best {best:.3f} s -> {n * w.simlen / best:.3e} point-timesteps/s")
 print("tsurf sample", r["tsurf"][0, :4], r["tsurf"][n // 2, -3:])

@@ -8,7 +8,7 @@ MODE=${1:-relax}; N=${2:-1000000}
 export TMPDIR=/tmp
 OUT=gpurun_out/r4_prof_drv_$MODE
 rm -rf $OUT; mkdir -p $OUT profiles
-export BENCH_UNIQUE=65536 BENCH_REPS=2
+export BENCH_UNIQUE=65536 BENCH_REPS=2 BENCH_PAUSE_S=0.25
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tools/bench_driver_path.py $N 48 $MODE > $OUT/bench.log 2> $OUT/trace.err || { tail -20 $OUT/trace.err; exit 1; }
 grep -E "rep |best" $OUT/bench.log
 STATS=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
@@ -20,9 +20,9 @@ out, mode, n, sha = sys.argv[1:5]
 rows=[]
 for fn in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(fn)):
-        rows.append((r["Kernel_Name"].replace("void ","").split("(")[0], int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r.get("Grid_Size",0) or 0), r.get("Queue_Id","?")))
+        rows.append((r["Kernel_Name"].replace("void ","").replace("(anonymous namespace)::","").split("(")[0], int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r.get("Grid_Size",0) or 0), r.get("Queue_Id","?")))
 rows.sort(key=lambda r:r[1])
-gaps=[i for i in range(1,len(rows)) if rows[i][1]-max(r[2] for r in rows[max(0,i-50):i])>30e6]
+gaps=[i for i in range(1,len(rows)) if rows[i][1]-max(r[2] for r in rows[max(0,i-50):i])>100e6]
 start=gaps[-1] if gaps else 0
 rows=rows[start:]
 t0=rows[0][1]; t1=max(r[2] for r in rows)
