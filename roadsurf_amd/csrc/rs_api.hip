@@ -500,6 +500,20 @@ static int cpl_replay_rounds(RsPlan *pl, rs::StepArgs a, bool lockstep = false) 
               (long long)pl->npoints);
     a.cpl_list = pl->cpl_list;
     a.cpl_nlist = n_again;
+    /* Late rounds hold a few per cent of the points each (on the driver benchmark 98 % of the points
+     * replay once, 30 % seven times, 2 % all 25) and follow one another as launches of a few dozen
+     * wavefronts.  ONE lock-step launch can let every listed point replay until its Coupling_control is
+     * content (cpl_inner) - but a wavefront then runs for as many replays as its slowest lane, where
+     * the rounds re-compact the list every time: measured at 1 M points (four blocks sharing the GPU),
+     * collapsing from round 1 / 4 / 7 on costs 25 / 10 / 6 % of the whole call (the half-empty wavefronts
+     * take issue slots from the other blocks' launches).  So it is done only for the tail of the tail:
+     * once the list is down to 1/64 of the plan's points.  ROADSURF_HIP_CPL_COLLAPSE=r collapses from
+     * round r on instead (tests; 0 = never). */
+    bool collapse = lockstep && (int64_t)n_again * 64 <= pl->npoints;
+    if (const char *e = getenv("ROADSURF_HIP_CPL_COLLAPSE"))
+      collapse = lockstep && atoi(e) > 0 && round + 1 >= atoi(e);
+    a.cpl_inner = collapse ? 64 : 1;
+    a.cpl_prio = ((int64_t)n_again * 4 <= pl->npoints) ? 1 : 0;
     if (lockstep)
       HIP_OK(rs_launch_step_cpl_replay(a, pl->c.NLayers, pl->stream));
     else
@@ -581,6 +595,7 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
   a.cpl_list = nullptr;
   a.cpl_nlist = 0;
   a.cpl_stop = 0;
+  a.cpl_inner = a.cpl_prio = 0;
   a.out_index = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (pl->timing) {
@@ -668,6 +683,7 @@ static int cpl_args(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const Rs
   a.cpl_list = nullptr;
   a.cpl_nlist = 0;
   a.cpl_stop = 0;
+  a.cpl_inner = a.cpl_prio = 0;
   a.out_index = (pl->output_by_point && pl->order) ? pl->order : nullptr;
   return 0;
 }

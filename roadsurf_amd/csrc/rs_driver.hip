@@ -727,6 +727,7 @@ struct Common {
   std::vector<int64_t> simtime;
   std::vector<std::vector<PlanStep>> plans;
   std::vector<ScanSeg> segs; /* shared axes only (scan_seg_kernel); empty: some source has per-point axes */
+  std::vector<std::vector<int32_t>> active_prefix; /* [source][i]: plan entries != K_NONE among indices < i */
 };
 
 int prepare(const RsDriverInput *in, const InputSettings *st, Common &c) {
@@ -761,6 +762,9 @@ int prepare(const RsDriverInput *in, const InputSettings *st, Common &c) {
       build_plan(rs.times, rs.n_times, c.simtime, c.plans[s]);
     }
   }
+  c.active_prefix.assign(c.nsrc, std::vector<int32_t>(c.L + 1, 0));
+  for (int s = 0; s < c.nsrc; ++s)
+    for (int i = 0; i < c.L; ++i) c.active_prefix[s][i + 1] = c.active_prefix[s][i] + (c.plans[s][i].kind != K_NONE ? 1 : 0);
   bool any_pp = false;
   for (int s = 0; s < c.nsrc; ++s) any_pp = any_pp || (in->sources[s].times_per_point && in->sources[s].n_times > 0);
   c.segs.clear();
@@ -1635,6 +1639,22 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     if (cluster)
       if (int rc = gather_params()) return rc;
     pt.lap(3);
+    /* The sources that can supply a value somewhere in [i0, i0+n): a shared-axis source whose plan is
+     * K_NONE over the whole range - the observations behind their last report, i.e. for seven windows
+     * out of eight of a 48 h run - is left out of the launch (it would cost a plan load and a branch
+     * per index and variable for nothing).  Order kept: later sources win. */
+    const SrcSet S_full = T.S;
+    auto sources_for = [&](int i0, int n) -> SrcSet {
+      SrcSet r = S_full;
+      if (T.any_pp) return r;
+      r.nsrc = 0;
+      for (int k = 0; k < S_full.nsrc; ++k) {
+        const std::vector<int32_t> &act = c.active_prefix[k];
+        if (act[std::min(i0 + n, L)] - act[std::min(i0, L)] > 0) r.src[r.nsrc++] = S_full.src[k];
+      }
+      for (int k = r.nsrc; k < RS_MAX_SOURCES; ++k) r.src[k] = SrcDev{};
+      return r;
+    };
     /* one window [t0, t0+len): raw series -> step-resolution forcing on the device */
     int walk_at = 0; /* 0-based index the per-point raw walks are positioned at */
     auto expand_window = [&](int t0, int len, RsForcing &fo) -> int {
@@ -1650,6 +1670,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
       }
       ea.i0 = t0 - 1;
       ea.nsteps = len;
+      ea.S = sources_for(t0 - 1, len);
       launch_expand_raw(T.any_pp, mp, ea, stream);
       HOK(hipGetLastError());
       if (T.any_pp && t0 + len <= L) { /* per-point walks: move to the start of the next window */
@@ -1702,6 +1723,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
         pe.out[R_VZ] = d_prev.as<double>() + (size_t)(2 * q + 1) * mp;
         pe.i0 = idx[q] - 1;
         pe.nsteps = 1;
+        pe.S = sources_for(idx[q] - 1, 1);
         launch_expand_raw(false, mp, pe, stream);
         HOK(hipGetLastError());
         pv.tair[q] = pe.out[R_TAIR];

@@ -39,6 +39,11 @@ struct StepArgs {
    * cpl_stop: a point parks right after the Coupling_control of its window end */
   const int32_t *cpl_list;
   int32_t cpl_nlist, cpl_stop;
+  /* lock-step replay kernels: a listed point may run up to this many replays of its window in ONE
+   * launch, until its Coupling_control stops asking (0 or 1: one replay, the round structure of
+   * rs_hip_cpl_replay); cpl_prio: raise the wavefronts' issue priority (a sparse late round beside
+   * another plan's full launches runs at the speed of its own dependency chain) */
+  int32_t cpl_inner, cpl_prio;
   /* coupling kernels: the outputs of slot s go to column out_index[s] of the output window
    * (NULL: column s).  With the plan order as index the (decimated) outputs land in point order
    * whatever order the slots are in (rs_hip_set_output_by_point). */

@@ -1452,13 +1452,22 @@ __global__ void __launch_bounds__(kBlock, W) step_kernel_cpl_replay_h(const Step
   const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (g >= (int64_t)a.cpl_nlist) return;
   const int64_t p = (int64_t)a.cpl_list[g];
+  if (a.cpl_prio) __builtin_amdgcn_s_setprio(2);
   HybridProfile<15, RS_HYBRID_REG> T;
   T.col = prof_lds + threadIdx.x;
   Scalars s;
   int32_t score = 0;
-  load_state<true>(a.state, a.np_pad, p, T, s);
-  time_loop<true, HybridProfile<15, RS_HYBRID_REG>, SKY, false, true, true>(mt, T, s, score, (uint32_t)p);
-  store_state<true>(a.state, a.np_pad, p, T, s);
+  /* cpl_inner replays of the point's window in this launch, as long as its Coupling_control asks for
+   * another (start_coupling_again, bit 0 of the flags it has just stored): the secant iteration of
+   * src/Coupling.f90:363-449 is per point - only the launches were sequential.  The state goes through
+   * the state block between two replays exactly as it does between two rounds. */
+  for (int32_t rnd = 0;; ++rnd) {
+    load_state<true>(a.state, a.np_pad, p, T, s);
+    time_loop<true, HybridProfile<15, RS_HYBRID_REG>, SKY, false, true, true>(mt, T, s, score, (uint32_t)p);
+    store_state<true>(a.state, a.np_pad, p, T, s);
+    if (rnd + 1 >= a.cpl_inner) break;
+    if ((((int32_t)a.state[(int64_t)RS_ST_CPL_FLAGS * a.np_pad + p]) & 1) == 0) break;
+  }
 }
 
 /* One replay round in lock step over the compacted list (time_loop<REPLAY>). */
@@ -1471,12 +1480,17 @@ __global__ void __launch_bounds__(kBlock, 3) step_kernel_cpl_replay(const StepAr
   const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (g >= (int64_t)a.cpl_nlist) return;
   const int64_t p = (int64_t)a.cpl_list[g];
+  if (a.cpl_prio) __builtin_amdgcn_s_setprio(2);
   LdsProfile T{lds + threadIdx.x, consts_of(&a).NLayers};
   Scalars s;
   int32_t score = 0;
-  load_state<true>(a.state, a.np_pad, p, T, s);
-  time_loop<true, LdsProfile, SKY, false, true, true>(mt, T, s, score, (uint32_t)p);
-  store_state<true>(a.state, a.np_pad, p, T, s);
+  for (int32_t rnd = 0;; ++rnd) { /* as in step_kernel_cpl_replay_h */
+    load_state<true>(a.state, a.np_pad, p, T, s);
+    time_loop<true, LdsProfile, SKY, false, true, true>(mt, T, s, score, (uint32_t)p);
+    store_state<true>(a.state, a.np_pad, p, T, s);
+    if (rnd + 1 >= a.cpl_inner) break;
+    if ((((int32_t)a.state[(int64_t)RS_ST_CPL_FLAGS * a.np_pad + p]) & 1) == 0) break;
+  }
 }
 
 /* Coupled variant: LDS profile (any NLayers), FULL feature set + coupling. */
@@ -1488,6 +1502,7 @@ __global__ void __launch_bounds__(kBlock, RS_CPL_WAVES) step_kernel_coupled(cons
   const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (g >= (a.cpl_list ? (int64_t)a.cpl_nlist : a.npoints)) return;
   const int64_t p = a.cpl_list ? (int64_t)a.cpl_list[g] : g;
+  if (a.cpl_prio) __builtin_amdgcn_s_setprio(2);
   const int NLc = consts_of(&a).NLayers;
   LdsProfile T{lds + threadIdx.x, NLc};
   Scalars s;

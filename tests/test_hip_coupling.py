@@ -109,7 +109,19 @@ def test_coupling_window_must_be_whole_series():
     plan.close()
 
 
-@pytest.mark.parametrize("replay", [None, "general", "lockstep"])
+def _set_replay_mode(monkeypatch, replay):
+    """general / lockstep: the kernel of the replay rounds; lockstep-collapsed: every listed point runs
+    all its replays in the first round's launch (ROADSURF_HIP_CPL_COLLAPSE=1); lockstep-rounds: one
+    launch per round throughout (=0).  The default collapses from round 7 on."""
+    if not replay:
+        return
+    kind, _, how = replay.partition("-")
+    monkeypatch.setenv("ROADSURF_HIP_CPL_REPLAY", kind)
+    if how:
+        monkeypatch.setenv("ROADSURF_HIP_CPL_COLLAPSE", "1" if how == "collapsed" else "0")
+
+
+@pytest.mark.parametrize("replay", [None, "general", "lockstep", "lockstep-collapsed", "lockstep-rounds"])
 @pytest.mark.parametrize("chunk", [97, 256])
 def test_chunked_coupling_equals_whole_series_and_the_reference(chunk, replay, monkeypatch):
     """rs_hip_step_cpl / rs_hip_cpl_replay: lock-step chunks that park a point behind its coupling
@@ -120,8 +132,7 @@ def test_chunked_coupling_equals_whole_series_and_the_reference(chunk, replay, m
     run in lock step over the list where the block is compact, with the general kernel (a time index
     per lane) where it is not; both are forced on every case here."""
     from roadsurf_amd import device
-    if replay:
-        monkeypatch.setenv("ROADSURF_HIP_CPL_REPLAY", replay)
+    _set_replay_mode(monkeypatch, replay)
     n, L = 384, 2881
     cases, base = _cases(n, L, 4242)
     for k, (f2, s, p, ls) in enumerate(cases):
@@ -131,14 +142,14 @@ def test_chunked_coupling_equals_whole_series_and_the_reference(chunk, replay, m
             assert np.array_equal(res[q], ora[q]), (k, q, int((res[q] != ora[q]).sum()))
 
 
-@pytest.mark.parametrize("replay", ["general", "lockstep"])
+@pytest.mark.parametrize("replay", ["general", "lockstep", "lockstep-collapsed"])
 def test_chunked_coupling_with_failing_points(replay, monkeypatch):
     """A point that fails inside its coupling window - in the first pass or in a replay - keeps the
     outputs earlier passes saved beyond the failure (SaveOutput only ever overwrites).  A bad value
     at the index BEHIND the window end is seen by CheckValues every time the loop arrives there,
     i.e. right before each rewind: the step at the window start still runs, then the loop exits."""
     from roadsurf_amd import device
-    monkeypatch.setenv("ROADSURF_HIP_CPL_REPLAY", replay)
+    _set_replay_mode(monkeypatch, replay)
     n, L = 256, 1441
     cases, _ = _cases(n, L, 11)
     f2, s, p, ls = cases[0]
