@@ -123,3 +123,36 @@ def ragged(src: driver.RawSource, seed=3, drop=0.25, pad_value=-9999.9):
         for k, a in src.fields.items():
             fields[k][p, :len(idx)] = a[p, idx]
     return driver.RawSource(times, fields, src.is_observation, lengths)
+
+
+# ---- the reference's operational shape (examples/example1/example_config.json:8-22) -----------------
+OPER_ANALYSIS_H, OPER_FORECAST_H = 48, 26
+OPER_SEED = 2026
+
+
+def operational_case(z, case: str):
+    """The run the reference's example configuration describes: 48 h analysis + 26 h forecast
+    (SimLen 8 881 at DTSecs 30), coupling and relaxation on, InitLenI / couplingIndexI at the end of the
+    analysis (forecast_time = start + 48 h), the stations of example_skyview.txt.  `z` = the fixture
+    tests/golden/e2e_operational.npz (latitudes, longitudes, sky-view factors and local horizons are the
+    NUMBERS of the reference's two data files; the raw series are this module's seeded scenario).
+    case "files": sky view and horizons as the files hold them (all 1.0 / 0.0: the branch is never taken);
+    case "sky": synthetic sky-view factors and horizons on the same stations.
+    Returns (sources, settings, params, start, forecast_time, local, horizons)."""
+    lat, lon = z["lat"], z["lon"]
+    n = len(lat)
+    hours = OPER_ANALYSIS_H + OPER_FORECAST_H
+    src, L, t0, tf = scenario(n, hours=hours, seed=OPER_SEED, obs_hours=OPER_ANALYSIS_H)
+    assert L == hours * 120 + 1 == 8881
+    s = abi.default_settings(L)
+    s.use_relaxation = 1
+    s.use_coupling = 1
+    p = abi.default_parameters()
+    sv = z["sky_view_files"] if case == "files" else z["sky_view_sky"]
+    hz = (z["horizons_files_tenths"] if case == "files" else z["horizons_sky_tenths"]).astype(np.float64) / 10.0
+    local = []
+    for i in range(n):
+        lp = abi.default_local()
+        lp.lat, lp.lon, lp.sky_view = float(lat[i]), float(lon[i]), float(sv[i])
+        local.append(lp)
+    return src, s, p, t0, tf, local, np.ascontiguousarray(hz)

@@ -219,3 +219,21 @@ def test_port_equals_reference_with_coupling():
     d, _, _ = oh.run_oracle("ref_cpl", f, s2, p, ls)
     for k in oh.F64_OUT:
         assert np.array_equal(c[k], d[k]), k
+
+
+@pytest.mark.parametrize("case", ["files", "sky"])
+def test_operational_shape_bit_exact(case):
+    """The reference's operational shape (examples/example1/example_config.json:8-22: SimLen 8 881,
+    coupling + relaxation, the stations of its data files): the C restatement behind the restated
+    read_input equals the fixture the reference itself produced (tests/golden/make_operational.py)."""
+    import driver_helpers as dh
+    from roadsurf_amd import driver
+    z = gh.load("e2e_operational.npz")
+    src, s, p, t0, tf, local, hz = dh.operational_case(z, case)
+    o = dh.oracle_run("port", src, s, p, t0, tf, local=local, horizons=hz)
+    assert np.array_equal(o["status"], z[f"{case}_status"])
+    rows = z["rows"]
+    for k in driver.OUT_FIELDS:
+        assert np.array_equal(o[k][:, rows], z[f"{case}_{k}"]), (case, k)
+    if case == "files":  # the example's own sky-view file switches the branch off everywhere
+        assert (z["sky_view_files"] == 1.0).all() and (z["horizons_files_tenths"] == 0).all()
