@@ -143,6 +143,18 @@ void runsimulation(OutputPointers *outPointers, const InputPointers *inPointers,
                    const InputParameters *inputParam,
                    const LocalParameters *localParam);
 
+/* Callers of runsimulation on several threads at once (the reference driver's worker pool,
+ * examples/example1/src/roadrunner.cpp:454-497): with the environment variable
+ * ROADSURF_HIP_COALESCE_US = w > 0 their points are gathered - the first caller waits up to w
+ * microseconds (or for ROADSURF_HIP_COALESCE_MAX callers, default 4096) and runs everything queued with
+ * its settings and parameters as ONE batch; the others sleep until their point is done.  Same bits as
+ * calls of their own.  rs_coalesce_run is what runsimulation calls (returns the batch status),
+ * rs_coalesce_stats the batches run and points served so far. */
+int32_t rs_coalesce_run(OutputPointers *outPointers, const InputPointers *inPointers,
+                        const InputSettings *inSettings, const InputParameters *inputParam,
+                        const LocalParameters *localParam);
+void rs_coalesce_stats(int64_t *batches, int64_t *points);
+
 /* Extension: n independent points with shared settings/parameters, one
  * OutputPointers/InputPointers/LocalParameters per point (exactly what the
  * reference driver builds per point, examples/example1/src/roadrunner.cpp:404-406).

@@ -139,7 +139,14 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
    * 16 -> 4.2e8, 8 -> 2.8e8 point-timesteps/s: short items keep the staging sets in the host's
    * caches and the five-stage pipeline full; below 16 the per-item launches take over, and a small
    * block (a few thousand points: a latency-bound step kernel) is served as well by 64 */
-  const int TC = coupled ? L : std::min(L, et ? std::max(1, atoi(et)) : (n >= 6144 ? 32 : 64));
+  /* A handful of points (the reference driver calling runsimulation per point, or the batches the
+   * coalescer makes of such calls): the step kernel is a few wavefronts' dependency chain whatever the
+   * item length, and every item costs a fixed round of copies, transposes and launches - so the items
+   * grow until one holds ~256 K values per variable (one point: the whole series in ONE item instead
+   * of 91: 41 -> ~36 ms per call, and far fewer runtime calls for concurrent callers to queue behind). */
+  const int TC = coupled ? L
+                         : std::min(L, et ? std::max(1, atoi(et))
+                                          : (n >= 6144 ? 32 : std::max(64, (int)(262144 / std::max<int64_t>(n, 1)))));
   const int Ppad = (P + RS_BLOCK - 1) / RS_BLOCK * RS_BLOCK;
 
   int ndev = 0;

@@ -135,6 +135,20 @@ module RoadSurfHip
       end function rs_host_default_device
    end interface
 
+   interface
+      !> roadsurf_amd/csrc/rs_coalesce.hip
+      function rs_coalesce_run(outPointers, inPointers, inSettings, inputParam, localParam) &
+         bind(C, name='rs_coalesce_run') result(rc)
+         import :: c_int, OutputPointers, InputPointers, InputSettings, InputParameters, LocalParameters
+         type(OutputPointers), intent(inout) :: outPointers
+         type(InputPointers), intent(in) :: inPointers
+         type(InputSettings), intent(in) :: inSettings
+         type(InputParameters), intent(in) :: inputParam
+         type(LocalParameters), intent(in) :: localParam
+         integer(c_int) :: rc
+      end function rs_coalesce_run
+   end interface
+
    public :: rs_build_constants, rs_bottom_temperature, runsimulation, runsimulation_batch
    public :: runsimulation_batch_ex
    public :: rs_fortran_sizeof, rs_sun_table, rs_point_geometry
@@ -620,16 +634,12 @@ contains
       type(InputSettings), intent(in) :: inSettings
       type(InputParameters), intent(in) :: inputParam
       type(LocalParameters), intent(in) :: localParam
-      type(OutputPointers) :: o(1)
-      type(InputPointers) :: i(1)
-      type(LocalParameters) :: l(1)
       integer(c_int) :: status
       real(c_double), pointer :: arr(:)
       integer :: k
-      o(1) = outPointers
-      i(1) = inPointers
-      l(1) = localParam
-      call runsimulation_batch(1_c_int, o, i, inSettings, inputParam, l, status)
+      ! one point - gathered with the points other threads are calling for at this moment when
+      ! ROADSURF_HIP_COALESCE_US > 0 (roadsurf_amd/csrc/rs_coalesce.hip), else a batch of one
+      status = rs_coalesce_run(outPointers, inPointers, inSettings, inputParam, localParam)
       if (status /= 0) then
          write (0, *) 'runsimulation (HIP): failed with status ', status
          ! src/Initialization.f90:397-412: unwritten outputs read -9999.0

@@ -241,3 +241,58 @@ def test_batch_fans_out_over_the_device_list(monkeypatch):
     assert k == 1
     for key in oh.F64_OUT:
         assert np.array_equal(one[key], small[key])
+
+
+_COALESCE_CHILD = r"""
+import ctypes as C, json, sys, threading
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import oracle_helpers as oh
+from roadsurf_amd import abi, lib
+from test_hip_boundary import _pointers
+L = lib.load()
+n, SL, T = 96, 721, 32
+f = oh.synth_forcing(n, SL, seed=77)
+f["tair"][5, 300] = 250.0          # one point fails CheckValues inside the series
+f["vz"][9, 0] = 0.1                # one gets the VZ(1) edit written back
+s = abi.default_settings(SL); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
+s2 = abi.default_settings(SL); s2.tsurfOutputDepth = 0.05   # a second group of callers: other settings
+ora, fm, _ = oh.run_oracle("ref" if oh.have_ref() else "port", f, s, p, l)
+ora2, _, _ = oh.run_oracle("ref" if oh.have_ref() else "port", f, s2, p, l)
+g = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in f.items()}
+g2 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in f.items()}
+out = {k: np.full((n, SL), np.nan) for k in oh.F64_OUT}
+out2 = {k: np.full((n, SL), np.nan) for k in oh.F64_OUT}
+ptrs = [_pointers(g, out, pt) for pt in range(n)] + [_pointers(g2, out2, pt) for pt in range(n)]
+nxt = [0]; lock = threading.Lock()
+def worker():
+    while True:
+        with lock:
+            k = nxt[0]; nxt[0] += 1
+        if k >= 2 * n: return
+        ip, op, _ = ptrs[k]
+        L.runsimulation(C.byref(op), C.byref(ip), C.byref(s if k < n else s2), C.byref(p), C.byref(l))
+th = [threading.Thread(target=worker) for _ in range(T)]
+[x.start() for x in th]; [x.join() for x in th]
+b = C.c_int64(0); q = C.c_int64(0)
+L.rs_coalesce_stats(C.byref(b), C.byref(q))
+same = all(np.array_equal(out[k], ora[k]) for k in oh.F64_OUT)
+same2 = all(np.array_equal(out2[k], ora2[k]) for k in oh.F64_OUT)
+print(json.dumps({"same": bool(same), "same2": bool(same2), "batches": b.value, "points": q.value,
+                  "vz_edit": bool(g["vz"][9, 0] == fm["vz"][9, 0] == np.float64(np.float32(0.4)))}))
+"""
+
+
+def test_runsimulation_coalesces_concurrent_callers():
+    """ROADSURF_HIP_COALESCE_US: 32 threads call runsimulation point by point, two groups with different
+    settings interleaved - every point carries the reference's bits, the points went through far fewer
+    batches than calls, and a batch never mixes settings (the second group's output depth differs)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ROADSURF_HIP_COALESCE_US="3000")
+    r = subprocess.run([sys.executable, "-c", _COALESCE_CHILD, root], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["same"] and d["same2"] and d["vz_edit"], d
+    assert d["points"] == 192 and d["batches"] < 96, d
