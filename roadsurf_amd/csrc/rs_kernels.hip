@@ -1206,11 +1206,35 @@ __global__ void __launch_bounds__(kBlock, WPE) step_kernel_lds(const StepArgs a)
  * step shrinks from ~1 460 to ~1 020 vector instructions and the shard occupies twice as many
  * wave slots.  Same arithmetic in the same order per point: same bits (layer_step is the one
  * function both flavours call).  LEAN feature set, NLayers = 15, 32-bit window offsets. */
+#define RS_DUO_NPREP 15
 struct DuoMail {
   double v[2][2][64]; /* [buffer][0: Tmp(2) from the surface wave, 1: Tmp(3) from the ground wave][lane] */
   uint32_t failed[64]; /* sticky, set by the surface wave: the point's loop has exited (the ground wave
                           then leaves Tmp(3..N) alone, as the one-point-per-lane flavours do) */
+  /* round 4: what a step needs of its forcing alone (ForcingPrep, rs_physics_body.inc), worked out by
+   * the ground wave one index ahead: [buffer = index parity][value][lane] */
+  double prep[2][RS_DUO_NPREP][64];
+  uint32_t prep_bad[2][64];
 };
+
+__device__ __forceinline__ void duo_put_prep(DuoMail &mail, int buf, uint32_t lane, const ForcingPrep &q) {
+  double (*w)[64] = mail.prep[buf];
+  w[0][lane] = q.tair; w[1][lane] = q.vz; w[2][lane] = q.rhz; w[3][lane] = q.rain; w[4][lane] = q.snow;
+  w[5][lane] = q.trffric; w[6][lane] = q.AirDens; w[7][lane] = q.AirHCap; w[8][lane] = q.PsychC;
+  w[9][lane] = q.den0; w[10][lane] = q.vkvz; w[11][lane] = q.avk; w[12][lane] = q.EAir;
+  w[13][lane] = q.sw; w[14][lane] = q.lw;
+  mail.prep_bad[buf][lane] = q.bad ? 1u : 0u;
+}
+__device__ __forceinline__ ForcingPrep duo_get_prep(const DuoMail &mail, int buf, uint32_t lane) {
+  const double (*w)[64] = mail.prep[buf];
+  ForcingPrep q;
+  q.tair = w[0][lane]; q.vz = w[1][lane]; q.rhz = w[2][lane]; q.rain = w[3][lane]; q.snow = w[4][lane];
+  q.trffric = w[5][lane]; q.AirDens = w[6][lane]; q.AirHCap = w[7][lane]; q.PsychC = w[8][lane];
+  q.den0 = w[9][lane]; q.vkvz = w[10][lane]; q.avk = w[11][lane]; q.EAir = w[12][lane];
+  q.sw = w[13][lane]; q.lw = w[14][lane];
+  q.bad = mail.prep_bad[buf][lane] != 0u;
+  return q;
+}
 
 /* LDS writes done, then the workgroup barrier.  Not __syncthreads(): that also waits for the global
  * memory counter, i.e. for the six output stores of the step and the prefetched forcing loads. */
@@ -1249,27 +1273,20 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
   };
   if (live && s.failed) blank_rows(t0);
   int32_t score = 0; /* scheduling hint of rs_hip_recluster, as in time_loop */
-  /* the windows need only span npoints columns (t_stride >= npoints): a lane beyond them fetches nothing
-   * (the one-point-per-lane flavours return before they load; here the lane walks on to the barriers) */
-  Forcing nxt = Forcing();
-  if (live) nxt = load_forcing<false, true>(ka, row0, lane, 0);
+  /* (the forcing windows are the ground wave's to read: this wave gets what a step needs of them
+   * through the mailbox, worked out one index ahead - ForcingPrep) */
   for (int32_t kv = 0; kv < nsteps; ++kv) {
     asm volatile("" : "+s"(ka));
     const ConstsAS &c = consts_of(ka);
     const int32_t k = __builtin_amdgcn_readfirstlane(kv);
     const int32_t i = t0 + k;
-    const Forcing f = nxt;
     int64_t orow = 0;
     const bool owrite = output_row<true>(ka, i, orow);
     const double t3 = mail.v[k & 1][1][lane]; /* Tmp(3) as the last step left it */
     if (!s.failed) {
-      double tair = f.tair, vz = f.vz, rhz = f.rhz;
-      if (i == 1 && vz < R4(0.4)) vz = R4(0.4); /* src/Initialization.f90:121-123 */
-      const double prec_ts = RS_DIVC(f.prec, 3600.0, r_3600) * c.DTSecs;
-      if (i < c.SimLen) {
-        Forcing chk = f;
-        chk.vz = vz;
-        if (check_values(c, chk, s.tsurf, false)) {
+      const ForcingPrep q = duo_get_prep(mail, k & 1, lane);
+      if (i < c.SimLen) { /* CheckValues: the forcing's verdict | the surface temperature's */
+        if (q.bad | check_values_tsurf(c, s.tsurf)) {
           s.failed = true;
           ka->state[(int64_t)RS_ST_FAILED * ka->np_pad + row0 + lane] = (double)i;
           mail.failed[lane] = 1u; /* this index still steps (the ground wave is in it already); the next does not */
@@ -1277,15 +1294,14 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
       }
       s.tnw1 = T.get(1);
       s.tnw2 = T.get(2);
-      const Fluxes fx =
-          model_step_fluxes<SCORE>(c, mt, s, tair, vz, rhz, prec_ts, f.sw, f.lw, f.phase, f.hour);
+      const double tair = q.tair;
+      const Fluxes fx = model_step_fluxes_prepped<SCORE>(c, mt, s, q);
       if (SCORE) {
         score += (fx.trips & 63) - 5;
         if ((fx.trips & 64) && k >= nsteps - RS_REGIME_WINDOW) score |= 1 << 30;
       }
-      if (k + 1 < nsteps) nxt = load_forcing<false, true>(ka, row0, lane, k + 1);
       /* layers 1-2 with Tmp(3) where a two-layer column has its lower boundary */
-      model_step_ground<RegProfile<2>, RegProfile<2>, false>(c, s, T, t3, tair, fx, f.depth);
+      model_step_ground<RegProfile<2>, RegProfile<2>, false>(c, s, T, t3, tair, fx, R4(-9999.9));
       if (owrite) store_outputs<false, true>(ka, orow, row0, lane, s, true);
       if (s.failed) blank_rows(i + 1);
     }
@@ -1314,7 +1330,7 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
 }
 
 template <int NL>
-__device__ __forceinline__ void duo_ground(DuoMail &mail, const StepArgs &a) {
+__device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, const StepArgs &a) {
   KernArgs ka = kernargs();
   const uint32_t lane = threadIdx.x & 63u;
   const int64_t p = (int64_t)blockIdx.x * 64 + lane;
@@ -1324,12 +1340,23 @@ __device__ __forceinline__ void duo_ground(DuoMail &mail, const StepArgs &a) {
   for (int j = 3; j <= NL; ++j) Tg[j - 3] = live ? a.state[(int64_t)(RS_ST_TMP0 + j - 1) * a.np_pad + p] : 0.0;
   const double tbot = live ? ka->pp.tbottom[p] : 0.0;
   mail.v[0][1][lane] = Tg[0];
+  const int32_t nsteps = ka->nsteps, t0 = ka->t0;
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  /* the forcing of the launch's first index, prepared before the first meeting (a lane beyond npoints
+   * reads nothing: the windows need only span npoints columns) */
+  Forcing nxt = Forcing();
+  {
+    const ConstsAS &c0 = consts_of(ka);
+    if (live) nxt = load_forcing<false, true>(ka, row0, lane, 0);
+    duo_put_prep(mail, 0, lane, forcing_prep(c0, mt, nxt, t0, t0 < c0.SimLen));
+  }
   duo_meet();
-  const int32_t nsteps = ka->nsteps;
   for (int32_t kv = 0; kv < nsteps; ++kv) {
     asm volatile("" : "+s"(ka));
     const ConstsAS &c = consts_of(ka);
     const int32_t k = __builtin_amdgcn_readfirstlane(kv);
+    /* next index's forcing: fetched here, used behind the layers */
+    if (k + 1 < nsteps && live) nxt = load_forcing<false, true>(ka, row0, lane, k + 1);
     const double t2 = mail.v[k & 1][0][lane]; /* Tmp(2) as the last step left it (melting included) */
     /* a failed point takes no further step in any flavour: its Tmp(3..N) stay as the failing index left
      * them (the flag was raised before the barrier that ended that index) */
@@ -1343,6 +1370,10 @@ __device__ __forceinline__ void duo_ground(DuoMail &mail, const StepArgs &a) {
       }
     }
     mail.v[(k & 1) ^ 1][1][lane] = Tg[0];
+    if (k + 1 < nsteps) {
+      const int32_t in = t0 + k + 1;
+      duo_put_prep(mail, (k & 1) ^ 1, lane, forcing_prep(c, mt, nxt, in, in < c.SimLen));
+    }
     duo_meet();
   }
   if (live) {
@@ -1362,7 +1393,7 @@ __global__ void __launch_bounds__(128, 4) step_kernel_duo(const StepArgs a) {
    * SIMD hosts both kinds, was measured: 1.08e10 and 1.13e10 against 1.12e10 with fixed roles at
    * 125 000 points - nothing to gain.) */
   if (threadIdx.x < 64) duo_surface<NL, SCORE>(mt, mail, a);
-  else duo_ground<NL>(mail, a);
+  else duo_ground<NL>(mt, mail, a);
 }
 
 /* FULL feature set + sky view in lock step, LDS profile (any NLayers). */
