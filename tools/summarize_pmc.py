@@ -10,7 +10,7 @@ for sub in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     for fn in files:
         with open(fn) as f:
             for row in csv.DictReader(f):
-                k = row.get("Kernel_Name", "?").split("(")[0]
+                k = row.get("Kernel_Name", "?").replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
                 acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
     print(f"== {os.path.basename(sub)}")
     for k, cs in acc.items():
