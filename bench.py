@@ -44,8 +44,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 ALGO_BYTES_PER_UNIT = 100.0    # 52 B read + 48 B written per point-timestep
-TRAFFIC_FILE = "profiles/r03_traffic.json"  # committed PMC summary the roofline's `traffic` is read from
-TRAFFIC_FILE_F32 = "profiles/r03_f32_traffic.json"
+TRAFFIC_FILE = "profiles/r04_traffic.json"  # committed PMC summary the roofline's `traffic` is read from
+TRAFFIC_FILE_F32 = "profiles/r04_f32_traffic.json"
 
 
 def effective_cpus() -> int:

@@ -487,7 +487,7 @@ contains
    !! CheckValues failed it.  ROADSURF_HIP_WRITEBACK=1: the reference's in-place edits of the input
    !! arrays (SW_dir clamp, sky-view SW/SW_dir/LW) are written back to the caller.
    subroutine runsimulation_batch_ex(n, outPointers, inPointers, inSettings, inputParam, localParam, status, &
-                                     first_failed) bind(C, name='runsimulation_batch_ex')
+                                     first_failed_arg) bind(C, name='runsimulation_batch_ex')
       integer(c_int), value :: n
       type(OutputPointers), intent(inout) :: outPointers(n)
       type(InputPointers), intent(in) :: inPointers(n)
@@ -495,7 +495,10 @@ contains
       type(InputParameters), intent(in) :: inputParam
       type(LocalParameters), intent(in) :: localParam(n)
       integer(c_int), intent(out) :: status
-      type(c_ptr), value :: first_failed
+      type(c_ptr), value :: first_failed_arg
+      type(c_ptr) :: first_failed
+      integer(c_int), allocatable, target :: ffdiag(:)
+      logical :: diag
       character(len=8) :: envv
       integer :: envl, envs
 
@@ -518,6 +521,16 @@ contains
 
       status = 0
       any_sky = .false.
+      ! ROADSURF_HIP_DIAGNOSTICS: print what the reference prints when CheckValues fails a point
+      ! (src/InputOutput.f90:63-65,72,80-81) - needs the per-point failure index
+      first_failed = first_failed_arg
+      call get_environment_variable('ROADSURF_HIP_DIAGNOSTICS', envv, envl, envs)
+      diag = (envs == 0 .and. envl > 0)
+      if (diag .and. .not. c_associated(first_failed) .and. n >= 1) then
+         allocate (ffdiag(n))
+         ffdiag = 0
+         first_failed = c_loc(ffdiag)
+      end if
       call rs_host_set_error(c_null_char)   ! rs_last_error() is empty unless THIS call fails
       if (n < 1) return
       call rs_build_constants(inSettings, inputParam, consts, rc)
@@ -622,7 +635,53 @@ contains
          if (rc /= 0) status = rc
       end if
       deallocate (tbottom)
+      if (diag .and. status == 0) call print_diagnostics(n, outPointers, inPointers, localParam, first_failed)
    end subroutine runsimulation_batch_ex
+
+   !> The reference's diagnostics for the points CheckValues failed (src/InputOutput.f90:55-82): the
+   !! same three messages on standard output, from the caller's arrays at the failing index.  The
+   !! surface temperature CheckValues saw at index i is the one SaveOutput wrote for index i-1.
+   subroutine print_diagnostics(n, outPointers, inPointers, localParam, first_failed)
+      integer(c_int), intent(in) :: n
+      type(OutputPointers), intent(in) :: outPointers(n)
+      type(InputPointers), intent(in) :: inPointers(n)
+      type(LocalParameters), intent(in) :: localParam(n)
+      type(c_ptr), intent(in) :: first_failed
+      integer(c_int), pointer :: ff(:)
+      real(c_double), pointer :: tair(:), tdew(:), rhz(:), vz(:), sw(:), lw(:), prec(:), swd(:), lwn(:), ts(:)
+      integer :: p, i, nt
+      if (.not. c_associated(first_failed)) return
+      call c_f_pointer(first_failed, ff, [n])
+      do p = 1, n
+         i = ff(p)
+         if (i < 1) cycle
+         nt = inPointers(p)%inputLen
+         if (i > nt) cycle
+         call c_f_pointer(inPointers(p)%c_tair, tair, [nt]); call c_f_pointer(inPointers(p)%c_tdew, tdew, [nt])
+         call c_f_pointer(inPointers(p)%c_Rhz, rhz, [nt]); call c_f_pointer(inPointers(p)%c_VZ, vz, [nt])
+         call c_f_pointer(inPointers(p)%c_SW, sw, [nt]); call c_f_pointer(inPointers(p)%c_LW, lw, [nt])
+         call c_f_pointer(inPointers(p)%c_prec, prec, [nt])
+         if (tair(i) < -90.0 .or. tair(i) > 100.0 .or. tdew(i) < -90 .or. tdew(i) > 100.0 &
+             .or. rhz(i) < -0.1 .or. rhz(i) > 120.0 .or. vz(i) < -1.0 .or. vz(i) > 100.0 &
+             .or. sw(i) < -0.1 .or. sw(i) > 4000.0 .or. lw(i) < -0.1 .or. lw(i) > 1000.0 &
+             .or. prec(i) < -0.1 .or. prec(i) > 500.0) then
+            write (*, *) "BAD input value! ", tair(i), tdew(i), rhz(i), vz(i), sw(i), lw(i), prec(i)
+         end if
+         if (localParam(p)%sky_view < 1.0 .and. localParam(p)%sky_view > -0.01) then
+            call c_f_pointer(inPointers(p)%c_SW_dir, swd, [nt]); call c_f_pointer(inPointers(p)%c_LW_net, lwn, [nt])
+            if (swd(i) < -0.1 .or. swd(i) > 4000.0 .or. lwn(i) < -1000.0 .or. lwn(i) > 1000.0) then
+               write (*, *) "BAD input value: SW_dir,LW_net", swd(i), lwn(i)
+            end if
+         end if
+         if (i > 1) then
+            call c_f_pointer(outPointers(p)%c_TsurfOut, ts, [outPointers(p)%outputLen])
+            if (ts(i - 1) < -100.0 .or. ts(i - 1) > 100.0) then
+               write (*, *) "Abnormal surface temperature", ts(i - 1), i, localParam(p)%lat, localParam(p)%lon
+            end if
+         end if
+      end do
+      flush (6)
+   end subroutine print_diagnostics
 
    !> Drop-in for the reference's runsimulation (examples/example1/src/Simulation.f90:4-117).
    !! No status argument, as in the reference: on a device/runtime error the

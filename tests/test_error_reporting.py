@@ -67,3 +67,36 @@ def test_a_successful_call_clears_the_message():
     ora, _, _ = oh.run_oracle("port", f, s, p, l)
     for k in oh.F64_OUT:
         assert np.array_equal(out[k], ora[k]), k
+
+
+@pytest.mark.gpu
+def test_reference_diagnostics_on_request(monkeypatch, capfd):
+    """ROADSURF_HIP_DIAGNOSTICS=1: the messages the reference prints when CheckValues fails a point
+    (src/InputOutput.f90:63-65,80-81), from the caller's arrays at the failing index."""
+    import sys
+    from test_hip_boundary import _pointers
+    Lb = lib.load()
+    n, SL = 5, 241
+    f = oh.synth_forcing(n, SL, seed=12)
+    f["tair"][1, 100] = 250.0          # BAD input value at index 101
+    f["lw"][3, 7] = -5.0               # ... and at index 8
+    s = abi.default_settings(SL); p = abi.default_parameters()
+    ls = []
+    for i in range(n):
+        li = abi.default_local(); li.InitLenI = 1; ls.append(li)
+    out = {k: np.full((n, SL), np.nan) for k in oh.F64_OUT}
+    ips = (abi.InputPointers * n)(); ops = (abi.OutputPointers * n)(); keep = []
+    for pt in range(n):
+        ip, op, hk = _pointers(f, out, pt)
+        ips[pt], ops[pt] = ip, op
+        keep.append(hk)
+    larr = (abi.LocalParameters * n)(*ls)
+    st = C.c_int32(99)
+    monkeypatch.setenv("ROADSURF_HIP_DIAGNOSTICS", "1")
+    Lb.runsimulation_batch(n, ops, ips, C.byref(s), C.byref(p), larr, C.byref(st))
+    sys.stdout.flush()
+    assert st.value == 0, lib.last_error()
+    text = capfd.readouterr().out
+    assert text.count("BAD input value!") == 2, text
+    assert "250." in text and "-5." in text
+    assert out["tsurf"][1, 100] != -9999.0 and out["tsurf"][1, 101] == -9999.0
