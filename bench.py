@@ -156,7 +156,7 @@ def main() -> None:
     ap.add_argument("--hours", type=int, default=48)
     ap.add_argument("--chunk", type=int, default=0,
                     help="time indices per step-kernel launch; 0 = auto: 120 for >= 400 000 points on "
-                         "the GPU, 240 for smaller shards (measured, tools/r3_small2.sh)")
+                         "the GPU, 240 for smaller shards (measured, tools/experiments/r3_small2.sh)")
     ap.add_argument("--control", choices=["gloo", "nccl"], default="gloo",
                     help="backend of the barriers / MAX / checksum SUM between ranks (no data-path collective)")
     ap.add_argument("--variant", type=int, default=0,
@@ -243,16 +243,16 @@ def main() -> None:
     if args.full:
         settings.use_relaxation = 1
     params = abi.default_parameters()
-    # measured on MI355X (tools/exp_plans.sh, tools/exp_small.sh): 4 plans from 200 000
+    # measured on MI355X (tools/experiments/exp_plans.sh, tools/experiments/exp_small.sh): 4 plans from 200 000
     # points, 2 from 100 000; launches of 120 indices for a full GPU, 240 for small shards
     K = args.plans_per_gpu if args.plans_per_gpu > 0 else (4 if n >= 200_000 else 2 if n >= 100_000 else 1)
     if args.chunk <= 0:
-        args.chunk = 120 if n >= 400_000 else 240  # measured: tools/r3_small2.sh
-    if args.full and n >= 750_000:  # measured (tools/r3_full3.sh): three plans, launches of 240 indices
+        args.chunk = 120 if n >= 400_000 else 240  # measured: tools/experiments/r3_small2.sh
+    if args.full and n >= 750_000:  # measured (tools/experiments/r3_full3.sh): three plans, launches of 240 indices
         K = args.plans_per_gpu if args.plans_per_gpu > 0 else 3
         args.chunk = 240
     if args.variant == 0 and not args.f32 and not args.full:
-        # measured (tools/r3_duo.sh): two plans of <= 100 000 points run faster with two wavefronts per
+        # measured (tools/experiments/r3_duo.sh): two plans of <= 100 000 points run faster with two wavefronts per
         # 64 points; with four plans in flight one point per lane fills the chip
         args.variant = 3 if n < 200_000 else 1
     def make_plans(K, settings, variant):
@@ -384,7 +384,7 @@ def main() -> None:
         # behind it) on the same synthetic points: what `bench.py --full` reports as its headline
         s_full = abi.default_settings(simlen)
         s_full.use_relaxation = 1
-        Kf, chunk_f = (3, 240) if n >= 750_000 else (K, args.chunk)  # measured: tools/r3_full3.sh
+        Kf, chunk_f = (3, 240) if n >= 750_000 else (K, args.chunk)  # measured: tools/experiments/r3_full3.sh
         fplans, foffs = make_plans(Kf, s_full, 0)
         f_steps = 2
         f_elapsed, _, f_nl, f_chunk, f_busy = timed_leg(True, fplans, foffs, chunk_f, True, steps=f_steps, warmup=1)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# driver-path rows: parity tests + rates at 1 M points (tiled inputs); usage: r4_drv.sh tag [modes...]
+# driver-path rows: parity tests + rates at 1 M points (tiled inputs); usage: check_driver_path.sh tag [modes...]
 TAG=${1:-drv}; shift
 MODES=${@:-relax coupling skyview skycoupling}
 mkdir -p gpurun_out/r4_$TAG

@@ -7,14 +7,15 @@ set -e
 MODE=${1:-relax}; N=${2:-1000000}
 export TMPDIR=/tmp
 OUT=gpurun_out/r4_prof_drv_$MODE
-rm -rf $OUT; mkdir -p $OUT profiles
+PROF=gpurun_out/profiles_r04   # (gpurun merges gpurun_out/ back; copy to profiles/ afterwards)
+rm -rf $OUT; mkdir -p $OUT $PROF
 export BENCH_UNIQUE=65536 BENCH_REPS=2 BENCH_PAUSE_S=0.25
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tools/bench_driver_path.py $N 48 $MODE > $OUT/bench.log 2> $OUT/trace.err || { tail -20 $OUT/trace.err; exit 1; }
 grep -E "rep |best" $OUT/bench.log
 STATS=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 SHA=$(python3 -c "from roadsurf_amd import provenance; print(provenance.csrc_sha16())")
-{ echo "# rocprofv3 --kernel-trace --stats -- python3 tools/bench_driver_path.py $N 48 $MODE (BENCH_UNIQUE=65536, 3 calls: 1 warm + 2 timed); kernel sources $SHA"; cat "$STATS"; } > profiles/r04_driver_path_${MODE}_kernel_stats.csv
-python3 - "$OUT" "$MODE" "$N" "$SHA" > profiles/r04_driver_path_${MODE}_timeline.txt <<'PY'
+{ echo "# rocprofv3 --kernel-trace --stats -- python3 tools/bench_driver_path.py $N 48 $MODE (BENCH_UNIQUE=65536, 3 calls: 1 warm + 2 timed); kernel sources $SHA"; cat "$STATS"; } > $PROF/r04_driver_path_${MODE}_kernel_stats.csv
+python3 - "$OUT" "$MODE" "$N" "$SHA" > $PROF/r04_driver_path_${MODE}_timeline.txt <<'PY'
 import csv, glob, collections, sys
 out, mode, n, sha = sys.argv[1:5]
 rows=[]
@@ -51,5 +52,5 @@ for q,v in sorted(byq.items(), key=lambda kv: min(a for n_,a,b in kv[1])):
     if not st: continue
     print(f"  queue {q}: {(min(a for n_,a,b in v)-t0)/1e6:7.1f} {(min(a for a,b in st)-t0)/1e6:7.1f} {(max(b for a,b in st)-t0)/1e6:7.1f} {(max(b for n_,a,b in v)-t0)/1e6:7.1f}   step kernels {len(st)}, sum {sum(b-a for a,b in st)/1e6:.1f} ms")
 PY
-cat profiles/r04_driver_path_${MODE}_timeline.txt
+cat $PROF/r04_driver_path_${MODE}_timeline.txt
 rm -rf $OUT/trace
