@@ -4,14 +4,19 @@
 Metric (BASELINE.json): point-timesteps/s at 1 M points x 48 h, fp64.
 
 One bench "step" = one full pass of the hot path over the workload:
-    init kernel  ->  for every time chunk:  expand kernel (hourly knots -> DTSecs
-    grid, the device twin of the reference driver's interpolation)  ->  step
-    kernel (the model: 5 761 time indices per point in all).
+    init kernel  ->  for every time chunk:  hourly knots -> DTSecs grid (the device
+    twin of the reference driver's interpolation)  ->  step kernel (the model:
+    5 761 time indices per point in all).
 Inputs resident in HBM before the timed region: the hourly forcing knots of every
 point (what an NWP source delivers).  Step-resolution forcing for 1 M points x
 5 761 indices is 300 GB (> 288 GB HBM), so it is produced per chunk
-on the device and consumed from HBM by the step kernel; the six outputs are
-written every time index (reference SaveOutput semantics) into a chunk buffer.
+on the device: by an expansion kernel into a forcing window the step kernel reads
+from HBM (--variant 1, 2; FULL; fp32; natural order), or - the default LEAN fp64
+flavour since round 4 - inside the step kernel itself, whose ground wavefront
+interpolates the next index's forcing from the knots while the surface wavefront
+works on the current one (rs_hip_step_knots; no forcing window exists).  The six
+outputs are written every time index (reference SaveOutput semantics) into a
+chunk buffer.
 
 The pass itself lives in roadsurf_amd/workload.py (SyntheticRun) and is the code the
 parity tests step at the same size (tests/test_hip_golden_and_scale.py).  Outputs stay
@@ -155,13 +160,14 @@ def main() -> None:
     ap.add_argument("--points", type=int, default=None, help="points per GPU (implies --scaling weak)")
     ap.add_argument("--hours", type=int, default=48)
     ap.add_argument("--chunk", type=int, default=0,
-                    help="time indices per step-kernel launch; 0 = auto: 120 for >= 400 000 points on "
-                         "the GPU, 240 for smaller shards (measured, tools/experiments/r3_small2.sh)")
+                    help="time indices per step-kernel launch; 0 = auto by flavour and shard size (see below "
+                         "--plans-per-gpu in the source)")
     ap.add_argument("--control", choices=["gloo", "nccl"], default="gloo",
                     help="backend of the barriers / MAX / checksum SUM between ranks (no data-path collective)")
     ap.add_argument("--variant", type=int, default=0,
-                    help="0 auto (by shard size: 3 below 200 000 points on the GPU, else 1), 1 register "
-                         "profile, 2 LDS profile, 3 two wavefronts per 64 points")
+                    help="0 auto (3 for the LEAN fp64 workload), 1 register profile (one point per lane), 2 LDS "
+                         "profile, 3 two wavefronts per 64 points - in plan order without a forcing window: the "
+                         "ground wave makes the forcing from the resident knots (rs_hip_step_knots)")
     ap.add_argument("--seed", type=int, default=20240110)
     ap.add_argument("--f32", action="store_true",
                     help="BASELINE config 5 flavour: fp32 state/forcing/outputs/arithmetic "
@@ -180,7 +186,7 @@ def main() -> None:
                     help="cut this GPU's points into K plans on K streams whose launches interleave: "
                          "one plan's HBM-bound window expansion and re-sort run beside another's "
                          "VALU-bound step kernel, and the tail of one launch under the head of the next. "
-                         "0 = auto: 4 from 200 000 points on the GPU, 2 from 100 000, else 1")
+                         "0 = auto by flavour and shard size")
     ap.add_argument("--no-natural-leg", action="store_true",
                     help="skip the second timed leg (natural order) that gives natural_order_value")
     ap.add_argument("--full", action="store_true",
@@ -243,18 +249,29 @@ def main() -> None:
     if args.full:
         settings.use_relaxation = 1
     params = abi.default_parameters()
-    # measured on MI355X (tools/experiments/exp_plans.sh, tools/experiments/exp_small.sh): 4 plans from 200 000
-    # points, 2 from 100 000; launches of 120 indices for a full GPU, 240 for small shards
-    K = args.plans_per_gpu if args.plans_per_gpu > 0 else (4 if n >= 200_000 else 2 if n >= 100_000 else 1)
+    if args.variant == 0 and not args.f32 and not args.full:
+        # Round 4: the two-wavefront flavour whose ground wave makes the forcing from the resident knots itself
+        # (roadsurf_amd/workload.py: no window expansion, no forcing window) is the faster one at every size -
+        # 1 M points, same box, alternating runs: 1.93e10 with one point per lane (4 plans x 120), 1.98e10 with
+        # this flavour in the same shape, 2.03-2.05e10 with 2 plans x 60
+        args.variant = 3
+    fused = args.variant == 3 and not args.f32 and not args.full and bool(args.cluster)
+    if fused:
+        # measured (round 4): with the expansion gone a launch cycle is short, so fewer plans hide it and shorter
+        # launches (a fresher sort key) pay: 2 x 60 from 750 000 points on the GPU, 3 x 90 from 400 000,
+        # 4 x 120 from 200 000, 2 x 240 below
+        K, ch = (2, 60) if n >= 750_000 else (3, 90) if n >= 400_000 else (4, 120) if n >= 200_000 else \
+            (2, 240) if n >= 100_000 else (1, 240)
+    else:
+        # measured on MI355X (tools/experiments/exp_plans.sh, r3_small2.sh; DESIGN_HISTORY.md 6)
+        K, ch = (4 if n >= 200_000 else 2 if n >= 100_000 else 1), (120 if n >= 400_000 else 240)
+    if args.plans_per_gpu > 0:
+        K = args.plans_per_gpu
     if args.chunk <= 0:
-        args.chunk = 120 if n >= 400_000 else 240  # measured: tools/experiments/r3_small2.sh
+        args.chunk = ch
     if args.full and n >= 750_000:  # measured (tools/experiments/r3_full3.sh): three plans, launches of 240 indices
         K = args.plans_per_gpu if args.plans_per_gpu > 0 else 3
         args.chunk = 240
-    if args.variant == 0 and not args.f32 and not args.full:
-        # measured (tools/experiments/r3_duo.sh): two plans of <= 100 000 points run faster with two wavefronts per
-        # 64 points; with four plans in flight one point per lane fills the chip
-        args.variant = 3 if n < 200_000 else 1
     def make_plans(K, settings, variant):
         plans, offsets = [], []
         for j in range(K):
@@ -341,7 +358,18 @@ def main() -> None:
     elapsed, step_ms, nlaunch, chunk, busy_ms = timed_leg(cluster)
     natural = None
     if cluster and not args.no_natural_leg:
-        natural = timed_leg(False)
+        if fused:
+            # natural order has no knot-reading flavour (nothing to gather through): its best shape is the
+            # round-3 one - one point per lane, expansion kernel + forcing window, 4 x 120 / 4 x 240 / 2 x 240
+            Kn, chn = (4 if n >= 200_000 else 2 if n >= 100_000 else 1), (120 if n >= 400_000 else 240)
+            nplans, noffs = make_plans(Kn, settings, 1)
+            natural = timed_leg(False, nplans, noffs, chn) + (Kn,)
+            for pl in nplans:
+                pl.close()
+            del nplans
+            torch.cuda.empty_cache()
+        else:
+            natural = timed_leg(False) + (K,)
     nfail = sum(pl.failed_count() for pl in plans)
     checksum = None
     if args.checksum:
@@ -484,6 +512,9 @@ def main() -> None:
                 "inputs_resident": "hourly knots of every point, made once before the timed region (since round "
                                    "3; round 2 regenerated the windows' and previews' knots inside it)",
                 "kernel_variant": args.variant,
+                "forcing_window": ("none: the step kernel's ground wavefront interpolates the forcing from the "
+                                   "resident knots (rs_hip_step_knots)" if fused else
+                                   "made per launch by the expansion kernel, read from HBM by the step kernel"),
                 "parallelism": f"points sharded over {world} GPU(s) ({scaling} scaling), no collectives",
                 "failed_points": int(nfail),
                 "checksum": checksum,
@@ -517,7 +548,9 @@ def main() -> None:
                           "concurrent_launches; per_launch_achieved is the single-launch figure",
                 "step_kernel_only_value": units_per_pass_rank * args.steps / (busy_ms / 1e3),
                 "note": ("fp32" if args.f32 else "fp64") + "-VALU-bound kernel (SURVEY.md 8d): the HBM fraction "
-                        "is reported as the contract asks, the binding roofline is vector-ALU issue",
+                        "is reported as the contract asks, the binding roofline is vector-ALU issue"
+                        + ("; in this flavour the 52 B/unit of forcing are never read from HBM (they are "
+                           "made from the knots in registers), so HBM traffic is below the algorithmic bytes" if fused else ""),
             },
         }
         for k, v in extra.items():
@@ -526,13 +559,16 @@ def main() -> None:
         if extra:
             line["extra_legs"] = extra
         if natural is not None:
-            n_elapsed, n_step_ms, n_nlaunch, _, n_busy = natural
+            n_elapsed, n_step_ms, n_nlaunch, n_chunk, n_busy, n_K = natural
             line["natural_order_value"] = units_per_pass_job * args.steps / n_elapsed
             line["natural_order"] = {
                 "ms_per_step": n_elapsed / args.steps * 1e3,
                 "avg_launch_ms": n_step_ms / max(n_nlaunch, 1),
                 "step_kernel_only_value": units_per_pass_rank * args.steps / (n_busy / 1e3),
-                "note": "second timed leg, same W/K and fences: points in natural order, no re-sort",
+                "plans_per_gpu": n_K, "chunk_steps": n_chunk,
+                "kernel_variant": 1 if fused else args.variant,
+                "note": "second timed leg, same W/K and fences: points in natural order, no re-sort"
+                        + (", expansion kernel + forcing window, one point per lane" if fused else ""),
             }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, simlen, args.seed)

@@ -448,6 +448,15 @@ int rs_hip_expand_forcing_ordered(RsPlan *plan, const RsSynthSpec *spec,
                                   const double *knots, int32_t k0, int32_t nknots,
                                   const RsForcing *f, int32_t t0, int32_t nsteps);
 
+/* rs_hip_expand_forcing_ordered + rs_hip_step in one launch, without the window: the two-wavefront
+ * flavour's ground wave interpolates the forcing of the next index from the knots itself (same arithmetic,
+ * same values).  knots in POINT order (spec->order NULL), read through the plan's order row.  LEAN feature
+ * set, NLayers = 15, fp64 only (anything else: an error - use the two calls).  What a small shard uses:
+ * there the window expansion is the longest link of the chain between two step launches of a plan. */
+int rs_hip_step_knots(RsPlan *plan, const RsSynthSpec *spec, const double *knots, int32_t k0,
+                      int32_t nknots, const RsOutputs *o, const RsPointParams *pp, int32_t t0,
+                      int32_t nsteps);
+
 /* Same, enqueued on another HIP stream (hipStream_t) than the plan's: lets a caller
  * overlap the HBM-bound expansion of window c+1 with the VALU-bound stepping of
  * window c (double-buffered windows, dependencies by HIP events on the caller's side). */
@@ -692,7 +701,7 @@ int rs_driver_expand(const RsDriverInput *in, const InputSettings *settings,
                      LocalParameters *local, double *merged, int32_t *status,
                      int32_t *missing_index, int32_t device);
 
-#define RS_ABI_VERSION 4 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles; 4: RsPointParams::horizon_index */
+#define RS_ABI_VERSION 4 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles; 4: RsPointParams::horizon_index, rs_hip_step_knots */
 int rs_abi_version(void);
 /* sizeof of the boundary structs as the C side / the Fortran side see them
  * (0 InputPointers, 1 OutputPointers, 2 InputSettings, 3 InputParameters,

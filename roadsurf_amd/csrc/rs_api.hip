@@ -75,6 +75,11 @@ struct RsPlan {
   bool cpl_windows_closed = false; /* rs_hip_coupling_windows_closed: re-sorts leave the saved state */
   bool history_score = true; /* the step kernels leave the sort key of rs_hip_recluster */
   bool f32 = false; /* single-precision flavour: windows and state hold floats */
+  /* wave table of the two-wavefront flavour (rs_cluster_wave_table): [2][wave_n] start, count; valid
+   * for the slot order the last forecast re-sort left */
+  int32_t *wave_tab = nullptr;
+  int32_t wave_n = 0;
+  bool wave_tab_valid = false;
   std::vector<void *> owned; /* hipMalloc-ed pieces (plan_malloc): what rs_hip_plan_destroy frees */
   std::vector<hipEvent_t> ev; /* start/stop pairs */
   size_t ev_used = 0;
@@ -345,10 +350,33 @@ int rs_hip_recluster_forecast(RsPlan *pl, const RsPreview *pv) {
   const bool lib_sort = getenv("ROADSURF_HIP_LIBRARY_SORT") != nullptr; /* read per call: the tests switch it */
   a.compact = (bits >= 1 && bits <= 12 && !lib_sort) ? 1 : 0;
   HIP_OK(rs_launch_forecast_keys(a, pl->stream));
-  if (a.compact)
+  pl->wave_tab_valid = false;
+  if (a.compact) {
+    /* For the two-wavefront flavour: the classes of the key - its five most significant
+     * bits: cover, unstable previews, table-path previews of the default field set - each start a wavefront
+     * of their own (rs_cluster_wave_table).  ROADSURF_HIP_WAVE_CLASS_BITS = 0 switches the table off,
+     * 1..6 sets the bits (tuning; classes hold at least 64 bins of the key). */
+    int cb = 5;
+    if (const char *e = getenv("ROADSURF_HIP_WAVE_CLASS_BITS")) cb = atoi(e);
+    const bool table = cb >= 1 && cb <= 6 && bits - cb >= 6 && !pl->f32;
+    uint32_t *class_total = nullptr;
+    int32_t maxw = 0;
+    if (table) {
+      maxw = (int32_t)((pl->npoints + 63) / 64) + (1 << cb);
+      if (!pl->wave_tab || pl->wave_n != maxw) {
+        HIP_OK(plan_malloc(pl, &pl->wave_tab, ((size_t)2 * maxw + 64) * sizeof(int32_t)));
+        pl->wave_n = maxw;
+        HIP_OK(hipMemsetAsync(pl->wave_tab + 2 * (size_t)maxw, 0, 64 * sizeof(int32_t), pl->stream));
+      }
+      class_total = reinterpret_cast<uint32_t *>(pl->wave_tab + 2 * (size_t)maxw);
+    }
     HIP_OK(rs_cluster_count_sort(pl->np_pad, pl->npoints, bits, pl->sort_keys, pl->sort_tmp,
-                                 pl->sort_tmp_bytes, pl->stream));
-  else
+                                 pl->sort_tmp_bytes, pl->stream, class_total, cb));
+    if (table) {
+      HIP_OK(rs_cluster_wave_table(cb, class_total, pl->wave_tab, pl->wave_tab + maxw, maxw, pl->stream));
+      pl->wave_tab_valid = true;
+    }
+  } else
     HIP_OK(rs_cluster_sort_keys(pl->np_pad, pl->npoints, pl->sort_keys, pl->sort_tmp, pl->sort_tmp_bytes,
                                 pl->stream));
   return recluster_apply(pl);
@@ -359,6 +387,7 @@ int rs_hip_recluster(RsPlan *pl) {
   if (!pl->history_score)
     return set_err("rs_hip_recluster: the plan's history score is switched off (rs_hip_set_history_score)");
   if (!rs_hip_plan_order(pl)) return -1;
+  pl->wave_tab_valid = false;
   HIP_OK(hipSetDevice(pl->device));
   if (recluster_buffers(pl)) return -1;
   HIP_OK(rs_cluster_sort(pl->state, pl->f32, pl->np_pad, pl->npoints, pl->sort_keys, pl->sort_tmp,
@@ -377,6 +406,7 @@ int rs_hip_plan_order_copy(RsPlan *pl, int32_t *dst) {
 
 int rs_hip_plan_reset_order(RsPlan *pl) {
   if (!pl) return set_err("rs_hip_plan_reset_order: null plan");
+  pl->wave_tab_valid = false;
   if (!pl->order) return rs_hip_plan_order(pl) ? 0 : -1; /* allocated as the identity */
   HIP_OK(hipSetDevice(pl->device));
   HIP_OK(rs_cluster_identity(pl->order, pl->np_pad, pl->stream));
@@ -597,6 +627,13 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
   a.cpl_stop = 0;
   a.cpl_inner = a.cpl_prio = 0;
   a.out_index = nullptr;
+  a.wave_start = pl->wave_tab_valid ? pl->wave_tab : nullptr;
+  a.wave_cnt = pl->wave_tab_valid ? pl->wave_tab + pl->wave_n : nullptr;
+  a.wave_n = pl->wave_n;
+  a.knots = nullptr;
+  a.knot_gather = nullptr;
+  a.knot_k0 = a.knot_n = a.spk = a.start_hour = 0;
+  a.r_spk = 0.0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (pl->timing) {
     if (pl->ev_used + 2 > pl->ev.size()) {
@@ -646,6 +683,87 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
   return 0;
 }
 
+/* The LEAN step of the two-wavefront flavour WITHOUT a forcing window: the ground wave of every
+ * workgroup makes the forcing of the next index from the hourly knots itself (expand_kernel's arithmetic,
+ * value for value), one index ahead of the surface wave.  For a small shard the window expansion is the
+ * longest link of the chain between two step launches (0.19 of 0.36 ms at 62 500 points, HBM-bound) and
+ * nothing of the same plan can run beside it; here it does not exist.  knots: [nknots][RS_KNOT_FIELDS]
+ * [np_pad] in POINT order (rs_hip_synth_knots), knot k0 first; the plan's order row maps slots to columns. */
+int rs_hip_step_knots(RsPlan *pl, const RsSynthSpec *spec, const double *knots, int32_t k0, int32_t nknots,
+                      const RsOutputs *o, const RsPointParams *pp, int32_t t0, int32_t nsteps) {
+  if (!pl || !spec || !knots) return set_err("rs_hip_step_knots: bad arguments");
+  if (!pp || !pp->tbottom) return set_err("rs_hip_step_knots: tbottom is required");
+  if (!o || !o->tsurf || !o->snow || !o->water || !o->ice || !o->deposit || !o->ice2)
+    return set_err("rs_hip_step_knots: all six output streams are required");
+  if (o->t_stride < pl->npoints) return set_err("rs_hip_step_knots: output t_stride < npoints");
+  if (o->decimate < 1) return set_err("rs_hip_step_knots: decimate must be >= 1");
+  if (t0 < 1 || nsteps < 1 || (int64_t)t0 + nsteps - 1 > pl->c.SimLen)
+    return set_err("rs_hip_step_knots: window [%d,%d) outside [1,SimLen=%d]", t0, t0 + nsteps, pl->c.SimLen);
+  const int32_t spk = spec->steps_per_knot;
+  if (spk < 1) return set_err("rs_hip_step_knots: steps_per_knot < 1");
+  {
+    const int32_t kfirst = (t0 - 1) / spk, tlast = t0 + nsteps - 2;
+    const int32_t klast = tlast / spk + ((tlast % spk) ? 1 : 0);
+    if (kfirst < k0 || klast >= k0 + nknots)
+      return set_err("rs_hip_step_knots: need knots %d..%d, buffer has %d..%d", kfirst, klast, k0, k0 + nknots - 1);
+    const int64_t first = ((int64_t)t0 - 1 + o->decimate - 1) / o->decimate;
+    if (first < o->row0) return set_err("rs_hip_step_knots: output row0 beyond first row");
+  }
+  const int64_t out_rows = ((int64_t)t0 + nsteps - 2) / o->decimate - o->row0 + 1;
+  if (pl->f32 || pl->c.NLayers != 15 || pp->initlen || pl->c.force_tsurf || pl->c.tsurfOutputDepth >= 0.0 ||
+      (pl->c.use_relaxation && pp->tair_relax) || pp->sky_view || pl->c.use_coupling ||
+      (uint64_t)o->t_stride * (uint64_t)(out_rows > 0 ? out_rows : 1) >= (1ull << 29))
+    return set_err("rs_hip_step_knots: the LEAN feature set, NLayers = 15, fp64 and an output window below 4 GiB "
+                   "per stream only - use rs_hip_expand_forcing_ordered + rs_hip_step");
+  const int32_t *order = rs_hip_plan_order(pl);
+  if (!order) return -1;
+  HIP_OK(hipSetDevice(pl->device));
+  rs::StepArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.consts = pl->consts_dev;
+  a.f.t_stride = pl->np_pad; /* no window: nothing of `f` is read */
+  a.o = *o;
+  a.pp = *pp;
+  a.state = pl->state;
+  a.npoints = pl->npoints;
+  a.np_pad = pl->np_pad;
+  a.t0 = t0;
+  a.nsteps = nsteps;
+  a.wave_start = pl->wave_tab_valid ? pl->wave_tab : nullptr;
+  a.wave_cnt = pl->wave_tab_valid ? pl->wave_tab + pl->wave_n : nullptr;
+  a.wave_n = pl->wave_n;
+  a.knots = knots;
+  a.knot_gather = order;
+  a.knot_k0 = k0;
+  a.knot_n = nknots;
+  a.spk = spk;
+  a.start_hour = spec->start_hour;
+  a.r_spk = 1.0 / (double)spk;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (pl->timing) {
+    if (pl->ev_used + 2 > pl->ev.size()) {
+      hipEvent_t x, y;
+      HIP_OK(hipEventCreate(&x));
+      if (hipEventCreate(&y) != hipSuccess) {
+        (void)hipEventDestroy(x);
+        return set_err("rs_hip_step_knots: hipEventCreate failed");
+      }
+      pl->ev.push_back(x);
+      pl->ev.push_back(y);
+    }
+    e0 = pl->ev[pl->ev_used];
+    e1 = pl->ev[pl->ev_used + 1];
+    HIP_OK(hipEventRecord(e0, pl->stream));
+  }
+  const hipError_t le = rs_launch_step_duo_knots(a, pl->history_score, pl->stream);
+  if (le != hipSuccess) return set_err("rs_hip_step_knots: kernel launch failed: %s", hipGetErrorString(le));
+  if (pl->timing) {
+    HIP_OK(hipEventRecord(e1, pl->stream));
+    pl->ev_used += 2;
+  }
+  return 0;
+}
+
 /* common validation + argument block of the two chunked-coupling entry points */
 static int cpl_args(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPointParams *pp,
                     int32_t t0, int32_t nsteps, const char *who, rs::StepArgs &a) {
@@ -685,6 +803,12 @@ static int cpl_args(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const Rs
   a.cpl_stop = 0;
   a.cpl_inner = a.cpl_prio = 0;
   a.out_index = (pl->output_by_point && pl->order) ? pl->order : nullptr;
+  a.wave_start = a.wave_cnt = nullptr;
+  a.wave_n = 0;
+  a.knots = nullptr;
+  a.knot_gather = nullptr;
+  a.knot_k0 = a.knot_n = a.spk = a.start_hour = 0;
+  a.r_spk = 0.0;
   return 0;
 }
 

@@ -151,17 +151,27 @@ __global__ void __launch_bounds__(256) cs_hist_kernel(const uint32_t *__restrict
 
 /* one lane per bin: walks the tiles in order (coalesced rows of H[tile][bin]), leaves the bin's
  * exclusive prefix over the tiles in place and its total in T[bin] */
-__global__ void __launch_bounds__(64) cs_binscan_kernel(uint32_t *H, uint32_t *T, int nbins, int ntiles) {
+__global__ void __launch_bounds__(64) cs_binscan_kernel(uint32_t *H, uint32_t *T, int nbins, int ntiles,
+                                                        uint32_t *class_total, int class_shift) {
   const int bin = (int)blockIdx.x * 64 + (int)threadIdx.x;
-  if (bin >= nbins) return;
   uint32_t run = 0u;
+  if (bin < nbins) {
 #pragma unroll 8
-  for (int t = 0; t < ntiles; ++t) {
-    const uint32_t v = H[(int64_t)t * nbins + bin];
-    H[(int64_t)t * nbins + bin] = run;
-    run += v;
+    for (int t = 0; t < ntiles; ++t) {
+      const uint32_t v = H[(int64_t)t * nbins + bin];
+      H[(int64_t)t * nbins + bin] = run;
+      run += v;
+    }
+    T[bin] = run;
   }
-  T[bin] = run;
+  /* for the wave table (cs_wave_table_kernel): the keys per CLASS, class = bin >> class_shift.  A
+   * workgroup's 64 bins belong to one class (class_shift >= 6): one atomic per workgroup */
+  if (class_total) {
+    uint32_t sum = run;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += (uint32_t)__shfl_xor((int)sum, off, 64);
+    if (threadIdx.x == 0 && (int)blockIdx.x * 64 < nbins) atomicAdd(&class_total[((int)blockIdx.x * 64) >> class_shift], sum);
+  }
 }
 
 __global__ void __launch_bounds__(64) cs_scatter_kernel(const uint32_t *__restrict__ keys, int64_t n,
@@ -242,6 +252,55 @@ __global__ void __launch_bounds__(64) cs_scatter_kernel(const uint32_t *__restri
 }
 }  // namespace
 
+/* Wave table for the two-wavefront flavour (rs_kernels.hip, step_kernel_duo): wavefront w steps the slots
+ * [start[w], start[w] + cnt[w]).  A CLASS = the slots whose sort key shares its class_bits most significant
+ * bits (cover, unstable previews, table-path previews for the default key): every class starts a wavefront of
+ * its own, so that no wavefront mixes two classes - the slowest wavefront of a small shard's launch is a MIXED
+ * one (tools/bl_makespan.py), and the launch is as long as its slowest wavefront.  The slot space is
+ * untouched (windows, state, order rows stay dense); only the kernel's wave -> slot mapping changes, at the
+ * price of at most one partly filled wavefront per class.  One workgroup of 64 lanes: lane c takes the
+ * keys of class c (counted by cs_binscan_kernel), two wavefront scans give every class its first slot and
+ * first wavefront. */
+__global__ void __launch_bounds__(64) cs_wave_table_kernel(uint32_t *__restrict__ class_total,
+                                                           int class_bits, int32_t *__restrict__ wstart,
+                                                           int32_t *__restrict__ wcnt, int32_t maxw) {
+  const uint32_t lane = threadIdx.x;
+  const int nclasses = 1 << class_bits;
+  uint32_t n = 0u;
+  if ((int)lane < nclasses) {
+    n = class_total[lane]; /* left by cs_binscan_kernel */
+    class_total[lane] = 0u; /* ... and zero again for the next sort */
+  }
+  const uint32_t waves = (n + 63u) >> 6;
+  const uint32_t sbase = wave_incl_scan(n, lane) - n, wbase = wave_incl_scan(waves, lane) - waves;
+  uint32_t total = 0u;
+  for (int c = 0; c < nclasses; ++c) {
+    const uint32_t nc = (uint32_t)__shfl((int)n, c, 64), sb = (uint32_t)__shfl((int)sbase, c, 64),
+                   wb = (uint32_t)__shfl((int)wbase, c, 64), wc = (nc + 63u) >> 6;
+    for (uint32_t k = lane; k < wc; k += 64u) {
+      const uint32_t idx = wb + k;
+      if ((int32_t)idx < maxw) {
+        wstart[idx] = (int32_t)(sb + 64u * k);
+        const uint32_t left = nc - 64u * k;
+        wcnt[idx] = (int32_t)(left < 64u ? left : 64u);
+      }
+    }
+    total = wb + wc;
+  }
+  for (uint32_t idx = total + lane; (int32_t)idx < maxw; idx += 64u) { /* the launch's spare wavefronts */
+    wstart[idx] = 0;
+    wcnt[idx] = 0;
+  }
+}
+
+/* class_total: the counters rs_cluster_count_sort filled (64 x uint32, zero before the sort; zero again after) */
+hipError_t rs_cluster_wave_table(int class_bits, uint32_t *class_total, int32_t *wstart, int32_t *wcnt,
+                                 int32_t maxw, hipStream_t stream) {
+  if (class_bits < 1 || class_bits > 6 || !class_total) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(cs_wave_table_kernel, dim3(1), dim3(64), 0, stream, class_total, class_bits, wstart, wcnt, maxw);
+  return hipGetLastError();
+}
+
 size_t rs_cluster_count_scratch_bytes(int64_t npoints, int nbits) {
   const int64_t ntiles = (npoints + CS_TILE - 1) / CS_TILE;
   return ((size_t)(1 << nbits) * (size_t)ntiles + (size_t)(1 << nbits)) * sizeof(uint32_t);
@@ -249,7 +308,7 @@ size_t rs_cluster_count_scratch_bytes(int64_t npoints, int nbits) {
 
 /* keys in scratch[0..npoints) (values < 2^nbits), permutation out to scratch + 3*np_pad */
 hipError_t rs_cluster_count_sort(int64_t np_pad, int64_t npoints, int nbits, uint32_t *scratch, void *tmp,
-                                 size_t tmp_bytes, hipStream_t stream) {
+                                 size_t tmp_bytes, hipStream_t stream, uint32_t *class_total, int class_bits) {
   if (nbits < 1 || nbits > 12 || tmp_bytes < rs_cluster_count_scratch_bytes(npoints, nbits))
     return hipErrorInvalidValue;
   const int nbins = 1 << nbits;
@@ -258,7 +317,10 @@ hipError_t rs_cluster_count_sort(int64_t np_pad, int64_t npoints, int nbits, uin
   uint32_t *T = H + (size_t)nbins * ntiles;
   hipLaunchKernelGGL(cs_hist_kernel, dim3(ntiles), dim3(256), nbins * sizeof(uint32_t), stream, scratch,
                      npoints, nbins, ntiles, H);
-  hipLaunchKernelGGL(cs_binscan_kernel, dim3((nbins + 63) / 64), dim3(64), 0, stream, H, T, nbins, ntiles);
+  /* classes of at least 64 bins only (a workgroup of the bin scan = one class) */
+  const bool classes = class_total && class_bits >= 1 && nbits - class_bits >= 6;
+  hipLaunchKernelGGL(cs_binscan_kernel, dim3((nbins + 63) / 64), dim3(64), 0, stream, H, T, nbins, ntiles,
+                     classes ? class_total : nullptr, nbits - class_bits);
   hipLaunchKernelGGL(cs_scatter_kernel, dim3(ntiles), dim3(64), nbins * sizeof(uint32_t), stream, scratch,
                      npoints, nbits, ntiles, H, T, scratch + 3 * np_pad);
   return hipGetLastError();

@@ -48,6 +48,19 @@ struct StepArgs {
    * (NULL: column s).  With the plan order as index the (decimated) outputs land in point order
    * whatever order the slots are in (rs_hip_set_output_by_point). */
   const int32_t *out_index;
+  /* two-wavefront flavour: wavefront w steps the slots [wave_start[w], wave_start[w] + wave_cnt[w]) and the
+   * launch has wave_n workgroups (rs_cluster_wave_table: no wavefront mixes two classes of the sort key);
+   * NULL: wavefront w steps the slots 64 w ... */
+  const int32_t *wave_start, *wave_cnt;
+  int32_t wave_n;
+  /* two-wavefront flavour on the synthetic workload (rs_hip_step_knots): no forcing window - the ground
+   * wave makes the forcing of the next index from the hourly knots itself, with expand_kernel's arithmetic
+   * (knots [knot - knot_k0][RS_KNOT_FIELDS][np_pad] in point order, column knot_gather[slot]; NULL knots:
+   * the window `f`) */
+  const double *knots;
+  const int32_t *knot_gather;
+  int32_t knot_k0, knot_n, spk, start_hour;
+  double r_spk;
 };
 
 struct InitArgs {
@@ -98,6 +111,8 @@ hipError_t rs_launch_humidity_fill(const double *tair, double *tdew, double *rhz
 hipError_t rs_upload_math_tables(hipStream_t stream);
 hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant, bool score,
                           hipStream_t stream);
+/* the two-wavefront flavour with the forcing made from the knots in the kernel (StepArgs::knots) */
+hipError_t rs_launch_step_duo_knots(const rs::StepArgs &a, bool score, hipStream_t stream);
 hipError_t rs_launch_step_cpl_replay(const rs::StepArgs &a, int NL, hipStream_t stream);
 hipError_t rs_launch_step_coupled(const rs::StepArgs &a, int NL, hipStream_t stream);
 hipError_t rs_launch_step_cpl(const rs::StepArgs &a, int NL, hipStream_t stream);
@@ -132,8 +147,11 @@ hipError_t rs_cluster_sort_keys(int64_t np_pad, int64_t npoints, uint32_t *scrat
                                 size_t tmp_bytes, hipStream_t stream);
 /* the plan's own stable counting sort for keys of at most 12 bits (rs_cluster.hip) */
 size_t rs_cluster_count_scratch_bytes(int64_t npoints, int nbits);
+hipError_t rs_cluster_wave_table(int class_bits, uint32_t *class_total, int32_t *wstart, int32_t *wcnt,
+                                 int32_t maxw, hipStream_t stream);
 hipError_t rs_cluster_count_sort(int64_t np_pad, int64_t npoints, int nbits, uint32_t *scratch, void *tmp,
-                                 size_t tmp_bytes, hipStream_t stream);
+                                 size_t tmp_bytes, hipStream_t stream, uint32_t *class_total = nullptr,
+                                 int class_bits = 0);
 /* significant bits of the forecast key for a field list (RsPreview::mode) */
 int rs_forecast_key_bits(int32_t mode);
 hipError_t rs_cluster_apply(const double *state_src, double *state_dst, bool f32,

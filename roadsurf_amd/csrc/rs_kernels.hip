@@ -1244,9 +1244,10 @@ template <int NL, bool SCORE>
 __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, const StepArgs &a) {
   KernArgs ka = kernargs();
   const uint32_t lane = threadIdx.x & 63u;
-  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  /* the workgroup's slots: 64 from 64 * blockIdx.x, or what the wave table says (rs_cluster_wave_table) */
+  const int64_t row0 = a.wave_start ? (int64_t)a.wave_start[blockIdx.x] : (int64_t)blockIdx.x * 64;
   const int64_t p = row0 + lane;
-  const bool live = p < a.npoints; /* a dead lane still walks to every barrier */
+  const bool live = a.wave_start ? (int32_t)lane < a.wave_cnt[blockIdx.x] : p < a.npoints; /* a dead lane still walks to every barrier */
   RegProfile<2> T;
   Scalars s;
   {
@@ -1329,25 +1330,76 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
   }
 }
 
-template <int NL>
+/* The forcing of (1-based) index i from the hourly knots: expand_kernel's arithmetic, value for value -
+ * v0 + (secs * (k1 - k0)) / span with the difference taken once per knot interval and the division by
+ * the uniform span as rs_div_u; PrecPhase from the later knot between knots; the hour of rs_sy_hour.
+ * (The LEAN feature set reads neither Tdew nor, after the initialization, TsurfObs.)  Knot columns are
+ * per point: gathered through the plan's order row, once per interval. */
+struct KnotLerp {
+  double v0[6], dv[6]; /* tair, vz, rhz, prec, sw, lw */
+  int32_t ph0, ph1;
+};
+__device__ __forceinline__ Forcing knot_forcing(KernArgs ka, int64_t col, bool live, KnotLerp &K,
+                                                int32_t &kcur, int32_t i) {
+  const int32_t spk = ka->spk;
+  const int32_t t = i - 1;
+  const int32_t k = __builtin_amdgcn_readfirstlane(t / spk);
+  const int32_t r = t - k * spk;
+  if (k != kcur) { /* uniform: a new knot interval */
+    kcur = k;
+    const int fld[6] = {0, 2, 3, 4, 5, 6};
+    const int64_t np = ka->np_pad;
+    const double *ka_ = ka->knots + ((int64_t)(k - ka->knot_k0) * RS_KNOT_FIELDS) * np + col;
+    const bool has_b = (k + 1 - ka->knot_k0) < ka->knot_n;
+    const double *kb_ = ka_ + (int64_t)RS_KNOT_FIELDS * np;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      K.v0[q] = live ? ka_[(int64_t)fld[q] * np] : 0.0;
+      const double v1 = (live && has_b) ? kb_[(int64_t)fld[q] * np] : K.v0[q];
+      K.dv[q] = v1 - K.v0[q];
+    }
+    K.ph0 = live ? (int32_t)ka_[8 * np] : 0;
+    K.ph1 = (live && has_b) ? (int32_t)kb_[8 * np] : K.ph0;
+  }
+  const double secs = (double)r, span = (double)spk;
+  Forcing f;
+  f.tair = K.v0[0] + rs_div_u(secs * K.dv[0], span, ka->r_spk);
+  f.vz = K.v0[1] + rs_div_u(secs * K.dv[1], span, ka->r_spk);
+  f.rhz = K.v0[2] + rs_div_u(secs * K.dv[2], span, ka->r_spk);
+  f.prec = K.v0[3] + rs_div_u(secs * K.dv[3], span, ka->r_spk);
+  f.sw = K.v0[4] + rs_div_u(secs * K.dv[4], span, ka->r_spk);
+  f.lw = K.v0[5] + rs_div_u(secs * K.dv[5], span, ka->r_spk);
+  f.phase = (r == 0) ? K.ph0 : K.ph1;
+  f.hour = rs_sy_hour(i, spk, ka->start_hour);
+  f.tdew = 0.0;
+  f.tsurfobs = R4(-9999.9);
+  f.depth = R4(-9999.9);
+  return f;
+}
+
+template <int NL, bool KNOTS = false>
 __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, const StepArgs &a) {
   KernArgs ka = kernargs();
   const uint32_t lane = threadIdx.x & 63u;
-  const int64_t p = (int64_t)blockIdx.x * 64 + lane;
-  const bool live = p < a.npoints;
+  const int64_t row0 = a.wave_start ? (int64_t)a.wave_start[blockIdx.x] : (int64_t)blockIdx.x * 64;
+  const int64_t p = row0 + lane;
+  const bool live = a.wave_start ? (int32_t)lane < a.wave_cnt[blockIdx.x] : p < a.npoints;
   double Tg[NL - 2]; /* Tmp(3..NL) */
 #pragma unroll
   for (int j = 3; j <= NL; ++j) Tg[j - 3] = live ? a.state[(int64_t)(RS_ST_TMP0 + j - 1) * a.np_pad + p] : 0.0;
   const double tbot = live ? ka->pp.tbottom[p] : 0.0;
   mail.v[0][1][lane] = Tg[0];
   const int32_t nsteps = ka->nsteps, t0 = ka->t0;
-  const int64_t row0 = (int64_t)blockIdx.x * 64;
   /* the forcing of the launch's first index, prepared before the first meeting (a lane beyond npoints
    * reads nothing: the windows need only span npoints columns) */
   Forcing nxt = Forcing();
+  KnotLerp klerp;
+  int32_t kcur = -1;
+  const int64_t kcol = (KNOTS && live) ? (ka->knot_gather ? (int64_t)ka->knot_gather[p] : p) : 0;
   {
     const ConstsAS &c0 = consts_of(ka);
-    if (live) nxt = load_forcing<false, true>(ka, row0, lane, 0);
+    if (KNOTS) nxt = knot_forcing(ka, kcol, live, klerp, kcur, t0);
+    else if (live) nxt = load_forcing<false, true>(ka, row0, lane, 0);
     duo_put_prep(mail, 0, lane, forcing_prep(c0, mt, nxt, t0, t0 < c0.SimLen));
   }
   duo_meet();
@@ -1356,7 +1408,7 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
     const ConstsAS &c = consts_of(ka);
     const int32_t k = __builtin_amdgcn_readfirstlane(kv);
     /* next index's forcing: fetched here, used behind the layers */
-    if (k + 1 < nsteps && live) nxt = load_forcing<false, true>(ka, row0, lane, k + 1);
+    if (!KNOTS && k + 1 < nsteps && live) nxt = load_forcing<false, true>(ka, row0, lane, k + 1);
     const double t2 = mail.v[k & 1][0][lane]; /* Tmp(2) as the last step left it (melting included) */
     /* a failed point takes no further step in any flavour: its Tmp(3..N) stay as the failing index left
      * them (the flag was raised before the barrier that ended that index) */
@@ -1372,6 +1424,7 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
     mail.v[(k & 1) ^ 1][1][lane] = Tg[0];
     if (k + 1 < nsteps) {
       const int32_t in = t0 + k + 1;
+      if (KNOTS) nxt = knot_forcing(ka, kcol, live, klerp, kcur, in);
       duo_put_prep(mail, (k & 1) ^ 1, lane, forcing_prep(c, mt, nxt, in, in < c.SimLen));
     }
     duo_meet();
@@ -1382,7 +1435,7 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
   }
 }
 
-template <int NL, bool SCORE>
+template <int NL, bool SCORE, bool KNOTS = false>
 __global__ void __launch_bounds__(128, 4) step_kernel_duo(const StepArgs a) {
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
   __shared__ DuoMail mail;
@@ -1392,8 +1445,9 @@ __global__ void __launch_bounds__(128, 4) step_kernel_duo(const StepArgs a) {
    * (Dealing the roles by the parity of the hardware wave slot or of the workgroup index, so that every
    * SIMD hosts both kinds, was measured: 1.08e10 and 1.13e10 against 1.12e10 with fixed roles at
    * 125 000 points - nothing to gain.) */
+  if (a.wave_start && a.wave_cnt[blockIdx.x] == 0) return; /* a spare workgroup of the wave table: both wavefronts leave */
   if (threadIdx.x < 64) duo_surface<NL, SCORE>(mt, mail, a);
-  else duo_ground<NL>(mt, mail, a);
+  else duo_ground<NL, KNOTS>(mt, mail, a);
 }
 
 /* FULL feature set + sky view in lock step, LDS profile (any NLayers). */
@@ -1989,6 +2043,13 @@ static int cpl_profile_mode(int NL) {
   return (NL == 15 && (m == 3 || m == 4)) ? m : 0;
 }
 
+hipError_t rs_launch_step_duo_knots(const rs::StepArgs &a, bool score, hipStream_t stream) {
+  const dim3 gd(a.wave_start ? (unsigned)a.wave_n : (unsigned)((a.npoints + 63) / 64));
+  if (score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, true>), gd, dim3(128), 0, stream, a);
+  else hipLaunchKernelGGL((rs::step_kernel_duo<15, false, true>), gd, dim3(128), 0, stream, a);
+  return hipGetLastError();
+}
+
 hipError_t rs_launch_step_cpl(const rs::StepArgs &a, int NL, hipStream_t stream) {
   /* measured (tools/r3_cpl.sh, rs_driver_run with coupling, 1 M points): hybrid profile at 3 waves/SIMD
    * 7.75e9, LDS profile at 3 waves 7.0e9, hybrid at 4 waves (spills) 6.6e9; a profile wholly in
@@ -2054,7 +2115,7 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
     variant = (NL == 15) ? RS_VARIANT_REG : RS_VARIANT_LDS;
     wpe = 0;
   } else if (variant == RS_VARIANT_DUO || (auto_variant && wpe == 0 && duo_ok && a.npoints <= duo_max)) {
-    const dim3 gd((unsigned)((a.npoints + 63) / 64));
+    const dim3 gd(a.wave_start ? (unsigned)a.wave_n : (unsigned)((a.npoints + 63) / 64));
     if (score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true>), gd, dim3(128), 0, stream, a);
     else hipLaunchKernelGGL((rs::step_kernel_duo<15, false>), gd, dim3(128), 0, stream, a);
     return hipGetLastError();

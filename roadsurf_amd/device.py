@@ -163,6 +163,14 @@ class Plan:
         lib.check(self.L.rs_hip_step(self._h, C.byref(f), C.byref(o), C.byref(pp), t0, nsteps),
                   "rs_hip_step")
 
+    def step_knots(self, spec, knots: torch.Tensor, out: OutputWindow, pp, t0: int, nsteps: int,
+                   out_row0: int | None = None) -> None:
+        """expand_ordered + step in one launch without a forcing window (rs_hip_step_knots: the
+        two-wavefront flavour's ground wave interpolates the forcing from the knots)."""
+        o = out.struct((t0 - 1 + out.decimate - 1) // out.decimate if out_row0 is None else out_row0)
+        lib.check(self.L.rs_hip_step_knots(self._h, C.byref(spec), C.c_void_p(knots.data_ptr()), 0, knots.shape[0],
+                                           C.byref(o), C.byref(pp), t0, nsteps), "rs_hip_step_knots")
+
     def step_cpl(self, window: ForcingWindow, out: OutputWindow, pp, t0: int, nsteps: int,
                  window_row: int = 0, out_row0: int | None = None) -> None:
         """A chunk of a coupled run in lock step (rs_hip_step_cpl): no replays, points park."""
@@ -196,6 +204,7 @@ class Plan:
 
     def set_variant(self, v: int) -> None:
         lib.check(self.L.rs_hip_set_variant(self._h, v), "rs_hip_set_variant")
+        self.variant = v
 
     def sync(self) -> None:
         lib.check(self.L.rs_hip_sync(self._h), "rs_hip_sync")

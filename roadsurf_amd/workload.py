@@ -7,6 +7,9 @@ One pass = the hot path over every time index of the shard's points::
         hourly knots (in the plan's current slot order) -> expand to the DTSecs grid ->
         step kernel -> [plan order: keep the order row of this launch, re-sort the slots]
 
+With the two-wavefront flavour in plan order the expansion is part of the step kernel (its ground
+wave interpolates the forcing from the knots, rs_hip_step_knots) and no forcing window exists.
+
 Outputs are attributable to points (reference ``SaveOutput`` is per point,
 src/InputOutput.f90:151-165): with plan order on, launch ``c`` wrote column ``s`` of its
 output window for local point ``orders[c, s]``; the row is copied (4 B per point and launch,
@@ -35,6 +38,12 @@ class SyntheticRun:
         self.simlen = hours * SPK + 1  # examples/example1/src/InputSettings.cpp:98
         self.chunk = min(chunk, self.simlen)
         self.plan_order = plan_order
+        # Small shards in plan order (the plan was given the two-wavefront flavour): no forcing window - the
+        # kernel's ground wave interpolates the forcing of the next index from the resident knots itself, with
+        # the expansion kernel's arithmetic (rs_hip_step_knots).  The expansion is the longest link of the chain
+        # between two step launches of a plan, and a small shard has nothing to hide it behind.
+        self.fused = bool(plan_order and not f32 and not full and getattr(plan, "variant", 0) == 3
+                          and plan.consts.NLayers == 15)
         # sort key of the re-sort: forecast of the next window (rs_hip_recluster_forecast) or the
         # history of the last one (rs_hip_recluster)
         self.forecast, self.forecast_alpha, self.forecast_mode = forecast, forecast_alpha, forecast_mode
@@ -47,7 +56,8 @@ class SyntheticRun:
         # every point here, so the plan order does not have to move them.
         self.full = full
         opt = ("tdew", "tsurfobs", "depth") if full else ()
-        self.win = device.ForcingWindow.empty(self.chunk, npad, dev, optional=opt, dtype=wdtype)
+        self.win = (None if self.fused else
+                    device.ForcingWindow.empty(self.chunk, npad, dev, optional=opt, dtype=wdtype))
         self.out = device.OutputWindow.empty(self.chunk, npad, dev, dtype=wdtype)
         # index-1 window for the init kernel: needs TsurfObs(1)
         self.win0 = device.ForcingWindow.empty(1, npad, dev, optional=("tsurfobs",), dtype=wdtype)
@@ -87,11 +97,14 @@ class SyntheticRun:
         plan.init_state(self.win0, self.pp)
         for c, t0 in enumerate(self.starts):
             ns = min(self.chunk, self.simlen - t0 + 1)
-            if self.plan_order:
-                plan.expand_ordered(spec, self.knots, self.win, t0, ns)
+            if self.fused:
+                plan.step_knots(spec, self.knots, self.out, self.pp, t0, ns, out_row0=t0 - 1)
             else:
-                plan.expand(spec, self.knots, self.win, t0, ns)
-            plan.step(self.win, self.out, self.pp, t0, ns, out_row0=t0 - 1)
+                if self.plan_order:
+                    plan.expand_ordered(spec, self.knots, self.win, t0, ns)
+                else:
+                    plan.expand(spec, self.knots, self.win, t0, ns)
+                plan.step(self.win, self.out, self.pp, t0, ns, out_row0=t0 - 1)
             if self.plan_order:
                 plan.copy_order_to(self.orders[c])  # which point each column of this launch is
                 if on_launch:

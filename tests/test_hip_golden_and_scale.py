@@ -224,11 +224,17 @@ def test_full_size_properties_1M_points_48h():
     del run
     plan.close()
     torch.cuda.empty_cache()
-    # bench.py's default at this size: FOUR plans of 250 000 points on four streams whose launches
-    # interleave (one plan's window expansion and re-sort under another's step kernel).  Same
+    # bench.py's round-3 default at this size (and the shape of its natural-order leg): FOUR plans of
+    # 250 000 points on four streams whose launches interleave (one plan's window expansion and re-sort
+    # under another's step kernel), one point per lane.  Same
     # points, same values: the four checksums add up to the single plan's, the sampled blocks -
     # found in whichever plan holds them, through that plan's order rows - carry the same bits
-    _interleaved_plans(4, 120, [0] * 4, n, s, p, seed, hours, cols, c1, samp1, plan.device)
+    _interleaved_plans(4, 120, [1] * 4, n, s, p, seed, hours, cols, c1, samp1, plan.device)
+    # bench.py's default at this size since round 4: TWO plans of 500 000 points, launches of 60 indices
+    # (windows that start between two knots), stepped by the two-wavefront flavour whose ground wave makes
+    # the forcing from the knots (no expansion kernel, no forcing window: rs_hip_step_knots)
+    _interleaved_plans(2, 60, [3] * 2, n, s, p, seed, hours, cols, c1, samp1, plan.device)
+    _interleaved_plans(3, 90, [3] * 3, n, s, p, seed, hours, cols, c1, samp1, plan.device)
     # BASELINE config 4's partition on the hardware at hand: the EIGHT blocks of 125 000 points the
     # eight ranks of a node would hold, at their global offsets, as eight plans on this one GPU -
     # four of them stepped by the two-wavefront flavour (what bench.py picks at that shard size),
@@ -246,3 +252,39 @@ def test_full_size_properties_1M_points_48h():
             assert np.abs(big - ora[k]).max() < TOL, ("oracle", k, b)
             assert np.array_equal(samp3[k][:, bi * 64:(bi + 1) * 64].T, ora[k]), \
                 ("plan order vs reference, bit for bit", k, b)
+
+
+@pytest.mark.parametrize("n,hours,chunk", [(5000, 6, 7), (5000, 6, 60), (4097, 5, 121), (64, 3, 240), (70000, 3, 90)])
+def test_knot_reading_flavour_matches_window_flavour(n, hours, chunk):
+    """rs_hip_step_knots (the two-wavefront flavour's ground wave interpolates the forcing from the resident
+    knots) against the expansion kernel + forcing window + one point per lane, both in plan order: every
+    output of every point at every index carries the same bits, whatever the launch length (windows that
+    start on, before and between knots; ragged last launch; point counts off the wavefront size)."""
+    import torch
+    from roadsurf_amd import device, workload
+    L = hours * SPK + 1
+    s = abi.default_settings(L); p = abi.default_parameters()
+    series = {}
+    for variant in (1, 3):
+        plan = device.Plan(n, s, p, 0)
+        plan.set_variant(variant)
+        run = workload.SyntheticRun(plan, 77, hours, chunk, point_offset=12345, plan_order=True)
+        assert run.fused == (variant == 3)
+        full = {k: torch.full((L, n), float("nan"), dtype=torch.float64, device=plan.device) for k in device.OUT_FIELDS}
+
+        def on_launch(c, t0, ns):
+            o = run.orders[c][:n].long()
+            for k in device.OUT_FIELDS:
+                full[k][t0 - 1:t0 - 1 + ns, o] = run.out.tensors[k][:ns, :n]
+
+        run.run_pass(on_launch)
+        plan.sync()
+        assert plan.failed_count() == 0
+        series[variant] = {k: v.cpu().numpy() for k, v in full.items()}
+        moved = int((run.orders[-1][:n].long() != torch.arange(n, device=plan.device)).sum())
+        assert n < 1000 or moved > 0
+        del run
+        plan.close()
+    for k in device.OUT_FIELDS:
+        assert not np.isnan(series[3][k]).any()
+        assert np.array_equal(series[1][k], series[3][k]), k
