@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Round-4 evidence, all from the kernels at HEAD: rocprofv3 kernel stats + timeline + PMC passes
 # (separate runs, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) for
-#   lean   bench.py default (1 M points x 48 h, fp64, 4 plans)          -> profiles/r04_*
+#   lean   bench.py default (1 M points x 48 h, fp64, 2 plans x 60)      -> profiles/r04_*
 #   f32    BASELINE config 5 shape (1.25 M points x 7 d, fp32)           -> profiles/r04_f32_*
 #   small  125 000 points (config 4's per-GPU shard), one point per lane
 #          against two wavefronts per 64 points                          -> profiles/r04_small_shard_*
@@ -24,9 +24,10 @@ profile() { # tag, bench flags...
   rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/pmc_sq -- python3 bench.py $B1 "$@" > $OUT/bench_pmc_sq.json 2> $OUT/pmc_sq.err || { tail -20 $OUT/pmc_sq.err; exit 1; }
   rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $B1 "$@" > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err || { tail -20 $OUT/pmc_fetch.err; exit 1; }
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py $B1 "$@" > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err || { tail -20 $OUT/pmc_write.err; exit 1; }
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq2 -- python3 bench.py $B1 "$@" > $OUT/bench_pmc_sq2.json 2> $OUT/pmc_sq2.err || { tail -20 $OUT/pmc_sq2.err; exit 1; }
   python3 tools/summarize_pmc.py $OUT > $OUT/pmc_summary.txt
   grep step_kernel $OUT/pmc_summary.txt | cut -c1-140
-  rm -rf $OUT/trace $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write
+  rm -rf $OUT/trace $OUT/pmc_sq $OUT/pmc_sq2 $OUT/pmc_fetch $OUT/pmc_write
 }
 
 for W in $WHAT; do case $W in
