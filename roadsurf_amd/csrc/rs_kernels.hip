@@ -1206,32 +1206,40 @@ __global__ void __launch_bounds__(kBlock, WPE) step_kernel_lds(const StepArgs a)
  * step shrinks from ~1 460 to ~1 020 vector instructions and the shard occupies twice as many
  * wave slots.  Same arithmetic in the same order per point: same bits (layer_step is the one
  * function both flavours call).  LEAN feature set, NLayers = 15, 32-bit window offsets. */
-#define RS_DUO_NPREP 15
+#define RS_DUO_NPREP 13
 struct DuoMail {
   double v[2][2][64]; /* [buffer][0: Tmp(2) from the surface wave, 1: Tmp(3) from the ground wave][lane] */
   uint32_t failed[64]; /* sticky, set by the surface wave: the point's loop has exited (the ground wave
                           then leaves Tmp(3..N) alone, as the one-point-per-lane flavours do) */
   /* round 4: what a step needs of its forcing alone (ForcingPrep, rs_physics_body.inc), worked out by
-   * the ground wave one index ahead: [buffer = index parity][value][lane] */
+   * the ground wave one index ahead: [buffer = index parity][value][lane].  13 values per lane - the
+   * traffic friction is the same for every point of an index (one word per buffer) and VK x VZ is one
+   * multiplication for the surface wave: with 15 the workgroup took 22 336 B of LDS, seven workgroups to
+   * a CU (3.5 wavefronts per SIMD where the registers allow 4); 20 288 B: eight. */
   double prep[2][RS_DUO_NPREP][64];
+  double trffric[2];
   uint32_t prep_bad[2][64];
 };
 
 __device__ __forceinline__ void duo_put_prep(DuoMail &mail, int buf, uint32_t lane, const ForcingPrep &q) {
   double (*w)[64] = mail.prep[buf];
   w[0][lane] = q.tair; w[1][lane] = q.vz; w[2][lane] = q.rhz; w[3][lane] = q.rain; w[4][lane] = q.snow;
-  w[5][lane] = q.trffric; w[6][lane] = q.AirDens; w[7][lane] = q.AirHCap; w[8][lane] = q.PsychC;
-  w[9][lane] = q.den0; w[10][lane] = q.vkvz; w[11][lane] = q.avk; w[12][lane] = q.EAir;
-  w[13][lane] = q.sw; w[14][lane] = q.lw;
+  w[5][lane] = q.AirDens; w[6][lane] = q.AirHCap; w[7][lane] = q.PsychC;
+  w[8][lane] = q.den0; w[9][lane] = q.avk; w[10][lane] = q.EAir;
+  w[11][lane] = q.sw; w[12][lane] = q.lw;
+  if (lane == 0) mail.trffric[buf] = q.trffric; /* day or night: the hour is the index's (lane 0 is never a dead lane) */
   mail.prep_bad[buf][lane] = q.bad ? 1u : 0u;
 }
-__device__ __forceinline__ ForcingPrep duo_get_prep(const DuoMail &mail, int buf, uint32_t lane) {
+template <class C>
+__device__ __forceinline__ ForcingPrep duo_get_prep(const C &c, const DuoMail &mail, int buf, uint32_t lane) {
   const double (*w)[64] = mail.prep[buf];
   ForcingPrep q;
   q.tair = w[0][lane]; q.vz = w[1][lane]; q.rhz = w[2][lane]; q.rain = w[3][lane]; q.snow = w[4][lane];
-  q.trffric = w[5][lane]; q.AirDens = w[6][lane]; q.AirHCap = w[7][lane]; q.PsychC = w[8][lane];
-  q.den0 = w[9][lane]; q.vkvz = w[10][lane]; q.avk = w[11][lane]; q.EAir = w[12][lane];
-  q.sw = w[13][lane]; q.lw = w[14][lane];
+  q.AirDens = w[5][lane]; q.AirHCap = w[6][lane]; q.PsychC = w[7][lane];
+  q.den0 = w[8][lane]; q.avk = w[9][lane]; q.EAir = w[10][lane];
+  q.sw = w[11][lane]; q.lw = w[12][lane];
+  q.trffric = mail.trffric[buf];
+  q.vkvz = c.VK_Const * q.vz; /* forcing_prep's expression on forcing_prep's VZ */
   q.bad = mail.prep_bad[buf][lane] != 0u;
   return q;
 }
@@ -1285,7 +1293,7 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
     const bool owrite = output_row<true>(ka, i, orow);
     const double t3 = mail.v[k & 1][1][lane]; /* Tmp(3) as the last step left it */
     if (!s.failed) {
-      const ForcingPrep q = duo_get_prep(mail, k & 1, lane);
+      const ForcingPrep q = duo_get_prep(c, mail, k & 1, lane);
       if (i < c.SimLen) { /* CheckValues: the forcing's verdict | the surface temperature's */
         if (q.bad | check_values_tsurf(c, s.tsurf)) {
           s.failed = true;
