@@ -180,7 +180,7 @@ def main() -> None:
                     help="plan order: sort by a forecast of the next window's boundary-layer regime and "
                          "passes (rs_hip_recluster_forecast) or by the passes of the last launch")
     ap.add_argument("--forecast-alpha", type=float, default=0.5)
-    ap.add_argument("--forecast-mode", type=int, default=37865,
+    ap.add_argument("--forecast-mode", type=int, default=378659,
                     help="fields of the forecast key, most significant first (roadsurf_amd/workload.py)")
     ap.add_argument("--plans-per-gpu", type=int, default=0,
                     help="cut this GPU's points into K plans on K streams whose launches interleave: "
@@ -252,16 +252,16 @@ def main() -> None:
     if args.variant == 0 and not args.f32 and not args.full:
         # Round 4: the two-wavefront flavour whose ground wave makes the forcing from the resident knots itself
         # (roadsurf_amd/workload.py: no window expansion, no forcing window) is the faster one at every size -
-        # 1 M points, same box, alternating runs: 1.93e10 with one point per lane (4 plans x 120), 1.98e10 with
-        # this flavour in the same shape, 2.03-2.05e10 with 2 plans x 60
+        # 1 M points: 1.93-1.97e10 with one point per lane (4 plans x 120), 2.11-2.13e10 with this flavour
+        # 
         args.variant = 3
     fused = args.variant == 3 and not args.f32 and not args.full and bool(args.cluster)
     if fused:
-        # measured (round 4): with the expansion gone a launch cycle is short, so fewer plans hide it and shorter
-        # launches (a fresher sort key) pay: 2 x 60 from 750 000 points on the GPU, 3 x 90 from 400 000,
-        # 4 x 120 from 200 000, 2 x 240 below
-        K, ch = (2, 60) if n >= 750_000 else (3, 90) if n >= 400_000 else (4, 120) if n >= 200_000 else \
-            (2, 240) if n >= 100_000 else (1, 240)
+        # measured (round 4, tools/experiments/r4_fused_{big,small}_sweep.sh): with the expansion gone a launch
+        # cycle is short, so fewer plans hide it and shorter launches (a fresher sort key) pay: 3 x 90 from
+        # 400 000 points on the GPU (1 M, r4_ground_sweep.sh: 2.29e10 for 3 x 90, 3 x 120 and 2 x 120 alike; 2.27e10
+        # for 4 x 90 / 4 x 120), 4 x 240 from 200 000, 2 x 240 below
+        K, ch = (3, 90) if n >= 400_000 else (4, 240) if n >= 200_000 else (2, 240) if n >= 100_000 else (1, 240)
     else:
         # measured on MI355X (tools/experiments/exp_plans.sh, r3_small2.sh; DESIGN_HISTORY.md 6)
         K, ch = (4 if n >= 200_000 else 2 if n >= 100_000 else 1), (120 if n >= 400_000 else 240)

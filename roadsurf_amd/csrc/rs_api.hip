@@ -349,6 +349,11 @@ int rs_hip_recluster_forecast(RsPlan *pl, const RsPreview *pv) {
   const int bits = rs_forecast_key_bits(pv->mode);
   const bool lib_sort = getenv("ROADSURF_HIP_LIBRARY_SORT") != nullptr; /* read per call: the tests switch it */
   a.compact = (bits >= 1 && bits <= 12 && !lib_sort) ? 1 : 0;
+  /* the ground digit (field 9 of the mode): below the others - a pass of its own in the plan's counting
+   * sort, the low bits of the key in the library's (where they fit) */
+  const int lowb = rs_forecast_key_low_bits(pv->mode);
+  const int low = (a.compact || (bits >= 1 && bits + lowb <= RS_SORT_KEY_BITS)) ? lowb : 0;
+  a.low_bits = low;
   HIP_OK(rs_launch_forecast_keys(a, pl->stream));
   pl->wave_tab_valid = false;
   if (a.compact) {
@@ -371,7 +376,7 @@ int rs_hip_recluster_forecast(RsPlan *pl, const RsPreview *pv) {
       class_total = reinterpret_cast<uint32_t *>(pl->wave_tab + 2 * (size_t)maxw);
     }
     HIP_OK(rs_cluster_count_sort(pl->np_pad, pl->npoints, bits, pl->sort_keys, pl->sort_tmp,
-                                 pl->sort_tmp_bytes, pl->stream, class_total, cb));
+                                 pl->sort_tmp_bytes, pl->stream, class_total, cb, low));
     if (table) {
       HIP_OK(rs_cluster_wave_table(cb, class_total, pl->wave_tab, pl->wave_tab + maxw, maxw, pl->stream));
       pl->wave_tab_valid = true;

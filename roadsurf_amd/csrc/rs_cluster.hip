@@ -135,7 +135,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
   return v;
 }
 
-__global__ void __launch_bounds__(256) cs_hist_kernel(const uint32_t *__restrict__ keys, int64_t n,
+/* via: the permutation an earlier (less significant) pass left - this pass takes its keys in that order
+ * (NULL: in slot order); shift: where this pass's digit starts in the key */
+__global__ void __launch_bounds__(256) cs_hist_kernel(const uint32_t *__restrict__ keys,
+                                                      const uint32_t *__restrict__ via, int64_t n, int shift,
                                                       int nbins, int ntiles, uint32_t *__restrict__ H) {
   extern __shared__ uint32_t cs_h[];
   for (int b = threadIdx.x; b < nbins; b += 256) cs_h[b] = 0u;
@@ -143,7 +146,7 @@ __global__ void __launch_bounds__(256) cs_hist_kernel(const uint32_t *__restrict
   const int64_t base = (int64_t)blockIdx.x * CS_TILE;
   for (int i = threadIdx.x; i < CS_TILE; i += 256) {
     const int64_t idx = base + i;
-    if (idx < n) atomicAdd(&cs_h[keys[idx] & (uint32_t)(nbins - 1)], 1u);
+    if (idx < n) atomicAdd(&cs_h[(keys[via ? (int64_t)via[idx] : idx] >> shift) & (uint32_t)(nbins - 1)], 1u);
   }
   __syncthreads();
   for (int b = threadIdx.x; b < nbins; b += 256) H[(int64_t)blockIdx.x * nbins + b] = cs_h[b];
@@ -174,8 +177,9 @@ __global__ void __launch_bounds__(64) cs_binscan_kernel(uint32_t *H, uint32_t *T
   }
 }
 
-__global__ void __launch_bounds__(64) cs_scatter_kernel(const uint32_t *__restrict__ keys, int64_t n,
-                                                        int nbits, int ntiles,
+__global__ void __launch_bounds__(64) cs_scatter_kernel(const uint32_t *__restrict__ keys,
+                                                        const uint32_t *__restrict__ via, int64_t n,
+                                                        int shift, int nbits, int ntiles,
                                                         const uint32_t *__restrict__ H,
                                                         const uint32_t *__restrict__ T,
                                                         uint32_t *__restrict__ perm_out) {
@@ -217,11 +221,16 @@ __global__ void __launch_bounds__(64) cs_scatter_kernel(const uint32_t *__restri
   constexpr int CS_BATCH = 8;
   for (int r0 = 0; r0 < CS_TILE / 64; r0 += CS_BATCH) {
     if (base + (int64_t)r0 * 64 >= n) break; /* uniform: behind the last key */
-    uint32_t kreg[CS_BATCH];
+    uint32_t kreg[CS_BATCH], sreg[CS_BATCH];
 #pragma unroll
     for (int q = 0; q < CS_BATCH; ++q) {
       const int64_t idx = base + (int64_t)(r0 + q) * 64 + lane;
-      kreg[q] = idx < n ? (keys[idx] & (uint32_t)(nbins - 1)) : 0u;
+      sreg[q] = (idx < n && via) ? via[idx] : (uint32_t)idx;
+    }
+#pragma unroll
+    for (int q = 0; q < CS_BATCH; ++q) {
+      const int64_t idx = base + (int64_t)(r0 + q) * 64 + lane;
+      kreg[q] = idx < n ? ((keys[sreg[q]] >> shift) & (uint32_t)(nbins - 1)) : 0u;
     }
 #pragma unroll
   for (int q = 0; q < CS_BATCH; ++q) {
@@ -238,7 +247,7 @@ __global__ void __launch_bounds__(64) cs_scatter_kernel(const uint32_t *__restri
     uint32_t start = 0u;
     if (valid) {
       start = cs_cur[key];
-      perm_out[start + rank] = (uint32_t)idx;
+      perm_out[start + rank] = sreg[q];
     }
     /* every lane has read its cursor before the first of its group moves it: the workgroup is ONE
      * wavefront, whose LDS accesses execute in program order - a scheduling fence for the compiler is
@@ -306,23 +315,40 @@ size_t rs_cluster_count_scratch_bytes(int64_t npoints, int nbits) {
   return ((size_t)(1 << nbits) * (size_t)ntiles + (size_t)(1 << nbits)) * sizeof(uint32_t);
 }
 
-/* keys in scratch[0..npoints) (values < 2^nbits), permutation out to scratch + 3*np_pad */
+/* keys in scratch[0..npoints) (values < 2^(nbits + low_bits)), permutation out to scratch + 3*np_pad.
+ * low_bits > 0: the key carries a second, less significant digit below its nbits - sorted first, by a pass
+ * of its own whose permutation (scratch + np_pad) the main pass reads its keys through: two stable passes,
+ * least significant digit first. */
 hipError_t rs_cluster_count_sort(int64_t np_pad, int64_t npoints, int nbits, uint32_t *scratch, void *tmp,
-                                 size_t tmp_bytes, hipStream_t stream, uint32_t *class_total, int class_bits) {
-  if (nbits < 1 || nbits > 12 || tmp_bytes < rs_cluster_count_scratch_bytes(npoints, nbits))
+                                 size_t tmp_bytes, hipStream_t stream, uint32_t *class_total, int class_bits,
+                                 int low_bits) {
+  if (nbits < 1 || nbits > 12 || low_bits < 0 || low_bits > 12 ||
+      tmp_bytes < rs_cluster_count_scratch_bytes(npoints, nbits > low_bits ? nbits : low_bits))
     return hipErrorInvalidValue;
-  const int nbins = 1 << nbits;
   const int ntiles = (int)((npoints + CS_TILE - 1) / CS_TILE);
   uint32_t *H = static_cast<uint32_t *>(tmp);
+  const uint32_t *via = nullptr;
+  if (low_bits > 0) {
+    const int nb = 1 << low_bits;
+    uint32_t *T = H + (size_t)nb * ntiles;
+    hipLaunchKernelGGL(cs_hist_kernel, dim3(ntiles), dim3(256), nb * sizeof(uint32_t), stream, scratch, via,
+                       npoints, 0, nb, ntiles, H);
+    hipLaunchKernelGGL(cs_binscan_kernel, dim3((nb + 63) / 64), dim3(64), 0, stream, H, T, nb, ntiles,
+                       (uint32_t *)nullptr, 0);
+    hipLaunchKernelGGL(cs_scatter_kernel, dim3(ntiles), dim3(64), nb * sizeof(uint32_t), stream, scratch, via,
+                       npoints, 0, low_bits, ntiles, H, T, scratch + np_pad);
+    via = scratch + np_pad;
+  }
+  const int nbins = 1 << nbits;
   uint32_t *T = H + (size_t)nbins * ntiles;
-  hipLaunchKernelGGL(cs_hist_kernel, dim3(ntiles), dim3(256), nbins * sizeof(uint32_t), stream, scratch,
-                     npoints, nbins, ntiles, H);
+  hipLaunchKernelGGL(cs_hist_kernel, dim3(ntiles), dim3(256), nbins * sizeof(uint32_t), stream, scratch, via,
+                     npoints, low_bits, nbins, ntiles, H);
   /* classes of at least 64 bins only (a workgroup of the bin scan = one class) */
   const bool classes = class_total && class_bits >= 1 && nbits - class_bits >= 6;
   hipLaunchKernelGGL(cs_binscan_kernel, dim3((nbins + 63) / 64), dim3(64), 0, stream, H, T, nbins, ntiles,
                      classes ? class_total : nullptr, nbits - class_bits);
-  hipLaunchKernelGGL(cs_scatter_kernel, dim3(ntiles), dim3(64), nbins * sizeof(uint32_t), stream, scratch,
-                     npoints, nbits, ntiles, H, T, scratch + 3 * np_pad);
+  hipLaunchKernelGGL(cs_scatter_kernel, dim3(ntiles), dim3(64), nbins * sizeof(uint32_t), stream, scratch, via,
+                     npoints, low_bits, nbits, ntiles, H, T, scratch + 3 * np_pad);
   return hipGetLastError();
 }
 

@@ -32,6 +32,13 @@ struct RsConstantsDev : RsConstants {
    * behind a coupling window, exp(-(DTSecs*i - DTSecs*couplingEndI)/reduction) of
    * src/Coupling.f90:80-88, for i - couplingEndI = d.  Same conditions as relax_tab. */
   const double *cpl_tab;
+  /* A frozen layer (Tmp < 0) has the constant heat capacity dryCap + WCont*(920*2100)
+   * (src/BalanceModel.f90:215-236), so its -1/(DyC*VSH) (calcCapDZCondDZ, :132-155) and, for layer 1,
+   * HS(1) = VSH*HSfac1/twoDT (:241) are constants of the plan: the same IEEE operations on the host.  A
+   * wavefront whose 64 points all have the layer frozen reads them instead of evaluating the water
+   * polynomials and a division (layer_step, rs_physics_body.inc). */
+  double capDZF[RS_MAX_LAYERS + 2];
+  double hs1F;
 };
 
 static inline void rs_consts_dev_fill(const RsConstants &c, RsConstantsDev &d) {
@@ -50,6 +57,19 @@ static inline void rs_consts_dev_fill(const RsConstants &c, RsConstantsDev &d) {
   for (int i = 0; i < 8; ++i) d.chk[i] = (double)chk[i];
   d.relax_tab = nullptr;
   d.cpl_tab = nullptr;
+  for (int j = 0; j < RS_MAX_LAYERS + 2; ++j) d.capDZF[j] = 0.0;
+  d.hs1F = 0.0;
+  for (int j = 1; j <= c.NLayers && j <= RS_MAX_LAYERS; ++j) {
+    const volatile double chwt = 920.0 * 2100.0; /* REAL(4) literals, exact product */
+    const volatile double wc = c.WCont[j] * chwt;  /* volatile: no contraction into an fma, whatever the flags */
+    const volatile double vsh = c.dryCap[j] + wc;
+    const volatile double den = c.DyC[j] * vsh;
+    d.capDZF[j] = -(1.0 / den);
+    if (j == 1) {
+      const volatile double num = vsh * c.HSfac1;
+      d.hs1F = num / c.twoDT;
+    }
+  }
   d.bareFastOk = (c.MaxWatmms >= 0.0 && c.MaxSnowmms >= 0.0 && c.MaxIcemms >= 0.0 && c.MaxDepmms >= 0.0) ? 1 : 0;
   d.precFastOk = (c.MinPrecmm >= 0.0) ? 1 : 0;
   if (getenv("ROADSURF_HIP_NO_BARE_FAST")) d.bareFastOk = d.precFastOk = 0; /* A/B switch: same bits either way */

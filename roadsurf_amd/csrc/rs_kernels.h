@@ -80,6 +80,7 @@ struct ForecastArgs {
   uint32_t *keys, *slots;
   int32_t compact; /* 1: the key is stored right-aligned in its own bits (counting sort), 0: left-aligned
                       in RS_SORT_KEY_BITS (library sort) */
+  int32_t low_bits; /* compact keys: bits of the ground digit below the others (rs_forecast_key_low_bits) */
 };
 
 struct KnotArgs {
@@ -151,9 +152,11 @@ hipError_t rs_cluster_wave_table(int class_bits, uint32_t *class_total, int32_t 
                                  int32_t maxw, hipStream_t stream);
 hipError_t rs_cluster_count_sort(int64_t np_pad, int64_t npoints, int nbits, uint32_t *scratch, void *tmp,
                                  size_t tmp_bytes, hipStream_t stream, uint32_t *class_total = nullptr,
-                                 int class_bits = 0);
-/* significant bits of the forecast key for a field list (RsPreview::mode) */
+                                 int class_bits = 0, int low_bits = 0);
+/* significant bits of the forecast key for a field list (RsPreview::mode), without the ground digit ... */
 int rs_forecast_key_bits(int32_t mode);
+/* ... and the bits of the ground digit below them (field 9: 7, else 0) */
+int rs_forecast_key_low_bits(int32_t mode);
 hipError_t rs_cluster_apply(const double *state_src, double *state_dst, bool f32,
                             const int32_t *order_src, int32_t *order_dst, const uint32_t *perm,
                             int64_t np_pad, int64_t npoints, int nlayers, int cpl_rows,

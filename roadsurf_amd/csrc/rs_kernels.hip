@@ -1942,6 +1942,30 @@ __global__ void __launch_bounds__(kBlock) forecast_key_kernel(const ForecastArgs
     }
   }
   if (extra > 4095) extra = 4095;
+  /* field 9, the ground digit: which layers are frozen.  The heat capacity of a layer is a constant below
+   * 0 C and two polynomials above (src/BalanceModel.f90:215-236), and a wavefront whose 64 points all have
+   * layer j frozen takes that layer's capDZ from a table (layer_step, rs_physics_body.inc).  The frozen
+   * layers of a point are nearly always one run: 4 bits for its deepest layer, 3 for the thawed layers on
+   * top of it (the daily thaw reaches a handful of the thin upper layers).  Sorted as a digit of its own BELOW the others (rs_cluster_count_sort, low_bits): the
+   * classes of the boundary-layer fields stay as they are, their points line up by frost depth. */
+  uint32_t ground = 0u;
+  {
+    int32_t m9 = a.pv.mode;
+    bool want = false;
+    for (; m9 > 0; m9 /= 10) want |= (m9 % 10) == 9;
+    if (want) {
+      const int NL = c.NLayers;
+      int32_t deepest = 0, first = 0;
+      for (int j = NL; j >= 1; --j)
+        if (st(RS_ST_TMP0 + j - 1) < 0.0) {
+          if (!deepest) deepest = j;
+          first = j;
+        }
+      if (NL > 15) deepest = (deepest * 15) / NL;
+      const int32_t top = first > 0 ? first - 1 : 0;
+      ground = ((uint32_t)deepest << 3) | (uint32_t)(top > 7 ? 7 : top);
+    }
+  }
   /* key fields, most significant first, named by the decimal digits of `mode`:
    * 1 unstable previews (4 bits), 2 of which on the table path of log (4 bits), 3 cover (1 bit),
    * 4 predicted extra passes (12 bits), 5 storage class snow > ice > wet > bare (2 bits).  Modes 0..3 are shorthands for 14, 124, 134, 1234. */
@@ -1965,7 +1989,11 @@ __global__ void __launch_bounds__(kBlock) forecast_key_kernel(const ForecastArgs
   }
   /* descending: the expensive points get the low slots (longest job first, rs_cluster.hip) */
   if (a.compact) { /* right-aligned in its own bits: the plan's counting sort */
-    a.keys[s] = ((1u << bits) - 1u) - key;
+    const int low = a.low_bits; /* the ground digit below them, if the mode has one */
+    a.keys[s] = ((((1u << bits) - 1u) - key) << low) | (low ? ground : 0u);
+  } else if (a.low_bits && bits + a.low_bits <= RS_SORT_KEY_BITS) { /* the same order from the library sort */
+    const int low = a.low_bits;
+    a.keys[s] = (((((1u << bits) - 1u) - key) << low) | ground) << (RS_SORT_KEY_BITS - bits - low);
   } else {
     if (bits < RS_SORT_KEY_BITS) key <<= (RS_SORT_KEY_BITS - bits); /* left-aligned in the sorted bits */
     else key >>= (bits - RS_SORT_KEY_BITS);
@@ -2012,6 +2040,12 @@ hipError_t rs_upload_math_tables(hipStream_t stream) {
   if (e != hipSuccess) return e;
   return hipMemcpyToSymbolAsync(HIP_SYMBOL(rs::c_gl_log_tab), rs_gl_log_tab, sizeof(rs_gl_log_tab), 0,
                                 hipMemcpyHostToDevice, stream);
+}
+
+int rs_forecast_key_low_bits(int32_t m) {
+  for (; m > 0; m /= 10)
+    if (m % 10 == 9) return 7;
+  return 0;
 }
 
 /* the same field widths as forecast_key_kernel */

@@ -43,7 +43,11 @@
 #define RS_PREC_FAST(c) ((c).precFastOk != 0)
 #define RS_CHK(c, i, lit) ((c).chk[i])         /* rs_consts_dev.h: CheckValues' bounds */
 #define R4(x) ((double)(x##f))
+#ifndef RS_NO_FROZEN_TABLE
+#define RS_FROZEN_TABLE 1 /* layer_step: capDZ of a layer that is frozen in all 64 points from RsConstantsDev::capDZF */
+#endif
 #include "rs_physics_body.inc"
+#undef RS_FROZEN_TABLE
 #undef RS_REAL
 #undef RS_NS
 #undef RS_CONSTS

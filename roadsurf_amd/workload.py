@@ -26,7 +26,11 @@ SPK = 120  # 3600 s / DTSecs 30 s: time indices per hourly knot
 # road, 7 unstable previews, 8 of which on the table path of log, 6 predicted extra passes (saturating
 # at 31), 5 storage class - 12 bits, sorted by the plan's own counting pass.  Measured equal in vector
 # instructions per wave-step to the 21-bit key 3124 of round 2 (+ the storage class: -9).
-DEFAULT_FORECAST_MODE = 37865
+# 9 (round 4): the ground digit - which layers are frozen, 7 bits, sorted by a pass of its own below the
+# others: a wavefront whose 64 points all have a layer frozen reads that layer's capDZ from the plan's
+# constants instead of evaluating the heat capacity of water (layer_step): about half of the 15 x 64
+# layer updates of a winter wave-step (1 M points: 2.11e10 -> 2.29e10).
+DEFAULT_FORECAST_MODE = 378659
 
 
 class SyntheticRun:
