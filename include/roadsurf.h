@@ -236,9 +236,12 @@ void rs_build_constants(const InputSettings *inSettings,
                         const InputParameters *inputParam, RsConstants *out,
                         int32_t *status);
 /* Time-only part of the solar position (src/SunPosition.f90:196-260 and :70-121,124-125):
- * for n time stamps writes table[k*4 + {0,1,2,3}] = apparent right ascension (rad, in
- * [0,2pi]), mean sidereal time at Greenwich (rad), sin and cos of the declination.
- * Fortran, host libm. */
+ * for n time stamps writes table[k*RS_SUN_COLS + {0,1,2,3}] = apparent right ascension (rad, in
+ * [0,2pi]), mean sidereal time at Greenwich (rad), sin and cos of the declination, and (ABI 5)
+ * {4,5} = cos and sin of (sidereal time - right ascension): the device forms the cosine of the hour
+ * angle of a point from them and the point's longitude by the addition theorem instead of a cosine
+ * per point-step.  Fortran, host libm. */
+#define RS_SUN_COLS 6
 void rs_sun_table(int32_t n, const int32_t *year, const int32_t *month,
                   const int32_t *day, const int32_t *hour, const int32_t *minute,
                   const int32_t *second, double *table);
@@ -280,7 +283,8 @@ typedef struct RsForcing {
   int64_t t_stride;     /* elements between consecutive time indices */
   int32_t hour_pstride; /* 0 shared axis, 1 per point */
   /* sky view (src/ModRadiation.f90): direct short-wave and net long-wave streams, and the
-   * time-only solar quantities of rs_sun_table, [nsteps][4] = {ra, stG, sin decl, cos decl}
+   * time-only solar quantities of rs_sun_table, [nsteps][RS_SUN_COLS] = {ra, stG, sin decl, cos decl,
+   * cos(stG - ra), sin(stG - ra)}
    * on a time axis shared by all points.  NULL when no point has 0 <= sky_view < 1. */
   const double *sw_dir, *lw_net;
   const double *sun;
@@ -589,7 +593,7 @@ int64_t rs_hip_plan_npoints_padded(const RsPlan *plan);
  * ---------------------------------------------------------------------- */
 typedef struct RsHostExtras {
   /* sky view: NULL/0 when no point has 0 <= sky_view < 1 */
-  const double *sun;      /* rs_sun_table of the shared time axis, [SimLen][4] */
+  const double *sun;      /* rs_sun_table of the shared time axis, [SimLen][RS_SUN_COLS] */
   const double *sin_lat;  /* rs_point_geometry, [n] each */
   const double *cos_lat;
   const double *lon_rad;
@@ -706,7 +710,7 @@ int rs_driver_expand(const RsDriverInput *in, const InputSettings *settings,
                      LocalParameters *local, double *merged, int32_t *status,
                      int32_t *missing_index, int32_t device);
 
-#define RS_ABI_VERSION 4 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles; 4: RsPointParams::horizon_index, rs_hip_step_knots */
+#define RS_ABI_VERSION 5 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles; 4: RsPointParams::horizon_index, rs_hip_step_knots */
 int rs_abi_version(void);
 /* sizeof of the boundary structs as the C side / the Fortran side see them
  * (0 InputPointers, 1 OutputPointers, 2 InputSettings, 3 InputParameters,

@@ -1293,7 +1293,12 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputP
     rsu::g_last_fanout = 1;
     return driver_run_range(in, st, params, local, out, device, 0, in->n_points);
   }
-  const std::vector<rsu::Shard> shards = rsu::make_shards(in->n_points, rsu::device_list());
+  /* blocks per device: four; six where every point brings 2.9 KB of local horizons (the uploads take
+   * turns on the link: smaller blocks start stepping sooner - measured at 1 M points, tools/experiments/
+   * r4_blocks.sh: sky view 1.025e10 / 1.069e10 / 1.048e10 for 4 / 6 / 8 blocks, relaxation alone the same
+   * for all three, coupling 9.2e9 / 8.6e9 / 8.3e9) */
+  const int per = (in->horizons && !(st && st->use_coupling)) ? 6 : 4;
+  const std::vector<rsu::Shard> shards = rsu::make_shards(in->n_points, rsu::device_list(per));
   return rsu::fan_out(shards, [&](const rsu::Shard &sh, int) {
     return driver_run_range(in, st, params, local, out, sh.device, sh.off, sh.off + sh.cnt);
   });
@@ -1398,7 +1403,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
   HOK(hipMemcpyAsync(d_hour.p, in->hour, (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice, stream));
   std::vector<double> sun, slat, clat, lrad;
   if (skyview) {
-    sun.resize((size_t)L * 4);
+    sun.resize((size_t)L * RS_SUN_COLS);
     rs_sun_table(L, in->year, in->month, in->day, in->hour, in->minute, in->second, sun.data());
     HOK(d_sun.alloc(sun.size() * sizeof(double)));
     HOK(hipMemcpyAsync(d_sun.p, sun.data(), sun.size() * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -1691,7 +1696,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
       if (skyview) {
         fo.sw_dir = ea.out[R_SWDIR];
         fo.lw_net = ea.out[R_LWNET];
-        fo.sun = d_sun.as<double>() + (size_t)(t0 - 1) * 4;
+        fo.sun = d_sun.as<double>() + (size_t)(t0 - 1) * RS_SUN_COLS;
       }
       return 0;
     };

@@ -204,8 +204,8 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
   Dev d_sun, d_hz_pt, d_hz;
   Pinned h_hz;
   if (skyview) {
-    HOK(d_sun.alloc((size_t)L * 4 * sizeof(double)));
-    HOK(hipMemcpyAsync(d_sun.p, extras->sun, (size_t)L * 4 * sizeof(double), hipMemcpyHostToDevice,
+    HOK(d_sun.alloc((size_t)L * RS_SUN_COLS * sizeof(double)));
+    HOK(hipMemcpyAsync(d_sun.p, extras->sun, (size_t)L * RS_SUN_COLS * sizeof(double), hipMemcpyHostToDevice,
                        stream));
     HOK(h_hz.alloc((size_t)P * 360 * sizeof(double)));
     HOK(d_hz_pt.alloc((size_t)P * 360 * sizeof(double)));
@@ -391,7 +391,7 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
     if (skyview) {
       fo.sw_dir = b + F_SWDIR * fs;
       fo.lw_net = b + F_LWNET * fs;
-      fo.sun = (double *)d_sun.p + (size_t)(t0 - 1) * 4;
+      fo.sun = (double *)d_sun.p + (size_t)(t0 - 1) * RS_SUN_COLS;
       /* the time axis is shared (checked by the Fortran caller): hour as a shared axis */
       fo.hour = (int32_t *)d_i32pt.p + (size_t)m * len; /* point 0's row of the [p][t] copy */
       fo.hour_pstride = 0;

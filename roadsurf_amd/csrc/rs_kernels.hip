@@ -503,7 +503,7 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
   const int64_t row0 = REPLAY ? 0 : (int64_t)blockIdx.x * kBlock; /* first point of this workgroup */
   const int32_t nsteps = ka->nsteps, t0 = ka->t0;
   const double tbot = (ka->pp.tbottom + row0)[lane];
-  double skyv = R4(1.0), sinlat = 0, coslat = 0, lonrad = 0;
+  double skyv = R4(1.0), sinlat = 0, coslat = 0, lonrad = 0, coslon = 1.0, sinlon = 0;
   bool sky_on = false;
   uint32_t hcol = 0; /* the point's column of the local-horizon table (RsPointParams::horizon_index) */
   if (SKY) {
@@ -513,6 +513,8 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
       sinlat = (ka->pp.sin_lat + row0)[lane];
       coslat = (ka->pp.cos_lat + row0)[lane];
       lonrad = (ka->pp.lon_rad + row0)[lane];
+      coslon = ::cos(lonrad); /* once per launch: the addition theorem's point half (sky_view_radiation) */
+      sinlon = ::sin(lonrad);
     }
     hcol = ka->pp.horizon_index ? (uint32_t)(ka->pp.horizon_index + row0)[lane] : (uint32_t)row0 + lane;
   }
@@ -793,7 +795,7 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
     if (SKY && sky_on) {
       /* the reference runs this between PrecipitationToStorage and BalanceModelOneStep
        * (Simulation.f90:151-162); the two do not share data, so the order is free */
-      if (!sky_view_radiation(ka->f.sun + (int64_t)k * 4, sinlat, coslat, lonrad, skyv,
+      if (!sky_view_radiation(ka->f.sun + (int64_t)k * RS_SUN_COLS, sinlat, coslat, lonrad, coslon, sinlon, skyv,
                               ka->pp.albedo_surroundings,
                               ka->pp.horizons ? ka->pp.horizons + hcol : nullptr, ka->np_pad,
                               sw_in, sw_dir, lw_in, lw_net))
@@ -910,7 +912,7 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Sc
   }
   (void)lane; (void)row0;
   /* sky view, examples/example1/src/Simulation.f90:154-156 */
-  double skyv = R4(1.0), sinlat = 0, coslat = 0, lonrad = 0;
+  double skyv = R4(1.0), sinlat = 0, coslat = 0, lonrad = 0, coslon = 1.0, sinlon = 0;
   bool sky_on = false;
   if (ka->pp.sky_view) {
     skyv = ka->pp.sky_view[p];
@@ -919,6 +921,8 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Sc
       sinlat = ka->pp.sin_lat[p];
       coslat = ka->pp.cos_lat[p];
       lonrad = ka->pp.lon_rad[p];
+      coslon = ::cos(lonrad);
+      sinlon = ::sin(lonrad);
     }
   }
 
@@ -1063,7 +1067,7 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Sc
     if (sky_on) {
       /* the reference runs this between PrecipitationToStorage and BalanceModelOneStep
        * (Simulation.f90:151-162); the two do not share data, so the order is free */
-      if (!sky_view_radiation(ka->f.sun + (int64_t)(i - t0) * 4, sinlat, coslat, lonrad, skyv,
+      if (!sky_view_radiation(ka->f.sun + (int64_t)(i - t0) * RS_SUN_COLS, sinlat, coslat, lonrad, coslon, sinlon, skyv,
                               ka->pp.albedo_surroundings,
                               ka->pp.horizons
                                   ? ka->pp.horizons + (ka->pp.horizon_index ? (int64_t)ka->pp.horizon_index[p] : p)

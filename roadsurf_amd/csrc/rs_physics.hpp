@@ -61,14 +61,16 @@ namespace rs {
 
 /* Sky view / local horizon: the per-point, per-step remainder of calcElevationAzimuth
  * (src/SunPosition.f90:123-193) and ModRadiationBySurroundings (src/ModRadiation.f90:7-73).
- * sun[4] = {ra, stG, sin decl, cos decl} comes from the host (rs_sun_table, libm).  The
+ * sun[RS_SUN_COLS] = {ra, stG, sin decl, cos decl, cos(stG - ra), sin(stG - ra)} comes from the host
+ * (rs_sun_table, libm).  The
  * solar position only ever acts through discrete outcomes (sun above the horizon line or
  * not, which degree of azimuth, elevation > 0), so the device cos/acos need not reproduce
  * libm's last bit: a different outcome needs the elevation within ~1e-14 deg of the horizon
  * value or the azimuth within ~1e-13 deg of a half degree.  Returns false where the
  * reference would `stop` (|cos| >= 1.001: cannot happen for real inputs). */
 __device__ __forceinline__ bool sky_view_radiation(const double *sun, double sin_lat,
-                                                   double cos_lat, double lon_rad, double sky_view,
+                                                   double cos_lat, double lon_rad, double cos_lon,
+                                                   double sin_lon, double sky_view,
                                                    double albedo_surr, const double *horizons,
                                                    int64_t hstride, double &sw, double &sw_dir,
                                                    double &lw, double lw_net) {
@@ -88,44 +90,57 @@ __device__ __forceinline__ bool sky_view_radiation(const double *sun, double sin
   const double cos_dec_lat = cos_decl * cos_lat;
   const double sin_dec_lat = sin_decl * sin_lat;
   double hac = (stG + lon_rad - ra);
-  const double cosah = ::cos(hac);
+  /* cos of the hour angle by the addition theorem: cos((stG - ra) + lon) from the table's cos/sin of
+   * stG - ra (host, once per time index) and the point's cos/sin of its longitude (once per launch) -
+   * three instructions instead of a cosine per point-step.  Like every value of this block it reaches
+   * the outputs only through decisions (elevation > 0, horizon > elevation, the rounded azimuth), see
+   * the note above: a result that differs from cos(hac) in its last bits moves those by ~1e-14 deg. */
+  const double cosah = sun[4] * cos_lon - sun[5] * sin_lon;
   const double cos_elev = sin_dec_lat + cos_dec_lat * cosah;
-  double chi;
-  if (cos_elev >= R4(1.0) && cos_elev < R4(1.001)) {
-    chi = R4(0.);
-  } else if (cos_elev >= R4(1.001)) {
-    return false;
-  } else if (cos_elev > R4(-1.001) && cos_elev <= R4(-1.0)) {
-    chi = pi;
-  } else {
-    chi = ::acos(cos_elev);
-  }
-  double elevation = R4(90.0) - chi * (R4(180.) / pi);
-  if (hac < R4(0.))
-    hac = 2 * pi + hac;
-  else if (hac > 2 * pi)
-    hac = hac - 2 * pi;
-  double azimuth;
-  if (elevation > 0) {
-    const double cosele = ::cos((pi / R4(2.0)) - chi);
-    if (cosele >= R4(-0.0001) && cosele < R4(0.0001)) {
-      azimuth = R4(-9999.9);
-    } else {
-      const double precos = (sin_decl * cos_lat - cos_decl * sin_lat * cosah) / cosele;
-      if (precos >= R4(1.0) && precos < R4(1.001))
-        azimuth = R4(0.0);
-      else if (precos >= R4(1.001))
-        return false;
-      else if (precos > R4(-1.001) && precos <= R4(-1.0))
-        azimuth = pi;
-      else
-        azimuth = ::acos(precos);
-    }
-    if (hac < pi) azimuth = 2 * pi - azimuth;
-    azimuth = azimuth * (R4(180.) / pi);
-  } else {
+  double elevation, azimuth;
+  if (cos_elev < -1e-9) {
+    /* the sun is below the horizon by more than any rounding of acos: elevation <= 0 in the reference,
+     * which then sets both to -9999.9 without looking at them again */
     azimuth = R4(-9999.9);
     elevation = R4(-9999.9);
+  } else {
+    double chi;
+    if (cos_elev >= R4(1.0) && cos_elev < R4(1.001)) {
+      chi = R4(0.);
+    } else if (cos_elev >= R4(1.001)) {
+      return false;
+    } else if (cos_elev > R4(-1.001) && cos_elev <= R4(-1.0)) {
+      chi = pi;
+    } else {
+      chi = ::acos(cos_elev);
+    }
+    elevation = R4(90.0) - chi * (R4(180.) / pi);
+    if (hac < R4(0.))
+      hac = 2 * pi + hac;
+    else if (hac > 2 * pi)
+      hac = hac - 2 * pi;
+    if (elevation > 0) {
+      /* cos(pi/2 - chi) = sin(chi) = sqrt((1 - x)(1 + x)) for chi = acos(x) in [0, pi] */
+      const double cosele = (cos_elev >= R4(1.0)) ? 0.0 : rs_sqrt((1.0 - cos_elev) * (1.0 + cos_elev));
+      if (cosele >= R4(-0.0001) && cosele < R4(0.0001)) {
+        azimuth = R4(-9999.9);
+      } else {
+        const double precos = rs_div(sin_decl * cos_lat - cos_decl * sin_lat * cosah, cosele);
+        if (precos >= R4(1.0) && precos < R4(1.001))
+          azimuth = R4(0.0);
+        else if (precos >= R4(1.001))
+          return false;
+        else if (precos > R4(-1.001) && precos <= R4(-1.0))
+          azimuth = pi;
+        else
+          azimuth = ::acos(precos);
+      }
+      if (hac < pi) azimuth = 2 * pi - azimuth;
+      azimuth = azimuth * (R4(180.) / pi);
+    } else {
+      azimuth = R4(-9999.9);
+      elevation = R4(-9999.9);
+    }
   }
   /* ModRadiationBySurroundings */
   double dif_sw = sw - sw_dir;

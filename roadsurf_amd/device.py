@@ -66,7 +66,7 @@ class ForcingWindow:
         for n in ("sw_dir", "lw_net"):
             t = self.tensors.get(n)
             setattr(f, n, None if t is None else C.c_void_p(t[row].data_ptr()))
-        sun = self.tensors.get("sun")  # [nsteps, 4]
+        sun = self.tensors.get("sun")  # [nsteps, RS_SUN_COLS = 6]
         f.sun = None if sun is None else C.c_void_p(sun[row].data_ptr())
         return f
 
@@ -380,7 +380,7 @@ def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputPara
         Lh = lib.load()
         tens["sw_dir"] = pad_t(forcing["sw_dir"], torch.float64)
         tens["lw_net"] = pad_t(forcing["lw_net"], torch.float64)
-        sun = np.zeros((L, 4))
+        sun = np.zeros((L, 6))  # RS_SUN_COLS
         ax = [np.ascontiguousarray(forcing[k], np.int32) for k in ("year", "month", "day", "hour", "minute", "second")]
         Lh.rs_sun_table(L, *[C.c_void_p(a.ctypes.data) for a in ax], C.c_void_p(sun.ctypes.data))
         tens["sun"] = torch.from_numpy(sun).to(dev)

@@ -367,7 +367,7 @@ contains
    subroutine rs_sun_table(n, year, month, day, hour, minute, second, table) bind(C, name='rs_sun_table')
       integer(c_int), value :: n
       integer(c_int), intent(in) :: year(n), month(n), day(n), hour(n), minute(n), second(n)
-      real(c_double), intent(out) :: table(4, n)
+      real(c_double), intent(out) :: table(6, n)
       real(8), parameter :: pi = 4*atan(1.0_8)
       real(8) :: cy, yr, mo, dayf, ca, cb, jde, t, lmean, anom, centre, lapp, obl, ra, decl, sidereal, node
       integer :: k
@@ -416,6 +416,9 @@ contains
          table(2, k) = sidereal*pi/180.
          table(3, k) = sin(decl)
          table(4, k) = cos(decl)
+         ! for the device: cos(hour angle) = cos((stG - ra) + lon) by the addition theorem
+         table(5, k) = cos(sidereal*pi/180. - ra)
+         table(6, k) = sin(sidereal*pi/180. - ra)
       end do
    end subroutine rs_sun_table
 
@@ -589,7 +592,7 @@ contains
                group(p) = ngroups
             end if
          end do
-         allocate (sun(4, nt), slat(n), clat(n), lrad(n))
+         allocate (sun(6, nt), slat(n), clat(n), lrad(n))
          call rs_point_geometry(n, localParam, slat, clat, lrad)
          if (ngroups == 1) then
             call axis_of(inPointers(1), nt, yy, mm, dd, hh, mi, ss)

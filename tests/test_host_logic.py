@@ -88,7 +88,7 @@ def test_fortran_sun_table_against_oracle_solar_position():
     y = np.full(n, 2024, np.int32); mo = rs.randint(1, 13, n).astype(np.int32)
     d = rs.randint(1, 29, n).astype(np.int32); h = rs.randint(0, 24, n).astype(np.int32)
     mi = rs.randint(0, 60, n).astype(np.int32); se = (30 * rs.randint(0, 2, n)).astype(np.int32)
-    tab = np.zeros((n, 4))
+    tab = np.zeros((n, 6))  # RS_SUN_COLS
     L.rs_sun_table(n, *[C.c_void_p(a.ctypes.data) for a in (y, mo, d, h, mi, se)], C.c_void_p(tab.ctypes.data))
     ls = []
     for k in range(n):
@@ -100,7 +100,8 @@ def test_fortran_sun_table_against_oracle_solar_position():
         el, az, jde = C.c_double(), C.c_double(), C.c_double()
         assert port.oracle_probe_sun(int(y[k]), int(mo[k]), int(d[k]), int(h[k]), int(mi[k]), int(se[k]),
                                      ls[k].lat, ls[k].lon, C.byref(el), C.byref(az), C.byref(jde)) == 0
-        ra, stg, sd, cd = tab[k]
+        ra, stg, sd, cd, ch, sh = tab[k]
+        assert abs(ch - np.cos(stg - ra)) < 1e-15 and abs(sh - np.sin(stg - ra)) < 1e-15
         assert 0.0 <= ra <= 2 * np.pi + 1e-12
         cosz = sd * g[0][k] + (cd * g[1][k]) * np.cos((stg + g[2][k]) - ra)
         elev = 90.0 - np.degrees(np.arccos(np.clip(cosz, -1, 1)))
