@@ -249,13 +249,13 @@ def main() -> None:
     if args.full:
         settings.use_relaxation = 1
     params = abi.default_parameters()
-    if args.variant == 0 and not args.f32 and not args.full:
+    if args.variant == 0 and not args.f32:
         # Round 4: the two-wavefront flavour whose ground wave makes the forcing from the resident knots itself
         # (roadsurf_amd/workload.py: no window expansion, no forcing window) is the faster one at every size -
         # 1 M points: 1.93-1.97e10 with one point per lane (4 plans x 120), 2.11-2.13e10 with this flavour
         # 
         args.variant = 3
-    fused = args.variant == 3 and not args.f32 and not args.full and bool(args.cluster)
+    fused = args.variant == 3 and not args.f32 and bool(args.cluster)
     if fused:
         # measured (round 4, tools/experiments/r4_fused_{big,small}_sweep.sh): with the expansion gone a launch
         # cycle is short, so fewer plans hide it and shorter launches (a fresher sort key) pay: 3 x 90 from
@@ -267,11 +267,16 @@ def main() -> None:
         K, ch = (4 if n >= 200_000 else 2 if n >= 100_000 else 1), (120 if n >= 400_000 else 240)
     if args.plans_per_gpu > 0:
         K = args.plans_per_gpu
-    if args.chunk <= 0:
+    chunk_auto = args.chunk <= 0
+    if chunk_auto:
         args.chunk = ch
-    if args.full and n >= 750_000:  # measured (tools/experiments/r3_full3.sh): three plans, launches of 240 indices
+    if args.full and n >= 400_000:
+        # measured: three plans; launches of 120 indices with the knot-reading flavour (tools/experiments/
+        # r4_full_duo.sh: 2.01e10 for 3 x 120, 2.00e10 for 3 x 240, 1.97e10 for 3 x 90 and 2 x 120), of 240
+        # with a forcing window (tools/experiments/r3_full3.sh)
         K = args.plans_per_gpu if args.plans_per_gpu > 0 else 3
-        args.chunk = 240
+        if chunk_auto:
+            args.chunk = 120 if fused else 240
     def make_plans(K, settings, variant):
         plans, offsets = [], []
         for j in range(K):
@@ -412,8 +417,8 @@ def main() -> None:
         # behind it) on the same synthetic points: what `bench.py --full` reports as its headline
         s_full = abi.default_settings(simlen)
         s_full.use_relaxation = 1
-        Kf, chunk_f = (3, 240) if n >= 750_000 else (K, args.chunk)  # measured: tools/experiments/r3_full3.sh
-        fplans, foffs = make_plans(Kf, s_full, 0)
+        Kf, chunk_f = (3, 120) if n >= 400_000 else (K, args.chunk)  # measured: tools/experiments/r4_full_duo.sh
+        fplans, foffs = make_plans(Kf, s_full, args.variant)
         f_steps = 2
         f_elapsed, _, f_nl, f_chunk, f_busy = timed_leg(True, fplans, foffs, chunk_f, True, steps=f_steps, warmup=1)
         extra["full_feature"] = {
@@ -421,8 +426,10 @@ def main() -> None:
             "ms_per_step": f_elapsed / f_steps * 1e3, "steps": f_steps, "warmup": 1,
             "step_kernel_only_value": units_per_pass_rank * f_steps / (f_busy / 1e3),
             "config": {"workload": f"{total_points} synthetic points x {args.hours} h (SimLen {simlen}), fp64, FULL "
-                                   "feature set (optional streams, 6 h initialization phase, relaxation), outputs "
-                                   "every time index, inputs resident in HBM",
+                                   "feature set (dew point and observation streams - no depth stream, as in the "
+                                   "reference driver -, 6 h initialization phase, relaxation), outputs every time "
+                                   "index, inputs resident in HBM",
+                       "kernel_variant": args.variant,
                        "plans_per_gpu": Kf, "chunk_steps": f_chunk, "plan_order": True, "launches": f_nl},
         }
         for pl in fplans:
@@ -503,7 +510,7 @@ def main() -> None:
                 "total_points": total_points,
                 "points_per_gpu": n,
                 "plans_per_gpu": K,
-                "feature_set": "FULL (optional streams, 6 h initialization phase, relaxation)" if args.full else "LEAN",
+                "feature_set": "FULL (dew point and observation streams, 6 h initialization phase, relaxation)" if args.full else "LEAN",
 
                 "simlen": simlen,
                 "chunk_steps": chunk,

@@ -635,6 +635,7 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
   a.wave_start = pl->wave_tab_valid ? pl->wave_tab : nullptr;
   a.wave_cnt = pl->wave_tab_valid ? pl->wave_tab + pl->wave_n : nullptr;
   a.wave_n = pl->wave_n;
+  a.duo_full_ok = (full && !skyview && !coupled && !f->depth && !(pl->c.tsurfOutputDepth >= 0.0)) ? 1 : 0;
   a.knots = nullptr;
   a.knot_gather = nullptr;
   a.knot_k0 = a.knot_n = a.spk = a.start_hour = 0;
@@ -715,11 +716,17 @@ int rs_hip_step_knots(RsPlan *pl, const RsSynthSpec *spec, const double *knots, 
     if (first < o->row0) return set_err("rs_hip_step_knots: output row0 beyond first row");
   }
   const int64_t out_rows = ((int64_t)t0 + nsteps - 2) / o->decimate - o->row0 + 1;
-  if (pl->f32 || pl->c.NLayers != 15 || pp->initlen || pl->c.force_tsurf || pl->c.tsurfOutputDepth >= 0.0 ||
-      (pl->c.use_relaxation && pp->tair_relax) || pp->sky_view || pl->c.use_coupling ||
+  if (pl->f32 || pl->c.NLayers != 15 || pl->c.tsurfOutputDepth >= 0.0 || pp->sky_view ||
+      (pl->c.use_coupling && pp->coupling_index) ||
       (uint64_t)o->t_stride * (uint64_t)(out_rows > 0 ? out_rows : 1) >= (1ull << 29))
-    return set_err("rs_hip_step_knots: the LEAN feature set, NLayers = 15, fp64 and an output window below 4 GiB "
-                   "per stream only - use rs_hip_expand_forcing_ordered + rs_hip_step");
+    return set_err("rs_hip_step_knots: NLayers = 15, fp64, no output depth, sky view or coupling and an output "
+                   "window below 4 GiB per stream only - use rs_hip_expand_forcing_ordered + rs_hip_step");
+  /* the FULL feature set as far as the knots carry it: the dew point (CheckValues' test), the observation
+   * of index 1, an initialization phase, relaxation - what rs_hip_step calls `full` for a window with the
+   * Tdew and TsurfObs streams and no depth stream */
+  const bool full = (pp->initlen != nullptr) || pl->c.force_tsurf || (pl->c.use_relaxation && pp->tair_relax != nullptr);
+  if (pl->c.use_relaxation && pp->tair_relax && (!pp->vz_relax || !pp->rh_relax || !pp->initlen))
+    return set_err("rs_hip_step_knots: relaxation needs tair_relax, vz_relax, rh_relax and initlen");
   const int32_t *order = rs_hip_plan_order(pl);
   if (!order) return -1;
   HIP_OK(hipSetDevice(pl->device));
@@ -737,6 +744,7 @@ int rs_hip_step_knots(RsPlan *pl, const RsSynthSpec *spec, const double *knots, 
   a.wave_start = pl->wave_tab_valid ? pl->wave_tab : nullptr;
   a.wave_cnt = pl->wave_tab_valid ? pl->wave_tab + pl->wave_n : nullptr;
   a.wave_n = pl->wave_n;
+  a.duo_full_ok = full ? 3 : 0; /* bit 1: the dew-point test (the knots always carry a dew point) */
   a.knots = knots;
   a.knot_gather = order;
   a.knot_k0 = k0;
@@ -810,6 +818,7 @@ static int cpl_args(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const Rs
   a.out_index = (pl->output_by_point && pl->order) ? pl->order : nullptr;
   a.wave_start = a.wave_cnt = nullptr;
   a.wave_n = 0;
+  a.duo_full_ok = 0;
   a.knots = nullptr;
   a.knot_gather = nullptr;
   a.knot_k0 = a.knot_n = a.spk = a.start_hour = 0;

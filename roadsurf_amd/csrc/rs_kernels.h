@@ -53,6 +53,9 @@ struct StepArgs {
    * NULL: wavefront w steps the slots 64 w ... */
   const int32_t *wave_start, *wave_cnt;
   int32_t wave_n;
+  /* the launch's FULL feature set is one the two-wavefront flavour has (rs_hip_step: no sky view, no
+   * coupling, no depth stream, no tsurfOutputDepth) */
+  int32_t duo_full_ok;
   /* two-wavefront flavour on the synthetic workload (rs_hip_step_knots): no forcing window - the ground
    * wave makes the forcing of the next index from the hourly knots itself, with expand_kernel's arithmetic
    * (knots [knot - knot_k0][RS_KNOT_FIELDS][np_pad] in point order, column knot_gather[slot]; NULL knots:

@@ -1210,40 +1210,47 @@ __global__ void __launch_bounds__(kBlock, WPE) step_kernel_lds(const StepArgs a)
  * step shrinks from ~1 460 to ~1 020 vector instructions and the shard occupies twice as many
  * wave slots.  Same arithmetic in the same order per point: same bits (layer_step is the one
  * function both flavours call).  LEAN feature set, NLayers = 15, 32-bit window offsets. */
-#define RS_DUO_NPREP 13
+#define RS_DUO_NPREP 12
 struct DuoMail {
   double v[2][2][64]; /* [buffer][0: Tmp(2) from the surface wave, 1: Tmp(3) from the ground wave][lane] */
   uint32_t failed[64]; /* sticky, set by the surface wave: the point's loop has exited (the ground wave
                           then leaves Tmp(3..N) alone, as the one-point-per-lane flavours do) */
   /* round 4: what a step needs of its forcing alone (ForcingPrep, rs_physics_body.inc), worked out by
-   * the ground wave one index ahead: [buffer = index parity][value][lane].  13 values per lane - the
-   * traffic friction is the same for every point of an index (one word per buffer) and VK x VZ is one
-   * multiplication for the surface wave: with 15 the workgroup took 22 336 B of LDS, seven workgroups to
-   * a CU (3.5 wavefronts per SIMD where the registers allow 4); 20 288 B: eight. */
+   * the ground wave one index ahead: [buffer = index parity][value][lane].  Eleven values per lane (+ the
+   * forced surface observation of the FULL feature set) - the traffic friction is the same for every
+   * point of an index (one word per buffer), VK x VZ and the two products with the air's volumetric heat
+   * capacity are four multiplications for the surface wave: with 15 values the workgroup took 22 336 B
+   * of LDS, seven workgroups to a CU (3.5 wavefronts per SIMD where the registers allow 4); now 19 280 B:
+   * eight. */
   double prep[2][RS_DUO_NPREP][64];
   double trffric[2];
   uint32_t prep_bad[2][64];
 };
 
+template <bool FULL>
 __device__ __forceinline__ void duo_put_prep(DuoMail &mail, int buf, uint32_t lane, const ForcingPrep &q) {
   double (*w)[64] = mail.prep[buf];
   w[0][lane] = q.tair; w[1][lane] = q.vz; w[2][lane] = q.rhz; w[3][lane] = q.rain; w[4][lane] = q.snow;
   w[5][lane] = q.AirDens; w[6][lane] = q.AirHCap; w[7][lane] = q.PsychC;
-  w[8][lane] = q.den0; w[9][lane] = q.avk; w[10][lane] = q.EAir;
-  w[11][lane] = q.sw; w[12][lane] = q.lw;
+  w[8][lane] = q.EAir; w[9][lane] = q.sw; w[10][lane] = q.lw;
+  if (FULL) w[11][lane] = q.tsurfobs;
   if (lane == 0) mail.trffric[buf] = q.trffric; /* day or night: the hour is the index's (lane 0 is never a dead lane) */
   mail.prep_bad[buf][lane] = q.bad ? 1u : 0u;
 }
-template <class C>
+template <bool FULL, class C>
 __device__ __forceinline__ ForcingPrep duo_get_prep(const C &c, const DuoMail &mail, int buf, uint32_t lane) {
   const double (*w)[64] = mail.prep[buf];
   ForcingPrep q;
   q.tair = w[0][lane]; q.vz = w[1][lane]; q.rhz = w[2][lane]; q.rain = w[3][lane]; q.snow = w[4][lane];
   q.AirDens = w[5][lane]; q.AirHCap = w[6][lane]; q.PsychC = w[7][lane];
-  q.den0 = w[8][lane]; q.avk = w[9][lane]; q.EAir = w[10][lane];
-  q.sw = w[11][lane]; q.lw = w[12][lane];
+  q.EAir = w[8][lane]; q.sw = w[9][lane]; q.lw = w[10][lane];
+  if (FULL) q.tsurfobs = w[11][lane];
   q.trffric = mail.trffric[buf];
-  q.vkvz = c.VK_Const * q.vz; /* forcing_prep's expression on forcing_prep's VZ */
+  /* forcing_prep_tail's expressions on forcing_prep_tail's values */
+  const double AirVCap = q.AirHCap * q.AirDens;
+  q.den0 = AirVCap * (q.tair + R4(273.15));
+  q.vkvz = c.VK_Const * q.vz;
+  q.avk = AirVCap * c.VK_Const;
   q.bad = mail.prep_bad[buf][lane] != 0u;
   return q;
 }
@@ -1252,7 +1259,7 @@ __device__ __forceinline__ ForcingPrep duo_get_prep(const C &c, const DuoMail &m
  * memory counter, i.e. for the six output stores of the step and the prefetched forcing loads. */
 __device__ __forceinline__ void duo_meet() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int NL, bool SCORE>
+template <int NL, bool SCORE, bool FULL = false>
 __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, const StepArgs &a) {
   KernArgs ka = kernargs();
   const uint32_t lane = threadIdx.x & 63u;
@@ -1297,7 +1304,7 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
     const bool owrite = output_row<true>(ka, i, orow);
     const double t3 = mail.v[k & 1][1][lane]; /* Tmp(3) as the last step left it */
     if (!s.failed) {
-      const ForcingPrep q = duo_get_prep(c, mail, k & 1, lane);
+      const ForcingPrep q = duo_get_prep<FULL>(c, mail, k & 1, lane);
       if (i < c.SimLen) { /* CheckValues: the forcing's verdict | the surface temperature's */
         if (q.bad | check_values_tsurf(c, s.tsurf)) {
           s.failed = true;
@@ -1307,6 +1314,21 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
       }
       s.tnw1 = T.get(1);
       s.tnw2 = T.get(2);
+      if (FULL) {
+        /* SetCurrentValues' observation forcing (src/InputOutput.f90:116-148; the ground wave decided
+         * whether it applies at this index and uses the same value for Tmp(2)), and lastValues' surface
+         * temperature (:169-198) - no depth stream and no tsurfOutputDepth in this flavour: the mean of
+         * the two top layers (surface_temperature) */
+        if (i < c.SimLen) {
+          if (q.tsurfobs > R4(-100.0)) {
+            T.set(1, q.tsurfobs);
+            T.set(2, q.tsurfobs);
+            s.tsurf = (T.get(1) + T.get(2)) / R4(2.0);
+          }
+        } else {
+          s.tsurf = (T.get(1) + T.get(2)) / R4(2.0);
+        }
+      }
       const double tair = q.tair;
       const Fluxes fx = model_step_fluxes_prepped<SCORE>(c, mt, s, q);
       if (SCORE) {
@@ -1347,11 +1369,13 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
  * the uniform span as rs_div_u; PrecPhase from the later knot between knots; the hour of rs_sy_hour.
  * (The LEAN feature set reads neither Tdew nor, after the initialization, TsurfObs.)  Knot columns are
  * per point: gathered through the plan's order row, once per interval. */
+template <bool FULL>
 struct KnotLerp {
-  double v0[6], dv[6]; /* tair, vz, rhz, prec, sw, lw */
+  double v0[FULL ? 7 : 6], dv[FULL ? 7 : 6]; /* tair, vz, rhz, prec, sw, lw [, tdew] */
   int32_t ph0, ph1;
 };
-__device__ __forceinline__ Forcing knot_forcing(KernArgs ka, int64_t col, bool live, KnotLerp &K,
+template <bool FULL>
+__device__ __forceinline__ Forcing knot_forcing(KernArgs ka, int64_t col, bool live, KnotLerp<FULL> &K,
                                                 int32_t &kcur, int32_t i) {
   const int32_t spk = ka->spk;
   const int32_t t = i - 1;
@@ -1359,13 +1383,13 @@ __device__ __forceinline__ Forcing knot_forcing(KernArgs ka, int64_t col, bool l
   const int32_t r = t - k * spk;
   if (k != kcur) { /* uniform: a new knot interval */
     kcur = k;
-    const int fld[6] = {0, 2, 3, 4, 5, 6};
+    const int fld[7] = {0, 2, 3, 4, 5, 6, 1};
     const int64_t np = ka->np_pad;
     const double *ka_ = ka->knots + ((int64_t)(k - ka->knot_k0) * RS_KNOT_FIELDS) * np + col;
     const bool has_b = (k + 1 - ka->knot_k0) < ka->knot_n;
     const double *kb_ = ka_ + (int64_t)RS_KNOT_FIELDS * np;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
+    for (int q = 0; q < (FULL ? 7 : 6); ++q) {
       K.v0[q] = live ? ka_[(int64_t)fld[q] * np] : 0.0;
       const double v1 = (live && has_b) ? kb_[(int64_t)fld[q] * np] : K.v0[q];
       K.dv[q] = v1 - K.v0[q];
@@ -1385,11 +1409,21 @@ __device__ __forceinline__ Forcing knot_forcing(KernArgs ka, int64_t col, bool l
   f.hour = rs_sy_hour(i, spk, ka->start_hour);
   f.tdew = 0.0;
   f.tsurfobs = R4(-9999.9);
+  if (FULL) { /* expand_kernel<TDEW, OBS>: the dew point like the others, the observation at index 1 only */
+    f.tdew = K.v0[6] + rs_div_u(secs * K.dv[6], span, ka->r_spk);
+    if (t == 0 && live) f.tsurfobs = (ka->knots + ((int64_t)(k - ka->knot_k0) * RS_KNOT_FIELDS + 7) * ka->np_pad)[col];
+  }
   f.depth = R4(-9999.9);
   return f;
 }
 
-template <int NL, bool KNOTS = false>
+/* FULL: the FULL feature set without sky view, coupling, a depth stream or tsurfOutputDepth (what the
+ * launcher checks): the optional streams, the initialization phase and relaxation.  The ground wave owns
+ * what they add to the forcing's share of a step - CheckValues' dew-point test, whether the observation
+ * is forced on Tmp(1:2) at an index (it needs the forced Tmp(2) itself, for the flux into layer 3), and
+ * RelaxationOperations (src/Relaxation.f90:10-47: the anchors at the end of the initialization, which go
+ * to the state block there and then, and the decaying correction behind it). */
+template <int NL, bool KNOTS = false, bool FULL = false>
 __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, const StepArgs &a) {
   KernArgs ka = kernargs();
   const uint32_t lane = threadIdx.x & 63u;
@@ -1402,17 +1436,85 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
   const double tbot = live ? ka->pp.tbottom[p] : 0.0;
   mail.v[0][1][lane] = Tg[0];
   const int32_t nsteps = ka->nsteps, t0 = ka->t0;
+  /* FULL: as time_loop sets them up */
+  int32_t initlen = 0;
+  bool relax = false;
+  double relax_dt = 0, relax_dv = 0, relax_dr = 0;
+  auto relax_targets = [&](double &tairR, double &vzR, double &rhR) { /* through REAL(4): src/InputOutput.f90:19-26 */
+    tairR = (double)(float)ka->pp.tair_relax[p];
+    vzR = (double)(float)ka->pp.vz_relax[p];
+    rhR = (double)(float)ka->pp.rh_relax[p];
+  };
+  if (FULL && live) {
+    initlen = ka->pp.initlen ? ka->pp.initlen[p] : 0;
+    if (consts_of(ka).use_relaxation && ka->pp.tair_relax) {
+      double tairR, vzR, rhR;
+      relax_targets(tairR, vzR, rhR);
+      relax = !(tairR < R4(-100.0) || tairR > R4(100.0) || vzR < R4(0.0) || vzR > R4(100.0) ||
+                rhR < R4(0.0) || rhR > 110);
+      relax_dt = tairR - a.state[(int64_t)RS_ST_TAIR_END * a.np_pad + p];
+      relax_dv = vzR - a.state[(int64_t)RS_ST_VZ_END * a.np_pad + p];
+      relax_dr = rhR - a.state[(int64_t)RS_ST_RH_END * a.np_pad + p];
+    }
+  }
+  /* the anchors of an index are stored at the START of that index's step, when the surface wave's
+   * verdict on the index before is in the mailbox (a point that has failed never reaches it) */
+  bool anchor_due = false;
+  double anchor_t = 0, anchor_v = 0, anchor_r = 0;
+  double obs_cur = R4(-9999.9); /* the observation forced on Tmp(1:2) at the current index, or missing */
+  /* the forcing's share of index `in`, from the forcing in `f` */
+  auto prep = [&](const ConstsAS &c, const Forcing &f, int32_t in, double &obs) -> ForcingPrep {
+    if (!FULL) return forcing_prep(c, mt, f, in, in < c.SimLen);
+    bool bad;
+    const bool has_tdew = KNOTS ? (ka->duo_full_ok & 2) != 0 : ka->f.tdew != nullptr;
+    double vz = forcing_prep_head(c, f, in, in < c.SimLen, has_tdew, bad);
+    double tair = f.tair, rhz = f.rhz;
+    obs = R4(-9999.9);
+    if (in < c.SimLen) {
+      if ((in <= initlen || c.force_tsurf) && f.tsurfobs > R4(-100.0)) obs = f.tsurfobs;
+      if (relax) {
+        if (in == initlen) { /* the anchors: once per point */
+          double tairR, vzR, rhR;
+          relax_targets(tairR, vzR, rhR);
+          relax_dt = tairR - tair;
+          relax_dv = vzR - vz;
+          relax_dr = rhR - rhz;
+          anchor_due = true;
+          anchor_t = tair;
+          anchor_v = vz;
+          anchor_r = rhz;
+        }
+        if (in > initlen) {
+          double e;
+          const uint32_t d = (uint32_t)(in - initlen);
+          if (c.relax_tab && d <= (uint32_t)c.SimLen) {
+            e = ((const double *)c.relax_tab)[d];
+          } else {
+            const double den = (double)(4.f * 3600.f);
+            e = rs_exp(mt, rs_div(-((c.DTSecs * in) - (c.DTSecs * initlen)), den));
+          }
+          tair = tair - relax_dt * e;
+          vz = vz - relax_dv * e;
+          rhz = rhz - relax_dr * e;
+          if (rhz > R4(100.)) rhz = R4(100.0);
+        }
+      }
+    }
+    ForcingPrep q = forcing_prep_tail(c, mt, f, tair, vz, rhz, bad);
+    q.tsurfobs = obs;
+    return q;
+  };
   /* the forcing of the launch's first index, prepared before the first meeting (a lane beyond npoints
    * reads nothing: the windows need only span npoints columns) */
   Forcing nxt = Forcing();
-  KnotLerp klerp;
+  KnotLerp<FULL> klerp;
   int32_t kcur = -1;
   const int64_t kcol = (KNOTS && live) ? (ka->knot_gather ? (int64_t)ka->knot_gather[p] : p) : 0;
   {
     const ConstsAS &c0 = consts_of(ka);
-    if (KNOTS) nxt = knot_forcing(ka, kcol, live, klerp, kcur, t0);
-    else if (live) nxt = load_forcing<false, true>(ka, row0, lane, 0);
-    duo_put_prep(mail, 0, lane, forcing_prep(c0, mt, nxt, t0, t0 < c0.SimLen));
+    if (KNOTS) nxt = knot_forcing<FULL>(ka, kcol, live, klerp, kcur, t0);
+    else if (live) nxt = load_forcing<FULL, true>(ka, row0, lane, 0);
+    duo_put_prep<FULL>(mail, 0, lane, prep(c0, nxt, t0, obs_cur));
   }
   duo_meet();
   for (int32_t kv = 0; kv < nsteps; ++kv) {
@@ -1420,11 +1522,20 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
     const ConstsAS &c = consts_of(ka);
     const int32_t k = __builtin_amdgcn_readfirstlane(kv);
     /* next index's forcing: fetched here, used behind the layers */
-    if (!KNOTS && k + 1 < nsteps && live) nxt = load_forcing<false, true>(ka, row0, lane, k + 1);
-    const double t2 = mail.v[k & 1][0][lane]; /* Tmp(2) as the last step left it (melting included) */
+    if (!KNOTS && k + 1 < nsteps && live) nxt = load_forcing<FULL, true>(ka, row0, lane, k + 1);
+    double t2 = mail.v[k & 1][0][lane]; /* Tmp(2) as the last step left it (melting included) */
     /* a failed point takes no further step in any flavour: its Tmp(3..N) stay as the failing index left
      * them (the flag was raised before the barrier that ended that index) */
     if (!mail.failed[lane]) {
+      if (FULL) {
+        if (obs_cur > R4(-100.0)) t2 = obs_cur; /* SetCurrentValues has forced Tmp(1:2) at this index */
+        if (anchor_due && live) {
+          double *st = ka->state;
+          st[(int64_t)RS_ST_TAIR_END * ka->np_pad + p] = anchor_t;
+          st[(int64_t)RS_ST_VZ_END * ka->np_pad + p] = anchor_v;
+          st[(int64_t)RS_ST_RH_END * ka->np_pad + p] = anchor_r;
+        }
+      }
       double Gprev = c.condDZ[2] * (Tg[0] - t2); /* G(2), the expression layer 2 itself evaluates */
 #pragma unroll
       for (int j = 3; j <= NL; ++j) {
@@ -1433,11 +1544,12 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
         Tg[j - 3] = layer_step(c, j, tj, tj, tnext, Gprev, nullptr);
       }
     }
+    if (FULL) anchor_due = false;
     mail.v[(k & 1) ^ 1][1][lane] = Tg[0];
     if (k + 1 < nsteps) {
       const int32_t in = t0 + k + 1;
-      if (KNOTS) nxt = knot_forcing(ka, kcol, live, klerp, kcur, in);
-      duo_put_prep(mail, (k & 1) ^ 1, lane, forcing_prep(c, mt, nxt, in, in < c.SimLen));
+      if (KNOTS) nxt = knot_forcing<FULL>(ka, kcol, live, klerp, kcur, in);
+      duo_put_prep<FULL>(mail, (k & 1) ^ 1, lane, prep(c, nxt, in, obs_cur));
     }
     duo_meet();
   }
@@ -1447,7 +1559,7 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
   }
 }
 
-template <int NL, bool SCORE, bool KNOTS = false>
+template <int NL, bool SCORE, bool KNOTS = false, bool FULL = false>
 __global__ void __launch_bounds__(128, 4) step_kernel_duo(const StepArgs a) {
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
   __shared__ DuoMail mail;
@@ -1458,8 +1570,8 @@ __global__ void __launch_bounds__(128, 4) step_kernel_duo(const StepArgs a) {
    * SIMD hosts both kinds, was measured: 1.08e10 and 1.13e10 against 1.12e10 with fixed roles at
    * 125 000 points - nothing to gain.) */
   if (a.wave_start && a.wave_cnt[blockIdx.x] == 0) return; /* a spare workgroup of the wave table: both wavefronts leave */
-  if (threadIdx.x < 64) duo_surface<NL, SCORE>(mt, mail, a);
-  else duo_ground<NL, KNOTS>(mt, mail, a);
+  if (threadIdx.x < 64) duo_surface<NL, SCORE, FULL>(mt, mail, a);
+  else duo_ground<NL, KNOTS, FULL>(mt, mail, a);
 }
 
 /* FULL feature set + sky view in lock step, LDS profile (any NLayers). */
@@ -2091,7 +2203,10 @@ static int cpl_profile_mode(int NL) {
 
 hipError_t rs_launch_step_duo_knots(const rs::StepArgs &a, bool score, hipStream_t stream) {
   const dim3 gd(a.wave_start ? (unsigned)a.wave_n : (unsigned)((a.npoints + 63) / 64));
-  if (score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, true>), gd, dim3(128), 0, stream, a);
+  const bool full = (a.duo_full_ok & 1) != 0;
+  if (full && score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, true, true>), gd, dim3(128), 0, stream, a);
+  else if (full) hipLaunchKernelGGL((rs::step_kernel_duo<15, false, true, true>), gd, dim3(128), 0, stream, a);
+  else if (score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, true>), gd, dim3(128), 0, stream, a);
   else hipLaunchKernelGGL((rs::step_kernel_duo<15, false, true>), gd, dim3(128), 0, stream, a);
   return hipGetLastError();
 }
@@ -2156,13 +2271,15 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
    * (tools/r3_eval.sh): faster than one point per lane below ROADSURF_HIP_DUO_MAX points per launch */
   const char *edm = getenv("ROADSURF_HIP_DUO_MAX"); /* read per launch: the tests switch it */
   const int64_t duo_max = edm ? atoll(edm) : RS_DUO_MAX_POINTS;
-  const bool duo_ok = !full && NL == 15 && a32;
+  const bool duo_ok = (!full || a.duo_full_ok) && NL == 15 && a32;
   if (variant == RS_VARIANT_DUO && !duo_ok) { /* not this launch: as AUTO */
-    variant = (NL == 15) ? RS_VARIANT_REG : RS_VARIANT_LDS;
+    variant = (NL != 15) ? RS_VARIANT_LDS : full ? RS_VARIANT_HYBRID : RS_VARIANT_REG;
     wpe = 0;
   } else if (variant == RS_VARIANT_DUO || (auto_variant && wpe == 0 && duo_ok && a.npoints <= duo_max)) {
     const dim3 gd(a.wave_start ? (unsigned)a.wave_n : (unsigned)((a.npoints + 63) / 64));
-    if (score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true>), gd, dim3(128), 0, stream, a);
+    if (full && score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, false, true>), gd, dim3(128), 0, stream, a);
+    else if (full) hipLaunchKernelGGL((rs::step_kernel_duo<15, false, false, true>), gd, dim3(128), 0, stream, a);
+    else if (score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true>), gd, dim3(128), 0, stream, a);
     else hipLaunchKernelGGL((rs::step_kernel_duo<15, false>), gd, dim3(128), 0, stream, a);
     return hipGetLastError();
   }

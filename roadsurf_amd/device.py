@@ -371,8 +371,11 @@ def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputPara
 
     tens = {k: pad_t(forcing[k], torch.float64) for k in ("tair", "vz", "rhz", "prec", "sw", "lw")}
     tens["tsurfobs"] = pad_t(forcing["tsurfobs"], torch.float64)
-    for k in ("tdew", "depth"):
-        tens[k] = pad_t(forcing[k], torch.float64) if need_full else None
+    tens["tdew"] = pad_t(forcing["tdew"], torch.float64) if need_full else None
+    # no depth stream where no value of it can act (depth(i) >= 0 takes the surface temperature from the
+    # profile at that depth): the kernels read a missing stream as -9999.9, and the two-wavefront flavour
+    # has the FULL feature set only without one
+    tens["depth"] = pad_t(forcing["depth"], torch.float64) if need_full and bool((forcing["depth"] >= 0).any()) else None
     tens["precphase"] = pad_t(forcing["precphase"], torch.int32)
     tens["hour"] = torch.from_numpy(np.ascontiguousarray(forcing["hour"])).to(dev)
     sky = None

@@ -37,7 +37,7 @@ class SyntheticRun:
     def __init__(self, plan: device.Plan, seed: int, hours: int, chunk: int, point_offset: int = 0,
                  plan_order: bool = True, f32: bool = False, year_month_day=(2024, 1, 10),
                  forecast: bool = True, forecast_alpha: float = 0.5, forecast_mode: int = DEFAULT_FORECAST_MODE,
-                 full: bool = False, initlen: int = 720):
+                 full: bool = False, initlen: int = 720, depth_stream: bool = False):
         self.plan, self.seed, self.hours = plan, seed, hours
         self.simlen = hours * SPK + 1  # examples/example1/src/InputSettings.cpp:98
         self.chunk = min(chunk, self.simlen)
@@ -46,7 +46,7 @@ class SyntheticRun:
         # kernel's ground wave interpolates the forcing of the next index from the resident knots itself, with
         # the expansion kernel's arithmetic (rs_hip_step_knots).  The expansion is the longest link of the chain
         # between two step launches of a plan, and a small shard has nothing to hide it behind.
-        self.fused = bool(plan_order and not f32 and not full and getattr(plan, "variant", 0) == 3
+        self.fused = bool(plan_order and not f32 and not (full and depth_stream) and getattr(plan, "variant", 0) == 3
                           and plan.consts.NLayers == 15)
         # sort key of the re-sort: forecast of the next window (rs_hip_recluster_forecast) or the
         # history of the last one (rs_hip_recluster)
@@ -54,12 +54,15 @@ class SyntheticRun:
         plan.set_history_score(not (plan_order and forecast))  # nobody reads it then
         dev, npad = plan.device, plan.np_pad
         wdtype = torch.float32 if f32 else torch.float64
-        # full: the FULL feature set as an operational run has it - Tdew, TsurfObs and depth streams
-        # present, an initialization phase of `initlen` indices and (if the plan's settings say so)
-        # relaxation towards per-point targets behind it.  The per-point parameters are the same for
-        # every point here, so the plan order does not have to move them.
+        # full: the FULL feature set as an operational run has it - Tdew and TsurfObs streams present, an
+        # initialization phase of `initlen` indices and (if the plan's settings say so) relaxation
+        # towards per-point targets behind it.  No depth stream unless asked for: the reference driver
+        # never fills it (examples/example1/src/InputData.cpp:18), and rs_driver_run passes none; with
+        # depth_stream the window has one (all -9999.9: rounds 2-4a timed the leg that way), which keeps
+        # the launch away from the two-wavefront flavour.  The per-point parameters are the same for every
+        # point here, so the plan order does not have to move them.
         self.full = full
-        opt = ("tdew", "tsurfobs", "depth") if full else ()
+        opt = (("tdew", "tsurfobs", "depth") if depth_stream else ("tdew", "tsurfobs")) if full else ()
         self.win = (None if self.fused else
                     device.ForcingWindow.empty(self.chunk, npad, dev, optional=opt, dtype=wdtype))
         self.out = device.OutputWindow.empty(self.chunk, npad, dev, dtype=wdtype)

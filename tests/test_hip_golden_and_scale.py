@@ -254,37 +254,46 @@ def test_full_size_properties_1M_points_48h():
                 ("plan order vs reference, bit for bit", k, b)
 
 
+@pytest.mark.parametrize("full", [False, True], ids=["lean", "full"])
 @pytest.mark.parametrize("n,hours,chunk", [(5000, 6, 7), (5000, 6, 60), (4097, 5, 121), (64, 3, 240), (70000, 3, 90)])
-def test_knot_reading_flavour_matches_window_flavour(n, hours, chunk):
+def test_knot_reading_flavour_matches_window_flavour(n, hours, chunk, full):
     """rs_hip_step_knots (the two-wavefront flavour's ground wave interpolates the forcing from the resident
     knots) against the expansion kernel + forcing window + one point per lane, both in plan order: every
     output of every point at every index carries the same bits, whatever the launch length (windows that
-    start on, before and between knots; ragged last launch; point counts off the wavefront size)."""
+    start on, before and between knots; ragged last launch; point counts off the wavefront size).  full:
+    the FULL feature set of bench.py's extra leg - dew point and observation streams, an initialization
+    phase that ends inside the run, relaxation behind it."""
     import torch
     from roadsurf_amd import device, workload
     L = hours * SPK + 1
     s = abi.default_settings(L); p = abi.default_parameters()
+    if full:
+        s.use_relaxation = 1
     series = {}
     for variant in (1, 3):
         plan = device.Plan(n, s, p, 0)
         plan.set_variant(variant)
-        run = workload.SyntheticRun(plan, 77, hours, chunk, point_offset=12345, plan_order=True)
+        run = workload.SyntheticRun(plan, 77, hours, chunk, point_offset=12345, plan_order=True, full=full,
+                                    initlen=200)
         assert run.fused == (variant == 3)
-        full = {k: torch.full((L, n), float("nan"), dtype=torch.float64, device=plan.device) for k in device.OUT_FIELDS}
+        full_out = {k: torch.full((L, n), float("nan"), dtype=torch.float64, device=plan.device) for k in device.OUT_FIELDS}
 
         def on_launch(c, t0, ns):
             o = run.orders[c][:n].long()
             for k in device.OUT_FIELDS:
-                full[k][t0 - 1:t0 - 1 + ns, o] = run.out.tensors[k][:ns, :n]
+                full_out[k][t0 - 1:t0 - 1 + ns, o] = run.out.tensors[k][:ns, :n]
 
         run.run_pass(on_launch)
         plan.sync()
         assert plan.failed_count() == 0
-        series[variant] = {k: v.cpu().numpy() for k, v in full.items()}
+        series[variant] = {k: v.cpu().numpy() for k, v in full_out.items()}
+        if full:  # the relaxation anchors went to the state block (in plan order: compare as multisets)
+            st = plan.state().numpy()
+            series[variant]["anchors"] = np.sort(st[abi.RS_MAX_LAYERS + 13:abi.RS_MAX_LAYERS + 16, :n], axis=1)
         moved = int((run.orders[-1][:n].long() != torch.arange(n, device=plan.device)).sum())
         assert n < 1000 or moved > 0
         del run
         plan.close()
-    for k in device.OUT_FIELDS:
+    for k in series[1]:
         assert not np.isnan(series[3][k]).any()
         assert np.array_equal(series[1][k], series[3][k]), k

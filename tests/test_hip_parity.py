@@ -96,9 +96,10 @@ def test_failed_points_in_every_flavour(variant):
         assert (ora["tsurf"][pt, idx + 1:] == -9999.0).all() and ora["tsurf"][pt, idx] != -9999.0
 
 
-@pytest.mark.parametrize("variant", [1, 2], ids=["reg", "lds"])
+@pytest.mark.parametrize("variant", [1, 2, 3], ids=["reg", "lds", "duo"])
 def test_full_variant_features(variant):
-    """Init-phase observation forcing, relaxation, output depth, failures."""
+    """Init-phase observation forcing, relaxation, output depth, failures.  (The two-wavefront flavour has
+    the FULL feature set without an output depth: those two cases fall back to one point per lane.)"""
     from roadsurf_amd import device
     n, L = 200, 5761
     f = oh.synth_forcing(n, L, seed=7)
