@@ -5,6 +5,7 @@ set -e
 python tools/make_traffic_json.py gpurun_out/prof_r04 profiles/r04_traffic.json
 TRAFFIC_POINTS=1250000 TRAFFIC_SIMLEN=20161 TRAFFIC_BYTES_PER_UNIT=52 python tools/make_traffic_json.py gpurun_out/prof_r04_f32 profiles/r04_f32_traffic.json "step_kernel_f32_lds" 120 4
 G=gpurun_out
+cp $G/prof_r04/bench.json profiles/r04_bench.json
 cp $G/prof_r04/bench_under_rocprof.json profiles/r04_bench_under_rocprof.json
 cp $G/prof_r04/kernel_stats.csv profiles/r04_kernel_stats.csv
 cp $G/prof_r04/pmc_summary.txt profiles/r04_pmc_summary.txt
