@@ -39,6 +39,10 @@ struct RsConstantsDev : RsConstants {
    * polynomials and a division (layer_step, rs_physics_body.inc). */
   double capDZF[RS_MAX_LAYERS + 2];
   double hs1F;
+  /* the REAL(4) coefficients of the density and heat capacity of water (src/BalanceModel.f90:222-229) as
+   * doubles, in the order layer_vsh uses them: as literals they cost the kernels two scalar moves each,
+   * per thawed layer and step */
+  double hcw[8];
 };
 
 static inline void rs_consts_dev_fill(const RsConstants &c, RsConstantsDev &d) {
@@ -57,6 +61,10 @@ static inline void rs_consts_dev_fill(const RsConstants &c, RsConstantsDev &d) {
   for (int i = 0; i < 8; ++i) d.chk[i] = (double)chk[i];
   d.relax_tab = nullptr;
   d.cpl_tab = nullptr;
+  {
+    const float h[8] = {-0.0050f, 0.0079f, 1000.0028f, 0.0000102f, 0.0017169f, 0.11516f, 3.4739f, 4217.2f};
+    for (int i = 0; i < 8; ++i) d.hcw[i] = (double)h[i];
+  }
   for (int j = 0; j < RS_MAX_LAYERS + 2; ++j) d.capDZF[j] = 0.0;
   d.hs1F = 0.0;
   for (int j = 1; j <= c.NLayers && j <= RS_MAX_LAYERS; ++j) {

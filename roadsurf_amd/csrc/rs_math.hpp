@@ -56,10 +56,24 @@ static __constant__ uint64_t c_gl_coef[RS_K_COUNT] = {
     RS_GL_LOG_A3,    RS_GL_LOG_B1, RS_GL_LOG_B4, RS_GL_LOG_B7};
 
 /* LDS copies of the tables; filled by fill_math_tables() at kernel start. */
+/* The coefficients that enter as MULTIPLIERS (a scalar operand of the fma): as literals they cost two
+ * scalar moves each at every use - 10 per exp, 10 / 22 per log -, from this table in constant memory
+ * the compiler fetches a group with one wide scalar load (-DRS_NO_SMEM_COEF: literals, round 1-3). */
+enum { RS_S_EXP_INVLN2N, RS_S_EXP_NEGLN2HIN, RS_S_EXP_NEGLN2LON, RS_S_EXP_C3, RS_S_EXP_C5, RS_S_PAD0, RS_S_PAD1, RS_S_PAD2,
+       RS_S_LOG_LN2HI, RS_S_LOG_A2, RS_S_LOG_LN2LO, RS_S_LOG_A4, RS_S_LOG_A0, RS_S_PAD3, RS_S_PAD4, RS_S_PAD5,
+       RS_S_LOG_B2, RS_S_LOG_B5, RS_S_LOG_B8, RS_S_LOG_B3, RS_S_LOG_B6, RS_S_LOG_B9, RS_S_LOG_B10, RS_S_LOG_B0,
+       RS_S_COUNT };
+static __constant__ uint64_t c_gl_scoef[RS_S_COUNT] = {
+    RS_GL_EXP_INVLN2N, RS_GL_EXP_NEGLN2HIN, RS_GL_EXP_NEGLN2LON, RS_GL_EXP_C3, RS_GL_EXP_C5, 0, 0, 0,
+    RS_GL_LOG_LN2HI, RS_GL_LOG_A2, RS_GL_LOG_LN2LO, RS_GL_LOG_A4, RS_GL_LOG_A0, 0, 0, 0,
+    RS_GL_LOG_B2, RS_GL_LOG_B5, RS_GL_LOG_B8, RS_GL_LOG_B3, RS_GL_LOG_B6, RS_GL_LOG_B9, RS_GL_LOG_B10, RS_GL_LOG_B0};
+typedef const double __attribute__((address_space(4))) *MathCoef;
+
 struct MathTab {
   const uint64_t *expT; /* [128][2]  {tail, sbits}  */
   const double *logT;   /* [128][2]  {invc, logc}   */
   const double *K;      /* [RS_K_COUNT] */
+  MathCoef S;           /* [RS_S_COUNT], constant memory */
 };
 
 #define RS_MATH_LDS_DOUBLES (512 + RS_K_COUNT)
@@ -74,6 +88,8 @@ __device__ __forceinline__ MathTab fill_math_tables(double *lds) {
   t.expT = w;
   t.logT = lds + 256;
   t.K = lds + 512;
+  t.S = (MathCoef)c_gl_scoef;
+  asm volatile("" : "+s"(t.S)); /* opaque: a load from a table whose initialiser the compiler sees is folded back into literals */
   return t;
 }
 
@@ -269,6 +285,11 @@ __device__ __forceinline__ float rs_exp(const MathTab &, float x) { return __exp
 __device__ __forceinline__ float rs_log(const MathTab &, float x) { return __logf(x); }
 
 __device__ __forceinline__ double gl_d(uint64_t bits) { return __longlong_as_double((long long)bits); }
+#ifdef RS_NO_SMEM_COEF
+#define RS_GLS(mt, NAME) gl_d(RS_GL_##NAME)
+#else
+#define RS_GLS(mt, NAME) ((mt).S[RS_S_##NAME])
+#endif
 
 /* glibc 2.35 sysdeps/ieee754/dbl-64/e_exp.c as built for x86-64 + FMA. */
 __device__ __forceinline__ double rs_exp(const MathTab &mt, double x) {
@@ -286,18 +307,18 @@ __device__ __forceinline__ double rs_exp(const MathTab &mt, double x) {
   }
   /* x = ln2/N*k + r, k integer, |r| <= ln2/2N */
   const double shift = mt.K[RS_K_EXP_SHIFT];
-  double kd = __builtin_fma(x, gl_d(RS_GL_EXP_INVLN2N), shift);
+  double kd = __builtin_fma(x, RS_GLS(mt, EXP_INVLN2N), shift);
   const uint64_t ki = (uint64_t)__double_as_longlong(kd);
   kd = kd - shift;
-  double r = __builtin_fma(kd, gl_d(RS_GL_EXP_NEGLN2HIN), x);
-  r = __builtin_fma(kd, gl_d(RS_GL_EXP_NEGLN2LON), r);
+  double r = __builtin_fma(kd, RS_GLS(mt, EXP_NEGLN2HIN), x);
+  r = __builtin_fma(kd, RS_GLS(mt, EXP_NEGLN2LON), r);
   const uint32_t idx = 2u * ((uint32_t)ki & 127u);
   const double tail = gl_d(mt.expT[idx]);
   const uint64_t sbits = mt.expT[idx + 1] + (ki << 45);
   const double r2 = r * r;
-  const double p23 = __builtin_fma(r, gl_d(RS_GL_EXP_C3), mt.K[RS_K_EXP_C2]);
+  const double p23 = __builtin_fma(r, RS_GLS(mt, EXP_C3), mt.K[RS_K_EXP_C2]);
   const double t0 = r + tail;
-  const double p45 = __builtin_fma(r, gl_d(RS_GL_EXP_C5), mt.K[RS_K_EXP_C4]);
+  const double p45 = __builtin_fma(r, RS_GLS(mt, EXP_C5), mt.K[RS_K_EXP_C4]);
   const double a = __builtin_fma(p23, r2, t0);
   const double r4 = r2 * r2;
   const double tmp = __builtin_fma(r4, p45, a);
@@ -318,26 +339,26 @@ __device__ __forceinline__ double rs_log(const MathTab &mt, double x) {
      * round-to-nearest the path below gives the same +0.0 - r, hi, lo and y are all +0 - so the
      * test is not spent here; tests/test_hip_math.py has log(1.0) among its arguments.) */
     const double r = x - 1.0;
-    const double p12 = __builtin_fma(r, gl_d(RS_GL_LOG_B2), mt.K[RS_K_LOG_B1]);
-    const double p45 = __builtin_fma(r, gl_d(RS_GL_LOG_B5), mt.K[RS_K_LOG_B4]);
+    const double p12 = __builtin_fma(r, RS_GLS(mt, LOG_B2), mt.K[RS_K_LOG_B1]);
+    const double p45 = __builtin_fma(r, RS_GLS(mt, LOG_B5), mt.K[RS_K_LOG_B4]);
     const double r2 = r * r;
-    const double p78 = __builtin_fma(r, gl_d(RS_GL_LOG_B8), mt.K[RS_K_LOG_B7]);
-    const double p123 = __builtin_fma(r2, gl_d(RS_GL_LOG_B3), p12);
-    const double p456 = __builtin_fma(r2, gl_d(RS_GL_LOG_B6), p45);
+    const double p78 = __builtin_fma(r, RS_GLS(mt, LOG_B8), mt.K[RS_K_LOG_B7]);
+    const double p123 = __builtin_fma(r2, RS_GLS(mt, LOG_B3), p12);
+    const double p456 = __builtin_fma(r2, RS_GLS(mt, LOG_B6), p45);
     const double r3 = r * r2;
-    double p = __builtin_fma(r2, gl_d(RS_GL_LOG_B9), p78);
-    p = __builtin_fma(r3, gl_d(RS_GL_LOG_B10), p);
+    double p = __builtin_fma(r2, RS_GLS(mt, LOG_B9), p78);
+    p = __builtin_fma(r3, RS_GLS(mt, LOG_B10), p);
     p = __builtin_fma(p, r3, p456);
     p = __builtin_fma(p, r3, p123);
     const double t = __builtin_fma(r, 0x1p27, r);
     const double rhi = __builtin_fma(-0x1p27, r, t);
     const double rhi2 = rhi * rhi;
     const double rlo = r - rhi;
-    const double hi = __builtin_fma(rhi2, gl_d(RS_GL_LOG_B0), r);
+    const double hi = __builtin_fma(rhi2, RS_GLS(mt, LOG_B0), r);
     const double d = r - hi;
     const double s = r + rhi;
-    double lo = __builtin_fma(rhi2, gl_d(RS_GL_LOG_B0), d);
-    const double m = gl_d(RS_GL_LOG_B0) * rlo;
+    double lo = __builtin_fma(rhi2, RS_GLS(mt, LOG_B0), d);
+    const double m = RS_GLS(mt, LOG_B0) * rlo;
     lo = __builtin_fma(m, s, lo);
     const double y = __builtin_fma(p, r3, lo);
     return hi + y;
@@ -359,15 +380,15 @@ __device__ __forceinline__ double rs_log(const MathTab &mt, double x) {
   const double z = gl_d(iz);
   const double r = __builtin_fma(z, invc, -1.0);
   const double kd = (double)k;
-  const double w = __builtin_fma(kd, gl_d(RS_GL_LOG_LN2HI), logc);
-  const double p12 = __builtin_fma(r, gl_d(RS_GL_LOG_A2), mt.K[RS_K_LOG_A1]);
+  const double w = __builtin_fma(kd, RS_GLS(mt, LOG_LN2HI), logc);
+  const double p12 = __builtin_fma(r, RS_GLS(mt, LOG_A2), mt.K[RS_K_LOG_A1]);
   const double hi = r + w;
   const double r2 = r * r;
   double lo = (w - hi) + r;
-  lo = __builtin_fma(kd, gl_d(RS_GL_LOG_LN2LO), lo);
+  lo = __builtin_fma(kd, RS_GLS(mt, LOG_LN2LO), lo);
   const double r3 = r * r2;
-  const double p34 = __builtin_fma(r, gl_d(RS_GL_LOG_A4), mt.K[RS_K_LOG_A3]);
-  const double q = __builtin_fma(r2, gl_d(RS_GL_LOG_A0), lo);
+  const double p34 = __builtin_fma(r, RS_GLS(mt, LOG_A4), mt.K[RS_K_LOG_A3]);
+  const double q = __builtin_fma(r2, RS_GLS(mt, LOG_A0), lo);
   const double p = __builtin_fma(p34, r2, p12);
   const double y = __builtin_fma(r3, p, q);
   return y + hi;

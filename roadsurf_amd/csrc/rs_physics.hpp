@@ -46,8 +46,12 @@
 #ifndef RS_NO_FROZEN_TABLE
 #define RS_FROZEN_TABLE 1 /* layer_step: capDZ of a layer that is frozen in all 64 points from RsConstantsDev::capDZF */
 #endif
+#ifndef RS_NO_HCW_TABLE
+#define RS_HCW_TABLE 1 /* layer_vsh: the water polynomials' coefficients from RsConstantsDev::hcw */
+#endif
 #include "rs_physics_body.inc"
 #undef RS_FROZEN_TABLE
+#undef RS_HCW_TABLE
 #undef RS_REAL
 #undef RS_NS
 #undef RS_CONSTS
