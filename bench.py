@@ -260,8 +260,10 @@ def main() -> None:
         # measured (round 4, tools/experiments/r4_fused_{big,small}_sweep.sh): with the expansion gone a launch
         # cycle is short, so fewer plans hide it and shorter launches (a fresher sort key) pay: 3 x 90 from
         # 400 000 points on the GPU (1 M, r4_ground_sweep.sh: 2.29e10 for 3 x 90, 3 x 120 and 2 x 120 alike; 2.27e10
-        # for 4 x 90 / 4 x 120), 4 x 240 from 200 000, 2 x 240 below
-        K, ch = (3, 90) if n >= 400_000 else (4, 240) if n >= 200_000 else (2, 240) if n >= 100_000 else (1, 240)
+        # for 4 x 90 / 4 x 120), 4 x 120 from 200 000, 2 x 240 below (last pass with the chain kernels at raised
+        # priority, tools/experiments/r4_prio_chain_sweep.sh: 2.35e10 / 2.33e10 / 2.11e10 / 1.37e10 at 1 M / 500 000 /
+        # 250 000 / 125 000 points)
+        K, ch = (3, 90) if n >= 400_000 else (4, 120) if n >= 200_000 else (2, 240) if n >= 100_000 else (1, 240)
     else:
         # measured on MI355X (tools/experiments/exp_plans.sh, r3_small2.sh; DESIGN_HISTORY.md 6)
         K, ch = (4 if n >= 200_000 else 2 if n >= 100_000 else 1), (120 if n >= 400_000 else 240)

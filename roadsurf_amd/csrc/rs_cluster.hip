@@ -61,6 +61,7 @@ __global__ void __launch_bounds__(RS_BLOCK) apply_kernel(const T *__restrict__ s
                                                          const uint32_t *__restrict__ perm,
                                                          int64_t np_pad, int64_t npoints,
                                                          const RowMap rows) {
+  __builtin_amdgcn_s_setprio(3); /* a link of the chain between two step launches of a plan: little work, all of it waited for */
   const int64_t s = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
   if (s >= np_pad) return;
   const int64_t from = (s < npoints) ? (int64_t)perm[s] : s;
@@ -140,6 +141,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
 __global__ void __launch_bounds__(256) cs_hist_kernel(const uint32_t *__restrict__ keys,
                                                       const uint32_t *__restrict__ via, int64_t n, int shift,
                                                       int nbins, int ntiles, uint32_t *__restrict__ H) {
+  __builtin_amdgcn_s_setprio(3); /* a link of the chain between two step launches of a plan: little work, all of it waited for */
   extern __shared__ uint32_t cs_h[];
   for (int b = threadIdx.x; b < nbins; b += 256) cs_h[b] = 0u;
   __syncthreads();
@@ -156,6 +158,7 @@ __global__ void __launch_bounds__(256) cs_hist_kernel(const uint32_t *__restrict
  * exclusive prefix over the tiles in place and its total in T[bin] */
 __global__ void __launch_bounds__(64) cs_binscan_kernel(uint32_t *H, uint32_t *T, int nbins, int ntiles,
                                                         uint32_t *class_total, int class_shift) {
+  __builtin_amdgcn_s_setprio(3); /* a link of the chain between two step launches of a plan: little work, all of it waited for */
   const int bin = (int)blockIdx.x * 64 + (int)threadIdx.x;
   uint32_t run = 0u;
   if (bin < nbins) {
@@ -183,6 +186,7 @@ __global__ void __launch_bounds__(64) cs_scatter_kernel(const uint32_t *__restri
                                                         const uint32_t *__restrict__ H,
                                                         const uint32_t *__restrict__ T,
                                                         uint32_t *__restrict__ perm_out) {
+  __builtin_amdgcn_s_setprio(3); /* a link of the chain between two step launches of a plan: little work, all of it waited for */
   extern __shared__ uint32_t cs_cur[];
   const int nbins = 1 << nbits;
   const uint32_t lane = threadIdx.x;
@@ -273,6 +277,7 @@ __global__ void __launch_bounds__(64) cs_scatter_kernel(const uint32_t *__restri
 __global__ void __launch_bounds__(64) cs_wave_table_kernel(uint32_t *__restrict__ class_total,
                                                            int class_bits, int32_t *__restrict__ wstart,
                                                            int32_t *__restrict__ wcnt, int32_t maxw) {
+  __builtin_amdgcn_s_setprio(3); /* a link of the chain between two step launches of a plan: little work, all of it waited for */
   const uint32_t lane = threadIdx.x;
   const int nclasses = 1 << class_bits;
   uint32_t n = 0u;

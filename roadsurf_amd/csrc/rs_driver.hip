@@ -530,6 +530,7 @@ struct ExpandRawArgs {
 
 template <bool PP>
 __global__ void __launch_bounds__(RS_BLOCK) expand_raw_kernel(const ExpandRawArgs A) {
+  __builtin_amdgcn_s_setprio(3); /* a link of the chain between two step launches of a block: all of it is waited for */
   const int64_t slot = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
   const int fld = blockIdx.y;
   double *out = A.out[fld];
@@ -604,6 +605,7 @@ __global__ void __launch_bounds__(RS_BLOCK) gather_params_kernel(
     double *rh_s, const int32_t *cidx_p = nullptr, int32_t *cidx_s = nullptr,
     const double *ctsurf_p = nullptr, double *ctsurf_s = nullptr,
     const double *geo_p = nullptr, double *geo_s = nullptr, int64_t geo_stride = 0) {
+  __builtin_amdgcn_s_setprio(3); /* a link of the chain between two step launches of a block: all of it is waited for */
   const int64_t s = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
   if (s >= npoints) return;
   const int64_t p = order[s];
@@ -625,6 +627,7 @@ __global__ void __launch_bounds__(RS_BLOCK) unpermute_rows_kernel(
     const int32_t *__restrict__ order, int64_t npoints, const double *__restrict__ chunk_out,
     int64_t chunk_rows, double *final_out, int64_t final_rows, int64_t row0, int32_t nrows,
     int64_t stride) {
+  __builtin_amdgcn_s_setprio(3); /* a link of the chain between two step launches of a block: all of it is waited for */
   const int64_t s = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
   if (s >= npoints) return;
   const int64_t p = order[s];

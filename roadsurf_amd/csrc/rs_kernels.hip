@@ -1836,6 +1836,7 @@ __global__ void __launch_bounds__(kBlock) synth_knots_kernel(const KnotArgs a) {
  * unchanged (no knot value is -0.0: rs_synth.h), so the first index needs no case of its own. */
 template <bool TDEW, bool OBS, bool DEPTH>
 __global__ void __launch_bounds__(kBlock) expand_kernel(const ExpandArgs a) {
+  __builtin_amdgcn_s_setprio(3); /* a link of the chain between two step launches of a block: all of it is waited for */
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= a.npoints) return;
   const int32_t k = a.kfirst + (int32_t)blockIdx.y;        /* knot interval [k, k+1) */
@@ -1994,6 +1995,7 @@ __global__ void __launch_bounds__(kBlock) cpl_window_bounds_kernel(const StepArg
  * surface temperature moved along with the air temperature.  A predictor: single precision,
  * hardware reciprocal/sqrt/log - it only orders the slots, no model value depends on it. */
 __global__ void __launch_bounds__(kBlock) forecast_key_kernel(const ForecastArgs a) {
+  __builtin_amdgcn_s_setprio(3); /* a link of the chain between two step launches of a plan: little work, all of it waited for */
   const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (s >= a.npoints) return;
   const ConstsAS &c = consts_of(&a);
