@@ -459,8 +459,7 @@ def main() -> None:
                                        + (", coupling" if mode == "coupling" else "")
                                        + (", per-point sky view and local horizons" if mode == "skyview" else ""),
                            "pcie_inclusive": True, "raw_input_bytes": dw.raw_bytes(mode),
-                           "blocks_per_device": int(os.environ.get("ROADSURF_HIP_PLANS_PER_DEVICE",
-                                                                  "6" if mode == "skyview" else "4"))},
+                           "blocks_per_device": int(os.environ.get("ROADSURF_HIP_PLANS_PER_DEVICE", "4"))},
             }
             del r
         del dw

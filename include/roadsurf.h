@@ -323,6 +323,11 @@ typedef struct RsPointParams {
    * order, the table stays where it is and the kernels read it through this row (the plan's own
    * order row, rs_hip_plan_order, is exactly that). */
   const int32_t *horizon_index;
+  /* Layout of `horizons` (ABI 5).  0: [360][npoints_padded], the degree of azimuth is the slow axis (above).
+   * 1: [npoints][360], the caller's own layout (LocalParameters' c_local_horizons rows, RsDriverInput::
+   * horizons) - element horizons[horizon_index[s] * 360 + deg]: no transpose on the way in, and a point's
+   * consecutive degrees share cache lines (the azimuth of the sun moves a degree in four minutes). */
+  int32_t horizons_by_point;
 } RsPointParams;
 
 const char *rs_last_error(void);
@@ -710,7 +715,7 @@ int rs_driver_expand(const RsDriverInput *in, const InputSettings *settings,
                      LocalParameters *local, double *merged, int32_t *status,
                      int32_t *missing_index, int32_t device);
 
-#define RS_ABI_VERSION 5 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles; 4: RsPointParams::horizon_index, rs_hip_step_knots */
+#define RS_ABI_VERSION 5 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles; 4: RsPointParams::horizon_index, rs_hip_step_knots; 5: RS_SUN_COLS 6, RsPointParams::horizons_by_point */
 int rs_abi_version(void);
 /* sizeof of the boundary structs as the C side / the Fortran side see them
  * (0 InputPointers, 1 OutputPointers, 2 InputSettings, 3 InputParameters,

@@ -1296,12 +1296,11 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputP
     rsu::g_last_fanout = 1;
     return driver_run_range(in, st, params, local, out, device, 0, in->n_points);
   }
-  /* blocks per device: four; six where every point brings 2.9 KB of local horizons (the uploads take
-   * turns on the link: smaller blocks start stepping sooner - measured at 1 M points, tools/experiments/
-   * r4_blocks.sh: sky view 1.025e10 / 1.069e10 / 1.048e10 for 4 / 6 / 8 blocks, relaxation alone the same
-   * for all three, coupling 9.2e9 / 8.6e9 / 8.3e9) */
-  const int per = (in->horizons && !(st && st->use_coupling)) ? 6 : 4;
-  const std::vector<rsu::Shard> shards = rsu::make_shards(in->n_points, rsu::device_list(per));
+  /* four blocks per device.  (Six for batches with local horizons were 4 % faster while the horizon table
+   * was transposed on the device, tools/experiments/r4_blocks.sh; with the table left in the caller's layout
+   * - RsPointParams::horizons_by_point - four and six are level: 1.047e10 / 1.046e10 over three alternating
+   * runs each.) */
+  const std::vector<rsu::Shard> shards = rsu::make_shards(in->n_points, rsu::device_list());
   return rsu::fan_out(shards, [&](const rsu::Shard &sh, int) {
     return driver_run_range(in, st, params, local, out, sh.device, sh.off, sh.off + sh.cnt);
   });
@@ -1473,7 +1472,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     pt.lap(2);
 
     /* per-point parameters */
-    Dev d_tb, d_geo, d_hz, d_hzpt;
+    Dev d_tb, d_geo, d_hzpt;
     HOK(d_tb.alloc(mp * sizeof(double)));
     hipLaunchKernelGGL(fill_f64_kernel, grid1(mp), dim3(RS_BLOCK), 0, stream, d_tb.as<double>(), mp,
                        tbottom);
@@ -1507,16 +1506,17 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
       pp.cos_lat = d_geo.as<double>() + 2 * mp;
       pp.lon_rad = d_geo.as<double>() + 3 * mp;
       pp.albedo_surroundings = params->Albedo_surroundings;
-      HOK(d_hz.alloc((size_t)360 * mp * sizeof(double)));
+      /* the horizon table as the caller holds it, [point][360] (RsPointParams::horizons_by_point): no
+       * transpose, half the device memory, and a point's neighbouring degrees in one cache line; no table
+       * at all where the caller has none (the kernels read a missing table as 0) */
+      pp.horizons = nullptr;
+      pp.horizons_by_point = 1;
       if (in->horizons) {
         HOK(d_hzpt.alloc((size_t)m * 360 * sizeof(double)));
         HOK(hipMemcpyAsync(d_hzpt.p, in->horizons + (size_t)p0 * 360, (size_t)m * 360 * sizeof(double),
                            hipMemcpyHostToDevice, stream));
-        HOK(transpose(d_hzpt.as<double>(), d_hz.as<double>(), m, 360, 360, mp, stream));
-      } else {
-        HOK(hipMemsetAsync(d_hz.p, 0, (size_t)360 * mp * sizeof(double), stream));
+        pp.horizons = d_hzpt.as<double>();
       }
-      pp.horizons = d_hz.as<double>();
     }
 
     /* chunked coupling: where the tile's coupling windows lie (the decisions are back in `local`) */

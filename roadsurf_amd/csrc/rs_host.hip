@@ -201,7 +201,7 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
   }
   double *hwb_b[2] = {(double *)h_wb.p, (double *)h_wb2.p};
   std::vector<int32_t> ff_tile((size_t)P);
-  Dev d_sun, d_hz_pt, d_hz;
+  Dev d_sun, d_hz_pt;
   Pinned h_hz;
   if (skyview) {
     HOK(d_sun.alloc((size_t)L * RS_SUN_COLS * sizeof(double)));
@@ -209,7 +209,6 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
                        stream));
     HOK(h_hz.alloc((size_t)P * 360 * sizeof(double)));
     HOK(d_hz_pt.alloc((size_t)P * 360 * sizeof(double)));
-    HOK(d_hz.alloc((size_t)Ppad * 360 * sizeof(double)));
   }
 
   /* ---- work items: (tile of points) x (chunk of time), processed as a two-stage pipeline.
@@ -351,6 +350,7 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
       pp.coupling_tsurf = coupled ? (double *)d_pp64.p + 4 * (size_t)Ppad : nullptr;
       pp.coupling_index = coupled ? (int32_t *)d_pp32.p + Ppad : nullptr;
       pp.sky_view = pp.sin_lat = pp.cos_lat = pp.lon_rad = pp.horizons = nullptr;
+      pp.horizons_by_point = 0;
       pp.albedo_surroundings = 0.0;
       if (skyview) {
         pp.sky_view = (double *)d_pp64.p + 5 * (size_t)Ppad;
@@ -358,11 +358,11 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
         pp.cos_lat = (double *)d_pp64.p + 7 * (size_t)Ppad;
         pp.lon_rad = (double *)d_pp64.p + 8 * (size_t)Ppad;
         pp.albedo_surroundings = extras->albedo_surroundings;
-        /* horizon table [point][360] -> [360][point] */
+        /* horizon table [point][360], as the rows come (RsPointParams::horizons_by_point) */
         HOK(hipMemcpyAsync(d_hz_pt.p, h_hz.p, (size_t)m * 360 * sizeof(double), hipMemcpyHostToDevice,
                            stream));
-        HOK(transpose((const double *)d_hz_pt.p, (double *)d_hz.p, m, 360, 360, mp, stream));
-        pp.horizons = (double *)d_hz.p;
+        pp.horizons = (double *)d_hz_pt.p;
+        pp.horizons_by_point = 1;
         /* h_hz is reused by the next tile: its copy must have left the host first */
         HOK(hipStreamSynchronize(stream));
       }

@@ -797,7 +797,8 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
        * (Simulation.f90:151-162); the two do not share data, so the order is free */
       if (!sky_view_radiation(ka->f.sun + (int64_t)k * RS_SUN_COLS, sinlat, coslat, lonrad, coslon, sinlon, skyv,
                               ka->pp.albedo_surroundings,
-                              ka->pp.horizons ? ka->pp.horizons + hcol : nullptr, ka->np_pad,
+                              ka->pp.horizons ? ka->pp.horizons + (ka->pp.horizons_by_point ? (int64_t)hcol * 360 : (int64_t)hcol) : nullptr,
+                              ka->pp.horizons_by_point ? (int64_t)1 : ka->np_pad,
                               sw_in, sw_dir, lw_in, lw_net))
         fail_at(i); /* the reference would `stop` the process here */
     }
@@ -1070,9 +1071,10 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Sc
       if (!sky_view_radiation(ka->f.sun + (int64_t)(i - t0) * RS_SUN_COLS, sinlat, coslat, lonrad, coslon, sinlon, skyv,
                               ka->pp.albedo_surroundings,
                               ka->pp.horizons
-                                  ? ka->pp.horizons + (ka->pp.horizon_index ? (int64_t)ka->pp.horizon_index[p] : p)
+                                  ? ka->pp.horizons + (ka->pp.horizon_index ? (int64_t)ka->pp.horizon_index[p] : p) *
+                                                          (ka->pp.horizons_by_point ? 360 : 1)
                                   : nullptr,
-                              np, sw_in, sw_dir, lw_in, lw_net))
+                              ka->pp.horizons_by_point ? (int64_t)1 : np, sw_in, sw_dir, lw_in, lw_net))
         fail_at(i); /* the reference would `stop` the process here */
     }
     if (ka->wb.sw_dir) { /* in-place input edits of the reference; a replay overwrites them */

@@ -66,7 +66,7 @@ class RsPointParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("tbottom", "initlen", "tair_relax", "vz_relax", "rh_relax",
                                           "coupling_index", "coupling_tsurf", "sky_view",
                                           "sin_lat", "cos_lat", "lon_rad", "horizons")] + \
-               [("albedo_surroundings", C.c_double), ("horizon_index", C.c_void_p)]
+               [("albedo_surroundings", C.c_double), ("horizon_index", C.c_void_p), ("horizons_by_point", C.c_int32)]
 
 
 class RsHostExtras(C.Structure):

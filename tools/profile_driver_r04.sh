@@ -28,7 +28,7 @@ start=gaps[-1] if gaps else 0
 rows=rows[start:]
 t0=rows[0][1]; t1=max(r[2] for r in rows)
 import os
-blocks = os.environ.get("ROADSURF_HIP_PLANS_PER_DEVICE", "6" if mode == "skyview" else "4")
+blocks = os.environ.get("ROADSURF_HIP_PLANS_PER_DEVICE", "4")
 print(f"# rs_driver_run, mode {mode}, {n} points x 48 h, default fan-out ({blocks} blocks on one GPU, 4 hardware queues); kernel sources {sha}")
 print(f"last call: {len(rows)} dispatches over {(t1-t0)/1e6:.1f} ms of kernel span")
 fam=collections.defaultdict(list)
