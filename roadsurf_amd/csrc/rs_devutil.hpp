@@ -15,6 +15,7 @@ template <typename T>
 __global__ void __launch_bounds__(TS * 8) transpose_kernel(const T *__restrict__ src,
                                                            T *__restrict__ dst, int rows, int cols,
                                                            int64_t ld_src, int64_t ld_dst) {
+  __builtin_amdgcn_s_setprio(3); /* on the way in or out of a block: waited for, beside other blocks' step kernels */
   __shared__ T tile[TS][TS + 1];
   const int c0 = blockIdx.x * TS, r0 = blockIdx.y * TS;
   for (int j = threadIdx.y; j < TS; j += 8) {

@@ -310,6 +310,7 @@ struct ScanArgs {
 
 template <bool PP>
 __global__ void __launch_bounds__(RS_BLOCK) scan_raw_kernel(const ScanArgs A) {
+  __builtin_amdgcn_s_setprio(3); /* before a block's first time step: all of it is waited for */
   const int64_t p = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
   if (p >= A.S.npoints) return;
   const int y = blockIdx.y;
@@ -383,6 +384,7 @@ __device__ __forceinline__ double merged_one(const SrcSet &S, int fld, int64_t p
 }
 
 __global__ void __launch_bounds__(RS_BLOCK) scan_seg_kernel(const ScanArgs A, const ScanSeg *segs, int32_t nseg) {
+  __builtin_amdgcn_s_setprio(3); /* before a block's first time step: all of it is waited for */
   const int64_t p = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
   if (p >= A.S.npoints) return;
   const int y = blockIdx.y;
@@ -465,6 +467,7 @@ struct FinalArgs {
 
 /* read_input after GetWeather, roadrunner.cpp:186-275 */
 __global__ void __launch_bounds__(RS_BLOCK) finalize_kernel(const FinalArgs A) {
+  __builtin_amdgcn_s_setprio(3); /* before a block's first time step: all of it is waited for */
   const int64_t p = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
   if (p >= A.S.np_pad) return;
   const int L = A.S.simlen;
