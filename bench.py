@@ -180,7 +180,7 @@ def main() -> None:
                     help="plan order: sort by a forecast of the next window's boundary-layer regime and "
                          "passes (rs_hip_recluster_forecast) or by the passes of the last launch")
     ap.add_argument("--forecast-alpha", type=float, default=0.5)
-    ap.add_argument("--forecast-mode", type=int, default=378659,
+    ap.add_argument("--forecast-mode", type=int, default=378059,
                     help="fields of the forecast key, most significant first (roadsurf_amd/workload.py)")
     ap.add_argument("--plans-per-gpu", type=int, default=0,
                     help="cut this GPU's points into K plans on K streams whose launches interleave: "

@@ -560,10 +560,11 @@ typedef struct RsPreview {
   int32_t mode;                          /* key fields in priority order as decimal digits: 1 unstable
                                             previews, 2 table-path previews, 3 cover, 4 predicted extra
                                             passes (e.g. 1234); 0..3 = 14, 124, 134, 1234; 5 storage
-                                            class, 6/7/8 = 4/1/2 in fewer bits; 9 (anywhere in the list)
+                                            class, 6/7/8 = 4/1/2 in fewer bits, 0 (inside a list) = 4 in
+                                            three bits; 9 (anywhere in the list)
                                             = the ground digit, which layers are frozen, always the LEAST
                                             significant field, honoured for keys of at most 12 bits without
-                                            it (the plan's counting sort; 378659 is what bench.py and
+                                            it (the plan's counting sort; 378059 is what bench.py and
                                             rs_driver_run use) */
   const int32_t *index;                  /* NULL: the preview rows are in SLOT order; else row element
                                             index[slot] belongs to that slot (rows kept in point order,

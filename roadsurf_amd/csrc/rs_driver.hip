@@ -1743,7 +1743,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
       }
       pv.tair_now = pv.tair[0];
       pv.alpha = 0.5;
-      pv.mode = 378659; /* 12 bits + the ground digit: the plan's own counting sort (rs_cluster.hip) */
+      pv.mode = 378059; /* 10 bits + the ground digit: the plan's own counting sort (rs_cluster.hip) */
       if (rs_hip_recluster_forecast(pg.p, &pv) != 0) return -14;
       return gather_params();
     };

@@ -2104,6 +2104,7 @@ __global__ void __launch_bounds__(kBlock) forecast_key_kernel(const ForecastArgs
     else if (d == 5) { key = (key << 2) | (uint32_t)sclass; bits += 2; }
     /* compact forms: extra passes saturating at 31 (5 bits), the two preview counts at 3 (2 bits) */
     else if (d == 6) { key = (key << 5) | (uint32_t)(extra > 31 ? 31 : extra); bits += 5; }
+    else if (d == 0) { key = (key << 3) | (uint32_t)(extra > 7 ? 7 : extra); bits += 3; } /* (inside a list) extra passes saturating at 7 */
     else if (d == 7) { key = (key << 2) | (uint32_t)(unst > 3 ? 3 : unst); bits += 2; }
     else if (d == 8) { key = (key << 2) | (uint32_t)(farc > 3 ? 3 : farc); bits += 2; }
   }
@@ -2174,7 +2175,7 @@ int rs_forecast_key_bits(int32_t m) {
   int bits = 0;
   for (; m > 0; m /= 10) {
     const int d = m % 10;
-    bits += d == 1 ? 4 : d == 2 ? 4 : d == 3 ? 1 : d == 4 ? 12 : d == 5 ? 2 : d == 6 ? 5 : d == 7 ? 2 : d == 8 ? 2 : 0;
+    bits += d == 1 ? 4 : d == 2 ? 4 : d == 3 ? 1 : d == 4 ? 12 : d == 5 ? 2 : d == 6 ? 5 : d == 7 ? 2 : d == 8 ? 2 : d == 0 ? 3 : 0;
   }
   return bits;
 }

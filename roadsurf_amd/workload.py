@@ -30,7 +30,12 @@ SPK = 120  # 3600 s / DTSecs 30 s: time indices per hourly knot
 # others: a wavefront whose 64 points all have a layer frozen reads that layer's capDZ from the plan's
 # constants instead of evaluating the heat capacity of water (layer_step): about half of the 15 x 64
 # layer updates of a winter wave-step (1 M points: 2.11e10 -> 2.29e10).
-DEFAULT_FORECAST_MODE = 378659
+# 0 instead of 6 (round 4, last pass): the predicted extra passes saturating at 7 (3 bits) - a 10-bit key, whose
+# classes hold more points (the frost depth lines up better inside them), whose sort is cheaper and for which
+# the wave table of the two-wavefront flavour switches itself off (it costs a small shard's chain more than
+# class-aligned wavefronts save once the chain kernels run at raised priority): +1 % at 1 M and 125 000
+# points, +3 % at 250 000 (profiles/r04_key_layouts.txt).
+DEFAULT_FORECAST_MODE = 378059
 
 
 class SyntheticRun:
