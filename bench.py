@@ -262,8 +262,9 @@ def main() -> None:
         # 400 000 points on the GPU (1 M, r4_ground_sweep.sh: 2.29e10 for 3 x 90, 3 x 120 and 2 x 120 alike; 2.27e10
         # for 4 x 90 / 4 x 120), 4 x 120 from 200 000, 2 x 240 below (last pass with the chain kernels at raised
         # priority, tools/experiments/r4_prio_chain_sweep.sh: 2.35e10 / 2.33e10 / 2.11e10 / 1.37e10 at 1 M / 500 000 /
-        # 250 000 / 125 000 points)
-        K, ch = (3, 90) if n >= 400_000 else (4, 120) if n >= 200_000 else (2, 240) if n >= 100_000 else (1, 240)
+        # 250 000 / 125 000 points; with the 10-bit key, r4_key10_sweep.sh: 3 x 60 2.39e10 / 2.37e10 at 1 M / 500 000,
+        # 3 x 90 2.38e10 / 2.36e10)
+        K, ch = (3, 60) if n >= 400_000 else (4, 120) if n >= 200_000 else (2, 240) if n >= 100_000 else (1, 240)
     else:
         # measured on MI355X (tools/experiments/exp_plans.sh, r3_small2.sh; DESIGN_HISTORY.md 6)
         K, ch = (4 if n >= 200_000 else 2 if n >= 100_000 else 1), (120 if n >= 400_000 else 240)

@@ -230,11 +230,11 @@ def test_full_size_properties_1M_points_48h():
     # points, same values: the four checksums add up to the single plan's, the sampled blocks -
     # found in whichever plan holds them, through that plan's order rows - carry the same bits
     _interleaved_plans(4, 120, [1] * 4, n, s, p, seed, hours, cols, c1, samp1, plan.device)
-    # bench.py's default at this size since round 4: THREE plans of 333 333 / 333 334 points, launches of 90
+    # bench.py's default at this size since round 4: THREE plans of 333 333 / 333 334 points, launches of 60
     # indices (windows that start between two knots), stepped by the two-wavefront flavour whose ground wave
     # makes the forcing from the knots (no expansion kernel, no forcing window: rs_hip_step_knots)
-    _interleaved_plans(3, 90, [3] * 3, n, s, p, seed, hours, cols, c1, samp1, plan.device)
-    _interleaved_plans(2, 60, [3] * 2, n, s, p, seed, hours, cols, c1, samp1, plan.device)
+    _interleaved_plans(3, 60, [3] * 3, n, s, p, seed, hours, cols, c1, samp1, plan.device)
+    _interleaved_plans(2, 90, [3] * 2, n, s, p, seed, hours, cols, c1, samp1, plan.device)
     # BASELINE config 4's partition on the hardware at hand: the EIGHT blocks of 125 000 points the
     # eight ranks of a node would hold, at their global offsets, as eight plans on this one GPU -
     # four of them stepped by the two-wavefront flavour (what bench.py picks at that shard size),
