@@ -43,6 +43,11 @@ struct RsConstantsDev : RsConstants {
    * doubles, in the order layer_vsh uses them: as literals they cost the kernels two scalar moves each,
    * per thawed layer and step */
   double hcw[8];
+  /* what layer_step reads of layer j, side by side: a frozen layer takes the first two with one scalar load,
+   * a thawed one the last four (the same values as the tables of RsConstants and capDZF above) */
+  struct LayerRow {
+    double capDZF, condDZ, DyC, dryCap, WCont, pad[3];
+  } lk[RS_MAX_LAYERS + 2];
 };
 
 static inline void rs_consts_dev_fill(const RsConstants &c, RsConstantsDev &d) {
@@ -61,6 +66,14 @@ static inline void rs_consts_dev_fill(const RsConstants &c, RsConstantsDev &d) {
   for (int i = 0; i < 8; ++i) d.chk[i] = (double)chk[i];
   d.relax_tab = nullptr;
   d.cpl_tab = nullptr;
+  for (int j = 0; j < RS_MAX_LAYERS + 2; ++j) {
+    d.lk[j].capDZF = 0.0; /* filled below */
+    d.lk[j].condDZ = c.condDZ[j];
+    d.lk[j].DyC = c.DyC[j];
+    d.lk[j].dryCap = c.dryCap[j];
+    d.lk[j].WCont = c.WCont[j];
+    d.lk[j].pad[0] = d.lk[j].pad[1] = d.lk[j].pad[2] = 0.0;
+  }
   {
     const float h[8] = {-0.0050f, 0.0079f, 1000.0028f, 0.0000102f, 0.0017169f, 0.11516f, 3.4739f, 4217.2f};
     for (int i = 0; i < 8; ++i) d.hcw[i] = (double)h[i];
@@ -73,6 +86,7 @@ static inline void rs_consts_dev_fill(const RsConstants &c, RsConstantsDev &d) {
     const volatile double vsh = c.dryCap[j] + wc;
     const volatile double den = c.DyC[j] * vsh;
     d.capDZF[j] = -(1.0 / den);
+    d.lk[j].capDZF = d.capDZF[j];
     if (j == 1) {
       const volatile double num = vsh * c.HSfac1;
       d.hs1F = num / c.twoDT;

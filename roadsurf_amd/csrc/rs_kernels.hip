@@ -1538,7 +1538,7 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
           st[(int64_t)RS_ST_RH_END * ka->np_pad + p] = anchor_r;
         }
       }
-      double Gprev = c.condDZ[2] * (Tg[0] - t2); /* G(2), the expression layer 2 itself evaluates */
+      double Gprev = c.lk[2].condDZ * (Tg[0] - t2); /* G(2), the expression layer 2 itself evaluates */
 #pragma unroll
       for (int j = 3; j <= NL; ++j) {
         const double tj = Tg[j - 3];

@@ -28,6 +28,7 @@
 #define RS_CHK(c, i, lit) (lit)
 #define RS_PREC_FAST(c) ((c).MinPrecmm >= 0.f)
 #define RS_BARE_FAST(c) ((c).MaxWatmms >= 0.f && (c).MaxSnowmms >= 0.f && (c).MaxIcemms >= 0.f && (c).MaxDepmms >= 0.f)
+#define RS_LK(c, j, name) ((c).name[j])
 /* (no RS_FROZEN_TABLE here: the fp32 division of this flavour is not the correctly rounded one, so a
  * host-made capDZ of a frozen layer would differ from the kernel's in the last bit and a point's values
  * would depend on which wavefront it shares - measured: the plan-order pass lost its checksum equality) */

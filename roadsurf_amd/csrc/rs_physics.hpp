@@ -46,12 +46,20 @@
 #ifndef RS_NO_FROZEN_TABLE
 #define RS_FROZEN_TABLE 1 /* layer_step: capDZ of a layer that is frozen in all 64 points from RsConstantsDev::capDZF */
 #endif
+/* the five per-layer constants of layer_step next to one another (RsConstantsDev::lk): one scalar load per
+ * layer instead of one per table (-DRS_NO_LAYER_ROWS: the tables of RsConstants) */
+#ifndef RS_NO_LAYER_ROWS
+#define RS_LK(c, j, name) ((c).lk[j].name)
+#else
+#define RS_LK(c, j, name) ((c).name[j])
+#endif
 #ifndef RS_NO_HCW_TABLE
 #define RS_HCW_TABLE 1 /* layer_vsh: the water polynomials' coefficients from RsConstantsDev::hcw */
 #endif
 #include "rs_physics_body.inc"
 #undef RS_FROZEN_TABLE
 #undef RS_HCW_TABLE
+#undef RS_LK
 #undef RS_REAL
 #undef RS_NS
 #undef RS_CONSTS
