@@ -111,7 +111,9 @@ const char *rs_last_error(void) { return g_err; }
 void rs_host_set_error(const char *msg) { set_err("%s", msg ? msg : ""); }
 int rs_abi_version(void) { return RS_ABI_VERSION; }
 /* layout cross-check for bindings: 0 InputPointers 1 OutputPointers 2 InputSettings
- * 3 InputParameters 4 LocalParameters 5 RsConstants */
+ * 3 InputParameters 4 LocalParameters 5 RsConstants; the device-resident API's structs: 6 RsForcing
+ * 7 RsOutputs 8 RsPointParams 9 RsHostExtras 10 RsPreview 11 RsSynthSpec; the raw-series boundary's:
+ * 12 RsRawSource 13 RsDriverInput 14 RsDriverOutput */
 int64_t rs_abi_sizeof(int which) {
   switch (which) {
     case 0: return sizeof(InputPointers);
@@ -120,6 +122,15 @@ int64_t rs_abi_sizeof(int which) {
     case 3: return sizeof(InputParameters);
     case 4: return sizeof(LocalParameters);
     case 5: return sizeof(RsConstants);
+    case 6: return sizeof(RsForcing);
+    case 7: return sizeof(RsOutputs);
+    case 8: return sizeof(RsPointParams);
+    case 9: return sizeof(RsHostExtras);
+    case 10: return sizeof(RsPreview);
+    case 11: return sizeof(RsSynthSpec);
+    case 12: return sizeof(RsRawSource);
+    case 13: return sizeof(RsDriverInput);
+    case 14: return sizeof(RsDriverOutput);
     default: return -1;
   }
 }

@@ -39,8 +39,7 @@ extern "C" void rs_host_set_error(const char *msg);
 
 namespace rsu {
 
-/* per_default: blocks per device where ROADSURF_HIP_PLANS_PER_DEVICE does not say */
-inline std::vector<int> device_list(int per_default = 4) {
+inline std::vector<int> device_list() {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return {};
   std::vector<int> out;
@@ -80,7 +79,7 @@ inline std::vector<int> device_list(int per_default = 4) {
       }
     }
   }
-  int per = per_default;
+  int per = 4;
   if (const char *k = getenv("ROADSURF_HIP_PLANS_PER_DEVICE"))
     if (atoi(k) >= 1 && atoi(k) <= 8) per = atoi(k);
   for (int r = 0; r < per; ++r) /* device-major: a batch too small for all entries still uses every device */

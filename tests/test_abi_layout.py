@@ -54,6 +54,16 @@ def test_c_fortran_ctypes_sizes_agree(hip_lib):
         assert hip_lib.rs_abi_sizeof(i) == hip_lib.rs_fortran_sizeof(i) == C.sizeof(cls), cls.__name__
 
 
+def test_device_api_structs_have_the_size_the_binding_assumes(hip_lib):
+    """The ctypes mirrors of the device-resident API's structs (roadsurf_amd/lib.py) against sizeof in the
+    library: a field added on one side only (RsPointParams grew twice in round 4) shows here, without a GPU."""
+    from roadsurf_amd import driver
+    py = [lib.RsForcing, lib.RsOutputs, lib.RsPointParams, lib.RsHostExtras, lib.RsPreview, lib.RsSynthSpec,
+          driver.RsRawSource, driver.RsDriverInput, driver.RsDriverOutput]
+    for i, cls in enumerate(py, start=6):
+        assert hip_lib.rs_abi_sizeof(i) == C.sizeof(cls), cls.__name__
+
+
 def test_defaults_match_reference_headers(hip_lib):
     p = abi.InputParameters()
     hip_lib.rs_default_parameters(C.byref(p), 30.0)
