@@ -7,6 +7,7 @@
  * the step kernel on that stream.
  */
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -198,6 +199,14 @@ void rs_default_local(LocalParameters *l) {
   l->InitLenI = 0;
 }
 
+/* Points of the live plans per device.  While ALL of them fit the device at once as wavefront pairs of the
+ * two-wavefront flavour (4 wavefronts x 4 SIMDs x 256 CUs = 4 096 slots = 131 072 points), the SIMDs are
+ * underfilled and a launch is as long as its slowest workgroup's chain: the surface wave - the longer chain of
+ * the two - then runs at raised issue priority (StepArgs::surface_prio; +2.6 % at 125 000 points, and -0.6 ...
+ * -5.5 % where more points are resident: profiles/r04_surface_wave_priority.txt). */
+static std::atomic<int64_t> g_live_points[64];
+static inline int32_t underfilled(const RsPlan *pl);
+
 RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints, const RsConstants *consts,
                            void *stream) {
   if (!consts || npoints <= 0) {
@@ -286,11 +295,17 @@ RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints, const RsConstants *c
     delete pl;
     return nullptr;
   }
+  g_live_points[device & 63] += npoints;
   return pl;
+}
+
+static inline int32_t underfilled(const RsPlan *pl) {
+  return g_live_points[pl->device & 63].load() <= 131072 ? 1 : 0;
 }
 
 void rs_hip_plan_destroy(RsPlan *pl) {
   if (!pl) return;
+  g_live_points[pl->device & 63] -= pl->npoints;
   (void)hipSetDevice(pl->device);
   (void)hipStreamSynchronize(pl->stream);
   for (hipEvent_t e : pl->ev) (void)hipEventDestroy(e);
@@ -647,6 +662,7 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
   a.wave_cnt = pl->wave_tab_valid ? pl->wave_tab + pl->wave_n : nullptr;
   a.wave_n = pl->wave_n;
   a.duo_full_ok = (full && !skyview && !coupled && !f->depth && !(pl->c.tsurfOutputDepth >= 0.0)) ? 1 : 0;
+  a.surface_prio = underfilled(pl);
   a.knots = nullptr;
   a.knot_gather = nullptr;
   a.knot_k0 = a.knot_n = a.spk = a.start_hour = 0;
@@ -756,6 +772,7 @@ int rs_hip_step_knots(RsPlan *pl, const RsSynthSpec *spec, const double *knots, 
   a.wave_cnt = pl->wave_tab_valid ? pl->wave_tab + pl->wave_n : nullptr;
   a.wave_n = pl->wave_n;
   a.duo_full_ok = full ? 3 : 0; /* bit 1: the dew-point test (the knots always carry a dew point) */
+  a.surface_prio = underfilled(pl);
   a.knots = knots;
   a.knot_gather = order;
   a.knot_k0 = k0;
@@ -830,6 +847,7 @@ static int cpl_args(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const Rs
   a.wave_start = a.wave_cnt = nullptr;
   a.wave_n = 0;
   a.duo_full_ok = 0;
+  a.surface_prio = 0;
   a.knots = nullptr;
   a.knot_gather = nullptr;
   a.knot_k0 = a.knot_n = a.spk = a.start_hour = 0;

@@ -56,6 +56,9 @@ struct StepArgs {
   /* the launch's FULL feature set is one the two-wavefront flavour has (rs_hip_step: no sky view, no
    * coupling, no depth stream, no tsurfOutputDepth) */
   int32_t duo_full_ok;
+  /* two-wavefront flavour: the surface wave runs at raised issue priority (rs_api.hip: set while all live
+   * plans of the device together leave its SIMDs underfilled) */
+  int32_t surface_prio;
   /* two-wavefront flavour on the synthetic workload (rs_hip_step_knots): no forcing window - the ground
    * wave makes the forcing of the next index from the hourly knots itself, with expand_kernel's arithmetic
    * (knots [knot - knot_k0][RS_KNOT_FIELDS][np_pad] in point order, column knot_gather[slot]; NULL knots:

@@ -1572,8 +1572,12 @@ __global__ void __launch_bounds__(128, 4) step_kernel_duo(const StepArgs a) {
    * SIMD hosts both kinds, was measured: 1.08e10 and 1.13e10 against 1.12e10 with fixed roles at
    * 125 000 points - nothing to gain.) */
   if (a.wave_start && a.wave_cnt[blockIdx.x] == 0) return; /* a spare workgroup of the wave table: both wavefronts leave */
-  if (threadIdx.x < 64) duo_surface<NL, SCORE, FULL>(mt, mail, a);
-  else duo_ground<NL, KNOTS, FULL>(mt, mail, a);
+  if (threadIdx.x < 64) {
+    if (a.surface_prio) __builtin_amdgcn_s_setprio(1); /* the longer chain of the two issues first (StepArgs::surface_prio) */
+    duo_surface<NL, SCORE, FULL>(mt, mail, a);
+  } else {
+    duo_ground<NL, KNOTS, FULL>(mt, mail, a);
+  }
 }
 
 /* FULL feature set + sky view in lock step, LDS profile (any NLayers). */
