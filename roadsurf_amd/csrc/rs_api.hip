@@ -662,6 +662,15 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
   a.wave_cnt = pl->wave_tab_valid ? pl->wave_tab + pl->wave_n : nullptr;
   a.wave_n = pl->wave_n;
   a.duo_full_ok = (full && !skyview && !coupled && !f->depth && !(pl->c.tsurfOutputDepth >= 0.0)) ? 1 : 0;
+  {
+    /* bit 2: a sky-view launch the two-wavefront flavour can take (rs_launch_step_sky): no output depth, and
+     * every stream of the windows within 32-bit offsets */
+    const int64_t orows = ((int64_t)t0 + nsteps - 2) / o->decimate - o->row0 + 1;
+    const bool a32 = (uint64_t)f->t_stride * (uint64_t)nsteps < (1ull << 29) &&
+                     (uint64_t)o->t_stride * (uint64_t)(orows > 0 ? orows : 1) < (1ull << 29) &&
+                     (!pl->wb.sw_dir || (uint64_t)pl->wb.t_stride * (uint64_t)nsteps < (1ull << 29));
+    if (skyview && !coupled && !f->depth && !(pl->c.tsurfOutputDepth >= 0.0) && a32) a.duo_full_ok |= 4;
+  }
   a.surface_prio = underfilled(pl);
   a.knots = nullptr;
   a.knot_gather = nullptr;
@@ -687,7 +696,7 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
   if (pl->f32)
     le = rs32_launch_step(a, pl->c.NLayers, pl->variant, pl->stream);
   else if (skyview && !coupled)
-    le = rs_launch_step_sky(a, pl->c.NLayers, pl->stream); /* lock-step FULL + sky view */
+    le = rs_launch_step_sky(a, pl->c.NLayers, pl->history_score, pl->stream); /* lock-step FULL + sky view */
   else if (coupled) {
     /* Rounds instead of "every wavefront replays until its slowest lane is through"
      * (src/Coupling.f90:61-78,324: up to 25 replays of a window of up to 360 indices, per point):

@@ -130,7 +130,7 @@ size_t rs_cpl_select_scratch_bytes(int64_t npoints);
 hipError_t rs_cpl_select_again(const double *state, int64_t np_pad, int64_t npoints, int32_t *flags,
                                int32_t *list, int32_t *count_dev, void *tmp, size_t tmp_bytes,
                                hipStream_t stream);
-hipError_t rs_launch_step_sky(const rs::StepArgs &a, int NL, hipStream_t stream);
+hipError_t rs_launch_step_sky(const rs::StepArgs &a, int NL, bool score, hipStream_t stream);
 hipError_t rs_launch_init(const rs::InitArgs &a, hipStream_t stream);
 hipError_t rs_launch_knots(const rs::KnotArgs &a, int32_t nknots, hipStream_t stream);
 hipError_t rs_launch_expand(const rs::ExpandArgs &a, int32_t nintervals, hipStream_t stream);

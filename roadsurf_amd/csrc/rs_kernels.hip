@@ -1261,8 +1261,13 @@ __device__ __forceinline__ ForcingPrep duo_get_prep(const C &c, const DuoMail &m
  * memory counter, i.e. for the six output stores of the step and the prefetched forcing loads. */
 __device__ __forceinline__ void duo_meet() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int NL, bool SCORE, bool FULL = false>
+/* SKY (with FULL): sky view and local horizons (src/ModRadiation.f90, examples/example1/src/Simulation.f90:
+ * 151-162) as the lock-step loop has them - the surface wave reads SW_dir and LW_net of the index itself (two
+ * coalesced loads), runs CheckValues' sky-view tests and ModRadiationBySurroundings on the short- and long-wave
+ * radiation the ground wave handed over, and writes the reference's in-place edits back where asked to. */
+template <int NL, bool SCORE, bool FULL = false, bool SKY = false>
 __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, const StepArgs &a) {
+  static_assert(FULL || !SKY, "sky view belongs to the FULL feature set");
   KernArgs ka = kernargs();
   const uint32_t lane = threadIdx.x & 63u;
   /* the workgroup's slots: 64 from 64 * blockIdx.x, or what the wave table says (rs_cluster_wave_table) */
@@ -1282,6 +1287,21 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
     }
     T.set(1, all.get(1));
     T.set(2, all.get(2));
+  }
+  double skyv = R4(1.0), sinlat = 0, coslat = 0, lonrad = 0, coslon = 1.0, sinlon = 0;
+  bool sky_on = false;
+  uint32_t hcol = 0;
+  if (SKY && live) { /* as time_loop<SKY> */
+    skyv = ka->pp.sky_view[p];
+    sky_on = (skyv < R4(1.0) && skyv > R4(-0.01));
+    if (sky_on) {
+      sinlat = ka->pp.sin_lat[p];
+      coslat = ka->pp.cos_lat[p];
+      lonrad = ka->pp.lon_rad[p];
+      coslon = ::cos(lonrad);
+      sinlon = ::sin(lonrad);
+    }
+    hcol = ka->pp.horizon_index ? (uint32_t)ka->pp.horizon_index[p] : (uint32_t)p;
   }
   mail.v[0][0][lane] = T.get(2);
   mail.failed[lane] = s.failed ? 1u : 0u; /* arrives failed (or a dead lane): frozen from the first index */
@@ -1332,7 +1352,39 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
         }
       }
       const double tair = q.tair;
-      const Fluxes fx = model_step_fluxes_prepped<SCORE>(c, mt, s, q);
+      ForcingPrep qs = q;
+      if (SKY) {
+        const int64_t row = (int64_t)k * ka->f.t_stride + row0;
+        const LaneOff L(lane);
+        double sw_dir = L.ld(ka->f.sw_dir + row), lw_net = L.ld(ka->f.lw_net + row);
+        if (i < c.SimLen) {
+          if (sky_on && (sw_dir < R4(-0.1) || sw_dir > R4(4000.0) || lw_net < R4(-1000.0) || lw_net > R4(1000.0))) {
+            s.failed = true; /* src/InputOutput.f90:68-74 */
+            ka->state[(int64_t)RS_ST_FAILED * ka->np_pad + row0 + lane] = (double)i;
+            mail.failed[lane] = 1u;
+          }
+          if (sw_dir > q.sw) sw_dir = q.sw; /* :75-77 */
+        }
+        if (sky_on) {
+          if (!sky_view_radiation(ka->f.sun + (int64_t)k * RS_SUN_COLS, sinlat, coslat, lonrad, coslon, sinlon, skyv,
+                                  ka->pp.albedo_surroundings,
+                                  ka->pp.horizons ? ka->pp.horizons + (ka->pp.horizons_by_point ? (int64_t)hcol * 360 : (int64_t)hcol) : nullptr,
+                                  ka->pp.horizons_by_point ? (int64_t)1 : ka->np_pad, qs.sw, sw_dir, qs.lw, lw_net)) {
+            s.failed = true; /* the reference would `stop` the process here */
+            ka->state[(int64_t)RS_ST_FAILED * ka->np_pad + row0 + lane] = (double)i;
+            mail.failed[lane] = 1u;
+          }
+        }
+        if (ka->wb.sw_dir) { /* the caller's arrays as the reference leaves them (time_loop<SKY>) */
+          const int64_t wrow = (int64_t)k * ka->wb.t_stride + row0;
+          L.st(ka->wb.sw_dir + wrow, sw_dir);
+          if (sky_on) {
+            L.st(ka->wb.sw + wrow, qs.sw);
+            L.st(ka->wb.lw + wrow, qs.lw);
+          }
+        }
+      }
+      const Fluxes fx = model_step_fluxes_prepped<SCORE>(c, mt, s, qs);
       if (SCORE) {
         score += (fx.trips & 63) - 5;
         if ((fx.trips & 64) && k >= nsteps - RS_REGIME_WINDOW) score |= 1 << 30;
@@ -1561,7 +1613,7 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
   }
 }
 
-template <int NL, bool SCORE, bool KNOTS = false, bool FULL = false>
+template <int NL, bool SCORE, bool KNOTS = false, bool FULL = false, bool SKY = false>
 __global__ void __launch_bounds__(128, 4) step_kernel_duo(const StepArgs a) {
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
   __shared__ DuoMail mail;
@@ -1574,7 +1626,7 @@ __global__ void __launch_bounds__(128, 4) step_kernel_duo(const StepArgs a) {
   if (a.wave_start && a.wave_cnt[blockIdx.x] == 0) return; /* a spare workgroup of the wave table: both wavefronts leave */
   if (threadIdx.x < 64) {
     if (a.surface_prio) __builtin_amdgcn_s_setprio(1); /* the longer chain of the two issues first (StepArgs::surface_prio) */
-    duo_surface<NL, SCORE, FULL>(mt, mail, a);
+    duo_surface<NL, SCORE, FULL, SKY>(mt, mail, a);
   } else {
     duo_ground<NL, KNOTS, FULL>(mt, mail, a);
   }
@@ -2189,14 +2241,29 @@ hipError_t rs_launch_forecast_keys(const rs::ForecastArgs &a, hipStream_t stream
   return hipGetLastError();
 }
 
-hipError_t rs_launch_step_sky(const rs::StepArgs &a, int NL, hipStream_t stream) {
+hipError_t rs_launch_step_sky(const rs::StepArgs &a, int NL, bool score, hipStream_t stream) {
   const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
   /* ROADSURF_HIP_SKY_PROFILE (tuning): 0 LDS profile at 3 waves/SIMD (any NLayers), 3 / 4 hybrid profile
    * at that many waves (NLayers = 15).  Measured (rs_driver_run, sky view, 262 144 points in four blocks):
    * 6.9e9 / 7.1e9 / 7.4e9 */
   const char *e = getenv("ROADSURF_HIP_SKY_PROFILE");
   const int m = (NL == 15) ? (e ? atoi(e) : RS_SKY_PROFILE_DEFAULT) : 0;
-  if (m == 4) hipLaunchKernelGGL((rs::step_kernel_sky_h<4>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
+  /* 5: two wavefronts per 64 points (no output depth, 32-bit window offsets: what rs_hip_step checked,
+   * StepArgs::duo_full_ok bit 2) - no spills (128 registers) where the one-point-per-lane sky kernels spill
+   * 62-106.  Taken by itself for launches of at most ROADSURF_HIP_DUO_MAX points, like the other
+   * two-wavefront instances: rs_driver_run with sky view, 65 536 points 3.5e9 -> 4.8e9, 200 000 points (four
+   * blocks) 7.6e9 -> 8.6e9; at 1 M points (blocks of 250 000) 1.06e10 -> 1.03e10 - four of its wavefronts
+   * leave a SIMD no register for the other blocks' window expansion, which then queues. */
+  const char *edm = getenv("ROADSURF_HIP_DUO_MAX");
+  const int64_t duo_max = edm ? atoll(edm) : RS_DUO_MAX_POINTS;
+  const bool duo_auto = !e && NL == 15 && a.npoints <= duo_max;
+  if ((m == 5 || duo_auto) && (a.duo_full_ok & 4)) {
+    const dim3 gd(a.wave_start ? (unsigned)a.wave_n : (unsigned)((a.npoints + 63) / 64));
+    if (score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, false, true, true>), gd, dim3(128), 0, stream, a);
+    else hipLaunchKernelGGL((rs::step_kernel_duo<15, false, false, true, true>), gd, dim3(128), 0, stream, a);
+    return hipGetLastError();
+  }
+  if (m == 4 || m == 5) hipLaunchKernelGGL((rs::step_kernel_sky_h<4>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
   else if (m == 3) hipLaunchKernelGGL((rs::step_kernel_sky_h<3>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
   else hipLaunchKernelGGL(rs::step_kernel_sky, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
   return hipGetLastError();
