@@ -107,8 +107,12 @@ int32_t rs_coalesce_run(OutputPointers *out, const InputPointers *in, const Inpu
         const auto again = std::chrono::steady_clock::now() + std::chrono::microseconds(w);
         g_cv.wait_until(lk, again, [&] { return g_queue.size() >= max_batch(); });
       }
+      /* the collector's own point first (a queue longer than the maximum must not leave it
+       * out of the batch it runs), then the others with its settings and parameters, in queue order */
       std::vector<Request *> batch, rest;
+      batch.push_back(&me);
       for (Request *r : g_queue) {
+        if (r == &me) continue;
         const bool same = batch.size() < max_batch() &&
                           std::memcmp(r->settings, me.settings, sizeof(InputSettings)) == 0 &&
                           std::memcmp(r->params, me.params, sizeof(InputParameters)) == 0;
@@ -133,11 +137,19 @@ int32_t rs_coalesce_run(OutputPointers *out, const InputPointers *in, const Inpu
       }
       int32_t st = 0;
       runsimulation_batch(n, o.data(), i.data(), me.settings, me.params, l.data(), &st);
+      /* a batch-level error is some ONE caller's (an array shorter than SimLen, ...): the header promises
+       * every caller the bits and the status of a call of its own, so the members run again one by one */
+      std::vector<int32_t> each((size_t)n, st);
+      if (st != 0 && n > 1)
+        for (int32_t k = 0; k < n; ++k) {
+          each[k] = 0;
+          runsimulation_batch(1, &o[k], &i[k], me.settings, me.params, &l[k], &each[k]);
+        }
       lk.lock();
       g_inflight -= 1;
-      for (Request *r : batch) {
-        r->status = st;
-        r->done = true;
+      for (int32_t k = 0; k < n; ++k) {
+        batch[k]->status = each[k];
+        batch[k]->done = true;
       }
       g_cv.notify_all();
       return me.status;

@@ -1225,7 +1225,9 @@ struct DuoMail {
    * of LDS, seven workgroups to a CU (3.5 wavefronts per SIMD where the registers allow 4); now 19 280 B:
    * eight. */
   double prep[2][RS_DUO_NPREP][64];
-  double trffric[2];
+  /* bit 0: CheckValues' verdict on the forcing; bit 1: the index falls in the night of
+   * SetDayDependendVariables (src/BalanceModel.f90:354-387) - per LANE: with RsForcing::hour_pstride = 1
+   * (runsimulation_batch: every point brings its own calendar) the hour is the point's, not the index's */
   uint32_t prep_bad[2][64];
 };
 
@@ -1236,8 +1238,7 @@ __device__ __forceinline__ void duo_put_prep(DuoMail &mail, int buf, uint32_t la
   w[5][lane] = q.AirDens; w[6][lane] = q.AirHCap; w[7][lane] = q.PsychC;
   w[8][lane] = q.EAir; w[9][lane] = q.sw; w[10][lane] = q.lw;
   if (FULL) w[11][lane] = q.tsurfobs;
-  if (lane == 0) mail.trffric[buf] = q.trffric; /* day or night: the hour is the index's (lane 0 is never a dead lane) */
-  mail.prep_bad[buf][lane] = q.bad ? 1u : 0u;
+  mail.prep_bad[buf][lane] = (q.bad ? 1u : 0u) | (q.night ? 2u : 0u);
 }
 template <bool FULL, class C>
 __device__ __forceinline__ ForcingPrep duo_get_prep(const C &c, const DuoMail &mail, int buf, uint32_t lane) {
@@ -1247,13 +1248,18 @@ __device__ __forceinline__ ForcingPrep duo_get_prep(const C &c, const DuoMail &m
   q.AirDens = w[5][lane]; q.AirHCap = w[6][lane]; q.PsychC = w[7][lane];
   q.EAir = w[8][lane]; q.sw = w[9][lane]; q.lw = w[10][lane];
   if (FULL) q.tsurfobs = w[11][lane];
-  q.trffric = mail.trffric[buf];
+  const uint32_t flags = mail.prep_bad[buf][lane];
+  { /* both constants first (scalar loads), then the lane picks a VALUE: see fluxes_pre */
+    const double fricN = c.TrfFricNgt, fricD = c.TrFfricDay;
+    q.night = (flags & 2u) != 0u;
+    q.trffric = q.night ? fricN : fricD;
+  }
   /* forcing_prep_tail's expressions on forcing_prep_tail's values */
   const double AirVCap = q.AirHCap * q.AirDens;
   q.den0 = AirVCap * (q.tair + R4(273.15));
   q.vkvz = c.VK_Const * q.vz;
   q.avk = AirVCap * c.VK_Const;
-  q.bad = mail.prep_bad[buf][lane] != 0u;
+  q.bad = (flags & 1u) != 0u;
   return q;
 }
 

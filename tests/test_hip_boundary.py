@@ -89,6 +89,37 @@ def test_runsimulation_batch_matches_oracle(monkeypatch):
     assert (out["tsurf"][5] == -9999.0).sum() == SL - 701
 
 
+def test_batch_points_with_their_own_calendars():
+    """runsimulation_batch hands every point's OWN hour array to the kernels (RsForcing::hour_pstride = 1):
+    points of one wavefront whose local hour differs take different branches of SetDayDependendVariables
+    (src/BalanceModel.f90:354-387) at the same index.  A batch small enough for the two-wavefront flavour,
+    two calendars interleaved lane by lane (the traffic friction used to travel as one word per
+    index, lane 0's)."""
+    L = lib.load()
+    n, SL = 200, 1441
+    fa = oh.synth_forcing(n, SL, seed=5, start_hour=0)
+    fb = oh.synth_forcing(n, SL, seed=5, start_hour=11)  # same values, the calendar eleven hours on
+    s = abi.default_settings(SL); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
+    oa, _, _ = oh.run_oracle(_kind(), fa, s, p, l)
+    ob, _, _ = oh.run_oracle(_kind(), fb, s, p, l)
+    assert not np.array_equal(oa["tsurf"], ob["tsurf"])  # the calendar matters
+    out = {k: np.full((n, SL), np.nan) for k in oh.F64_OUT}
+    ga = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in fa.items()}
+    gb = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in fb.items()}
+    ips = (abi.InputPointers * n)(); ops = (abi.OutputPointers * n)(); keep = []
+    odd = np.arange(n) % 3 == 1
+    for pt in range(n):
+        ips[pt], ops[pt], hz = _pointers(gb if odd[pt] else ga, out, pt)
+        keep.append(hz)
+    larr = (abi.LocalParameters * n)(*([l] * n))
+    st = C.c_int32(99)
+    L.runsimulation_batch(n, ops, ips, C.byref(s), C.byref(p), larr, C.byref(st))
+    assert st.value == 0, lib.last_error()
+    for k in oh.F64_OUT:
+        want = np.where(odd[:, None], ob[k], oa[k])
+        assert np.array_equal(out[k], want), k
+
+
 def test_batch_rejects_bad_arguments_loudly():
     L = lib.load()
     n, SL = 1, 241
@@ -283,16 +314,23 @@ print(json.dumps({"same": bool(same), "same2": bool(same2), "batches": b.value, 
 """
 
 
-def test_runsimulation_coalesces_concurrent_callers():
+@pytest.mark.parametrize("max_batch", [None, 5])
+def test_runsimulation_coalesces_concurrent_callers(max_batch):
     """ROADSURF_HIP_COALESCE_US: 32 threads call runsimulation point by point, two groups with different
     settings interleaved - every point carries the reference's bits, the points went through far fewer
-    batches than calls, and a batch never mixes settings (the second group's output depth differs)."""
+    batches than calls, and a batch never mixes settings (the second group's output depth differs).
+    max_batch = 5: ROADSURF_HIP_COALESCE_MAX below the thread count - queues longer than a batch, the
+    collector's own point must be in the batch it runs."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ROADSURF_HIP_COALESCE_US="3000")
+    if max_batch:
+        env["ROADSURF_HIP_COALESCE_MAX"] = str(max_batch)
     r = subprocess.run([sys.executable, "-c", _COALESCE_CHILD, root], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["same"] and d["same2"] and d["vz_edit"], d
-    assert d["points"] == 192 and d["batches"] < 96, d
+    assert d["points"] == 192 and d["batches"] < (96 if not max_batch else 193), d
+    if max_batch:
+        assert d["batches"] >= 192 // max_batch, d
