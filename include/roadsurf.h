@@ -706,6 +706,11 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *settings,
  * - stations whose observations ended hours apart - is cut in halves, down to 4 096 points.
  * rs_driver_last_tiles(): tiles the calling thread's last call with device >= 0 stepped. */
 int rs_driver_last_tiles(void);
+/* Since ABI 6 the blocks of rs_driver_run step with a kernel that makes its forcing from the raw series itself
+ * (no forcing windows, no expansion kernel) wherever it can: sources on shared time axes, NLayers = 15, no
+ * coupling, no output depth; ROADSURF_HIP_DRIVER_WINDOWS=1 keeps the windows.  Step launches of that kind in
+ * the calling thread's last call with device >= 0 (tests). */
+int rs_driver_last_raw_launches(void);
 /* rs_driver_run keeps its forcing-window block (up to 64 GB of HBM with coupling) for the next
  * call, because releasing and re-acquiring that much VRAM costs seconds (the driver wipes it).
  * This frees it. */
@@ -716,7 +721,7 @@ int rs_driver_expand(const RsDriverInput *in, const InputSettings *settings,
                      LocalParameters *local, double *merged, int32_t *status,
                      int32_t *missing_index, int32_t device);
 
-#define RS_ABI_VERSION 5 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles; 4: RsPointParams::horizon_index, rs_hip_step_knots; 5: RS_SUN_COLS 6, RsPointParams::horizons_by_point */
+#define RS_ABI_VERSION 6 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles; 4: RsPointParams::horizon_index, rs_hip_step_knots; 5: RS_SUN_COLS 6, RsPointParams::horizons_by_point; 6: rs_driver_last_raw_launches (rs_driver_run without forcing windows) */
 int rs_abi_version(void);
 /* sizeof of the boundary structs as the C side / the Fortran side see them
  * (0 InputPointers, 1 OutputPointers, 2 InputSettings, 3 InputParameters,

@@ -676,6 +676,7 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
   a.knot_gather = nullptr;
   a.knot_k0 = a.knot_n = a.spk = a.start_hour = 0;
   a.r_spk = 0.0;
+  std::memset(&a.raw, 0, sizeof(a.raw));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (pl->timing) {
     if (pl->ev_used + 2 > pl->ev.size()) {
@@ -814,6 +815,69 @@ int rs_hip_step_knots(RsPlan *pl, const RsSynthSpec *spec, const double *knots, 
   return 0;
 }
 
+} /* extern "C" */
+
+/* The step of rs_driver_run's blocks (internal, declared in rs_kernels.h): the two-wavefront flavour whose
+ * ground wave makes the forcing from the RAW series - JsonSource::interpolate + the GetWeather overlay per
+ * variable, one index ahead (examples/example1/src/JsonSource.cpp:49-176, DataHandler.cpp:75-84; rs_raw.hpp)
+ * - so that neither a forcing window nor its expansion kernel exists on that path.  FULL feature set as the
+ * driver has it (dew point, observations, initialization phase, relaxation), optionally per-point sky view
+ * (pp->sky_view with the geometry, the horizon table and `sun` = rs_sun_table rows from index t0 on): the
+ * ground wave runs CheckValues' sky-view tests and ModRadiationBySurroundings too (they depend on the
+ * forcing and the geometry alone, src/ModRadiation.f90:7-73).  pp in SLOT order; raw series in point order
+ * behind raw->col. */
+int rs_step_raw(RsPlan *pl, const rs::RawForcing *raw, const double *sun, const RsOutputs *o,
+                const RsPointParams *pp, int32_t t0, int32_t nsteps) {
+  if (!pl || !raw || raw->nsrc < 1 || raw->nsrc > RS_MAX_SOURCES || !raw->segs || !raw->hour)
+    return set_err("rs_step_raw: bad arguments");
+  if (!pp || !pp->tbottom || !pp->initlen) return set_err("rs_step_raw: tbottom and initlen are required");
+  if (!o || !o->tsurf || !o->snow || !o->water || !o->ice || !o->deposit || !o->ice2)
+    return set_err("rs_step_raw: all six output streams are required");
+  if (o->t_stride < pl->npoints || o->decimate < 1) return set_err("rs_step_raw: bad output window");
+  if (t0 < 1 || nsteps < 1 || (int64_t)t0 + nsteps - 1 > pl->c.SimLen)
+    return set_err("rs_step_raw: window [%d,%d) outside [1,SimLen=%d]", t0, t0 + nsteps, pl->c.SimLen);
+  const int64_t first = ((int64_t)t0 - 1 + o->decimate - 1) / o->decimate;
+  if (first < o->row0) return set_err("rs_step_raw: output row0 beyond first row");
+  const int64_t out_rows = ((int64_t)t0 + nsteps - 2) / o->decimate - o->row0 + 1;
+  if (!rs_step_raw_ok(pl) || (uint64_t)o->t_stride * (uint64_t)(out_rows > 0 ? out_rows : 1) >= (1ull << 29))
+    return set_err("rs_step_raw: NLayers = 15, fp64, no coupling, no output depth and an output window below "
+                   "4 GiB per stream only");
+  if (pl->c.use_relaxation && pp->tair_relax && (!pp->vz_relax || !pp->rh_relax))
+    return set_err("rs_step_raw: relaxation needs tair_relax, vz_relax, rh_relax and initlen");
+  const bool sky = pp->sky_view != nullptr;
+  if (sky && (!pp->sin_lat || !pp->cos_lat || !pp->lon_rad || !sun))
+    return set_err("rs_step_raw: sky view needs sin_lat, cos_lat, lon_rad and the sun table");
+  if (raw->seg0 < 0 || raw->seg0 >= raw->nseg) return set_err("rs_step_raw: seg0 outside the segment table");
+  HIP_OK(hipSetDevice(pl->device));
+  rs::StepArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.consts = pl->consts_dev;
+  a.f.t_stride = pl->np_pad; /* no window: nothing of `f` but the sun rows is read */
+  a.f.sun = sun;
+  a.o = *o;
+  a.pp = *pp;
+  a.state = pl->state;
+  a.npoints = pl->npoints;
+  a.np_pad = pl->np_pad;
+  a.t0 = t0;
+  a.nsteps = nsteps;
+  a.wave_start = pl->wave_tab_valid ? pl->wave_tab : nullptr;
+  a.wave_cnt = pl->wave_tab_valid ? pl->wave_tab + pl->wave_n : nullptr;
+  a.wave_n = pl->wave_n;
+  a.duo_full_ok = 3; /* the driver's series always carry a dew point (completed from the humidity where absent) */
+  a.surface_prio = underfilled(pl);
+  a.raw = *raw;
+  const hipError_t le = rs_launch_step_duo_raw(a, pl->history_score, sky, pl->stream);
+  if (le != hipSuccess) return set_err("rs_step_raw: kernel launch failed: %s", hipGetErrorString(le));
+  return 0;
+}
+
+bool rs_step_raw_ok(const RsPlan *pl) {
+  return pl && !pl->f32 && pl->c.NLayers == 15 && !(pl->c.tsurfOutputDepth >= 0.0) && !pl->c.use_coupling;
+}
+
+extern "C" {
+
 /* common validation + argument block of the two chunked-coupling entry points */
 static int cpl_args(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPointParams *pp,
                     int32_t t0, int32_t nsteps, const char *who, rs::StepArgs &a) {
@@ -861,6 +925,7 @@ static int cpl_args(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const Rs
   a.knot_gather = nullptr;
   a.knot_k0 = a.knot_n = a.spk = a.start_hour = 0;
   a.r_spk = 0.0;
+  std::memset(&a.raw, 0, sizeof(a.raw));
   return 0;
 }
 

@@ -41,6 +41,7 @@
 #include "rs_state.h"
 #include "rs_devices.hpp"
 #include "rs_kernels.h"
+#include "rs_raw.hpp"
 
 extern "C" void rs_host_set_error(const char *msg);
 
@@ -49,36 +50,16 @@ namespace {
 using rsu::Dev;
 using rsu::transpose;
 
-constexpr int NFLD = 10;
-/* order of `merged` in rs_driver_expand and of the window buffers */
-enum { R_TAIR, R_TDEW, R_VZ, R_RHZ, R_PREC, R_SW, R_LW, R_SWDIR, R_LWNET, R_OBS };
-enum { K_NONE = 0, K_COPY = 1, K_INTERP = 2 };
-
-struct PlanStep {
-  int32_t kind; /* K_* */
-  int32_t rp;   /* rawPos */
-  double num;   /* simtime[simPos] - rawtime[rawPos]      (JsonSource.cpp:116 ff.) */
-  double den;   /* rawtime[rawPos+1] - rawtime[rawPos] */
-  double rden;  /* RN(1 / den) for the shared-axis plans (division by a uniform denominator,
-                   rs_math.hpp rs_div_u); 0 = not available: IEEE division */
-};
-
-/* A shared-axis plan entry, read as constant memory (address space 4): one scalar load of the
- * 32-byte entry.  Through a generic pointer the compiler loads the two doubles with a VECTOR load
- * from the uniform address (it cannot prove the array apart from the window it is writing) and
- * the lane waits a vector-memory round trip per source and time index.  The plans are uploaded
- * before any kernel of the run and never written on the device. */
-__device__ __forceinline__ PlanStep plan_at(const PlanStep *plan, int32_t i) {
-  const PlanStep __attribute__((address_space(4))) *q =
-      (const PlanStep __attribute__((address_space(4))) *)plan + i;
-  PlanStep st;
-  st.kind = q->kind;
-  st.rp = q->rp;
-  st.num = q->num;
-  st.den = q->den;
-  st.rden = q->rden;
-  return st;
-}
+#ifndef RS_DRIVER_RAW_CHUNK
+#define RS_DRIVER_RAW_CHUNK 240 /* indices per launch of a block whose step kernel reads the raw series */
+#endif
+constexpr int NFLD = rs::RAW_NFLD;
+/* order of `merged` in rs_driver_expand and of the window buffers (rs_raw.hpp) */
+enum { R_TAIR = rs::RAW_TAIR, R_TDEW = rs::RAW_TDEW, R_VZ = rs::RAW_VZ, R_RHZ = rs::RAW_RHZ, R_PREC = rs::RAW_PREC,
+       R_SW = rs::RAW_SW, R_LW = rs::RAW_LW, R_SWDIR = rs::RAW_SWDIR, R_LWNET = rs::RAW_LWNET, R_OBS = rs::RAW_OBS };
+enum { K_NONE = rs::RAW_NONE, K_COPY = rs::RAW_COPY, K_INTERP = rs::RAW_INTERP };
+using PlanStep = rs::RawPlanStep; /* one per source and simulation index (rs_raw.hpp) */
+__device__ __forceinline__ PlanStep plan_at(const PlanStep *plan, int32_t i) { return rs::raw_plan_at(plan, i); }
 
 struct SrcDev {
   const double *fld[NFLD]; /* [n_times][np_pad], nullptr = variable absent */
@@ -101,38 +82,10 @@ struct SrcSet {
   int32_t dt;
 };
 
-/* examples/example1/src/InputData.cpp:5-26: every series starts out missing */
-__device__ __forceinline__ double miss_r() { return -9999.9; }
-/* JsonSource.cpp:92-111,323-345: `> -100.0`, except LW_net `> -1000.0` */
-__device__ __forceinline__ double threshold(int fld) { return fld == R_LWNET ? -1000.0 : -100.0; }
-
-/* Value of one variable of one source at one simulation index: JsonSource::interpolate
- * (JsonSource.cpp:86-170) followed by GetWeather's own test (JsonSource.cpp:337-356).
- * a, b = raw[rawPos], raw[rawPos+1]. */
-__device__ __forceinline__ bool source_value(const PlanStep &st, double a, double b, double thr,
-                                             double &v) {
-  if (st.kind == K_COPY) {
-    v = a;
-    return a > thr;
-  }
-  if (!(a > thr && b > thr)) return false;
-  /* raw[rawPos] + (simtime-rawtime[rawPos]) * (raw[rawPos+1]-raw[rawPos]) / (rawtime[rawPos+1]-rawtime[rawPos]) */
-  const double x = st.num * (b - a);
-  double q;
-  /* shared axis: the denominator is uniform and comes with its correctly rounded reciprocal, so
-   * the quotient is two fused multiply-adds (Markstein; rs_math.hpp rs_div_u: the IEEE quotient
-   * for a numerator of moderate exponent - a zero numerator is +0.0 here, b - a cannot be -0.0
-   * unless b is, and then a + q is the same for either zero).  Anything else: IEEE division. */
-  const double ax = __builtin_fabs(x);
-  if (st.rden != 0.0 && !(ax >= 1e290) && !(ax > 0.0 && ax < 1e-290)) {
-    const double q0 = x * st.rden;
-    const double rem = __builtin_fma(-st.den, q0, x);
-    q = __builtin_fma(rem, st.rden, q0);
-  } else {
-    q = x / st.den;
-  }
-  v = a + q;
-  return v > thr;
+__device__ __forceinline__ double miss_r() { return rs::raw_miss(); }
+__device__ __forceinline__ double threshold(int fld) { return rs::raw_threshold(fld); }
+__device__ __forceinline__ bool source_value(const PlanStep &st, double a, double b, double thr, double &v) {
+  return rs::raw_source_value(st, a, b, thr, v);
 }
 
 /* ---- per-point time axes: JsonSource::interpolate's walk (JsonSource.cpp:57-85,113-114,171)
@@ -356,10 +309,7 @@ __global__ void __launch_bounds__(RS_BLOCK) scan_raw_kernel(const ScanArgs A) {
  * That holds for finite ends; a run with a non-finite end above the threshold is walked index by
  * index like the general scan.  ~250 segments instead of SimLen = 5 761 indices per point and
  * variable: the scan was 18 ms of a block's 35 ms before its first time step. */
-struct ScanSeg {
-  int32_t i0, i1; /* [i0, i1) */
-  int32_t kind[RS_MAX_SOURCES], rp[RS_MAX_SOURCES];
-};
+using ScanSeg = rs::RawSeg;
 
 __device__ __forceinline__ bool rs_finite(double x) { return __builtin_fabs(x) < __builtin_inf(); }
 
@@ -579,6 +529,31 @@ __global__ void __launch_bounds__(RS_BLOCK) blank_rejected_kernel(double *out, i
     for (int32_t r = 0; r < nrows; ++r) out[((int64_t)f * nrows + r) * stride + p] = -9999.0;
 }
 
+/* A few (variable, index) rows of the merged series in slot order - what the driver path still needs as
+ * ROWS once the step kernel makes its own forcing from the raw series (rs_step_raw): air temperature and
+ * road-temperature observation of index 1 for the initial profile (src/Initialization.f90:256-259), air
+ * temperature and wind speed at the three preview indices of the forecast sort key.  Shared time axes. */
+constexpr int RAWROWS_MAX = 8;
+struct RawRowsArgs {
+  SrcSet S;
+  const int32_t *status, *order; /* as ExpandRawArgs */
+  int32_t nrows;
+  int32_t fld[RAWROWS_MAX], idx[RAWROWS_MAX]; /* variable and 0-based simulation index of row y */
+  double *out[RAWROWS_MAX];                   /* [np_pad] each */
+};
+__global__ void __launch_bounds__(RS_BLOCK) raw_rows_kernel(const RawRowsArgs A) {
+  __builtin_amdgcn_s_setprio(3); /* a link of the chain between two step launches of a block: all of it is waited for */
+  const int64_t slot = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
+  const int y = blockIdx.y;
+  if (slot >= A.S.npoints || y >= A.nrows) return;
+  const int64_t p = A.order ? (int64_t)A.order[slot] : slot;
+  const int fld = A.fld[y];
+  uint32_t mask;
+  double v = merged_one(A.S, fld, p, A.idx[y], mask);
+  if (A.status && A.status[p] != 0 && fld == R_TAIR) v = miss_r(); /* a rejected point: as expand_raw_kernel */
+  A.out[y][slot] = v;
+}
+
 /* Per-point walks: position at simulation index 0 ... */
 __global__ void __launch_bounds__(RS_BLOCK) pp_init_kernel(const SrcSet S) {
   const int64_t p = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x;
@@ -705,8 +680,13 @@ void build_plan(const int64_t *rawtime, int rawLen, const std::vector<int64_t> &
       const double den = (double)(rawtime[rawPos + 1] - rawtime[rawPos]);
       /* a positive whole number of seconds below 2^53: its significand is never all ones, the
        * one case rs_div_u's reciprocal does not cover; anything else divides the IEEE way */
-      const double rden = (den >= 1.0 && den < 9.0e15) ? 1.0 / den : 0.0;
-      plan[simPos] = PlanStep{K_INTERP, rawPos, (double)(simtime[simPos] - rawtime[rawPos]), den, rden};
+      /* ... and for 0 < num < den < 2^40 (times that increase, as the reference assumes) the interpolated
+       * value provably lies between the two raw ends (rs_raw.hpp): what the segment scan and the step
+       * kernel's own interpolation (rs_kernels.hip raw_forcing) rely on; an entry outside that is marked
+       * by rden = 0 and handled index by index */
+      const double num = (double)(simtime[simPos] - rawtime[rawPos]);
+      const double rden = (den >= 1.0 && den < 1.0995e12 && num > 0.0 && num < den) ? 1.0 / den : 0.0;
+      plan[simPos] = PlanStep{K_INTERP, rawPos, num, den, rden};
       simPos++;
     }
   }
@@ -1285,8 +1265,10 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
                             const RsDriverOutput *out, int32_t device, int64_t pbeg, int64_t pend);
 
 /* tiles the calling thread's last single-device rs_driver_run stepped (tests: the window budget) */
-static thread_local int g_last_tiles = 0;
+static thread_local int g_last_tiles = 0, g_last_raw_launches = 0;
 int rs_driver_last_tiles(void) { return g_last_tiles; }
+/* ... and how many of its step launches made their forcing from the raw series (rs_step_raw) */
+int rs_driver_last_raw_launches(void) { return g_last_raw_launches; }
 
 /* device >= 0: that device.  device < 0: the points are cut into contiguous blocks over the
  * device list (rs_devices.hpp: ROADSURF_HIP_DEVICES, default every visible device), one host
@@ -1356,13 +1338,20 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
    * lock-step chunks again - with sky view too (in natural order: the per-point geometry is not
    * gathered into a plan order). */
   const bool cpl_chunked = coupled && !getenv("ROADSURF_HIP_CPL_WHOLE");
+  /* The blocks' step kernel makes its forcing from the raw series itself (rs_step_raw: the two-wavefront
+   * flavour, ground wave = JsonSource::interpolate + overlay one index ahead) wherever it can: sources on
+   * shared time axes (the segment table exists), NLayers = 15, no coupling, no output depth.  No forcing
+   * window, no expansion kernel.  ROADSURF_HIP_DRIVER_WINDOWS=1: the windows and the one-point-per-lane
+   * kernels as before (tests compare the two). */
+  const bool use_raw = !c.segs.empty() && !coupled && consts.NLayers == 15 && !(st->tsurfOutputDepth >= 0.0) &&
+                       !getenv("ROADSURF_HIP_DRIVER_WINDOWS");
   int64_t Pdef = 524288;
   if (coupled && !cpl_chunked) {
     Pdef = (int64_t)(64e9 / ((double)L * NFLD * sizeof(double)));
     Pdef = std::max<int64_t>(4096, std::min<int64_t>(262144, Pdef / 4096 * 4096));
   }
   const int P = (int)std::min<int64_t>(pend - pbeg, ep ? std::max(1, atoi(ep)) : Pdef);
-  const int TC = (coupled && !cpl_chunked) ? L : std::min(L, et ? std::max(1, atoi(et)) : 256);
+  const int TC = (coupled && !cpl_chunked) ? L : std::min(L, et ? std::max(1, atoi(et)) : use_raw ? RS_DRIVER_RAW_CHUNK : 256);
 
   /* Every buffer of a tile other than the forcing windows comes out of one block this worker keeps
    * across calls (rs_devutil.hpp: Arena): no hipMalloc / hipFree inside the tile loop.  The size is
@@ -1429,8 +1418,8 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     /* chunked coupling: the replay block spans a coupling window plus the index behind it
      * (usually more rows than a chunk); a tile whose windows are spread further re-leases below */
     const int rows0 = cpl_chunked ? std::max(TC, std::min(L, c.cplLen + 2)) : TC;
-    win_bytes = (size_t)nwin * Ppad * rows0 * sizeof(double);
-    HOK(win.acquire(win_bytes, device));
+    win_bytes = use_raw ? 0 : (size_t)nwin * Ppad * rows0 * sizeof(double);
+    if (win_bytes) HOK(win.acquire(win_bytes, device));
   }
   pt.lap(6);
   /* Budget of one worker's forcing windows.  Chunked coupling sizes its replay block from the
@@ -1441,6 +1430,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
   const size_t win_budget = eb ? (size_t)std::max(1, atoi(eb)) << 20 : (size_t)24 << 30;
   int Pcur = P;
   g_last_tiles = 0;
+  g_last_raw_launches = 0;
   const size_t arena_mark = arena.off; /* the shared axes stay; a tile's buffers go when it is done */
   for (int64_t p0 = pbeg, m_done = 0; p0 < pend; p0 += m_done) {
     m_done = 0; /* a tile that has to be cut is started again at the same p0 */
@@ -1542,7 +1532,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
       Pcur = std::max(4096, (m / 2 + 4095) / 4096 * 4096);
       continue;
     }
-    if ((size_t)nwin * mp * WR * sizeof(double) > win_bytes) {
+    if (!use_raw && (size_t)nwin * mp * WR * sizeof(double) > win_bytes) {
       win.release();
       win_bytes = (size_t)nwin * mp * WR * sizeof(double);
       HOK(win.acquire(win_bytes, device));
@@ -1551,10 +1541,12 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     /* windows */
     const size_t fs = (size_t)mp * WR;
     Dev d_phase, d_out, d_outpt;
-    HOK(d_phase.alloc(fs * sizeof(int32_t)));
-    hipLaunchKernelGGL(fill_i32_kernel, grid1((int64_t)fs), dim3(RS_BLOCK), 0, stream,
-                       d_phase.as<int32_t>(), (int64_t)fs, -9999); /* InputData.cpp:16 */
-    HOK(hipGetLastError());
+    if (!use_raw) {
+      HOK(d_phase.alloc(fs * sizeof(int32_t)));
+      hipLaunchKernelGGL(fill_i32_kernel, grid1((int64_t)fs), dim3(RS_BLOCK), 0, stream,
+                         d_phase.as<int32_t>(), (int64_t)fs, -9999); /* InputData.cpp:16 */
+      HOK(hipGetLastError());
+    }
     const size_t os = (size_t)mp * n_out;
     HOK(d_out.alloc((size_t)6 * os * sizeof(double)));
     /* OutputData.cpp:5-13: rows the simulation never saves read -9999.0 */
@@ -1568,7 +1560,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     /* window f lives at slot wslot[f] of the leased block (SW_dir / LW_net only with sky view) */
     double *wb = static_cast<double *>(win.p);
     for (int f = 0, k = 0; f < NFLD; ++f) {
-      const bool used = skyview || (f != R_SWDIR && f != R_LWNET);
+      const bool used = !use_raw && (skyview || (f != R_SWDIR && f != R_LWNET));
       ea.out[f] = used ? wb + (size_t)(k++) * fs : nullptr;
     }
     ea.status = D.status.as<int32_t>();
@@ -1728,6 +1720,26 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
       RsPreview pv;
       std::memset(&pv, 0, sizeof(pv));
       pv.n = 3;
+      if (use_raw) { /* the six rows in one launch */
+        RawRowsArgs ra;
+        std::memset(&ra, 0, sizeof(ra));
+        ra.S = S_full;
+        ra.status = ea.status;
+        ra.order = ea.order;
+        ra.nrows = 6;
+        for (int q = 0; q < 3; ++q) {
+          ra.fld[2 * q] = R_TAIR;
+          ra.fld[2 * q + 1] = R_VZ;
+          ra.idx[2 * q] = ra.idx[2 * q + 1] = idx[q] - 1;
+          ra.out[2 * q] = d_prev.as<double>() + (size_t)(2 * q) * mp;
+          ra.out[2 * q + 1] = d_prev.as<double>() + (size_t)(2 * q + 1) * mp;
+          pv.tair[q] = ra.out[2 * q];
+          pv.vz[q] = ra.out[2 * q + 1];
+          pv.hour[q] = in->hour[idx[q] - 1];
+        }
+        hipLaunchKernelGGL(raw_rows_kernel, dim3((unsigned)(mp / RS_BLOCK), 6), dim3(RS_BLOCK), 0, stream, ra);
+        HOK(hipGetLastError());
+      } else
       for (int q = 0; q < 3; ++q) {
         for (int f = 0; f < NFLD; ++f) pe.out[f] = nullptr;
         pe.out[R_TAIR] = d_prev.as<double>() + (size_t)(2 * q) * mp;
@@ -1787,6 +1799,71 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
           if (t0 + len <= L)
             if (int rc = resort(t0 + len)) return rc;
         }
+      }
+    } else if (use_raw) {
+      /* no windows: the step kernel's ground wave reads the raw series (rs_step_raw) */
+      rs::RawForcing rf;
+      std::memset(&rf, 0, sizeof(rf));
+      rf.nsrc = S_full.nsrc;
+      for (int k = 0; k < S_full.nsrc; ++k) {
+        for (int f = 0; f < NFLD; ++f) rf.src[k].fld[f] = S_full.src[k].fld[f];
+        rf.src[k].plan = S_full.src[k].plan;
+      }
+      rf.nseg = (int32_t)c.segs.size();
+      rf.segs = T.segs.as<ScanSeg>();
+      rf.np_pad = mp;
+      rf.status = D.status.as<int32_t>();
+      rf.hour = d_hour.as<int32_t>();
+      Dev d_row1;
+      HOK(d_row1.alloc((size_t)2 * mp * sizeof(double)));
+      { /* index 1's air temperature and observation, for the initial profile */
+        RawRowsArgs ra;
+        std::memset(&ra, 0, sizeof(ra));
+        ra.S = S_full;
+        ra.status = ea.status;
+        ra.order = cluster ? ea.order : nullptr;
+        ra.nrows = 2;
+        ra.fld[0] = R_TAIR;
+        ra.fld[1] = R_OBS;
+        ra.out[0] = d_row1.as<double>();
+        ra.out[1] = d_row1.as<double>() + mp;
+        hipLaunchKernelGGL(raw_rows_kernel, dim3((unsigned)(mp / RS_BLOCK), 2), dim3(RS_BLOCK), 0, stream, ra);
+        HOK(hipGetLastError());
+        RsForcing f1;
+        std::memset(&f1, 0, sizeof(f1));
+        f1.tair = f1.vz = f1.rhz = f1.prec = f1.sw = f1.lw = ra.out[0]; /* (only tair and tsurfobs are read) */
+        f1.tsurfobs = ra.out[1];
+        f1.precphase = reinterpret_cast<const int32_t *>(ra.out[0]);
+        f1.hour = d_hour.as<int32_t>();
+        f1.t_stride = mp;
+        if (rs_hip_init_state(pg.p, &f1, cluster ? &pps : &pp) != 0) return -12;
+      }
+      size_t seg = 0;
+      for (int t0 = 1; t0 <= L; t0 += TC) {
+        const int len = std::min(TC, L - t0 + 1);
+        while (seg + 1 < c.segs.size() && c.segs[seg].i1 <= t0 - 1) ++seg;
+        rf.seg0 = (int32_t)seg;
+        rf.col = cluster ? ea.order : nullptr;
+        const double *sunrows = skyview ? d_sun.as<double>() + (size_t)(t0 - 1) * RS_SUN_COLS : nullptr;
+        if (!cluster) {
+          if (rs_step_raw(pg.p, &rf, sunrows, &oo, &pp, t0, len) != 0) return -13;
+          ++g_last_raw_launches;
+          continue;
+        }
+        const int64_t r_first = ((int64_t)t0 - 1 + step - 1) / step;
+        const int64_t r_last = ((int64_t)t0 + len - 2) / step;
+        oc.row0 = r_first;
+        if (rs_step_raw(pg.p, &rf, sunrows, &oc, &pps, t0, len) != 0) return -13;
+        ++g_last_raw_launches;
+        if (r_last >= r_first) {
+          hipLaunchKernelGGL(unpermute_rows_kernel, dim3((unsigned)(mp / RS_BLOCK), 6), dim3(RS_BLOCK), 0,
+                             stream, ea.order, (int64_t)m, (const double *)d_outc.as<double>(),
+                             (int64_t)rows_c, ob, (int64_t)n_out, r_first, (int32_t)(r_last - r_first + 1),
+                             (int64_t)mp);
+          HOK(hipGetLastError());
+        }
+        if (t0 + len <= L)
+          if (int rc = resort_for(t0 + len, std::min(TC, L - (t0 + len) + 1))) return rc;
       }
     } else
     for (int t0 = 1; t0 <= L; t0 += TC) {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "../../include/roadsurf.h"
 #include "rs_synth.h"
+#include "rs_raw.hpp"
 
 #define RS_BLOCK 256
 
@@ -67,6 +68,10 @@ struct StepArgs {
   const int32_t *knot_gather;
   int32_t knot_k0, knot_n, spk, start_hour;
   double r_spk;
+  /* two-wavefront flavour behind rs_driver_run (rs_step_raw): no forcing window either - the ground wave
+   * makes the forcing of the next index from the RAW series (JsonSource::interpolate + the GetWeather
+   * overlay, rs_raw.hpp); raw.nsrc = 0: not this launch */
+  RawForcing raw;
 };
 
 struct InitArgs {
@@ -120,6 +125,14 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
                           hipStream_t stream);
 /* the two-wavefront flavour with the forcing made from the knots in the kernel (StepArgs::knots) */
 hipError_t rs_launch_step_duo_knots(const rs::StepArgs &a, bool score, hipStream_t stream);
+/* ... and from the raw series of the driver path (StepArgs::raw); sky: per-point sky view on the ground wave */
+hipError_t rs_launch_step_duo_raw(const rs::StepArgs &a, bool score, bool sky, hipStream_t stream);
+/* the step of rs_driver_run's blocks (rs_api.hip): NLayers = 15, fp64, no coupling, no output depth; pp in
+ * SLOT order, raw series in point order behind raw.col */
+struct RsPlan;
+bool rs_step_raw_ok(const RsPlan *pl); /* a plan whose settings rs_step_raw can run */
+int rs_step_raw(RsPlan *pl, const rs::RawForcing *raw, const double *sun, const RsOutputs *o,
+                const RsPointParams *pp, int32_t t0, int32_t nsteps);
 hipError_t rs_launch_step_cpl_replay(const rs::StepArgs &a, int NL, hipStream_t stream);
 hipError_t rs_launch_step_coupled(const rs::StepArgs &a, int NL, hipStream_t stream);
 hipError_t rs_launch_step_cpl(const rs::StepArgs &a, int NL, hipStream_t stream);

@@ -1231,24 +1231,30 @@ struct DuoMail {
   uint32_t prep_bad[2][64];
 };
 
-template <bool FULL>
+template <bool FULL, bool SKYG = false>
 __device__ __forceinline__ void duo_put_prep(DuoMail &mail, int buf, uint32_t lane, const ForcingPrep &q) {
   double (*w)[64] = mail.prep[buf];
   w[0][lane] = q.tair; w[1][lane] = q.vz; w[2][lane] = q.rhz; w[3][lane] = q.rain; w[4][lane] = q.snow;
   w[5][lane] = q.AirDens; w[6][lane] = q.AirHCap; w[7][lane] = q.PsychC;
-  w[8][lane] = q.EAir; w[9][lane] = q.sw; w[10][lane] = q.lw;
+  w[8][lane] = q.EAir;
+  if (!SKYG) { /* (SKYG: the radiation is the sky wave's to hand over, duo_sky) */
+    w[9][lane] = q.sw;
+    w[10][lane] = q.lw;
+  }
   if (FULL) w[11][lane] = q.tsurfobs;
   mail.prep_bad[buf][lane] = (q.bad ? 1u : 0u) | (q.night ? 2u : 0u);
 }
-template <bool FULL, class C>
-__device__ __forceinline__ ForcingPrep duo_get_prep(const C &c, const DuoMail &mail, int buf, uint32_t lane) {
+template <bool FULL, bool SKYG = false, class C>
+__device__ __forceinline__ ForcingPrep duo_get_prep(const C &c, const DuoMail &mail, int buf, uint32_t lane,
+                                                    const uint32_t *skyfl = nullptr) {
   const double (*w)[64] = mail.prep[buf];
   ForcingPrep q;
   q.tair = w[0][lane]; q.vz = w[1][lane]; q.rhz = w[2][lane]; q.rain = w[3][lane]; q.snow = w[4][lane];
   q.AirDens = w[5][lane]; q.AirHCap = w[6][lane]; q.PsychC = w[7][lane];
   q.EAir = w[8][lane]; q.sw = w[9][lane]; q.lw = w[10][lane];
   if (FULL) q.tsurfobs = w[11][lane];
-  const uint32_t flags = mail.prep_bad[buf][lane];
+  uint32_t flags = mail.prep_bad[buf][lane];
+  if (SKYG) flags |= skyfl[buf * 64 + lane]; /* the sky wave's share of CheckValues (bit 0) and its `stop` (bit 2) */
   { /* both constants first (scalar loads), then the lane picks a VALUE: see fluxes_pre */
     const double fricN = c.TrfFricNgt, fricD = c.TrFfricDay;
     q.night = (flags & 2u) != 0u;
@@ -1260,6 +1266,7 @@ __device__ __forceinline__ ForcingPrep duo_get_prep(const C &c, const DuoMail &m
   q.vkvz = c.VK_Const * q.vz;
   q.avk = AirVCap * c.VK_Const;
   q.bad = (flags & 1u) != 0u;
+  q.stop = SKYG && (flags & 4u) != 0u; /* only an instance with a sky wave raises it */
   return q;
 }
 
@@ -1271,9 +1278,13 @@ __device__ __forceinline__ void duo_meet() { asm volatile("s_waitcnt lgkmcnt(0)\
  * 151-162) as the lock-step loop has them - the surface wave reads SW_dir and LW_net of the index itself (two
  * coalesced loads), runs CheckValues' sky-view tests and ModRadiationBySurroundings on the short- and long-wave
  * radiation the ground wave handed over, and writes the reference's in-place edits back where asked to. */
-template <int NL, bool SCORE, bool FULL = false, bool SKY = false>
-__device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, const StepArgs &a) {
+/* SKYG: a third wavefront does the sky view (duo_sky, the raw-series flavour): this wave gets the radiation as
+ * the sky view leaves it and the sky wave's flags beside the ground wave's. */
+template <int NL, bool SCORE, bool FULL = false, bool SKY = false, bool SKYG = false>
+__device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, const StepArgs &a,
+                                            const uint32_t *skyfl = nullptr) {
   static_assert(FULL || !SKY, "sky view belongs to the FULL feature set");
+  static_assert(!(SKY && SKYG), "the sky view is this wave's or the ground wave's");
   KernArgs ka = kernargs();
   const uint32_t lane = threadIdx.x & 63u;
   /* the workgroup's slots: 64 from 64 * blockIdx.x, or what the wave table says (rs_cluster_wave_table) */
@@ -1332,13 +1343,18 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
     const bool owrite = output_row<true>(ka, i, orow);
     const double t3 = mail.v[k & 1][1][lane]; /* Tmp(3) as the last step left it */
     if (!s.failed) {
-      const ForcingPrep q = duo_get_prep<FULL>(c, mail, k & 1, lane);
+      const ForcingPrep q = duo_get_prep<FULL, SKYG>(c, mail, k & 1, lane, skyfl);
       if (i < c.SimLen) { /* CheckValues: the forcing's verdict | the surface temperature's */
         if (q.bad | check_values_tsurf(c, s.tsurf)) {
           s.failed = true;
           ka->state[(int64_t)RS_ST_FAILED * ka->np_pad + row0 + lane] = (double)i;
           mail.failed[lane] = 1u; /* this index still steps (the ground wave is in it already); the next does not */
         }
+      }
+      if (SKYG && q.stop) { /* as duo_surface<SKY> flags it: at any index */
+        s.failed = true;
+        ka->state[(int64_t)RS_ST_FAILED * ka->np_pad + row0 + lane] = (double)i;
+        mail.failed[lane] = 1u;
       }
       s.tnw1 = T.get(1);
       s.tnw2 = T.get(2);
@@ -1477,14 +1493,194 @@ __device__ __forceinline__ Forcing knot_forcing(KernArgs ka, int64_t col, bool l
   return f;
 }
 
+/* ---- the forcing from the RAW series (rs_driver_run's blocks, rs_step_raw) ---------------------------
+ * What the driver path's expansion kernel wrote into forcing windows, the ground wave now forms in
+ * registers, one index ahead of the surface wave: per variable JsonSource::interpolate's value of every
+ * source (examples/example1/src/JsonSource.cpp:86-170), GetWeather's own test of it (:337-356) and the
+ * overlay in source order (DataHandler.cpp:75-84), value for value as rs_raw.hpp raw_source_value has them.
+ * The sources share their time axes, so which raw interval an index falls into and whether it copies or
+ * interpolates there is the same for every point: a SEGMENT (RawSeg) is a run of indices over which every
+ * source keeps its (kind, rawPos).  At the first index of a segment the wavefront RESOLVES each variable:
+ * every lane loads its two raw ends of every source that has the variable (its column of the series, through
+ * the plan's order row), applies the supply test (a copy: raw > threshold; an interpolation: both ends >
+ * threshold - the value then lies between them, RawPlanStep::rden) and keeps the ends of the LAST source that
+ * supplies.  Where all 64 lanes agree on that source - the rule, not the exception: whether a source has a
+ * variable at a time is a property of the data set - the variable costs five instructions per index,
+ * v0 + RN(num (v1 - v0) / den) with the source's uniform (num, den, 1/den) on the scalar unit; a copy, or a
+ * variable nobody supplies, is v0 + 0.  Anything else - lanes that disagree, a non-finite end, a difference
+ * so large or so small that the division by reciprocal is not the IEEE one, a raw -0.0 to be copied, a plan
+ * entry with rden = 0 - is evaluated index by index with raw_source_value itself (RAW_SLOW). */
+/* Who evaluates which variables: the ground wave alone {tair, vz, rhz, prec, tdew, tsurfobs, sw, lw}
+ * (FSET_ALL); with per-point sky view the ground wave the first six of them (FSET_GROUND) and the sky wave
+ * {sw, lw, sw_dir, lw_net} (FSET_SKY, duo_sky). */
+enum { FSET_ALL = 0, FSET_GROUND = 1, FSET_SKY = 2 };
+__device__ __forceinline__ constexpr int raw_nfields(int fset) { return fset == FSET_ALL ? 8 : fset == FSET_GROUND ? 6 : 4; }
+__device__ __forceinline__ constexpr int raw_field_of(int fset, int q) {
+  return fset == FSET_SKY ? (q == 0 ? RAW_SW : q == 1 ? RAW_LW : q == 2 ? RAW_SWDIR : RAW_LWNET)
+                          : (q == 0 ? RAW_TAIR : q == 1 ? RAW_VZ : q == 2 ? RAW_RHZ : q == 3 ? RAW_PREC
+                             : q == 4 ? RAW_TDEW : q == 5 ? RAW_OBS : q == 6 ? RAW_SW : RAW_LW);
+}
+constexpr int kRawObs = 5; /* tsurfobs in FSET_ALL / FSET_GROUND */
+template <int NF>
+struct RawLerp {
+  double v0[NF], dv[NF];
+  /* uniform: bit 10 s + q: variable q is interpolated from source s in this segment (s = 4: copied, or
+   * missing: v0 + 0); bit 50 + q: index by index (RAW_SLOW) */
+  uint64_t mode;
+  int32_t seg, seg_end; /* current segment and its end (0-based, exclusive) */
+};
+
+/* one variable of one point at 0-based index i, the long way: every source, every test */
+__device__ __forceinline__ double raw_slow_value(KernArgs ka, int fld, int64_t col, int32_t i) {
+  const double thr = raw_threshold(fld);
+  double v = raw_miss();
+  const int nsrc = ka->raw.nsrc;
+  const int64_t np = ka->raw.np_pad;
+  for (int s = 0; s < nsrc; ++s) {
+    const double *x = ka->raw.src[s].fld[fld];
+    if (!x) continue;
+    const RawPlanStep st = raw_plan_at(ka->raw.src[s].plan, i);
+    if (st.kind == RAW_NONE) continue;
+    const double a = x[(int64_t)st.rp * np + col], b = x[(int64_t)(st.rp + 1) * np + col];
+    double vs;
+    if (raw_source_value(st, a, b, thr, vs)) v = vs;
+  }
+  return v;
+}
+
+template <int FSET>
+__device__ __forceinline__ void raw_resolve(KernArgs ka, int64_t col, bool live, RawLerp<raw_nfields(FSET)> &R) {
+  constexpr int NF = raw_nfields(FSET);
+  const RawSeg __attribute__((address_space(4))) *sg =
+      (const RawSeg __attribute__((address_space(4))) *)ka->raw.segs + R.seg;
+  R.seg_end = sg->i1;
+  const int32_t i0 = sg->i0;
+  const int nsrc = ka->raw.nsrc;
+  const int64_t np = ka->raw.np_pad;
+  uint64_t mode = 0;
+#pragma unroll
+  for (int q = 0; q < NF; ++q) {
+    const int fld = raw_field_of(FSET, q);
+    const double thr = raw_threshold(fld);
+    int32_t wl = 4;  /* the lane's winner: a source that interpolates, or 4 (copy / nobody) */
+    bool okl = true; /* ... and its ends allow the short form */
+    double a_w = raw_miss(), d_w = 0.0;
+    for (int s = 0; s < nsrc; ++s) {
+      const double *x = ka->raw.src[s].fld[fld];
+      const int32_t kind = sg->kind[s], rp = sg->rp[s];
+      if (!x || kind == RAW_NONE) continue; /* uniform */
+      const double *xa = x + (int64_t)rp * np + col;
+      const double a = *xa; /* (a dead lane reads column 0) */
+      if (kind == RAW_COPY) {
+        if (a > thr) {
+          wl = 4;
+          a_w = a;
+          d_w = 0.0;
+          okl = !rs_is_neg_zero(a); /* v0 + 0 would lose the sign */
+        }
+      } else {
+        const double b = xa[np];
+        if (a > thr && b > thr) {
+          const double d = b - a;
+          const double den = raw_plan_at(ka->raw.src[s].plan, i0).den;
+          const double ad = __builtin_fabs(d);
+          wl = s;
+          a_w = a;
+          d_w = d;
+          /* |num d| stays inside the range in which the division by reciprocal is the IEEE one for every
+           * 1 <= num < den of the segment (raw_source_value's own test, once per segment) */
+          okl = (__builtin_fabs(a) < __builtin_inf()) && (__builtin_fabs(b) < __builtin_inf()) &&
+                (den * ad < 1e290) && (d == 0.0 || ad >= 1e-290);
+        }
+      }
+    }
+    const int32_t w0 = __builtin_amdgcn_readfirstlane(wl); /* lane 0 is never a dead lane */
+    const bool uni = __builtin_amdgcn_ballot_w64(live && (wl != w0 || !okl)) == 0ull;
+    mode |= uni ? (1ull << (10 * w0 + q)) : (1ull << (50 + q));
+    R.v0[q] = a_w;
+    R.dv[q] = d_w;
+  }
+  R.mode = mode;
+}
+
+/* The merged raw values of the set's variables at (1-based) index i, in val[].  `need_obs` (FSET_ALL /
+ * FSET_GROUND): the step can use the road-temperature observation (initialization phase or force_tsurf),
+ * else val[kRawObs] is left unset. */
+template <int FSET>
+__device__ __forceinline__ void raw_values(KernArgs ka, int64_t col, bool live, RawLerp<raw_nfields(FSET)> &R,
+                                           int32_t i, bool need_obs, double (&val)[raw_nfields(FSET)]) {
+  constexpr int NF = raw_nfields(FSET);
+  const int32_t t = i - 1;
+  if (t >= R.seg_end) { /* uniform: a new segment (a segment is never empty) */
+    R.seg += 1;
+    raw_resolve<FSET>(ka, col, live, R);
+  }
+#pragma unroll
+  for (int q = 0; q < NF; ++q) asm volatile("" : "=v"(val[q])); /* each is written by exactly one block below */
+  const uint32_t keep = (FSET != FSET_SKY && !need_obs) ? ~(1u << kRawObs) : ~0u;
+  uint32_t slow = (uint32_t)(R.mode >> 50) & 1023u & keep;
+  for (int s = 0; s < RS_MAX_SOURCES; ++s) {
+    const uint32_t m = (uint32_t)(R.mode >> (10 * s)) & 1023u & keep;
+    if (m == 0u) continue;
+    const RawPlanStep st = raw_plan_at(ka->raw.src[s].plan, t);
+    if (st.rden == 0.0) { /* this entry promises nothing (rs_raw.hpp): the long way for this index */
+      slow |= m;
+      continue;
+    }
+#pragma unroll
+    for (int q = 0; q < NF; ++q)
+      if (m & (1u << q)) val[q] = R.v0[q] + raw_quot(st.num * R.dv[q], st.den, st.rden);
+  }
+  {
+    const uint32_t m = (uint32_t)(R.mode >> 40) & 1023u & keep;
+#pragma unroll
+    for (int q = 0; q < NF; ++q)
+      if (m & (1u << q)) val[q] = R.v0[q] + 0.0; /* a copy, or missing: what the short form gives for dv = 0 */
+  }
+  if (slow) {
+#pragma unroll
+    for (int q = 0; q < NF; ++q)
+      if (slow & (1u << q)) val[q] = raw_slow_value(ka, raw_field_of(FSET, q), col, t);
+  }
+}
+
+/* The forcing of index i for the ground wave.  FSET_GROUND: the short- and long-wave radiation are the
+ * sky wave's (duo_sky: it tests them and hands them on); here they read 0, inside every bound of CheckValues. */
+template <int FSET>
+__device__ __forceinline__ Forcing raw_forcing(KernArgs ka, int64_t col, bool live, bool rejected,
+                                               RawLerp<raw_nfields(FSET)> &R, int32_t i, bool need_obs) {
+  double val[raw_nfields(FSET)];
+  raw_values<FSET>(ka, col, live, R, i, need_obs, val);
+  Forcing f;
+  f.tair = rejected ? raw_miss() : val[0];
+  f.vz = val[1];
+  f.rhz = val[2];
+  f.prec = val[3];
+  f.tdew = val[4];
+  f.tsurfobs = need_obs ? val[kRawObs] : raw_miss();
+  f.sw = FSET == FSET_ALL ? val[FSET == FSET_ALL ? 6 : 0] : 0.0;
+  f.lw = FSET == FSET_ALL ? val[FSET == FSET_ALL ? 7 : 0] : 0.0;
+  f.phase = -9999; /* InputData.cpp:16: the driver never hands PrecPhase on */
+  f.hour = ((const int32_t __attribute__((address_space(4))) *)ka->raw.hour)[i - 1]; /* uniform: a scalar load */
+  f.depth = raw_miss(); /* InputData.cpp:18 */
+  return f;
+}
+
 /* FULL: the FULL feature set without sky view, coupling, a depth stream or tsurfOutputDepth (what the
  * launcher checks): the optional streams, the initialization phase and relaxation.  The ground wave owns
  * what they add to the forcing's share of a step - CheckValues' dew-point test, whether the observation
  * is forced on Tmp(1:2) at an index (it needs the forced Tmp(2) itself, for the flux into layer 3), and
  * RelaxationOperations (src/Relaxation.f90:10-47: the anchors at the end of the initialization, which go
  * to the state block there and then, and the decaying correction behind it). */
-template <int NL, bool KNOTS = false, bool FULL = false>
+enum { SRC_WINDOW = 0, SRC_KNOTS = 1, SRC_RAW = 2 }; /* where the ground wave's forcing comes from */
+/* SKYG (with SRC_RAW): the launch has per-point sky view and a THIRD wavefront for it (duo_sky): the short- and
+ * long-wave radiation, their share of CheckValues and ModRadiationBySurroundings are that wave's; this one
+ * makes the other six variables. */
+template <int NL, int SRC = SRC_WINDOW, bool FULL = false, bool SKYG = false>
 __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, const StepArgs &a) {
+  constexpr bool KNOTS = SRC == SRC_KNOTS, RAW = SRC == SRC_RAW;
+  static_assert(!RAW || FULL, "the driver's series carry the FULL feature set");
+  static_assert(!SKYG || RAW, "a sky wave exists only where the forcing is made from the raw series");
   KernArgs ka = kernargs();
   const uint32_t lane = threadIdx.x & 63u;
   const int64_t row0 = a.wave_start ? (int64_t)a.wave_start[blockIdx.x] : (int64_t)blockIdx.x * 64;
@@ -1526,7 +1722,7 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
   auto prep = [&](const ConstsAS &c, const Forcing &f, int32_t in, double &obs) -> ForcingPrep {
     if (!FULL) return forcing_prep(c, mt, f, in, in < c.SimLen);
     bool bad;
-    const bool has_tdew = KNOTS ? (ka->duo_full_ok & 2) != 0 : ka->f.tdew != nullptr;
+    const bool has_tdew = RAW ? true : KNOTS ? (ka->duo_full_ok & 2) != 0 : ka->f.tdew != nullptr;
     double vz = forcing_prep_head(c, f, in, in < c.SimLen, has_tdew, bad);
     double tair = f.tair, rhz = f.rhz;
     obs = R4(-9999.9);
@@ -1570,11 +1766,26 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
   KnotLerp<FULL> klerp;
   int32_t kcur = -1;
   const int64_t kcol = (KNOTS && live) ? (ka->knot_gather ? (int64_t)ka->knot_gather[p] : p) : 0;
+  /* RAW: the point's column of the raw series, read_input's verdict on it, the segment of the first index */
+  constexpr int FSET = SKYG ? FSET_GROUND : FSET_ALL;
+  RawLerp<raw_nfields(FSET)> rlerp;
+  const int64_t rcol = (RAW && live) ? (ka->raw.col ? (int64_t)ka->raw.col[p] : p) : 0;
+  const bool rejected = RAW && live && ka->raw.status && ka->raw.status[rcol] != 0;
+  /* the observation can act at index `in`: SetCurrentValues' own condition (src/InputOutput.f90:116-121),
+   * for the whole wavefront */
+  auto obs_wanted = [&](const ConstsAS &c, int32_t in) -> bool {
+    return c.force_tsurf || __builtin_amdgcn_ballot_w64(live && in <= initlen) != 0ull;
+  };
+  if (RAW) {
+    rlerp.seg = ka->raw.seg0;
+    raw_resolve<FSET>(ka, rcol, live, rlerp);
+  }
   {
     const ConstsAS &c0 = consts_of(ka);
     if (KNOTS) nxt = knot_forcing<FULL>(ka, kcol, live, klerp, kcur, t0);
+    else if (RAW) nxt = raw_forcing<FSET>(ka, rcol, live, rejected, rlerp, t0, obs_wanted(c0, t0));
     else if (live) nxt = load_forcing<FULL, true>(ka, row0, lane, 0);
-    duo_put_prep<FULL>(mail, 0, lane, prep(c0, nxt, t0, obs_cur));
+    duo_put_prep<FULL, SKYG>(mail, 0, lane, prep(c0, nxt, t0, obs_cur));
   }
   duo_meet();
   for (int32_t kv = 0; kv < nsteps; ++kv) {
@@ -1582,7 +1793,7 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
     const ConstsAS &c = consts_of(ka);
     const int32_t k = __builtin_amdgcn_readfirstlane(kv);
     /* next index's forcing: fetched here, used behind the layers */
-    if (!KNOTS && k + 1 < nsteps && live) nxt = load_forcing<FULL, true>(ka, row0, lane, k + 1);
+    if (!KNOTS && !RAW && k + 1 < nsteps && live) nxt = load_forcing<FULL, true>(ka, row0, lane, k + 1);
     double t2 = mail.v[k & 1][0][lane]; /* Tmp(2) as the last step left it (melting included) */
     /* a failed point takes no further step in any flavour: its Tmp(3..N) stay as the failing index left
      * them (the flag was raised before the barrier that ended that index) */
@@ -1609,7 +1820,8 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
     if (k + 1 < nsteps) {
       const int32_t in = t0 + k + 1;
       if (KNOTS) nxt = knot_forcing<FULL>(ka, kcol, live, klerp, kcur, in);
-      duo_put_prep<FULL>(mail, (k & 1) ^ 1, lane, prep(c, nxt, in, obs_cur));
+      if (RAW) nxt = raw_forcing<FSET>(ka, rcol, live, rejected, rlerp, in, obs_wanted(c, in));
+      duo_put_prep<FULL, SKYG>(mail, (k & 1) ^ 1, lane, prep(c, nxt, in, obs_cur));
     }
     duo_meet();
   }
@@ -1619,22 +1831,97 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
   }
 }
 
-template <int NL, bool SCORE, bool KNOTS = false, bool FULL = false, bool SKY = false>
-__global__ void __launch_bounds__(128, 4) step_kernel_duo(const StepArgs a) {
+/* The sky wave: third wavefront of the workgroup in launches with per-point sky view whose forcing comes from
+ * the raw series.  CheckValues' tests of the radiation, the SW_dir clamp and ModRadiationBySurroundings with the
+ * sun's position (src/InputOutput.f90:45-84, src/ModRadiation.f90:7-73, src/SunPosition.f90:123-193; examples/
+ * example1/src/Simulation.f90:151-162) depend on the forcing and the point's geometry alone: like the rest of
+ * the forcing's share of a step they are worked out one index AHEAD, here - four variables from the raw series
+ * (global and direct short wave, long wave, net long wave), the tests, the sky view - and the surface wave
+ * receives the radiation as the sky view leaves it (mailbox values 9 and 10) plus this wave's flags.  Done on
+ * the ground wave, beside thirteen layers and the other six variables, the sky view spilled 86-106 registers;
+ * on the surface wave it lengthens the step's serial chain. */
+__device__ __forceinline__ void duo_sky(DuoMail &mail, uint32_t *skyfl, const StepArgs &a) {
+  KernArgs ka = kernargs();
+  const uint32_t lane = threadIdx.x & 63u;
+  const int64_t row0 = a.wave_start ? (int64_t)a.wave_start[blockIdx.x] : (int64_t)blockIdx.x * 64;
+  const int64_t p = row0 + lane;
+  const bool live = a.wave_start ? (int32_t)lane < a.wave_cnt[blockIdx.x] : p < a.npoints;
+  double skyv = R4(1.0), sinlat = 0, coslat = 0, lonrad = 0, coslon = 1.0, sinlon = 0;
+  bool sky_on = false;
+  uint32_t hcol = 0;
+  if (live) { /* as time_loop<SKY> sets the point up */
+    skyv = ka->pp.sky_view[p];
+    sky_on = (skyv < R4(1.0) && skyv > R4(-0.01));
+    if (sky_on) {
+      sinlat = ka->pp.sin_lat[p];
+      coslat = ka->pp.cos_lat[p];
+      lonrad = ka->pp.lon_rad[p];
+      coslon = ::cos(lonrad);
+      sinlon = ::sin(lonrad);
+    }
+    hcol = ka->pp.horizon_index ? (uint32_t)ka->pp.horizon_index[p] : (uint32_t)p;
+  }
+  const int64_t rcol = live ? (ka->raw.col ? (int64_t)ka->raw.col[p] : p) : 0;
+  RawLerp<4> R;
+  R.seg = ka->raw.seg0;
+  raw_resolve<FSET_SKY>(ka, rcol, live, R);
+  const int32_t nsteps = ka->nsteps, t0 = ka->t0;
+  auto put = [&](int buf, int32_t in) {
+    const ConstsAS &c = consts_of(ka);
+    double val[4];
+    raw_values<FSET_SKY>(ka, rcol, live, R, in, false, val);
+    double sw = val[0], lw = val[1], sw_dir = val[2], lw_net = val[3];
+    bool bad = false, stop = false;
+    if (in < c.SimLen) {
+      /* check_values_forcing's tests of SW and LW (the ground wave runs the others with 0 in their place) */
+      bad = (sw < c.chk[1]) | (lw < c.chk[1]) | (sw > c.chk[5]) | (lw > c.chk[6]);
+      if (sky_on && (sw_dir < R4(-0.1) || sw_dir > R4(4000.0) || lw_net < R4(-1000.0) || lw_net > R4(1000.0)))
+        bad = true; /* src/InputOutput.f90:68-74 */
+      if (sw_dir > sw) sw_dir = sw; /* :75-77 */
+    }
+    if (sky_on) {
+      const double *sunrow = ka->f.sun + (int64_t)(in - t0) * RS_SUN_COLS;
+      if (!sky_view_radiation(sunrow, sinlat, coslat, lonrad, coslon, sinlon, skyv, ka->pp.albedo_surroundings,
+                              ka->pp.horizons ? ka->pp.horizons + (ka->pp.horizons_by_point ? (int64_t)hcol * 360 : (int64_t)hcol) : nullptr,
+                              ka->pp.horizons_by_point ? (int64_t)1 : ka->np_pad, sw, sw_dir, lw, lw_net))
+        stop = true; /* the reference would `stop` the process here: the point is failed at this index, checked or not */
+    }
+    mail.prep[buf][9][lane] = sw;
+    mail.prep[buf][10][lane] = lw;
+    skyfl[buf * 64 + lane] = (bad ? 1u : 0u) | (stop ? 4u : 0u);
+  };
+  put(0, t0);
+  duo_meet();
+  for (int32_t kv = 0; kv < nsteps; ++kv) {
+    asm volatile("" : "+s"(ka));
+    const int32_t k = __builtin_amdgcn_readfirstlane(kv);
+    if (k + 1 < nsteps) put((k & 1) ^ 1, t0 + k + 1);
+    duo_meet();
+  }
+}
+
+/* SRC: SRC_WINDOW / SRC_KNOTS / SRC_RAW.  SKY: per-point sky view - on the surface wave (forcing windows)
+ * or, with SRC_RAW, on a third wavefront (duo_sky). */
+template <int NL, bool SCORE, int SRC = SRC_WINDOW, bool FULL = false, bool SKY = false>
+__global__ void __launch_bounds__((SKY && SRC == SRC_RAW) ? 192 : 128, 4) step_kernel_duo(const StepArgs a) {
+  constexpr bool SKYG = SKY && SRC == SRC_RAW;
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
   __shared__ DuoMail mail;
+  __shared__ uint32_t skyfl[SKYG ? 2 * 64 : 1]; /* duo_sky's flags, [buffer][lane] */
   const MathTab mt = fill_math_tables(math_lds);
   __syncthreads();
-  /* no early return: both wavefronts walk to every barrier, lanes beyond npoints are dead weight.
+  /* no early return: the wavefronts walk to every barrier, lanes beyond npoints are dead weight.
    * (Dealing the roles by the parity of the hardware wave slot or of the workgroup index, so that every
    * SIMD hosts both kinds, was measured: 1.08e10 and 1.13e10 against 1.12e10 with fixed roles at
    * 125 000 points - nothing to gain.) */
-  if (a.wave_start && a.wave_cnt[blockIdx.x] == 0) return; /* a spare workgroup of the wave table: both wavefronts leave */
+  if (a.wave_start && a.wave_cnt[blockIdx.x] == 0) return; /* a spare workgroup of the wave table: all wavefronts leave */
   if (threadIdx.x < 64) {
     if (a.surface_prio) __builtin_amdgcn_s_setprio(1); /* the longer chain of the two issues first (StepArgs::surface_prio) */
-    duo_surface<NL, SCORE, FULL, SKY>(mt, mail, a);
+    duo_surface<NL, SCORE, FULL, SKY && !SKYG, SKYG>(mt, mail, a, skyfl);
+  } else if (!SKYG || threadIdx.x < 128) {
+    duo_ground<NL, SRC, FULL, SKYG>(mt, mail, a);
   } else {
-    duo_ground<NL, KNOTS, FULL>(mt, mail, a);
+    duo_sky(mail, skyfl, a);
   }
 }
 
@@ -2265,8 +2552,8 @@ hipError_t rs_launch_step_sky(const rs::StepArgs &a, int NL, bool score, hipStre
   const bool duo_auto = !e && NL == 15 && a.npoints <= duo_max;
   if ((m == 5 || duo_auto) && (a.duo_full_ok & 4)) {
     const dim3 gd(a.wave_start ? (unsigned)a.wave_n : (unsigned)((a.npoints + 63) / 64));
-    if (score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, false, true, true>), gd, dim3(128), 0, stream, a);
-    else hipLaunchKernelGGL((rs::step_kernel_duo<15, false, false, true, true>), gd, dim3(128), 0, stream, a);
+    if (score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, rs::SRC_WINDOW, true, true>), gd, dim3(128), 0, stream, a);
+    else hipLaunchKernelGGL((rs::step_kernel_duo<15, false, rs::SRC_WINDOW, true, true>), gd, dim3(128), 0, stream, a);
     return hipGetLastError();
   }
   if (m == 4 || m == 5) hipLaunchKernelGGL((rs::step_kernel_sky_h<4>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
@@ -2286,10 +2573,19 @@ static int cpl_profile_mode(int NL) {
 hipError_t rs_launch_step_duo_knots(const rs::StepArgs &a, bool score, hipStream_t stream) {
   const dim3 gd(a.wave_start ? (unsigned)a.wave_n : (unsigned)((a.npoints + 63) / 64));
   const bool full = (a.duo_full_ok & 1) != 0;
-  if (full && score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, true, true>), gd, dim3(128), 0, stream, a);
-  else if (full) hipLaunchKernelGGL((rs::step_kernel_duo<15, false, true, true>), gd, dim3(128), 0, stream, a);
-  else if (score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, true>), gd, dim3(128), 0, stream, a);
-  else hipLaunchKernelGGL((rs::step_kernel_duo<15, false, true>), gd, dim3(128), 0, stream, a);
+  if (full && score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, rs::SRC_KNOTS, true>), gd, dim3(128), 0, stream, a);
+  else if (full) hipLaunchKernelGGL((rs::step_kernel_duo<15, false, rs::SRC_KNOTS, true>), gd, dim3(128), 0, stream, a);
+  else if (score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, rs::SRC_KNOTS>), gd, dim3(128), 0, stream, a);
+  else hipLaunchKernelGGL((rs::step_kernel_duo<15, false, rs::SRC_KNOTS>), gd, dim3(128), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t rs_launch_step_duo_raw(const rs::StepArgs &a, bool score, bool sky, hipStream_t stream) {
+  const dim3 gd(a.wave_start ? (unsigned)a.wave_n : (unsigned)((a.npoints + 63) / 64));
+  if (sky && score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, rs::SRC_RAW, true, true>), gd, dim3(192), 0, stream, a);
+  else if (sky) hipLaunchKernelGGL((rs::step_kernel_duo<15, false, rs::SRC_RAW, true, true>), gd, dim3(192), 0, stream, a);
+  else if (score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, rs::SRC_RAW, true>), gd, dim3(128), 0, stream, a);
+  else hipLaunchKernelGGL((rs::step_kernel_duo<15, false, rs::SRC_RAW, true>), gd, dim3(128), 0, stream, a);
   return hipGetLastError();
 }
 
@@ -2359,8 +2655,8 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
     wpe = 0;
   } else if (variant == RS_VARIANT_DUO || (auto_variant && wpe == 0 && duo_ok && a.npoints <= duo_max)) {
     const dim3 gd(a.wave_start ? (unsigned)a.wave_n : (unsigned)((a.npoints + 63) / 64));
-    if (full && score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, false, true>), gd, dim3(128), 0, stream, a);
-    else if (full) hipLaunchKernelGGL((rs::step_kernel_duo<15, false, false, true>), gd, dim3(128), 0, stream, a);
+    if (full && score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, rs::SRC_WINDOW, true>), gd, dim3(128), 0, stream, a);
+    else if (full) hipLaunchKernelGGL((rs::step_kernel_duo<15, false, rs::SRC_WINDOW, true>), gd, dim3(128), 0, stream, a);
     else if (score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true>), gd, dim3(128), 0, stream, a);
     else hipLaunchKernelGGL((rs::step_kernel_duo<15, false>), gd, dim3(128), 0, stream, a);
     return hipGetLastError();

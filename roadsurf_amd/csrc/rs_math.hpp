@@ -249,6 +249,7 @@ __device__ __forceinline__ double rs_sq(double x) {
 /* x is +0.0, by its bits (x == 0 would admit -0.0) */
 __device__ __forceinline__ bool rs_is_pos_zero(double x) { return __double_as_longlong(x) == 0; }
 __device__ __forceinline__ bool rs_is_pos_zero(float x) { return __float_as_int(x) == 0; }
+__device__ __forceinline__ bool rs_is_neg_zero(double x) { return __double_as_longlong(x) == (long long)0x8000000000000000ull; }
 /* true in every ACTIVE lane of the wavefront (lanes that have left the time step do not vote) */
 __device__ __forceinline__ bool rs_wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
 

@@ -148,6 +148,50 @@ def test_run_matches_checker_bitwise(mode, monkeypatch):
         assert moved > (~rejected).sum() // 2     # coupling really acts
 
 
+@pytest.mark.parametrize("mode", ["relaxation", "skyview"])
+def test_step_kernel_reads_the_raw_series(mode, monkeypatch):
+    """rs_driver_run's blocks step with the two-wavefront kernel whose ground wave makes the forcing from the
+    raw series itself (JsonSource::interpolate + the GetWeather overlay in registers, rs_raw.hpp; with sky view
+    a third wavefront for the radiation): no forcing window, no expansion kernel.  Same bits as the window
+    flavour (ROADSURF_HIP_DRIVER_WINDOWS=1) and as the checker - also where the short form cannot be used:
+    lanes of a wavefront whose observations are missing in different places, an infinite raw value, a raw
+    -0.0 that is copied, and every launch boundary position relative to the raw times."""
+    n = 500
+    src, L, t0, tf = dh.scenario(n, hours=12, seed=29)
+    src[0].fields["tair"][7, 3] = np.inf       # poisons two raw intervals of one point
+    src[0].fields["prec"][9, 4] = -0.0          # copied at a raw time: the sign must survive
+    src[0].fields["sw"][11, 5] = np.inf
+    src[1].fields["vz"][13, 2] = np.inf
+    s = _settings(L, outputStep=10, use_relaxation=1)
+    p = abi.default_parameters()
+    local, hz = None, None
+    if mode == "skyview":
+        rs = np.random.RandomState(5)
+        local = []
+        for i in range(n):
+            lp = abi.default_local()
+            lp.lat, lp.lon = 60.0 + rs.uniform(0, 8), 21.0 + rs.uniform(0, 8)
+            lp.sky_view = float(rs.uniform(0.3, 1.0)) if i % 4 else 1.0
+            local.append(lp)
+        hz = rs.uniform(0, 25, (n, 360))
+    o = dh.oracle_run("port", src, s, p, t0, tf, local=local, horizons=hz)
+    L_ = lib.load()
+    for chunk in (256, 97, 1):
+        if chunk == 1 and mode == "skyview":
+            continue
+        monkeypatch.setenv("ROADSURF_HIP_CHUNK_STEPS", str(chunk) if chunk > 1 else str(L))
+        g = driver.run(src, s, p, t0, tf, local=local, horizons=hz, device=0)
+        assert L_.rs_driver_last_raw_launches() == (-(-L // chunk) if chunk > 1 else 1)
+        monkeypatch.setenv("ROADSURF_HIP_DRIVER_WINDOWS", "1")
+        w = driver.run(src, s, p, t0, tf, local=local, horizons=hz, device=0)
+        assert L_.rs_driver_last_raw_launches() == 0
+        monkeypatch.delenv("ROADSURF_HIP_DRIVER_WINDOWS")
+        assert np.array_equal(g["status"], o["status"]) and np.array_equal(w["status"], o["status"])
+        for k in driver.OUT_FIELDS:
+            assert _same_bits(g[k], w[k]), (mode, chunk, k, int((g[k] != w[k]).sum()))
+            assert _same_bits(g[k], o[k]), (mode, chunk, k, int((g[k] != o[k]).sum()))
+
+
 def test_tiling_does_not_change_results(monkeypatch):
     n = 333
     src, L, t0, tf = dh.scenario(n, hours=6, seed=5, obs_hours=3)
