@@ -825,9 +825,9 @@ int rs_hip_step_knots(RsPlan *pl, const RsSynthSpec *spec, const double *knots, 
  * (pp->sky_view with the geometry, the horizon table and `sun` = rs_sun_table rows from index t0 on): the
  * ground wave runs CheckValues' sky-view tests and ModRadiationBySurroundings too (they depend on the
  * forcing and the geometry alone, src/ModRadiation.f90:7-73).  pp in SLOT order; raw series in point order
- * behind raw->col. */
+ * behind raw->col; out_by_point: the output rows leave in point order whatever the slots' order. */
 int rs_step_raw(RsPlan *pl, const rs::RawForcing *raw, const double *sun, const RsOutputs *o,
-                const RsPointParams *pp, int32_t t0, int32_t nsteps) {
+                const RsPointParams *pp, int32_t t0, int32_t nsteps, bool out_by_point) {
   if (!pl || !raw || raw->nsrc < 1 || raw->nsrc > RS_MAX_SOURCES || !raw->segs || !raw->hour)
     return set_err("rs_step_raw: bad arguments");
   if (!pp || !pp->tbottom || !pp->initlen) return set_err("rs_step_raw: tbottom and initlen are required");
@@ -867,6 +867,8 @@ int rs_step_raw(RsPlan *pl, const rs::RawForcing *raw, const double *sun, const 
   a.duo_full_ok = 3; /* the driver's series always carry a dew point (completed from the humidity where absent) */
   a.surface_prio = underfilled(pl);
   a.raw = *raw;
+  /* out_by_point: the rows of slot s go to column order[s] of `o` (scattered stores: meant for decimated rows) */
+  a.out_index = (out_by_point && pl->order) ? pl->order : nullptr;
   const hipError_t le = rs_launch_step_duo_raw(a, pl->history_score, sky, pl->stream);
   if (le != hipSuccess) return set_err("rs_step_raw: kernel launch failed: %s", hipGetErrorString(le));
   return 0;

@@ -1604,11 +1604,13 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
       pps.lon_rad = d_geo_s.as<double>() + 3 * mp;
     }
     if (cluster) {
-      HOK(d_outc.alloc((size_t)6 * rows_c * mp * sizeof(double)));
-      double *cb = d_outc.as<double>();
-      const size_t cs = (size_t)rows_c * mp;
-      oc.tsurf = cb; oc.snow = cb + cs; oc.water = cb + 2 * cs; oc.ice = cb + 3 * cs;
-      oc.deposit = cb + 4 * cs; oc.ice2 = cb + 5 * cs;
+      if (!use_raw) { /* (the raw-series step kernel writes its rows straight into point order) */
+        HOK(d_outc.alloc((size_t)6 * rows_c * mp * sizeof(double)));
+        double *cb = d_outc.as<double>();
+        const size_t cs = (size_t)rows_c * mp;
+        oc.tsurf = cb; oc.snow = cb + cs; oc.water = cb + 2 * cs; oc.ice = cb + 3 * cs;
+        oc.deposit = cb + 4 * cs; oc.ice2 = cb + 5 * cs;
+      }
       /* slot-order copies: 4 doubles (3 relaxation targets, coupling observation), 2 int32 */
       HOK(d_pp_s.alloc((size_t)mp * (2 * sizeof(int32_t) + 4 * sizeof(double))));
       double *pd = d_pp_s.as<double>();
@@ -1845,23 +1847,10 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
         rf.seg0 = (int32_t)seg;
         rf.col = cluster ? ea.order : nullptr;
         const double *sunrows = skyview ? d_sun.as<double>() + (size_t)(t0 - 1) * RS_SUN_COLS : nullptr;
-        if (!cluster) {
-          if (rs_step_raw(pg.p, &rf, sunrows, &oo, &pp, t0, len) != 0) return -13;
-          ++g_last_raw_launches;
-          continue;
-        }
-        const int64_t r_first = ((int64_t)t0 - 1 + step - 1) / step;
-        const int64_t r_last = ((int64_t)t0 + len - 2) / step;
-        oc.row0 = r_first;
-        if (rs_step_raw(pg.p, &rf, sunrows, &oc, &pps, t0, len) != 0) return -13;
+        /* the (decimated) rows of a launch go straight to their point's column of the result */
+        if (rs_step_raw(pg.p, &rf, sunrows, &oo, cluster ? &pps : &pp, t0, len, cluster) != 0) return -13;
         ++g_last_raw_launches;
-        if (r_last >= r_first) {
-          hipLaunchKernelGGL(unpermute_rows_kernel, dim3((unsigned)(mp / RS_BLOCK), 6), dim3(RS_BLOCK), 0,
-                             stream, ea.order, (int64_t)m, (const double *)d_outc.as<double>(),
-                             (int64_t)rows_c, ob, (int64_t)n_out, r_first, (int32_t)(r_last - r_first + 1),
-                             (int64_t)mp);
-          HOK(hipGetLastError());
-        }
+        if (!cluster) continue;
         if (t0 + len <= L)
           if (int rc = resort_for(t0 + len, std::min(TC, L - (t0 + len) + 1))) return rc;
       }

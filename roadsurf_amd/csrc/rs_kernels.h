@@ -132,7 +132,7 @@ hipError_t rs_launch_step_duo_raw(const rs::StepArgs &a, bool score, bool sky, h
 struct RsPlan;
 bool rs_step_raw_ok(const RsPlan *pl); /* a plan whose settings rs_step_raw can run */
 int rs_step_raw(RsPlan *pl, const rs::RawForcing *raw, const double *sun, const RsOutputs *o,
-                const RsPointParams *pp, int32_t t0, int32_t nsteps);
+                const RsPointParams *pp, int32_t t0, int32_t nsteps, bool out_by_point);
 hipError_t rs_launch_step_cpl_replay(const rs::StepArgs &a, int NL, hipStream_t stream);
 hipError_t rs_launch_step_coupled(const rs::StepArgs &a, int NL, hipStream_t stream);
 hipError_t rs_launch_step_cpl(const rs::StepArgs &a, int NL, hipStream_t stream);

@@ -1280,7 +1280,9 @@ __device__ __forceinline__ void duo_meet() { asm volatile("s_waitcnt lgkmcnt(0)\
  * radiation the ground wave handed over, and writes the reference's in-place edits back where asked to. */
 /* SKYG: a third wavefront does the sky view (duo_sky, the raw-series flavour): this wave gets the radiation as
  * the sky view leaves it and the sky wave's flags beside the ground wave's. */
-template <int NL, bool SCORE, bool FULL = false, bool SKY = false, bool SKYG = false>
+/* OUTIDX: the launch may ask for its output rows in POINT order (StepArgs::out_index, the plan's order row:
+ * the decimated rows of rs_driver_run go straight to their point's column, no copy kernel behind the launch). */
+template <int NL, bool SCORE, bool FULL = false, bool SKY = false, bool SKYG = false, bool OUTIDX = false>
 __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, const StepArgs &a,
                                             const uint32_t *skyfl = nullptr) {
   static_assert(FULL || !SKY, "sky view belongs to the FULL feature set");
@@ -1327,7 +1329,10 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
   auto blank_rows = [&](int32_t i_from) { /* as in time_loop */
     for (int32_t ii = i_from; ii < t0 + nsteps; ++ii) {
       int64_t r;
-      if (output_row<false>(ka, ii, r)) store_outputs<false, false>(ka, r, row0, lane, s, false);
+      if (output_row<false>(ka, ii, r)) {
+        if (OUTIDX && ka->out_index) store_outputs<true, false>(ka, r, row0, lane, s, false);
+        else store_outputs<false, false>(ka, r, row0, lane, s, false);
+      }
     }
   };
   if (live && s.failed) blank_rows(t0);
@@ -1413,7 +1418,10 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
       }
       /* layers 1-2 with Tmp(3) where a two-layer column has its lower boundary */
       model_step_ground<RegProfile<2>, RegProfile<2>, false>(c, s, T, t3, tair, fx, R4(-9999.9));
-      if (owrite) store_outputs<false, true>(ka, orow, row0, lane, s, true);
+      if (owrite) {
+        if (OUTIDX && ka->out_index) store_outputs<true, false>(ka, orow, row0, lane, s, true);
+        else store_outputs<false, true>(ka, orow, row0, lane, s, true);
+      }
       if (s.failed) blank_rows(i + 1);
     }
     mail.v[(k & 1) ^ 1][0][lane] = T.get(2);
@@ -1527,6 +1535,11 @@ struct RawLerp {
   /* uniform: bit 10 s + q: variable q is interpolated from source s in this segment (s = 4: copied, or
    * missing: v0 + 0); bit 50 + q: index by index (RAW_SLOW) */
   uint64_t mode;
+  /* uniform: >= 0: nothing is evaluated index by index in this segment and at most ONE source interpolates
+   * (that one; 4: none - every variable is copied or missing): the whole set is one straight line of
+   * v0 + RN(num dv / den) with that source's scalars - for a copied or missing variable dv = 0 and the term is
+   * +0, as in the general form.  The rule outside the hours in which observations overlay the forecast. */
+  int32_t single;
   int32_t seg, seg_end; /* current segment and its end (0-based, exclusive) */
 };
 
@@ -1601,6 +1614,10 @@ __device__ __forceinline__ void raw_resolve(KernArgs ka, int64_t col, bool live,
     R.dv[q] = d_w;
   }
   R.mode = mode;
+  int32_t single = ((mode >> 50) & 1023ull) ? -1 : 4;
+  for (int s = 0; s < RS_MAX_SOURCES; ++s)
+    if ((mode >> (10 * s)) & 1023ull) single = (single == 4) ? s : -1;
+  R.single = single;
 }
 
 /* The merged raw values of the set's variables at (1-based) index i, in val[].  `need_obs` (FSET_ALL /
@@ -1615,10 +1632,25 @@ __device__ __forceinline__ void raw_values(KernArgs ka, int64_t col, bool live, 
     R.seg += 1;
     raw_resolve<FSET>(ka, col, live, R);
   }
+  if (R.single >= 0) { /* uniform */
+    double num = 0.0, den = 1.0, rden = 1.0;
+    if (R.single < RS_MAX_SOURCES) {
+      const RawPlanStep st = raw_plan_at(ka->raw.src[R.single].plan, t);
+      num = st.num;
+      den = st.den;
+      rden = st.rden;
+    }
+    if (rden != 0.0) {
+#pragma unroll
+      for (int q = 0; q < NF; ++q) val[q] = R.v0[q] + raw_quot(num * R.dv[q], den, rden);
+      return;
+    }
+  }
 #pragma unroll
   for (int q = 0; q < NF; ++q) asm volatile("" : "=v"(val[q])); /* each is written by exactly one block below */
   const uint32_t keep = (FSET != FSET_SKY && !need_obs) ? ~(1u << kRawObs) : ~0u;
   uint32_t slow = (uint32_t)(R.mode >> 50) & 1023u & keep;
+#pragma nounroll
   for (int s = 0; s < RS_MAX_SOURCES; ++s) {
     const uint32_t m = (uint32_t)(R.mode >> (10 * s)) & 1023u & keep;
     if (m == 0u) continue;
@@ -1917,7 +1949,7 @@ __global__ void __launch_bounds__((SKY && SRC == SRC_RAW) ? 192 : 128, 4) step_k
   if (a.wave_start && a.wave_cnt[blockIdx.x] == 0) return; /* a spare workgroup of the wave table: all wavefronts leave */
   if (threadIdx.x < 64) {
     if (a.surface_prio) __builtin_amdgcn_s_setprio(1); /* the longer chain of the two issues first (StepArgs::surface_prio) */
-    duo_surface<NL, SCORE, FULL, SKY && !SKYG, SKYG>(mt, mail, a, skyfl);
+    duo_surface<NL, SCORE, FULL, SKY && !SKYG, SKYG, SRC == SRC_RAW>(mt, mail, a, skyfl);
   } else if (!SKYG || threadIdx.x < 128) {
     duo_ground<NL, SRC, FULL, SKYG>(mt, mail, a);
   } else {

@@ -25,7 +25,7 @@ for b in blocks[1:]:
     if pat not in dem:
         continue
     dem = re.sub(r"\(rs::StepArgs\)|void |rs::", "", dem)
-    rows.append((dem, g("vgpr_count"), g("vgpr_spill_count"), g("sgpr_count"), g("sgpr_spill_count"), g("group_segment_fixed_size"), g("private_segment_fixed_size")))
+    rows.append((dem if dem else name, g("vgpr_count"), g("vgpr_spill_count"), g("sgpr_count"), g("sgpr_spill_count"), g("group_segment_fixed_size"), g("private_segment_fixed_size")))
 print(f"{'kernel':70s} {'vgpr':>5s} {'vspill':>6s} {'sgpr':>5s} {'sspill':>6s} {'lds':>6s} {'scratch':>7s}")
 for r in sorted(rows):
     print(f"{r[0][:70]:70s} {r[1]:>5s} {r[2]:>6s} {r[3]:>5s} {r[4]:>6s} {r[5]:>6s} {r[6]:>7s}")
