@@ -113,6 +113,52 @@ def measured_traffic(points: int, chunk: int, plans: int, f32: bool):
     return t.get("traffic_bytes_per_launch"), t.get("derived"), name, None
 
 
+def host_batch_leg(n: int, simlen: int, seed: int) -> dict:
+    """runsimulation_batch (the Fortran entry over the C-ABI shim) on `n` synthetic points held as the
+    reference holds them: one array per point and variable at step resolution, outputs at every index."""
+    import ctypes as C
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_helpers as oh
+    from roadsurf_amd import abi, lib as rslib
+
+    L = rslib.load()
+    f = oh.synth_forcing(n, simlen, seed=seed)
+    out = {k: np.empty((n, simlen)) for k in oh.F64_OUT}
+    s = abi.default_settings(simlen)
+    p = abi.default_parameters()
+    l = abi.default_local()
+    l.InitLenI = 1
+    ips = (abi.InputPointers * n)()
+    ops = (abi.OutputPointers * n)()
+    keep = []
+    for pt in range(n):
+        ips[pt], ops[pt], kp = oh.point_pointers(f, pt, out)
+        keep.append(kp)
+    larr = (abi.LocalParameters * n)(*([l] * n))
+    st = C.c_int32(0)
+    times = []
+    for rep in range(4):
+        t = time.perf_counter()
+        L.runsimulation_batch(n, ops, ips, C.byref(s), C.byref(p), larr, C.byref(st))
+        dt = time.perf_counter() - t
+        if st.value != 0:
+            raise RuntimeError(f"runsimulation_batch: {rslib.last_error()}")
+        if rep:
+            times.append(dt)
+    mean = sum(times) / len(times)
+    bytes_per_unit = 11 * 8 + 2 * 4 + 6 * 8
+    return {"value": n * simlen / mean, "unit": "point-timesteps/s", "seconds_per_call": mean,
+            "seconds_per_call_all": times, "calls_timed": len(times), "calls_warm": 1,
+            "boundary_GBps": n * simlen * bytes_per_unit / mean / 1e9,
+            "config": {"workload": f"runsimulation_batch: {n} synthetic points x SimLen {simlen} from step-resolution "
+                                   "host arrays (one per point and variable, as the reference driver holds them), "
+                                   "LEAN feature set, outputs at every index back in host arrays",
+                       "value_is": "mean of the timed calls", "pcie_inclusive": True,
+                       "bytes_over_the_boundary_per_unit": bytes_per_unit}}
+
+
 class ClockProbe:
     """Engine clock of the GPU while the timed passes run: rs_hip_clock_probe kernels (one wavefront
     that reads the shader-clock counter and the constant 100 MHz counter about 0.2 ms apart) enqueued
@@ -201,9 +247,12 @@ def main() -> None:
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the short extra legs of the default run (N = 1, fp64, LEAN headline only): the FULL "
                          "feature set on the same synthetic points (full_feature_value) and the driver data path "
-                         "rs_driver_run with relaxation / coupling / sky view (driver_path_*_value)")
+                         "rs_driver_run with relaxation / coupling / sky view (driver_path_*_value), and runsimulation_batch "
+                         "from step-resolution host arrays (host_batch_value)")
     ap.add_argument("--extra-points", type=int, default=1_000_000,
                     help="points of the driver-path legs (host arrays in, hourly outputs back: PCIe inclusive)")
+    ap.add_argument("--host-batch-points", type=int, default=32768,
+                    help="points of the runsimulation_batch leg (step-resolution host arrays in and out)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16384)
     args = ap.parse_args()
@@ -446,11 +495,15 @@ def main() -> None:
 
         if not (os.environ.get("ROADSURF_HIP_DEVICES") or os.environ.get("ROADSURF_HIP_DEVICE")):
             os.environ["ROADSURF_HIP_DEVICE"] = str(dev_index)  # the library's fan-out stays on THIS GPU
-        dw = driver_workload.DriverWorkload(args.extra_points, args.hours, unique=65536)
+        # distinct series for every point (tiles of 65 536 series put identical lanes side by
+        # side after the forecast sort) and the MEAN of three timed calls, like the headline's mean over passes
+        dw = driver_workload.DriverWorkload(args.extra_points, args.hours, unique=None)
         for mode in ("relax", "coupling", "skyview"):
-            best, times, r = dw.time_calls(mode, reps=2, warm=1, device=-1)
+            best, times, r = dw.time_calls(mode, reps=3, warm=1, device=-1)
+            mean = sum(times) / len(times)
             extra["driver_path_" + ("sky" if mode == "skyview" else mode)] = {
-                "value": dw.n * dw.simlen / best, "unit": "point-timesteps/s", "seconds_per_call": best,
+                "value": dw.n * dw.simlen / mean, "unit": "point-timesteps/s", "seconds_per_call": mean,
+                "seconds_per_call_all": times, "best_call_value": dw.n * dw.simlen / best,
                 "calls_timed": len(times), "calls_warm": 1, "points_ok": int((r["status"] == 0).sum()),
                 "config": {"workload": f"rs_driver_run: {dw.n} points x {args.hours} h (SimLen {dw.simlen}) from raw series "
                                        f"in pageable host arrays (hourly forecast + 10-minute observations over the "
@@ -459,11 +512,19 @@ def main() -> None:
                                        f"mode {mode}: relaxation"
                                        + (", coupling" if mode == "coupling" else "")
                                        + (", per-point sky view and local horizons" if mode == "skyview" else ""),
+                           "series": "distinct for every point (generated once, before the timed calls)",
+                           "value_is": "mean of the timed calls",
                            "pcie_inclusive": True, "raw_input_bytes": dw.raw_bytes(mode),
+                           "forcing_window": "with coupling only" if mode == "coupling" else
+                                             "none: the step kernel's ground wavefront interpolates and overlays the "
+                                             "raw series itself (rs_step_raw)",
                            "blocks_per_device": int(os.environ.get("ROADSURF_HIP_PLANS_PER_DEVICE", "4"))},
             }
             del r
         del dw
+        # (3) the drop-in batch entry from STEP-RESOLUTION host arrays (runsimulation_batch: 11 f64 + 2 i32 in,
+        # 6 f64 out per point and index over the boundary): PCIe-bound by construction
+        extra["host_batch"] = host_batch_leg(args.host_batch_points, simlen, args.seed)
         extra["seconds"] = time.perf_counter() - t_x
     # dominant kernel: step kernel, HIP events on its own stream around every launch (this rank).
     # achieved = algorithmic bytes of the launches / time the device spent in them.  With one plan
