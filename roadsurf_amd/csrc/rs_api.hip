@@ -1107,6 +1107,16 @@ int rs_hip_div_samples(RsPlan *pl, double *out) {
   return 0;
 }
 
+/* experiment builds with -DRS_BL_STATS (`make blstats`): rs_math.hpp g_bl_stats; zeros otherwise */
+int rs_hip_bl_stats(RsPlan *pl, int64_t *out) {
+  if (!pl || !out) return set_err("rs_hip_bl_stats: bad arguments");
+  HIP_OK(hipSetDevice(pl->device));
+  unsigned long long v[8];
+  HIP_OK(rs_read_bl_stats(v, pl->stream));
+  for (int k = 0; k < 8; ++k) out[k] = (int64_t)v[k];
+  return 0;
+}
+
 int rs_hip_division_mode(void) {
 #if defined(RS_IEEE_DIV)
   return 0;

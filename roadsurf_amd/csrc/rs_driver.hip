@@ -796,10 +796,25 @@ struct TileRaw {
 struct TileLanding {
   size_t off[RS_MAX_SOURCES][NFLD + 1] = {}; /* byte offset of (source, field) in the landing block; NFLD: the times */
   bool has[RS_MAX_SOURCES][NFLD + 1] = {};
+  /* copies issued on a stream of their own (the worker's copy stream): landed[s][f] is recorded behind the
+   * copy of (source, field), and the worker's stream waits for it before it touches the piece - the
+   * transposes of the first fields run while the last fields are still on the link (round 5: a block's first
+   * step launch used to wait for all copies AND then all transposes, 16 + 6 ms at 250 000 points) */
+  hipEvent_t landed[RS_MAX_SOURCES][NFLD + 1] = {};
+  bool transposed[RS_MAX_SOURCES][NFLD] = {}; /* upload_copies has issued the piece's transpose already */
+  hipEvent_t extra[2] = {nullptr, nullptr};    /* tile start, horizons landed */
+  bool async = false;
+  ~TileLanding() {
+    for (auto &row : landed)
+      for (hipEvent_t e : row)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : extra)
+      if (e) (void)hipEventDestroy(e);
+  }
 };
 
 int upload_copies(const RsDriverInput *in, const Common &c, int64_t p0, int m, int64_t mp,
-                  TileRaw &T, TileLanding &Ld, hipStream_t stream) {
+                  TileRaw &T, TileLanding &Ld, hipStream_t stream, hipStream_t work = nullptr) {
   size_t total = 0;
   for (int s = 0; s < c.nsrc; ++s) {
     const RsRawSource &rs = in->sources[s];
@@ -821,15 +836,32 @@ int upload_copies(const RsDriverInput *in, const Common &c, int64_t p0, int m, i
   char *base = T.stage.as<char>();
   for (int s = 0; s < c.nsrc; ++s) {
     const RsRawSource &rs = in->sources[s];
-    if (Ld.has[s][NFLD])
+    if (Ld.has[s][NFLD]) {
       HOK(hipMemcpyAsync(base + Ld.off[s][NFLD], rs.times + (size_t)p0 * rs.n_times,
                          (size_t)m * rs.n_times * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+      if (Ld.async) {
+        HOK(hipEventCreateWithFlags(&Ld.landed[s][NFLD], hipEventDisableTiming));
+        HOK(hipEventRecord(Ld.landed[s][NFLD], stream));
+      }
+    }
     for (int f = 0; f < NFLD; ++f)
-      if (Ld.has[s][f])
+      if (Ld.has[s][f]) {
         HOK(hipMemcpyAsync(base + Ld.off[s][f], raw_field(rs, f) + (size_t)p0 * rs.n_times,
                            (size_t)m * rs.n_times * sizeof(double), hipMemcpyHostToDevice, stream));
+        if (Ld.async) {
+          HOK(hipEventCreateWithFlags(&Ld.landed[s][f], hipEventDisableTiming));
+          HOK(hipEventRecord(Ld.landed[s][f], stream));
+          if (work) { /* the piece's transpose right behind it, on the worker's stream, beside the next copy
+                         (a copy from pageable memory returns when its bytes are on their way) */
+            HOK(T.fld[s][f].alloc((size_t)rs.n_times * mp * sizeof(double)));
+            HOK(hipStreamWaitEvent(work, Ld.landed[s][f], 0));
+            HOK(transpose(reinterpret_cast<const double *>(base + Ld.off[s][f]), T.fld[s][f].as<double>(), m,
+                          rs.n_times, rs.n_times, mp, work));
+            Ld.transposed[s][f] = true;
+          }
+        }
+      }
   }
-  (void)mp;
   return 0;
 }
 
@@ -854,6 +886,7 @@ int upload_finish(const RsDriverInput *in, const Common &c, int64_t p0, int m, i
     if (rs.times_per_point && rs.n_times > 0) {
       /* per-point axes: times [m][n_times] -> [n_times][mp], lengths, walk positions */
       HOK(T.ptimes[s].alloc((size_t)rs.n_times * mp * sizeof(int64_t)));
+      if (Ld.landed[s][NFLD]) HOK(hipStreamWaitEvent(stream, Ld.landed[s][NFLD], 0));
       HOK(transpose(reinterpret_cast<const int64_t *>(base + Ld.off[s][NFLD]), T.ptimes[s].as<int64_t>(), m,
                     rs.n_times, rs.n_times, mp, stream));
       HOK(T.plen[s].alloc(mp * sizeof(int32_t)));
@@ -884,9 +917,14 @@ int upload_finish(const RsDriverInput *in, const Common &c, int64_t p0, int m, i
       const bool derived = (f == R_TDEW && rs.rhz && rs.tair) || (f == R_RHZ && rs.tdew && rs.tair);
       if ((!h && !derived) || rs.n_times == 0) continue;
       const size_t ne = (size_t)rs.n_times * mp;
+      if (h && Ld.transposed[s][f]) {
+        d.fld[f] = T.fld[s][f].as<double>();
+        continue;
+      }
       HOK(T.fld[s][f].alloc(ne * sizeof(double)));
       double *dst = T.fld[s][f].as<double>();
       if (h) {
+        if (Ld.landed[s][f]) HOK(hipStreamWaitEvent(stream, Ld.landed[s][f], 0));
         HOK(transpose(reinterpret_cast<const double *>(base + Ld.off[s][f]), dst, m, rs.n_times, rs.n_times,
                       mp, stream));
       } else {
@@ -1318,9 +1356,10 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     return fail_msg("rs_driver_run: bad settings (NLayers in 5..32, SimLen >= 1, DTSecs > 0)", -1);
   if (int rc = check_device(device)) return rc;
   HOK(hipSetDevice(device));
-  StreamGuard sg;
+  StreamGuard sg, sg_copy;
   HOK(hipStreamCreate(&sg.s));
-  hipStream_t stream = sg.s;
+  HOK(hipStreamCreate(&sg_copy.s)); /* the uploads of a tile: TileLanding */
+  hipStream_t stream = sg.s, copy_stream = sg_copy.s;
 
   const int L = c.L;
   const bool coupled = st->use_coupling == 1;
@@ -1401,10 +1440,11 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     rs_sun_table(L, in->year, in->month, in->day, in->hour, in->minute, in->second, sun.data());
     HOK(d_sun.alloc(sun.size() * sizeof(double)));
     HOK(hipMemcpyAsync(d_sun.p, sun.data(), sun.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-    slat.resize(c.n);
-    clat.resize(c.n);
-    lrad.resize(c.n);
-    rs_point_geometry(c.n, local, slat.data(), clat.data(), lrad.data());
+    /* (this worker's points only: index q of the three vectors is point pbeg + q) */
+    slat.resize(pend - pbeg);
+    clat.resize(pend - pbeg);
+    lrad.resize(pend - pbeg);
+    rs_point_geometry((int32_t)(pend - pbeg), local + pbeg, slat.data(), clat.data(), lrad.data());
   }
 
   PhaseTimer pt(stream);
@@ -1442,18 +1482,44 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     const int64_t mp = rs_hip_plan_npoints_padded(pg.p);
     TileRaw T;
     TileLanding landing;
+    Dev d_hzpt;
     {
       const double tg0 = PhaseTimer::now();
       std::lock_guard<std::mutex> turn(rsu::copy_gate(device)); /* rs_devices.hpp: uploads take turns */
       const double tg1 = PhaseTimer::now();
-      if (int rc = upload_copies(in, c, p0, m, mp, T, landing, stream)) return rc;
+      /* ROADSURF_HIP_UPLOAD_INLINE=1 (A/B): copies and transposes one after the other on the worker's stream */
+      static const bool inline_upload = getenv("ROADSURF_HIP_UPLOAD_INLINE") != nullptr;
+      landing.async = !inline_upload;
+      hipStream_t cs = inline_upload ? stream : copy_stream;
+      if (!inline_upload) { /* the landing block comes out of the arena the last tile's kernels may still be reading */
+        HOK(hipEventCreateWithFlags(&landing.extra[0], hipEventDisableTiming));
+        HOK(hipEventRecord(landing.extra[0], stream));
+        HOK(hipStreamWaitEvent(copy_stream, landing.extra[0], 0));
+      }
+      if (int rc = upload_copies(in, c, p0, m, mp, T, landing, cs, inline_upload ? nullptr : stream)) return rc;
+      /* the tile's local horizons (2.9 KB per point: as many bytes as all the series together) in the same
+       * turn on the link, so that the block's first launch waits for ITS bytes only - enqueued later, the
+       * copy shared the link with the next block's series and the first step started 58 ms into the call */
+      if (skyview && in->horizons) {
+        HOK(d_hzpt.alloc((size_t)m * 360 * sizeof(double)));
+        HOK(hipMemcpyAsync(d_hzpt.p, in->horizons + (size_t)p0 * 360, (size_t)m * 360 * sizeof(double),
+                           hipMemcpyHostToDevice, cs));
+      }
+      if (inline_upload) HOK(hipStreamSynchronize(stream));
+      /* the worker's own stream starts on the pieces as they land (upload_finish); the turn on the link
+       * ends when the last byte has */
+      if (int rc = upload_finish(in, c, p0, m, mp, T, landing, stream)) return rc;
       const double tg2 = PhaseTimer::now();
-      HOK(hipStreamSynchronize(stream));
+      HOK(hipStreamSynchronize(cs));
+      if (!inline_upload && skyview && in->horizons) { /* (the copy is done: the event orders the worker's stream behind it) */
+        HOK(hipEventCreateWithFlags(&landing.extra[1], hipEventDisableTiming));
+        HOK(hipEventRecord(landing.extra[1], copy_stream));
+        HOK(hipStreamWaitEvent(stream, landing.extra[1], 0));
+      }
       if (pt.on)
         fprintf(stderr, "rs_driver_run upload: waited %.1f ms for the link, issued the copies in %.1f ms, "
                         "drained in %.1f ms\n", 1e3 * (tg1 - tg0), 1e3 * (tg2 - tg1), 1e3 * (PhaseTimer::now() - tg2));
     }
-    if (int rc = upload_finish(in, c, p0, m, mp, T, landing, stream)) return rc;
     pt.lap(1);
     TileDecisions D;
     if (int rc = decide_tile(c, st, T, D, stream)) return rc;
@@ -1465,7 +1531,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     pt.lap(2);
 
     /* per-point parameters */
-    Dev d_tb, d_geo, d_hzpt;
+    Dev d_tb, d_geo;
     HOK(d_tb.alloc(mp * sizeof(double)));
     hipLaunchKernelGGL(fill_f64_kernel, grid1(mp), dim3(RS_BLOCK), 0, stream, d_tb.as<double>(), mp,
                        tbottom);
@@ -1488,9 +1554,9 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
       std::vector<double> g((size_t)4 * mp, 1.0);
       for (int p = 0; p < m; ++p) {
         g[p] = local[p0 + p].sky_view;
-        g[(size_t)mp + p] = slat[p0 + p];
-        g[(size_t)2 * mp + p] = clat[p0 + p];
-        g[(size_t)3 * mp + p] = lrad[p0 + p];
+        g[(size_t)mp + p] = slat[p0 - pbeg + p];
+        g[(size_t)2 * mp + p] = clat[p0 - pbeg + p];
+        g[(size_t)3 * mp + p] = lrad[p0 - pbeg + p];
       }
       HOK(hipMemcpyAsync(d_geo.p, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice, stream));
       HOK(hipStreamSynchronize(stream)); /* g goes out of scope */
@@ -1504,12 +1570,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
        * at all where the caller has none (the kernels read a missing table as 0) */
       pp.horizons = nullptr;
       pp.horizons_by_point = 1;
-      if (in->horizons) {
-        HOK(d_hzpt.alloc((size_t)m * 360 * sizeof(double)));
-        HOK(hipMemcpyAsync(d_hzpt.p, in->horizons + (size_t)p0 * 360, (size_t)m * 360 * sizeof(double),
-                           hipMemcpyHostToDevice, stream));
-        pp.horizons = d_hzpt.as<double>();
-      }
+      if (in->horizons) pp.horizons = d_hzpt.as<double>(); /* (uploaded with the series, above) */
     }
 
     /* chunked coupling: where the tile's coupling windows lie (the decisions are back in `local`) */

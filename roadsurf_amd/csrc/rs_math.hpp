@@ -122,6 +122,10 @@ __device__ __forceinline__ MathTab fill_math_tables(double *lds) {
  * [1]: one of them inf/NaN - x/0, x/inf, inf/x, where the bare sequence
  * gives NaN: the operands the boundary-layer guard exists for (rs_physics_body.inc) */
 static __device__ unsigned long long g_div_mismatch[3] = {0ull, 0ull, 0ull};
+/* -DRS_BL_STATS (an experiment build, `make blstats`): how often the boundary-layer fixed point repeats its
+ * bits before the fifth pass - [0] wave-steps, [1] lane-steps, [2..4] wave-steps in which EVERY active lane's
+ * (PSIM, PSIH) came out of pass 2 / 3 / 4 as they went in, [5..7] the same counted per lane */
+static __device__ unsigned long long g_bl_stats[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
 /* the first RS_DIV_SAMPLES finite mismatches: {numerator (or sqrt argument), denominator (0 for
  * sqrt), IEEE result, bare result} */
 #define RS_DIV_SAMPLES 64
