@@ -724,7 +724,33 @@ int rs_driver_expand(const RsDriverInput *in, const InputSettings *settings,
                      LocalParameters *local, double *merged, int32_t *status,
                      int32_t *missing_index, int32_t device);
 
-#define RS_ABI_VERSION 6 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles; 4: RsPointParams::horizon_index, rs_hip_step_knots; 5: RS_SUN_COLS 6, RsPointParams::horizons_by_point; 6: rs_driver_last_raw_launches (rs_driver_run without forcing windows) */
+/* ------------------------------------------------------------------------
+ * Layer 5: the device side of `module RoadSurf`'s per-step procedures
+ * (roadsurf_amd/fortran/RoadSurfCompat.f90 over roadsurf_amd/csrc/rs_compat.hip; reference:
+ * src/RoadSurf.f90:6-270, driven by examples/example1/src/Simulation.f90:57-115).  ONE point, ONE time
+ * index per call: a compatibility path for callers that own the time loop, not a fast one.
+ * ---------------------------------------------------------------------- */
+typedef struct RsCompat RsCompat;
+/* the caller's series of one point (HOST pointers, [SimLen] each, reference layout; NULL = absent) */
+typedef struct RsCompatArrays {
+  const double *tair, *tdew, *vz, *rhz, *prec, *sw, *lw, *sw_dir, *lw_net, *tsurfobs, *depth;
+  const int32_t *precphase, *hour;
+  const double *horizons; /* [360] */
+  double *out[6];         /* Tsurf, Snow, Water, Ice, Deposit, Ice2: rows a coupling replay rewrites */
+} RsCompatArrays;
+/* state_out: the point's state column, RS_COMPAT_NSTATE doubles in the order of roadsurf_amd/csrc/rs_state.h */
+#define RS_COMPAT_NSTATE (RS_MAX_LAYERS + 17 + 21 + 2 * RS_MAX_LAYERS)
+RsCompat *rs_compat_begin(const RsConstants *consts, const LocalParameters *local, double tbottom,
+                          const RsCompatArrays *arrays, const double *sun, const double *geo,
+                          double albedo_surroundings, double *state_out);
+int rs_compat_step(RsCompat *ctx, int32_t i, double *state_out, double *edits);
+int rs_compat_replay(RsCompat *ctx, int32_t i, double *state_out, int32_t *rewritten);
+int rs_compat_last_state(const RsCompat *ctx, double *state_out);
+int rs_compat_outputs(const RsCompat *ctx, int32_t i, double *out6);
+int32_t rs_compat_failed_index(const RsCompat *ctx);
+void rs_compat_end(RsCompat *ctx);
+
+#define RS_ABI_VERSION 7 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles; 4: RsPointParams::horizon_index, rs_hip_step_knots; 5: RS_SUN_COLS 6, RsPointParams::horizons_by_point; 6: rs_driver_last_raw_launches (rs_driver_run without forcing windows); 7: rs_compat_* (module RoadSurf's per-step procedures) */
 int rs_abi_version(void);
 /* sizeof of the boundary structs as the C side / the Fortran side see them
  * (0 InputPointers, 1 OutputPointers, 2 InputSettings, 3 InputParameters,

@@ -88,6 +88,23 @@ $FC -shared -o "$OUT/libroadsurf_ref_cpl.so" "$TMP"/obj/*.o -fopenmp -lgomp 2>/d
 $FC -shared -o "$OUT/libroadsurf_ref_cpl.so" "$TMP"/obj/*.o -L/usr/lib/gcc/x86_64-linux-gnu/11 -lgomp
 echo "built $OUT/libroadsurf_ref_cpl.so"
 
+# ---- the reference's own time loop over THIS library's module surface -------------------
+# examples/example1/src/Simulation.f90 (runsimulation + roadModelOneStep) compiled UNCHANGED against the
+# product's `module RoadSurfVariables` / `module RoadSurf` (roadsurf_amd/fortran/RoadSurfCompat.f90; the .mod
+# files of roadsurf_amd/build) and linked against libroadsurf_hip.so: the proof that the module surface is the
+# reference's at the source level (tests/test_abi_layout.py) and, on a GPU, that it computes the reference's
+# bits (tests/test_hip_module_surface.py).  Skipped while the product has not been built.
+PROD="$HERE/../roadsurf_amd"
+if [ -f "$PROD/build/roadsurf.mod" ] && [ -f "$PROD/lib/libroadsurf_hip.so" ]; then
+  mkdir -p "$TMP/over"
+  # (through the symlink in the temp directory: its Constants.h is the one without `#pragma once`)
+  $FC $FFLAGS -I"$TMP/src" -I"$PROD/build" -module-dir "$TMP/over" -c "$TMP/src/Simulation.f90" \
+      -o "$TMP/over/Simulation.o"
+  $FC -shared -o "$OUT/libsimulation_over_hip.so" "$TMP/over/Simulation.o" -L"$PROD/lib" -lroadsurf_hip \
+      -Wl,-rpath,'$ORIGIN/../../roadsurf_amd/lib'
+  echo "built $OUT/libsimulation_over_hip.so"
+fi
+
 # ---- the driver's one self-contained C++ file -----------------------------------------
 # examples/example1/src/MeteorologyTools.cpp (CalcTdewOrRH) needs only <cmath>; it pins
 # oracle/driver_oracle.c's restatement.  The rest of the driver (JsonSource.cpp,

@@ -109,48 +109,14 @@ module RoadSurfHip
    end type RsHostExtras
 
    interface
-      !> C shim, roadsurf_amd/csrc/rs_host.hip
-      function rs_host_run_batch(n, outPointers, inPointers, consts, localParam, tbottom, extras, device) &
-         bind(C, name='rs_host_run_batch') result(rc)
-         import :: c_int, c_double, OutputPointers, InputPointers, RsConstants, LocalParameters, RsHostExtras
-         integer(c_int), value :: n
-         type(OutputPointers), intent(inout) :: outPointers(*)
-         type(InputPointers), intent(in) :: inPointers(*)
-         type(RsConstants), intent(in) :: consts
-         type(LocalParameters), intent(in) :: localParam(*)
-         real(c_double), intent(in) :: tbottom(*)
-         type(RsHostExtras), intent(in) :: extras
-         integer(c_int), value :: device
-         integer(c_int) :: rc
-      end function rs_host_run_batch
-
       subroutine rs_host_set_error(msg) bind(C, name='rs_host_set_error')
          import :: c_char
          character(kind=c_char), intent(in) :: msg(*)
       end subroutine rs_host_set_error
-
-      function rs_host_default_device() bind(C, name='rs_host_default_device') result(dev)
-         import :: c_int
-         integer(c_int) :: dev
-      end function rs_host_default_device
    end interface
+   public :: rs_host_set_error
 
-   interface
-      !> roadsurf_amd/csrc/rs_coalesce.hip
-      function rs_coalesce_run(outPointers, inPointers, inSettings, inputParam, localParam) &
-         bind(C, name='rs_coalesce_run') result(rc)
-         import :: c_int, OutputPointers, InputPointers, InputSettings, InputParameters, LocalParameters
-         type(OutputPointers), intent(inout) :: outPointers
-         type(InputPointers), intent(in) :: inPointers
-         type(InputSettings), intent(in) :: inSettings
-         type(InputParameters), intent(in) :: inputParam
-         type(LocalParameters), intent(in) :: localParam
-         integer(c_int) :: rc
-      end function rs_coalesce_run
-   end interface
-
-   public :: rs_build_constants, rs_bottom_temperature, runsimulation, runsimulation_batch
-   public :: runsimulation_batch_ex
+   public :: rs_build_constants, rs_bottom_temperature
    public :: rs_fortran_sizeof, rs_sun_table, rs_point_geometry
 
 contains
@@ -438,6 +404,59 @@ contains
       end do
    end subroutine rs_point_geometry
 
+end module RoadSurfHip
+
+!> The entry points of the library: `runsimulation` (the reference's BIND(C) procedure, examples/example1/src/
+!! Simulation.f90:4-6) and `runsimulation_batch[_ex]`.  A module of their own since round 5: a program unit
+!! that DEFINES `runsimulation` itself - the reference's Simulation.f90 compiled against this library's
+!! `module RoadSurf` (RoadSurfCompat.f90) - must not see a second definition of that global name through the
+!! modules it uses.
+module RoadSurfHipEntry
+   use, intrinsic :: iso_c_binding
+   use RoadSurfHip
+   implicit none
+   private
+
+   interface
+      !> C shim, roadsurf_amd/csrc/rs_host.hip
+      function rs_host_run_batch(n, outPointers, inPointers, consts, localParam, tbottom, extras, device) &
+         bind(C, name='rs_host_run_batch') result(rc)
+         import :: c_int, c_double, OutputPointers, InputPointers, RsConstants, LocalParameters, RsHostExtras
+         integer(c_int), value :: n
+         type(OutputPointers), intent(inout) :: outPointers(*)
+         type(InputPointers), intent(in) :: inPointers(*)
+         type(RsConstants), intent(in) :: consts
+         type(LocalParameters), intent(in) :: localParam(*)
+         real(c_double), intent(in) :: tbottom(*)
+         type(RsHostExtras), intent(in) :: extras
+         integer(c_int), value :: device
+         integer(c_int) :: rc
+      end function rs_host_run_batch
+
+      function rs_host_default_device() bind(C, name='rs_host_default_device') result(dev)
+         import :: c_int
+         integer(c_int) :: dev
+      end function rs_host_default_device
+   end interface
+
+   interface
+      !> roadsurf_amd/csrc/rs_coalesce.hip
+      function rs_coalesce_run(outPointers, inPointers, inSettings, inputParam, localParam) &
+         bind(C, name='rs_coalesce_run') result(rc)
+         import :: c_int, OutputPointers, InputPointers, InputSettings, InputParameters, LocalParameters
+         type(OutputPointers), intent(inout) :: outPointers
+         type(InputPointers), intent(in) :: inPointers
+         type(InputSettings), intent(in) :: inSettings
+         type(InputParameters), intent(in) :: inputParam
+         type(LocalParameters), intent(in) :: localParam
+         integer(c_int) :: rc
+      end function rs_coalesce_run
+   end interface
+
+   public :: runsimulation, runsimulation_batch, runsimulation_batch_ex
+
+contains
+
    subroutine fail(msg, status, code)
       character(len=*), intent(in) :: msg
       integer(c_int), intent(out) :: status
@@ -715,4 +734,4 @@ contains
       k = 0
    end subroutine runsimulation
 
-end module RoadSurfHip
+end module RoadSurfHipEntry

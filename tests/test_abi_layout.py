@@ -44,7 +44,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
     for sym in declared:
         assert hasattr(hip_lib, sym), sym
-    assert hip_lib.rs_abi_version() == 6
+    assert hip_lib.rs_abi_version() == 7
 
 
 def test_c_fortran_ctypes_sizes_agree(hip_lib):
@@ -186,7 +186,9 @@ int main() {{
 def test_reference_module_names_resolve_for_fortran_callers(tmp_path, hip_lib):
     """Caller code written against the reference says `use RoadSurfVariables` (and `use RoadSurf`):
     it must compile against this library's module files and see the five Bind(C) types with the
-    reference's component names, plus the entry points."""
+    reference's component names, plus the many-point entry; `runsimulation` itself comes from
+    `module RoadSurfHipEntry` (module RoadSurf cannot export it: the reference's own Simulation.f90
+    DEFINES that name while using the module)."""
     import shutil
     if shutil.which("amdflang") is None:
         pytest.skip("no Fortran compiler")
@@ -197,6 +199,7 @@ subroutine caller(outp, inp, n)
    use, intrinsic :: iso_c_binding
    use RoadSurfVariables
    use RoadSurf
+   use RoadSurfHipEntry, only: runsimulation
    implicit none
    integer(c_int), value :: n
    type(OutputPointers), intent(inout) :: outp(n)
@@ -215,3 +218,37 @@ subroutine caller(outp, inp, n)
 end subroutine caller
 ''')
     _run(["amdflang", "-c", f"-I{moddir}", str(src), "-o", str(tmp_path / "caller.o")], tmp_path)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SRC), reason="build container only: needs /root/reference")
+def test_reference_time_loop_compiles_and_links_unchanged_against_the_module_surface(tmp_path, hip_lib):
+    """Row b' of the coverage table, decided by a compiler: the reference's own examples/example1/src/
+    Simulation.f90 - runsimulation's time loop over the fourteen public procedures of `module RoadSurf` and the
+    eleven state types of `module RoadSurfVariables` (src/RoadSurf.f90:6-270, src/RoadSurfVariables.f90:13-28),
+    plus the external lastValues - compiles UNCHANGED against this library's module files and links against
+    libroadsurf_hip.so with no undefined symbol.  (tests/test_hip_module_surface.py runs it on a GPU.)"""
+    import shutil
+    if shutil.which("amdflang") is None:
+        pytest.skip("no Fortran compiler")
+    ref = "/root/reference"
+    sim = os.path.join(REF_SRC, "Simulation.f90")
+    moddir = os.path.join(ROOT, "roadsurf_amd", "build")
+    libdir = os.path.join(ROOT, "roadsurf_amd", "lib")
+    # flang's preprocessor rejects `#pragma once` (src/Constants.h:1): the same header without that line,
+    # and the source through a symlink so that its `#include "Constants.h"` finds it (oracle/build_ref.sh)
+    hdr = open(os.path.join(ref, "src", "Constants.h")).read().splitlines()
+    (tmp_path / "Constants.h").write_text("\n".join(l for l in hdr if "#pragma once" not in l) + "\n")
+    os.symlink(sim, tmp_path / "Simulation.f90")
+    _run(["amdflang", "-cpp", "-O2", "-fPIC", "-w", f"-I{tmp_path}", f"-I{moddir}", "-module-dir", str(tmp_path),
+          "-c", str(tmp_path / "Simulation.f90"), "-o", str(tmp_path / "Simulation.o")], tmp_path)
+    so = tmp_path / "libsim.so"
+    _run(["amdflang", "-shared", "-o", str(so), str(tmp_path / "Simulation.o"), f"-L{libdir}", "-lroadsurf_hip",
+          f"-Wl,-rpath,{libdir}", "-Wl,--no-undefined"], tmp_path)
+    syms = _run(["nm", "-D", "--defined-only", str(so)], tmp_path).stdout
+    assert " T runsimulation" in syms and "roadmodelonestep_" in syms
+    und = _run(["nm", "-D", "--undefined-only", str(so)], tmp_path).stdout
+    for name in ("initialization", "checkvalues", "couplingoperations1", "relaxationoperations", "setcurrentvalues",
+                 "balancemodelonestep", "saveoutput", "checkendcoupling", "precipitationtostorage",
+                 "modradiationbysurroundings", "wearfactors", "roadcond", "calcalbedo", "connectfortran2carrays"):
+        assert f"_QMroadsurfP{name}" in und, name     # the time loop really calls the module's procedures
+    assert "lastvalues_" in und
