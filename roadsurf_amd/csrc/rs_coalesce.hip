@@ -3,24 +3,29 @@
  * reference driver's worker threads (examples/example1/src/roadrunner.cpp:454-497: `-j` threads, each
  * takes a point off the queue and calls runsimulation for it).
  *
- * One such call steps ONE lane of one wavefront through the whole series - the latency of 5 761
- * dependent time steps, tens of milliseconds, whatever else the GPU could be doing - and a process gets
- * four hardware queues, so 64 callers do not even run 64 such kernels at once (INTEGRATION.md section 1
- * has the measured table).  With ROADSURF_HIP_COALESCE_US = w > 0 concurrent callers are gathered
- * instead: a caller that finds nobody collecting becomes the collector, waits up to w microseconds (or
- * until ROADSURF_HIP_COALESCE_MAX callers, default 4096, are queued) and runs everything queued with
- * ITS settings and parameters (compared byte for byte) as one runsimulation_batch; the others sleep
- * until their point is done.  Same kernels, same bits: a batch is bit-identical to its points run alone
- * (tests/test_hip_boundary.py).  Callers with other settings are left in the queue and one of them
- * collects next; a batch starts when the one before it has finished (everybody who arrived meanwhile
- * is in it).
+ * One such call steps ONE lane of one wavefront pair through the whole series - the latency of 5 761
+ * dependent time steps, tens of milliseconds, whatever else the GPU could be doing.  So concurrent callers
+ * are GATHERED: a caller that finds nobody collecting becomes the collector, waits a window (or until
+ * ROADSURF_HIP_COALESCE_MAX callers, default 4096, are queued) and runs everything queued with ITS settings
+ * and parameters (compared byte for byte) as one runsimulation_batch; the others sleep until their point is
+ * done.  Same kernels, same bits: a batch is bit-identical to its points run alone
+ * (tests/test_hip_boundary.py).  Callers with other settings are left in the queue and one of them collects
+ * next; a batch starts when the one before it has finished (everybody who arrived meanwhile is in it).
+ *
+ * ROADSURF_HIP_COALESCE_US: unset (round 5: the default) - AUTOMATIC: a caller that finds no other call of
+ * this process inside the library runs its point at once, as a batch of one (a single-threaded caller never
+ * waits); one that finds another call in flight coalesces, with a window of 1/16 of the last batch's duration
+ * (0.2 ... 3 ms).  w > 0: every caller coalesces with a window of w microseconds.  0: never (every call a
+ * batch of one, on the calling thread's own stream: rs_host.hip CallerCache).
  */
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/roadsurf.h"
@@ -49,10 +54,20 @@ int g_inflight = 0; /* batches running: the next one is held back until the GPU 
                        callers arriving meanwhile join it instead of trickling in as batches of a few */
 long g_batches = 0, g_points = 0; /* diagnostics: rs_coalesce_stats */
 
+int g_active = 0;        /* calls of this process inside rs_coalesce_run (automatic mode) */
+long g_last_batch_us = 16000; /* duration of the last batch: the automatic window is 1/16 of it */
+size_t g_last_batch_n = 0;    /* callers in the last batch: the next window closes when as many are back */
+/* automatic mode: when the last batch of several callers ended.  Its callers are on their way back with their
+ * next points - the first of them must wait for the others rather than run alone (16 worker threads would
+ * otherwise alternate between a batch of one and a batch of fifteen) */
+std::chrono::steady_clock::time_point g_last_multi{};
+bool g_seen_multi = false;
+
+/* -1: automatic (unset), 0: off, w > 0: fixed window */
 int window_us() {
   static const int w = [] {
     const char *e = getenv("ROADSURF_HIP_COALESCE_US");
-    return e ? atoi(e) : 0;
+    return e ? std::max(0, atoi(e)) : -1;
   }();
   return w;
 }
@@ -63,6 +78,60 @@ size_t max_batch() {
     return (size_t)(v >= 1 ? v : 1);
   }();
   return m;
+}
+
+/* Batches of several callers run on ONE thread of the library's own (started with the first such batch): its
+ * stream, its cached buffers (rs_host.hip CallerCache) and its OpenMP team for the row copies serve every
+ * batch.  Run on whichever caller happened to collect, sixty-four worker threads each raised a team of their
+ * own, whose idle members spin on the cores the next collector's team needs: 64 callers got 630 points/s where
+ * they get 900 with the rows copied by a single thread. */
+struct Runner {
+  std::mutex m;
+  std::condition_variable cv;
+  bool started = false, has_job = false, job_done = false;
+  int32_t n = 0;
+  OutputPointers *o = nullptr;
+  const InputPointers *i = nullptr;
+  const InputSettings *s = nullptr;
+  const InputParameters *p = nullptr;
+  const LocalParameters *l = nullptr;
+  int32_t status = 0;
+  void loop() {
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      cv.wait(lk, [&] { return has_job; });
+      lk.unlock();
+      int32_t st = 0;
+      runsimulation_batch(n, o, i, s, p, l, &st);
+      lk.lock();
+      status = st;
+      has_job = false;
+      job_done = true;
+      cv.notify_all();
+    }
+  }
+  /* one job at a time (callers queue on the mutex's condition) */
+  int32_t run(int32_t n_, OutputPointers *o_, const InputPointers *i_, const InputSettings *s_,
+              const InputParameters *p_, const LocalParameters *l_) {
+    std::unique_lock<std::mutex> lk(m);
+    if (!started) {
+      started = true;
+      std::thread([this] { loop(); }).detach();
+    }
+    cv.wait(lk, [&] { return !has_job && !job_done; });
+    n = n_; o = o_; i = i_; s = s_; p = p_; l = l_;
+    has_job = true;
+    cv.notify_all();
+    cv.wait(lk, [&] { return job_done; });
+    const int32_t st = status;
+    job_done = false;
+    cv.notify_all();
+    return st;
+  }
+};
+Runner &runner() {
+  static Runner *r = new Runner(); /* never destroyed: its thread outlives main() */
+  return *r;
 }
 
 }  // namespace
@@ -80,8 +149,8 @@ void rs_coalesce_stats(int64_t *batches, int64_t *points) {
  * ROADSURF_HIP_COALESCE_US > 0, else a batch of one.  Returns the batch status (0 = ok). */
 int32_t rs_coalesce_run(OutputPointers *out, const InputPointers *in, const InputSettings *settings,
                         const InputParameters *params, const LocalParameters *local) {
-  const int w = window_us();
-  if (w <= 0) {
+  int w = window_us();
+  if (w == 0) {
     int32_t st = 0;
     runsimulation_batch(1, out, in, settings, params, local, &st);
     return st;
@@ -89,6 +158,32 @@ int32_t rs_coalesce_run(OutputPointers *out, const InputPointers *in, const Inpu
   Request me;
   me.out = out; me.in = in; me.settings = settings; me.params = params; me.local = local;
   std::unique_lock<std::mutex> lk(g_m);
+  struct Active { /* this call is inside the library (counted under g_m) */
+    Active() { ++g_active; }
+    ~Active() { --g_active; }
+  };
+  if (w < 0) {
+    const bool gathering = g_seen_multi &&
+        std::chrono::steady_clock::now() - g_last_multi < std::chrono::microseconds(std::max<long>(50000, 4 * g_last_batch_us));
+    if (g_active == 0 && g_queue.empty() && !g_collecting && !gathering) {
+      /* nobody else is here: the point runs at once.  It counts as a batch in flight, so that callers
+       * arriving meanwhile gather behind it instead of starting batches of one beside it. */
+      Active a;
+      g_inflight += 1;
+      lk.unlock();
+      const auto t0 = std::chrono::steady_clock::now();
+      int32_t st = 0;
+      runsimulation_batch(1, out, in, settings, params, local, &st);
+      const long us = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+      lk.lock();
+      g_last_batch_us = us;
+      g_inflight -= 1;
+      g_cv.notify_all();
+      return st;
+    }
+    w = (int)std::min<long>(3000, std::max<long>(200, g_last_batch_us / 16));
+  }
+  Active active; /* (destroyed before lk: under the lock) */
   g_queue.push_back(&me);
   g_cv.notify_all(); /* a collector waiting for its batch to fill looks again */
   for (;;) {
@@ -96,8 +191,10 @@ int32_t rs_coalesce_run(OutputPointers *out, const InputPointers *in, const Inpu
     if (!me.taken && !g_collecting) {
       /* collect: wait for the window to close or the batch to fill */
       g_collecting = true;
+      /* ... or until as many callers as the last batch had are back (a worker pool returns as one) */
+      auto full = [&] { return g_queue.size() >= max_batch() || (g_last_batch_n > 1 && g_queue.size() >= g_last_batch_n); };
       const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(w);
-      g_cv.wait_until(lk, deadline, [&] { return g_queue.size() >= max_batch(); });
+      g_cv.wait_until(lk, deadline, full);
       /* a batch steps its points' whole series in a few wavefronts: a second batch beside it would be
        * as slow and hold fewer points.  Wait for the running one (callers keep arriving). */
       if (g_inflight > 0 && g_queue.size() < max_batch()) {
@@ -105,7 +202,7 @@ int32_t rs_coalesce_run(OutputPointers *out, const InputPointers *in, const Inpu
         /* the callers that batch has just released are on their way back with their next points:
          * one more window for them, so that the batches do not settle into two alternating halves */
         const auto again = std::chrono::steady_clock::now() + std::chrono::microseconds(w);
-        g_cv.wait_until(lk, again, [&] { return g_queue.size() >= max_batch(); });
+        g_cv.wait_until(lk, again, full);
       }
       /* the collector's own point first (a queue longer than the maximum must not leave it
        * out of the batch it runs), then the others with its settings and parameters, in queue order */
@@ -136,7 +233,10 @@ int32_t rs_coalesce_run(OutputPointers *out, const InputPointers *in, const Inpu
         l[k] = *batch[k]->local;
       }
       int32_t st = 0;
-      runsimulation_batch(n, o.data(), i.data(), me.settings, me.params, l.data(), &st);
+      const auto tb0 = std::chrono::steady_clock::now();
+      if (n > 1) st = runner().run(n, o.data(), i.data(), me.settings, me.params, l.data());
+      else runsimulation_batch(n, o.data(), i.data(), me.settings, me.params, l.data(), &st);
+      const long batch_us = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tb0).count();
       /* a batch-level error is some ONE caller's (an array shorter than SimLen, ...): the header promises
        * every caller the bits and the status of a call of its own, so the members run again one by one */
       std::vector<int32_t> each((size_t)n, st);
@@ -147,6 +247,12 @@ int32_t rs_coalesce_run(OutputPointers *out, const InputPointers *in, const Inpu
         }
       lk.lock();
       g_inflight -= 1;
+      g_last_batch_us = batch_us;
+      g_last_batch_n = (size_t)n;
+      if (n > 1) {
+        g_seen_multi = true;
+        g_last_multi = std::chrono::steady_clock::now();
+      }
       for (int32_t k = 0; k < n; ++k) {
         batch[k]->status = each[k];
         batch[k]->done = true;

@@ -84,15 +84,31 @@ struct Dev {
   template <typename T>
   T *as() const { return static_cast<T *>(p); }
 };
+/* the same for page-locked host memory (rs_host.hip: a caller thread that comes back with small batches -
+ * the reference driver calling runsimulation point by point - keeps one block instead of nine
+ * hipHostMalloc / hipHostFree per call, each of which takes milliseconds and serialises the callers) */
+inline Arena *&tls_pinned_arena() {
+  static thread_local Arena *a = nullptr;
+  return a;
+}
 struct Pinned {
   void *p = nullptr;
+  bool owned = true;
   Pinned() = default;
   Pinned(const Pinned &) = delete;
   Pinned &operator=(const Pinned &) = delete;
   ~Pinned() {
-    if (p) (void)hipHostFree(p);
+    if (p && owned) (void)hipHostFree(p);
   }
-  hipError_t alloc(size_t n) { return hipHostMalloc(&p, n ? n : 8, hipHostMallocDefault); }
+  hipError_t alloc(size_t n) {
+    if (Arena *a = tls_pinned_arena())
+      if (void *q = a->take(n ? n : 8)) {
+        p = q;
+        owned = false;
+        return hipSuccess;
+      }
+    return hipHostMalloc(&p, n ? n : 8, hipHostMallocDefault);
+  }
 };
 
 /* Host worker threads for row gather/scatter: the CPUs this process may actually use

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 #include <omp.h>
 
@@ -25,6 +26,7 @@
 #include "rs_kernels.h"
 #include "rs_devutil.hpp"
 #include "rs_devices.hpp"
+#include "rs_state.h"
 
 extern "C" void rs_host_set_error(const char *msg);
 static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const InputPointers *inPointers,
@@ -78,6 +80,88 @@ inline double *out_f64(const OutputPointers &op, int f) {
     default: return op.c_Ice2Out;
   }
 }
+
+/* What a caller thread keeps between SMALL batches (round 5): the reference driver calls
+ * runsimulation once per point from `-j` worker threads (examples/example1/src/roadrunner.cpp:454-497), and a
+ * one-point call used to create a stream, two events, nine page-locked and a dozen device buffers and a plan -
+ * and free them again, every hipFree waiting for the whole device: 16 callers got 25 points/s out of a GPU on
+ * which one got 28.  Now the thread's stream, events and two blocks (device, page-locked) survive the call;
+ * the buffers of a call are carved out of the blocks (rs_devutil.hpp: Arena), the plan's too. */
+struct CallerCacheData {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  rsu::Arena dev, pin;
+};
+/* caches of threads that have ended: adopted by the next thread that needs one (a thread's end - or the
+ * process's, when the runtime may be gone already - is no place for HIP calls) */
+std::mutex g_orphans_m;
+std::vector<CallerCacheData> g_orphans;
+
+struct CallerCache : CallerCacheData {
+  ~CallerCache() {
+    if (device < 0) return;
+    std::lock_guard<std::mutex> lk(g_orphans_m);
+    g_orphans.push_back(static_cast<const CallerCacheData &>(*this));
+  }
+  void adopt(int d) {
+    std::lock_guard<std::mutex> lk(g_orphans_m);
+    for (size_t k = 0; k < g_orphans.size(); ++k)
+      if (g_orphans[k].device == d) {
+        static_cast<CallerCacheData &>(*this) = g_orphans[k];
+        g_orphans.erase(g_orphans.begin() + (long)k);
+        return;
+      }
+  }
+  void drop() {
+    if (device < 0) return;
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (dev.base) (void)hipFree(dev.base);
+    if (pin.base) (void)hipHostFree(pin.base);
+    for (hipEvent_t &e : ev)
+      if (e) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+    static_cast<CallerCacheData &>(*this) = CallerCacheData();
+  }
+  /* blocks of at least these sizes on `d`; false: the call allocates the old way */
+  bool reserve(int d, size_t dev_bytes, size_t pin_bytes) {
+    if (device != d) drop();
+    if (device < 0) adopt(d);
+    if (device < 0) {
+      if (hipStreamCreate(&stream) != hipSuccess) return false;
+      if (hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) {
+        device = d;
+        drop();
+        return false;
+      }
+      device = d;
+    }
+    if (dev.cap < dev_bytes) {
+      (void)hipStreamSynchronize(stream);
+      if (dev.base) (void)hipFree(dev.base);
+      dev = rsu::Arena();
+      void *q = nullptr;
+      if (hipMalloc(&q, dev_bytes) != hipSuccess) return false;
+      dev.base = static_cast<char *>(q);
+      dev.cap = dev_bytes;
+    }
+    if (pin.cap < pin_bytes) {
+      (void)hipStreamSynchronize(stream);
+      if (pin.base) (void)hipHostFree(pin.base);
+      pin = rsu::Arena();
+      void *q = nullptr;
+      if (hipHostMalloc(&q, pin_bytes, hipHostMallocDefault) != hipSuccess) return false;
+      pin.base = static_cast<char *>(q);
+      pin.cap = pin_bytes;
+    }
+    dev.off = pin.off = 0;
+    return true;
+  }
+};
+thread_local CallerCache t_cache;
+constexpr size_t kCacheDevMax = (size_t)768 << 20, kCachePinMax = (size_t)256 << 20;
 
 }  // namespace
 
@@ -155,21 +239,56 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
     return -9;
   }
   HOK(hipSetDevice(device));
+  const size_t in_elems = (size_t)P * TC, tp_elems = (size_t)Ppad * TC;
+  /* a small batch lives in the calling thread's cached blocks (CallerCache): no allocation, no free */
+  const bool writeback_dev = extras && extras->writeback && skyview;
+  size_t need_pin = in_elems * ((size_t)2 * nf64 * 8 + 2 * 6 * 8 + 2 * 2 * 4) + (writeback_dev ? in_elems * 6 * 8 : 0) +
+                    (skyview ? (size_t)P * 360 * 8 : 0) + ((size_t)64 << 10);
+  size_t need_dev = in_elems * ((size_t)nf64 * 8 + 2 * 4 + 6 * 8 + (writeback_dev ? 3 * 8 : 0)) +
+                    tp_elems * ((size_t)nf64 * 8 + 2 * 4 + 6 * 8 + (writeback_dev ? 3 * 8 : 0)) +
+                    (size_t)Ppad * (9 * 8 + 2 * 4) + (skyview ? (size_t)L * RS_SUN_COLS * 8 + (size_t)P * 360 * 8 : 0) +
+                    (size_t)Ppad * ((size_t)2 * RS_NSTATE * 8 + 64) + (size_t)2 * L * 8 + ((size_t)4 << 20);
+  need_pin += need_pin / 8;
+  need_dev += need_dev / 8;
+  const bool cached = !getenv("ROADSURF_HIP_NO_CALLER_CACHE") && need_dev <= kCacheDevMax && need_pin <= kCachePinMax &&
+                      n <= P && t_cache.reserve(device, need_dev, need_pin);
+  struct ArenaScope { /* the thread's blocks serve Dev::alloc / Pinned::alloc / plan_malloc during this call */
+    rsu::Arena *pd, *pp;
+    bool on;
+    explicit ArenaScope(bool use) : pd(rsu::tls_arena()), pp(rsu::tls_pinned_arena()), on(use) {
+      if (on) {
+        rsu::tls_arena() = &t_cache.dev;
+        rsu::tls_pinned_arena() = &t_cache.pin;
+      }
+    }
+    ~ArenaScope() {
+      if (on) {
+        rsu::tls_arena() = pd;
+        rsu::tls_pinned_arena() = pp;
+      }
+    }
+  };
   /* declared before every buffer, so destroyed after them: error returns below leave work in
    * flight, and the stream must outlive it (buffers are released by hipFree, which waits) */
   struct StreamGuard {
     hipStream_t s = nullptr;
+    bool own = true;
     ~StreamGuard() {
       if (s) {
         (void)hipStreamSynchronize(s);
-        (void)hipStreamDestroy(s);
+        if (own) (void)hipStreamDestroy(s);
       }
     }
   } stream_guard;
-  HOK(hipStreamCreate(&stream_guard.s));
+  if (cached) {
+    stream_guard.s = t_cache.stream;
+    stream_guard.own = false;
+  } else {
+    HOK(hipStreamCreate(&stream_guard.s));
+  }
   hipStream_t stream = stream_guard.s;
+  ArenaScope arena_scope(cached); /* (after the stream guard: the buffers go first, then the stream drains) */
 
-  const size_t in_elems = (size_t)P * TC, tp_elems = (size_t)Ppad * TC;
   Pinned h_in, h_out, h_i32;
   Dev d_pt, d_tp, d_i32pt, d_i32tp, d_out_tp, d_out_pt, d_pp64, d_pp32;
   HOK(h_in.alloc(in_elems * nf64 * sizeof(double)));
@@ -233,23 +352,38 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
   double *hin_b[2] = {(double *)h_in.p, (double *)h_in2.p};
   double *hout_b[2] = {(double *)h_out.p, (double *)h_out2.p};
   int32_t *hi_b[2] = {(int32_t *)h_i32.p, (int32_t *)h_i322.p};
-  hipEvent_t done[2];
-  HOK(hipEventCreateWithFlags(&done[0], hipEventDisableTiming));
-  HOK(hipEventCreateWithFlags(&done[1], hipEventDisableTiming));
+  hipEvent_t done[2] = {nullptr, nullptr};
   struct EventGuard {
     hipEvent_t *e;
+    bool own;
     ~EventGuard() {
-      (void)hipEventDestroy(e[0]);
-      (void)hipEventDestroy(e[1]);
+      if (!own) return;
+      if (e[0]) (void)hipEventDestroy(e[0]);
+      if (e[1]) (void)hipEventDestroy(e[1]);
     }
-  } event_guard{done};
+  } event_guard{done, !cached};
+  if (cached) {
+    done[0] = t_cache.ev[0];
+    done[1] = t_cache.ev[1];
+  } else {
+    HOK(hipEventCreateWithFlags(&done[0], hipEventDisableTiming));
+    HOK(hipEventCreateWithFlags(&done[1], hipEventDisableTiming));
+  }
 
+  /* (a team of OpenMP threads only where the rows are worth it: a caller thread of the reference driver that
+   * brings a few points would otherwise raise - and keep - a team of its own) */
+  const bool omp_rows = n >= 8;
+  const int row_threads = std::max(1, std::min(nthreads, (int)(n / 4)));
+  /* an item none of whose points has an output depth (depth(i) >= 0) needs no depth stream: the kernels read a
+   * missing stream as -9999.9, and without one the launch can take the two-wavefront flavour (rs_hip_step) */
+  int item_depth[2] = {1, 1};
   auto gather = [&](const Item &it, int buf) {
     double *hin = hin_b[buf];
     int32_t *hi = hi_b[buf];
     const int m = it.m, len = it.len, t0 = it.t0;
     const int64_t p0 = it.p0;
-#pragma omp parallel for schedule(static) num_threads(nthreads)
+    int any_depth = 0;
+#pragma omp parallel for schedule(static) num_threads(row_threads) reduction(| : any_depth) if (omp_rows)
     for (int p = 0; p < m; ++p) {
       const InputPointers &ip = inPointers[p0 + p];
       for (int f = 0; f < nf64; ++f)
@@ -257,13 +391,18 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
                     (size_t)len * sizeof(double));
       std::memcpy(hi + (size_t)p * len, ip.c_PrecPhase + (t0 - 1), (size_t)len * sizeof(int32_t));
       std::memcpy(hi + ((size_t)m + p) * len, ip.c_hour + (t0 - 1), (size_t)len * sizeof(int32_t));
+      const double *dp = ip.c_Depth + (t0 - 1);
+      int d = 0;
+      for (int t = 0; t < len; ++t) d |= (dp[t] >= 0.0) ? 1 : 0;
+      any_depth |= d;
     }
+    item_depth[buf] = any_depth;
   };
   auto scatter = [&](const Item &it, int buf) {
     const double *hout = hout_b[buf];
     const int m = it.m, len = it.len, t0 = it.t0;
     const int64_t p0 = it.p0;
-#pragma omp parallel for schedule(static) num_threads(nthreads)
+#pragma omp parallel for schedule(static) num_threads(row_threads) if (omp_rows)
     for (int p = 0; p < m; ++p) {
       for (int f = 0; f < 6; ++f)
         std::memcpy(out_f64(outPointers[p0 + p], f) + (t0 - 1), hout + ((size_t)f * m + p) * len,
@@ -285,7 +424,7 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
     if (rs_hip_first_failed_index(pl, ff_tile.data()) != 0) return -15;
     if (first_failed) std::memcpy(first_failed + p0, ff_tile.data(), (size_t)m * sizeof(int32_t));
     if (writeback && !wb_dev) {
-#pragma omp parallel for schedule(static) num_threads(nthreads)
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (omp_rows)
       for (int p = 0; p < m; ++p) {
         const InputPointers &ip = inPointers[p0 + p];
         if (!ip.c_SW_dir) continue;
@@ -382,7 +521,8 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
     const size_t fs = (size_t)mp * TC;
     fo.tair = b + F_TAIR * fs; fo.tdew = b + F_TDEW * fs; fo.vz = b + F_VZ * fs;
     fo.rhz = b + F_RHZ * fs; fo.prec = b + F_PREC * fs; fo.sw = b + F_SW * fs;
-    fo.lw = b + F_LW * fs; fo.tsurfobs = b + F_OBS * fs; fo.depth = b + F_DEPTH * fs;
+    fo.lw = b + F_LW * fs; fo.tsurfobs = b + F_OBS * fs;
+    fo.depth = item_depth[buf] ? b + F_DEPTH * fs : nullptr;
     fo.precphase = (int32_t *)d_i32tp.p;
     fo.hour = (int32_t *)d_i32tp.p + fs;
     fo.t_stride = mp;
