@@ -840,8 +840,10 @@ int rs_step_raw(RsPlan *pl, const rs::RawForcing *raw, const double *sun, const 
   if (first < o->row0) return set_err("rs_step_raw: output row0 beyond first row");
   const int64_t out_rows = ((int64_t)t0 + nsteps - 2) / o->decimate - o->row0 + 1;
   if (!rs_step_raw_ok(pl) || (uint64_t)o->t_stride * (uint64_t)(out_rows > 0 ? out_rows : 1) >= (1ull << 29))
-    return set_err("rs_step_raw: NLayers = 15, fp64, no coupling, no output depth and an output window below "
-                   "4 GiB per stream only");
+    return set_err("rs_step_raw: NLayers = 15, fp64, no output depth and an output window below 4 GiB per stream only");
+  const bool coupled = pl->c.use_coupling != 0;
+  if (coupled && (!pp->coupling_index || !pp->coupling_tsurf))
+    return set_err("rs_step_raw: use_coupling is set: pass coupling_index and coupling_tsurf");
   if (pl->c.use_relaxation && pp->tair_relax && (!pp->vz_relax || !pp->rh_relax))
     return set_err("rs_step_raw: relaxation needs tair_relax, vz_relax, rh_relax and initlen");
   const bool sky = pp->sky_view != nullptr;
@@ -869,13 +871,13 @@ int rs_step_raw(RsPlan *pl, const rs::RawForcing *raw, const double *sun, const 
   a.raw = *raw;
   /* out_by_point: the rows of slot s go to column order[s] of `o` (scattered stores: meant for decimated rows) */
   a.out_index = (out_by_point && pl->order) ? pl->order : nullptr;
-  const hipError_t le = rs_launch_step_duo_raw(a, pl->history_score, sky, pl->stream);
+  const hipError_t le = rs_launch_step_duo_raw(a, pl->history_score, sky, coupled, pl->stream);
   if (le != hipSuccess) return set_err("rs_step_raw: kernel launch failed: %s", hipGetErrorString(le));
   return 0;
 }
 
 bool rs_step_raw_ok(const RsPlan *pl) {
-  return pl && !pl->f32 && pl->c.NLayers == 15 && !(pl->c.tsurfOutputDepth >= 0.0) && !pl->c.use_coupling;
+  return pl && !pl->f32 && pl->c.NLayers == 15 && !(pl->c.tsurfOutputDepth >= 0.0);
 }
 
 extern "C" {

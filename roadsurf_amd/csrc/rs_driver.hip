@@ -1379,11 +1379,12 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
   const bool cpl_chunked = coupled && !getenv("ROADSURF_HIP_CPL_WHOLE");
   /* The blocks' step kernel makes its forcing from the raw series itself (rs_step_raw: the two-wavefront
    * flavour, ground wave = JsonSource::interpolate + overlay one index ahead) wherever it can: sources on
-   * shared time axes (the segment table exists), NLayers = 15, no coupling, no output depth.  No forcing
-   * window, no expansion kernel.  ROADSURF_HIP_DRIVER_WINDOWS=1: the windows and the one-point-per-lane
+   * shared time axes (the segment table exists), NLayers = 15, no output depth.  No forcing window, no
+   * expansion kernel - with coupling for the lock-step chunks; the replay rounds keep a window over the
+   * coupling windows of the tile (rs_hip_cpl_replay).  ROADSURF_HIP_DRIVER_WINDOWS=1: the windows and the one-point-per-lane
    * kernels as before (tests compare the two). */
-  const bool use_raw = !c.segs.empty() && !coupled && consts.NLayers == 15 && !(st->tsurfOutputDepth >= 0.0) &&
-                       !getenv("ROADSURF_HIP_DRIVER_WINDOWS");
+  const bool use_raw = !c.segs.empty() && (!coupled || cpl_chunked) && consts.NLayers == 15 &&
+                       !(st->tsurfOutputDepth >= 0.0) && !getenv("ROADSURF_HIP_DRIVER_WINDOWS");
   int64_t Pdef = 524288;
   if (coupled && !cpl_chunked) {
     Pdef = (int64_t)(64e9 / ((double)L * NFLD * sizeof(double)));
@@ -1458,6 +1459,8 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     /* chunked coupling: the replay block spans a coupling window plus the index behind it
      * (usually more rows than a chunk); a tile whose windows are spread further re-leases below */
     const int rows0 = cpl_chunked ? std::max(TC, std::min(L, c.cplLen + 2)) : TC;
+    /* (a block that steps from the raw series needs windows for the replay rounds of coupling only: sized
+     * per tile, below) */
     win_bytes = use_raw ? 0 : (size_t)nwin * Ppad * rows0 * sizeof(double);
     if (win_bytes) HOK(win.acquire(win_bytes, device));
   }
@@ -1588,12 +1591,13 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
       }
     }
     const int r_lo = cs_min, r_hi = std::min(ce_max + 1, L); /* replay block, 1-based inclusive */
-    const int WR = (cpl_chunked && any_on) ? std::max(TC, r_hi - r_lo + 1) : TC;
+    const bool need_win = !use_raw || (cpl_chunked && any_on); /* raw-series stepping: windows for the replays only */
+    const int WR = (cpl_chunked && any_on) ? (use_raw ? r_hi - r_lo + 1 : std::max(TC, r_hi - r_lo + 1)) : TC;
     if (cpl_chunked && WR > TC && (size_t)nwin * mp * WR * sizeof(double) > win_budget && m > 4096) {
       Pcur = std::max(4096, (m / 2 + 4095) / 4096 * 4096);
       continue;
     }
-    if (!use_raw && (size_t)nwin * mp * WR * sizeof(double) > win_bytes) {
+    if (need_win && (size_t)nwin * mp * WR * sizeof(double) > win_bytes) {
       win.release();
       win_bytes = (size_t)nwin * mp * WR * sizeof(double);
       HOK(win.acquire(win_bytes, device));
@@ -1602,7 +1606,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     /* windows */
     const size_t fs = (size_t)mp * WR;
     Dev d_phase, d_out, d_outpt;
-    if (!use_raw) {
+    if (need_win) {
       HOK(d_phase.alloc(fs * sizeof(int32_t)));
       hipLaunchKernelGGL(fill_i32_kernel, grid1((int64_t)fs), dim3(RS_BLOCK), 0, stream,
                          d_phase.as<int32_t>(), (int64_t)fs, -9999); /* InputData.cpp:16 */
@@ -1621,7 +1625,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     /* window f lives at slot wslot[f] of the leased block (SW_dir / LW_net only with sky view) */
     double *wb = static_cast<double *>(win.p);
     for (int f = 0, k = 0; f < NFLD; ++f) {
-      const bool used = !use_raw && (skyview || (f != R_SWDIR && f != R_LWNET));
+      const bool used = need_win && (skyview || (f != R_SWDIR && f != R_LWNET));
       ea.out[f] = used ? wb + (size_t)(k++) * fs : nullptr;
     }
     ea.status = D.status.as<int32_t>();
@@ -1838,12 +1842,66 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
         if (rs_hip_recluster(pg.p) != 0) return -14;
         return gather_params();
       };
+      /* a lock-step chunk: from the raw series (rs_step_raw: no window) where the block steps that way */
+      rs::RawForcing rf;
+      std::memset(&rf, 0, sizeof(rf));
+      Dev d_row1;
+      size_t seg = 0;
+      if (use_raw) {
+        rf.nsrc = S_full.nsrc;
+        for (int k = 0; k < S_full.nsrc; ++k) {
+          for (int f = 0; f < NFLD; ++f) rf.src[k].fld[f] = S_full.src[k].fld[f];
+          rf.src[k].plan = S_full.src[k].plan;
+        }
+        rf.nseg = (int32_t)c.segs.size();
+        rf.segs = T.segs.as<ScanSeg>();
+        rf.np_pad = mp;
+        rf.status = D.status.as<int32_t>();
+        rf.hour = d_hour.as<int32_t>();
+        HOK(d_row1.alloc((size_t)2 * mp * sizeof(double)));
+      }
+      auto lockstep = [&](int t0, int len) -> int {
+        if (!use_raw) {
+          if (int rc = expand_window(t0, len, fo)) return rc;
+          if (t0 == 1 && rs_hip_init_state(pg.p, &fo, &ppx) != 0) return -12;
+          if (rs_hip_step_cpl(pg.p, &fo, &oo, &ppx, t0, len) != 0) return -13;
+          return 0;
+        }
+        if (t0 == 1) { /* index 1's air temperature and observation, for the initial profile */
+          RawRowsArgs ra;
+          std::memset(&ra, 0, sizeof(ra));
+          ra.S = S_full;
+          ra.status = ea.status;
+          ra.order = cluster ? ea.order : nullptr;
+          ra.nrows = 2;
+          ra.fld[0] = R_TAIR;
+          ra.fld[1] = R_OBS;
+          ra.out[0] = d_row1.as<double>();
+          ra.out[1] = d_row1.as<double>() + mp;
+          hipLaunchKernelGGL(raw_rows_kernel, dim3((unsigned)(mp / RS_BLOCK), 2), dim3(RS_BLOCK), 0, stream, ra);
+          HOK(hipGetLastError());
+          RsForcing f1;
+          std::memset(&f1, 0, sizeof(f1));
+          f1.tair = f1.vz = f1.rhz = f1.prec = f1.sw = f1.lw = ra.out[0]; /* (only tair and tsurfobs are read) */
+          f1.tsurfobs = ra.out[1];
+          f1.precphase = reinterpret_cast<const int32_t *>(ra.out[0]);
+          f1.hour = d_hour.as<int32_t>();
+          f1.t_stride = mp;
+          if (rs_hip_init_state(pg.p, &f1, &ppx) != 0) return -12;
+        }
+        while (seg > 0 && c.segs[seg].i0 > t0 - 1) --seg; /* (stage 3 starts behind the first window end: back) */
+        while (seg + 1 < c.segs.size() && c.segs[seg].i1 <= t0 - 1) ++seg;
+        rf.seg0 = (int32_t)seg;
+        rf.col = cluster ? ea.order : nullptr;
+        const double *sunrows = skyview ? d_sun.as<double>() + (size_t)(t0 - 1) * RS_SUN_COLS : nullptr;
+        if (rs_step_raw(pg.p, &rf, sunrows, &oo, &ppx, t0, len, cluster) != 0) return -13;
+        ++g_last_raw_launches;
+        return 0;
+      };
       const int s1_hi = any_on ? std::min(ce_max, L) : L;
       for (int t0 = 1; t0 <= s1_hi; t0 += TC) {
         const int len = std::min(TC, s1_hi - t0 + 1);
-        if (int rc = expand_window(t0, len, fo)) return rc;
-        if (t0 == 1 && rs_hip_init_state(pg.p, &fo, &ppx) != 0) return -12;
-        if (rs_hip_step_cpl(pg.p, &fo, &oo, &ppx, t0, len) != 0) return -13;
+        if (int rc = lockstep(t0, len)) return rc;
         /* the next lock-step chunk: the one behind this, or stage 3's first */
         const int t_next = (t0 + len <= s1_hi) ? t0 + len : (any_on && ce_min + 1 <= L) ? ce_min + 1 : 0;
         if (t_next > 0)
@@ -1857,8 +1915,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
         if (rs_hip_coupling_windows_closed(pg.p, 1) != 0) return -14;
         for (int t0 = ce_min + 1; t0 <= L; t0 += TC) {
           const int len = std::min(TC, L - t0 + 1);
-          if (int rc = expand_window(t0, len, fo)) return rc;
-          if (rs_hip_step_cpl(pg.p, &fo, &oo, &ppx, t0, len) != 0) return -13;
+          if (int rc = lockstep(t0, len)) return rc;
           if (t0 + len <= L)
             if (int rc = resort(t0 + len)) return rc;
         }

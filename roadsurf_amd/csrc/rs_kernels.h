@@ -127,9 +127,10 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
 /* the two-wavefront flavour with the forcing made from the knots in the kernel (StepArgs::knots) */
 hipError_t rs_launch_step_duo_knots(const rs::StepArgs &a, bool score, hipStream_t stream);
 /* ... and from the raw series of the driver path (StepArgs::raw); sky: per-point sky view on the ground wave */
-hipError_t rs_launch_step_duo_raw(const rs::StepArgs &a, bool score, bool sky, hipStream_t stream);
-/* the step of rs_driver_run's blocks (rs_api.hip): NLayers = 15, fp64, no coupling, no output depth; pp in
- * SLOT order, raw series in point order behind raw.col */
+hipError_t rs_launch_step_duo_raw(const rs::StepArgs &a, bool score, bool sky, bool cpl, hipStream_t stream);
+/* the step of rs_driver_run's blocks (rs_api.hip): NLayers = 15, fp64, no output depth; pp in SLOT order, raw
+ * series in point order behind raw.col.  A coupled plan (use_coupling, pp->coupling_index): a LOCK-STEP chunk as
+ * rs_hip_step_cpl runs it - points park behind their coupling window until rs_hip_cpl_replay has run. */
 struct RsPlan;
 bool rs_step_raw_ok(const RsPlan *pl); /* a plan whose settings rs_step_raw can run */
 int rs_step_raw(RsPlan *pl, const rs::RawForcing *raw, const double *sun, const RsOutputs *o,

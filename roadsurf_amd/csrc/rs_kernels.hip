@@ -1282,11 +1282,18 @@ __device__ __forceinline__ void duo_meet() { asm volatile("s_waitcnt lgkmcnt(0)\
  * the sky view leaves it and the sky wave's flags beside the ground wave's. */
 /* OUTIDX: the launch may ask for its output rows in POINT order (StepArgs::out_index, the plan's order row:
  * the decimated rows of rs_driver_run go straight to their point's column, no copy kernel behind the launch). */
-template <int NL, bool SCORE, bool FULL = false, bool SKY = false, bool SKYG = false, bool OUTIDX = false>
+/* CPL: coupling in lock step, as time_loop<CPL> has it (src/Coupling.f90; everything but the replays): the state
+ * saved at the window start (this wave its scalars and layers 1-2, the ground wave layers 3..N), the coupling
+ * phase, Coupling_control at the window end - a point that has to replay PARKS -, the decaying corrections
+ * behind the window.  A lane steps index i only if it is the index it is due for (RS_ST_CPL_RESUME); parked or
+ * ahead, it is frozen for that index in both wavefronts (DuoMail::failed is rewritten before every meeting). */
+template <int NL, bool SCORE, bool FULL = false, bool SKY = false, bool SKYG = false, bool OUTIDX = false,
+          bool CPL = false>
 __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, const StepArgs &a,
                                             const uint32_t *skyfl = nullptr) {
   static_assert(FULL || !SKY, "sky view belongs to the FULL feature set");
   static_assert(!(SKY && SKYG), "the sky view is this wave's or the ground wave's");
+  static_assert(FULL || !CPL, "coupling belongs to the FULL feature set");
   KernArgs ka = kernargs();
   const uint32_t lane = threadIdx.x & 63u;
   /* the workgroup's slots: 64 from 64 * blockIdx.x, or what the wave table says (rs_cluster_wave_table) */
@@ -1322,10 +1329,32 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
     }
     hcol = ka->pp.horizon_index ? (uint32_t)ka->pp.horizon_index[p] : (uint32_t)p;
   }
-  mail.v[0][0][lane] = T.get(2);
-  mail.failed[lane] = s.failed ? 1u : 0u; /* arrives failed (or a dead lane): frozen from the first index */
-  duo_meet();
   const int32_t nsteps = ka->nsteps, t0 = ka->t0;
+  /* coupling, lock-step part (time_loop<CPL>): what a lane needs every step in registers, the rest of
+   * CouplingVariables in the state block, touched at the two events only */
+  bool cpl_on = false, parked = false;
+  int32_t cpl_cs = -99, cpl_ce = -99, next_i = t0;
+  double cpl_lastobs = 0.0, cpl_swcorr = 0.0, cpl_lwcorr = 0.0;
+  if (CPL && live) {
+    const double *st = a.state;
+    const int64_t np = a.np_pad;
+    const int32_t cidx = ka->pp.coupling_index ? ka->pp.coupling_index[p] : 0;
+    /* setInputParam + initCouplingTimes, src/InputOutput.f90:30-36, src/Coupling.f90:486-534 */
+    cpl_on = consts_of(ka).use_coupling && ka->pp.coupling_index && !(ka->pp.coupling_tsurf[p] < -100 || cidx < 1);
+    if (cpl_on) {
+      cpl_ce = cidx;
+      cpl_cs = ((double)cidx <= consts_of(ka).cplLenR) ? 1 : cidx - consts_of(ka).cplLenI;
+    }
+    cpl_lastobs = st[(int64_t)RS_ST_CPL_LASTOBS * np + p];
+    cpl_swcorr = st[(int64_t)RS_ST_CPL_SWCORR * np + p];
+    cpl_lwcorr = st[(int64_t)RS_ST_CPL_LWCORR * np + p];
+    parked = (((int32_t)st[(int64_t)RS_ST_CPL_FLAGS * np + p]) & 1) != 0;
+    next_i = (int32_t)st[(int64_t)RS_ST_CPL_RESUME * np + p];
+  }
+  mail.v[0][0][lane] = T.get(2);
+  /* arrives failed (or a dead lane): frozen from the first index; CPL: or not due for it */
+  mail.failed[lane] = (s.failed || (CPL && (parked || t0 != next_i))) ? 1u : 0u;
+  duo_meet();
   auto blank_rows = [&](int32_t i_from) { /* as in time_loop */
     for (int32_t ii = i_from; ii < t0 + nsteps; ++ii) {
       int64_t r;
@@ -1335,7 +1364,9 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
       }
     }
   };
-  if (live && s.failed) blank_rows(t0);
+  /* (CPL: from the index the point is due for - rows before it were written when it was stepped there, by a
+   * replay launch that ran ahead of this chunk) */
+  if (live && s.failed) blank_rows(CPL && next_i > t0 ? next_i : t0);
   int32_t score = 0; /* scheduling hint of rs_hip_recluster, as in time_loop */
   /* (the forcing windows are the ground wave's to read: this wave gets what a step needs of them
    * through the mailbox, worked out one index ahead - ForcingPrep) */
@@ -1347,7 +1378,12 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
     int64_t orow = 0;
     const bool owrite = output_row<true>(ka, i, orow);
     const double t3 = mail.v[k & 1][1][lane]; /* Tmp(3) as the last step left it */
-    if (!s.failed) {
+    bool go = true; /* CPL: the lane is due for this index (a failed lane keeps counting: its rows are blanked) */
+    if (CPL) {
+      go = !(parked || i != next_i);
+      if (go) next_i = i + 1;
+    }
+    if (go && !s.failed) {
       const ForcingPrep q = duo_get_prep<FULL, SKYG>(c, mail, k & 1, lane, skyfl);
       if (i < c.SimLen) { /* CheckValues: the forcing's verdict | the surface temperature's */
         if (q.bad | check_values_tsurf(c, s.tsurf)) {
@@ -1363,6 +1399,49 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
       }
       s.tnw1 = T.get(1);
       s.tnw2 = T.get(2);
+      CouplingInputs cp;
+      if (CPL && cpl_on) { /* CouplingOperations1, src/Coupling.f90:10-96, first pass of the window: time_loop<CPL> */
+        if (i < c.SimLen) {
+          cp.in_phase = (i >= cpl_cs && i <= cpl_ce);
+          if (i == cpl_cs) { /* saveDataForCoupling :172-210 - this wave's share (the ground wave saves layers 3..N) */
+            double *st = ka->state;
+            const int64_t np = ka->np_pad, pp_ = row0 + lane;
+            st[(int64_t)RS_ST_CPL_SAVE_TSURF * np + pp_] = s.tsurf;
+            st[(int64_t)RS_ST_CPL_SAVE_WAT * np + pp_] = s.wat;
+            st[(int64_t)RS_ST_CPL_SAVE_ICE2 * np + pp_] = s.ice2;
+            st[(int64_t)RS_ST_CPL_SAVE_DEP * np + pp_] = s.dep;
+            st[(int64_t)RS_ST_CPL_SAVE_SNOW * np + pp_] = s.snow;
+            st[(int64_t)RS_ST_CPL_SAVE_ALBEDO * np + pp_] = s.albedo;
+            const int32_t fl = ((int32_t)st[(int64_t)RS_ST_CPL_FLAGS * np + pp_]) & 3;
+            st[(int64_t)RS_ST_CPL_FLAGS * np + pp_] = (double)(fl | (s.verycold ? 4 : 0));
+            st[(int64_t)(RS_ST_CPL_SAVE_TMP0 + 0) * np + pp_] = T.get(1);
+            st[(int64_t)(RS_ST_CPL_SAVE_TMP0 + 1) * np + pp_] = T.get(2);
+          }
+          if (i > cpl_ce) {
+            const double e = cpl_decay(c, mt, i, cpl_ce);
+            cp.sw_cof = R4(1.0) + cpl_swcorr * e;
+            cp.lw_cof = R4(1.0) + cpl_lwcorr * e;
+          }
+          if (cp.in_phase) { /* snowIceCheck :259-289 */
+            if (cpl_lastobs > c.TLimMeltSnow && s.snow > R4(0.00)) { s.wat = s.wat + s.snow; s.snow = R4(0.00); }
+            if (cpl_lastobs > c.TLimMeltIce && s.ice > R4(0.00)) { s.wat = s.wat + s.ice; s.ice = R4(0.00); }
+            if (cpl_lastobs > c.TLimMeltIce && s.ice2 > R4(0.00)) s.ice2 = R4(0.00);
+            if (cpl_lastobs > c.TLimMeltDep && s.dep > R4(0.00)) { s.wat = s.wat + s.dep; s.dep = R4(0.00); }
+          }
+        } else { /* lastValues: inCouplingPhase and the coefficients keep the values of index SimLen - 1 */
+          const int32_t j = c.SimLen - 1;
+          cp.in_phase = (j >= cpl_cs && j <= cpl_ce);
+          if (j > cpl_ce) {
+            const double e = cpl_decay(c, mt, j, cpl_ce);
+            cp.sw_cof = R4(1.0) + cpl_swcorr * e;
+            cp.lw_cof = R4(1.0) + cpl_lwcorr * e;
+          } else if (j >= cpl_cs) {
+            cp.sw_cof = ka->state[(int64_t)RS_ST_CPL_SWCOF * ka->np_pad + row0 + lane];
+            cp.lw_cof = ka->state[(int64_t)RS_ST_CPL_LWCOF * ka->np_pad + row0 + lane];
+          }
+        }
+      }
+      if (CPL) cp.last_tsurf_obs = cpl_lastobs;
       if (FULL) {
         /* SetCurrentValues' observation forcing (src/InputOutput.f90:116-148; the ground wave decided
          * whether it applies at this index and uses the same value for Tmp(2)), and lastValues' surface
@@ -1411,22 +1490,44 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
           }
         }
       }
-      const Fluxes fx = model_step_fluxes_prepped<SCORE>(c, mt, s, qs);
+      const Fluxes fx = model_step_fluxes_prepped<SCORE>(c, mt, s, qs, cp);
       if (SCORE) {
         score += (fx.trips & 63) - 5;
         if ((fx.trips & 64) && k >= nsteps - RS_REGIME_WINDOW) score |= 1 << 30;
       }
       /* layers 1-2 with Tmp(3) where a two-layer column has its lower boundary */
-      model_step_ground<RegProfile<2>, RegProfile<2>, false>(c, s, T, t3, tair, fx, R4(-9999.9));
+      model_step_ground<RegProfile<2>, RegProfile<2>, false>(c, s, T, t3, tair, fx, R4(-9999.9), cp);
       if (owrite) {
         if (OUTIDX && ka->out_index) store_outputs<true, false>(ka, orow, row0, lane, s, true);
         else store_outputs<false, true>(ka, orow, row0, lane, s, true);
       }
       if (s.failed) blank_rows(i + 1);
+      if (CPL && cpl_on && i < c.SimLen && i == cpl_ce) {
+        /* CheckEndCoupling + CouplingOperations2, src/Coupling.f90:98-141: as time_loop<CPL> */
+        double *st = ka->state;
+        const int64_t np = ka->np_pad, pp_ = row0 + lane;
+        Coupling cq;
+        load_coupling(st, np, pp_, cq);
+        cq.cs = cpl_cs; cq.ce = cpl_ce; cq.on = true;
+        if (!cq.failed) {
+          if (cq.iter == 0) cq.tend1 = s.tsurf;
+          coupling_control(cq, s.tsurf);
+          cq.iter = cq.iter + 1;
+          if (s.failed) cq.again = false; /* its loop exits before any rewind: not parked, not listed */
+          store_coupling(st, np, pp_, cq);
+          cpl_swcorr = cq.swcorr;
+          cpl_lwcorr = cq.lwcorr;
+          cpl_lastobs = cq.lastobs;
+          parked = cq.again;
+        }
+      }
     }
+    /* CPL: frozen at the NEXT index? (failed, parked, or not due for it) */
+    if (CPL) mail.failed[lane] = (s.failed || parked || (i + 1) != next_i) ? 1u : 0u;
     mail.v[(k & 1) ^ 1][0][lane] = T.get(2);
     duo_meet();
   }
+  if (CPL && live) a.state[(int64_t)RS_ST_CPL_RESUME * a.np_pad + p] = (double)next_i;
   if (live) {
     double *st = a.state;
     const int64_t np = a.np_pad;
@@ -1708,9 +1809,10 @@ enum { SRC_WINDOW = 0, SRC_KNOTS = 1, SRC_RAW = 2 }; /* where the ground wave's 
 /* SKYG (with SRC_RAW): the launch has per-point sky view and a THIRD wavefront for it (duo_sky): the short- and
  * long-wave radiation, their share of CheckValues and ModRadiationBySurroundings are that wave's; this one
  * makes the other six variables. */
-template <int NL, int SRC = SRC_WINDOW, bool FULL = false, bool SKYG = false>
+template <int NL, int SRC = SRC_WINDOW, bool FULL = false, bool SKYG = false, bool CPL = false>
 __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, const StepArgs &a) {
   constexpr bool KNOTS = SRC == SRC_KNOTS, RAW = SRC == SRC_RAW;
+  static_assert(FULL || !CPL, "coupling belongs to the FULL feature set");
   static_assert(!RAW || FULL, "the driver's series carry the FULL feature set");
   static_assert(!SKYG || RAW, "a sky wave exists only where the forcing is made from the raw series");
   KernArgs ka = kernargs();
@@ -1745,6 +1847,14 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
       relax_dr = rhR - a.state[(int64_t)RS_ST_RH_END * a.np_pad + p];
     }
   }
+  /* CPL: where the point's coupling window starts - from there on the observation is no longer forced on the
+   * two top layers (src/InputOutput.f90:120-121), and at that index the layers are saved (src/Coupling.f90:172-210) */
+  int32_t cpl_cs = 0x7fffffff;
+  if (CPL && live) {
+    const int32_t cidx = ka->pp.coupling_index ? ka->pp.coupling_index[p] : 0;
+    if (consts_of(ka).use_coupling && ka->pp.coupling_index && !(ka->pp.coupling_tsurf[p] < -100 || cidx < 1))
+      cpl_cs = ((double)cidx <= consts_of(ka).cplLenR) ? 1 : cidx - consts_of(ka).cplLenI;
+  }
   /* the anchors of an index are stored at the START of that index's step, when the surface wave's
    * verdict on the index before is in the mailbox (a point that has failed never reaches it) */
   bool anchor_due = false;
@@ -1759,7 +1869,7 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
     double tair = f.tair, rhz = f.rhz;
     obs = R4(-9999.9);
     if (in < c.SimLen) {
-      if ((in <= initlen || c.force_tsurf) && f.tsurfobs > R4(-100.0)) obs = f.tsurfobs;
+      if ((in <= initlen || c.force_tsurf) && f.tsurfobs > R4(-100.0) && (!CPL || in < cpl_cs)) obs = f.tsurfobs;
       if (relax) {
         if (in == initlen) { /* the anchors: once per point */
           double tairR, vzR, rhR;
@@ -1830,6 +1940,10 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
     /* a failed point takes no further step in any flavour: its Tmp(3..N) stay as the failing index left
      * them (the flag was raised before the barrier that ended that index) */
     if (!mail.failed[lane]) {
+      if (CPL && t0 + k == cpl_cs && t0 + k < c.SimLen && live) { /* saveDataForCoupling: layers 3..N as they stand */
+#pragma unroll
+        for (int j = 3; j <= NL; ++j) ka->state[(int64_t)(RS_ST_CPL_SAVE_TMP0 + j - 1) * ka->np_pad + p] = Tg[j - 3];
+      }
       if (FULL) {
         if (obs_cur > R4(-100.0)) t2 = obs_cur; /* SetCurrentValues has forced Tmp(1:2) at this index */
         if (anchor_due && live) {
@@ -1934,8 +2048,9 @@ __device__ __forceinline__ void duo_sky(DuoMail &mail, uint32_t *skyfl, const St
 
 /* SRC: SRC_WINDOW / SRC_KNOTS / SRC_RAW.  SKY: per-point sky view - on the surface wave (forcing windows)
  * or, with SRC_RAW, on a third wavefront (duo_sky). */
-template <int NL, bool SCORE, int SRC = SRC_WINDOW, bool FULL = false, bool SKY = false>
+template <int NL, bool SCORE, int SRC = SRC_WINDOW, bool FULL = false, bool SKY = false, bool CPL = false>
 __global__ void __launch_bounds__((SKY && SRC == SRC_RAW) ? 192 : 128, 4) step_kernel_duo(const StepArgs a) {
+  static_assert(!CPL || SRC == SRC_RAW, "coupling in the two-wavefront flavour: the driver path's lock-step chunks");
   constexpr bool SKYG = SKY && SRC == SRC_RAW;
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
   __shared__ DuoMail mail;
@@ -1949,9 +2064,9 @@ __global__ void __launch_bounds__((SKY && SRC == SRC_RAW) ? 192 : 128, 4) step_k
   if (a.wave_start && a.wave_cnt[blockIdx.x] == 0) return; /* a spare workgroup of the wave table: all wavefronts leave */
   if (threadIdx.x < 64) {
     if (a.surface_prio) __builtin_amdgcn_s_setprio(1); /* the longer chain of the two issues first (StepArgs::surface_prio) */
-    duo_surface<NL, SCORE, FULL, SKY && !SKYG, SKYG, SRC == SRC_RAW>(mt, mail, a, skyfl);
+    duo_surface<NL, SCORE, FULL, SKY && !SKYG, SKYG, SRC == SRC_RAW, CPL>(mt, mail, a, skyfl);
   } else if (!SKYG || threadIdx.x < 128) {
-    duo_ground<NL, SRC, FULL, SKYG>(mt, mail, a);
+    duo_ground<NL, SRC, FULL, SKYG, CPL>(mt, mail, a);
   } else {
     duo_sky(mail, skyfl, a);
   }
@@ -2619,8 +2734,13 @@ hipError_t rs_launch_step_duo_knots(const rs::StepArgs &a, bool score, hipStream
   return hipGetLastError();
 }
 
-hipError_t rs_launch_step_duo_raw(const rs::StepArgs &a, bool score, bool sky, hipStream_t stream) {
+hipError_t rs_launch_step_duo_raw(const rs::StepArgs &a, bool score, bool sky, bool cpl, hipStream_t stream) {
   const dim3 gd(a.wave_start ? (unsigned)a.wave_n : (unsigned)((a.npoints + 63) / 64));
+  if (cpl) { /* lock-step chunk of a coupled plan (rs_step_raw with coupling): the history score is kept */
+    if (sky) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, rs::SRC_RAW, true, true, true>), gd, dim3(192), 0, stream, a);
+    else hipLaunchKernelGGL((rs::step_kernel_duo<15, true, rs::SRC_RAW, true, false, true>), gd, dim3(128), 0, stream, a);
+    return hipGetLastError();
+  }
   if (sky && score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, rs::SRC_RAW, true, true>), gd, dim3(192), 0, stream, a);
   else if (sky) hipLaunchKernelGGL((rs::step_kernel_duo<15, false, rs::SRC_RAW, true, true>), gd, dim3(192), 0, stream, a);
   else if (score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, rs::SRC_RAW, true>), gd, dim3(128), 0, stream, a);

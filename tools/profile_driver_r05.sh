@@ -9,12 +9,12 @@ export TMPDIR=/tmp
 OUT=gpurun_out/r5_prof_drv_$MODE
 PROF=gpurun_out/profiles_r05   # (gpurun merges gpurun_out/ back; copy to profiles/ afterwards)
 rm -rf $OUT; mkdir -p $OUT $PROF
-export BENCH_UNIQUE=65536 BENCH_REPS=2 BENCH_PAUSE_S=0.25
+export BENCH_REPS=2 BENCH_PAUSE_S=0.25  # (distinct series for every point, as bench.py times them since round 5)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tools/bench_driver_path.py $N 48 $MODE > $OUT/bench.log 2> $OUT/trace.err || { tail -20 $OUT/trace.err; exit 1; }
 grep -E "rep |best" $OUT/bench.log
 STATS=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 SHA=$(python3 -c "from roadsurf_amd import provenance; print(provenance.csrc_sha16())")
-{ echo "# rocprofv3 --kernel-trace --stats -- python3 tools/bench_driver_path.py $N 48 $MODE (BENCH_UNIQUE=65536, 3 calls: 1 warm + 2 timed); kernel sources $SHA"; cat "$STATS"; } > $PROF/r05_driver_path_${MODE}_kernel_stats.csv
+{ echo "# rocprofv3 --kernel-trace --stats -- python3 tools/bench_driver_path.py $N 48 $MODE (distinct series, 3 calls: 1 warm + 2 timed); kernel sources $SHA"; cat "$STATS"; } > $PROF/r05_driver_path_${MODE}_kernel_stats.csv
 python3 - "$OUT" "$MODE" "$N" "$SHA" > $PROF/r05_driver_path_${MODE}_timeline.txt <<'PY'
 import csv, glob, collections, sys
 out, mode, n, sha = sys.argv[1:5]
