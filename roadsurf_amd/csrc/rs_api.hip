@@ -82,6 +82,12 @@ struct RsPlan {
   int32_t wave_n = 0;
   bool wave_tab_valid = false;
   std::vector<void *> owned; /* hipMalloc-ed pieces (plan_malloc): what rs_hip_plan_destroy frees */
+  /* the arena the plan's first pieces came out of (nullptr: hipMalloc) and where it stood: a later piece is
+   * taken from an arena only if it is still THAT arena and it has not been rewound since (a plan
+   * that outlives its tile, or is touched from another thread, must not alias another tile's buffers) */
+  rsu::Arena *arena = nullptr;
+  uint64_t arena_epoch = 0;
+  bool arena_set = false;
   std::vector<hipEvent_t> ev; /* start/stop pairs */
   size_t ev_used = 0;
   bool timing = false;
@@ -92,7 +98,13 @@ struct RsPlan {
  * RsPlan::owned for rs_hip_plan_destroy. */
 template <class T>
 static hipError_t plan_malloc(RsPlan *pl, T **p, size_t bytes) {
-  if (rsu::Arena *a = rsu::tls_arena())
+  rsu::Arena *a = rsu::tls_arena();
+  if (!pl->arena_set) { /* the plan's first allocation decides */
+    pl->arena_set = true;
+    pl->arena = a;
+    pl->arena_epoch = a ? a->epoch : 0;
+  }
+  if (a && a == pl->arena && a->epoch == pl->arena_epoch)
     if (void *q = a->take(bytes ? bytes : 8)) {
       *p = static_cast<T *>(q);
       return hipSuccess;

@@ -47,6 +47,11 @@ inline hipError_t transpose(const T *src, T *dst, int rows, int cols, int64_t ld
 struct Arena {
   char *base = nullptr;
   size_t cap = 0, off = 0;
+  uint64_t epoch = 0; /* bumped by every rewind: what was carved out before it is dead */
+  void rewind(size_t to) {
+    off = to;
+    ++epoch;
+  }
   void *take(size_t n) {
     const size_t a = (off + 255) & ~(size_t)255;
     if (!base || a + n > cap) return nullptr;

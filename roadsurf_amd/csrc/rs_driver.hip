@@ -1477,7 +1477,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
   const size_t arena_mark = arena.off; /* the shared axes stay; a tile's buffers go when it is done */
   for (int64_t p0 = pbeg, m_done = 0; p0 < pend; p0 += m_done) {
     m_done = 0; /* a tile that has to be cut is started again at the same p0 */
-    arena.off = arena_mark; /* the last tile's buffers are gone (same stream: what still runs there runs first) */
+    arena.rewind(arena_mark); /* the last tile's buffers are gone (same stream: what still runs there runs first) */
     const int m = (int)std::min<int64_t>(Pcur, pend - p0);
     PlanGuard pg;
     pg.p = rs_hip_plan_create(device, m, &consts, stream);

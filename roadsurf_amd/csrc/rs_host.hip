@@ -156,7 +156,8 @@ struct CallerCache : CallerCacheData {
       pin.base = static_cast<char *>(q);
       pin.cap = pin_bytes;
     }
-    dev.off = pin.off = 0;
+    dev.rewind(0);
+    pin.rewind(0);
     return true;
   }
 };
