@@ -49,8 +49,12 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 ALGO_BYTES_PER_UNIT = 100.0    # 52 B read + 48 B written per point-timestep
-TRAFFIC_FILE = "profiles/r04_traffic.json"  # committed PMC summary the roofline's `traffic` is read from
-TRAFFIC_FILE_F32 = "profiles/r04_f32_traffic.json"
+# the knot-reading flavour's own compulsory HBM bytes per point-timestep: 48 B of outputs + 9 knot doubles per
+# 120 indices (0.6 B) + the state block once per launch (134 slots x 8 B over >= 60 indices, read and written: <= 36 B
+# at 60 indices per launch, ~18 B at 120) - reported beside the contract's 100 B figure, never instead of it
+FUSED_BYTES_PER_UNIT = 48.0 + 9 * 8 / 120.0 + 2 * 49 * 8 / 60.0
+TRAFFIC_FILE = "profiles/r05_traffic.json"  # committed PMC summary the roofline's `traffic` is read from
+TRAFFIC_FILE_F32 = "profiles/r05_f32_traffic.json"
 
 
 def effective_cpus() -> int:
@@ -614,6 +618,11 @@ def main() -> None:
                 "busy_ms": busy_ms,
                 "concurrent_launches": concurrency,
                 "per_launch_achieved": algo_bytes * units_per_launch / avg_launch_s / 1e9,
+                # in the knot-reading flavour the 52 B/unit of forcing never exist in HBM - what the
+                # flavour itself has to move is the outputs plus the knots and the state, amortised
+                "flavour_compulsory_bytes_per_unit": (FUSED_BYTES_PER_UNIT if fused and not args.f32 else algo_bytes),
+                "flavour_compulsory_achieved": (FUSED_BYTES_PER_UNIT if fused and not args.f32 else algo_bytes)
+                                               * units_per_pass_rank * args.steps / (busy_ms / 1e3) / 1e9,
                 "method": "achieved = algorithmic bytes of all step launches / union of their HIP-event "
                           "intervals (busy_ms); = units_per_launch x bytes / avg_launch_ms x "
                           "concurrent_launches; per_launch_achieved is the single-launch figure",

@@ -1,0 +1,24 @@
+#!/usr/bin/env bash
+# after tools/profile_r05.sh on the GPU box: traffic summaries (stamped with the hash of the kernel
+# sources) and the rocprofv3 summaries from gpurun_out/prof_r05* into profiles/
+set -e
+python tools/make_traffic_json.py gpurun_out/prof_r05 profiles/r05_traffic.json
+TRAFFIC_POINTS=1250000 TRAFFIC_SIMLEN=20161 TRAFFIC_BYTES_PER_UNIT=52 python tools/make_traffic_json.py gpurun_out/prof_r05_f32 profiles/r05_f32_traffic.json "step_kernel_f32_lds" 120 4
+G=gpurun_out
+cp $G/prof_r05/bench.json profiles/r05_bench.json
+cp $G/prof_r05/bench_under_rocprof.json profiles/r05_bench_under_rocprof.json
+cp $G/prof_r05/kernel_stats.csv profiles/r05_kernel_stats.csv
+cp $G/prof_r05/pmc_summary.txt profiles/r05_pmc_summary.txt
+cp $G/prof_r05/timeline.txt profiles/r05_timeline.txt
+cp $G/prof_r05_f32/kernel_stats.csv profiles/r05_f32_kernel_stats.csv
+cp $G/prof_r05_f32/pmc_summary.txt profiles/r05_f32_pmc_summary.txt
+cp $G/prof_r05_f32/timeline.txt profiles/r05_f32_timeline.txt
+cp $G/prof_r05_full/bench.json profiles/r05_full_bench.json
+cp $G/prof_r05_full/kernel_stats.csv profiles/r05_full_kernel_stats.csv
+cp $G/prof_r05_full/pmc_summary.txt profiles/r05_full_pmc_summary.txt
+cp $G/prof_r05_full/timeline.txt profiles/r05_full_timeline.txt
+cp $G/prof_r05_small_v1/bench_250k.json profiles/r05_small_shard_bench_250k.json
+cp $G/prof_r05_small_v1/bench.json profiles/r05_small_shard_one_point_per_lane_bench_125k.json
+cp $G/prof_r05_small_v1/pmc_summary.txt profiles/r05_small_shard_one_point_per_lane_pmc_summary.txt
+cp $G/prof_r05_small_v3/bench.json profiles/r05_small_shard_two_wavefronts_bench_125k.json
+cp $G/prof_r05_small_v3/pmc_summary.txt profiles/r05_small_shard_two_wavefronts_pmc_summary.txt
