@@ -572,6 +572,13 @@ typedef struct RsPreview {
   const int32_t *index;                  /* NULL: the preview rows are in SLOT order; else row element
                                             index[slot] belongs to that slot (rows kept in point order,
                                             index = rs_hip_plan_order(): no regeneration after a re-sort) */
+  const double *prec[RS_PREVIEW_MAX];    /* ABI 8.  precipitation at preview time q, or all NULL.  With rows: the
+                                            key gets one more bit, its MOST significant - "some preview of the
+                                            next window has precipitation" - whatever `mode` says.  A wavefront
+                                            none of whose points has precipitation at an index skips
+                                            PrecipitationToStorage / CalcPrecType there (exact: they add zeros);
+                                            precipitating points are a few per cent of a batch at any time but, in
+                                            arbitrary order, sit in most wavefronts */
 } RsPreview;
 int rs_hip_recluster_forecast(RsPlan *plan, const RsPreview *preview);
 /* A plan that is only ever sorted by forecast can tell the step kernels not to keep the history
@@ -750,7 +757,7 @@ int rs_compat_outputs(const RsCompat *ctx, int32_t i, double *out6);
 int32_t rs_compat_failed_index(const RsCompat *ctx);
 void rs_compat_end(RsCompat *ctx);
 
-#define RS_ABI_VERSION 7 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles; 4: RsPointParams::horizon_index, rs_hip_step_knots; 5: RS_SUN_COLS 6, RsPointParams::horizons_by_point; 6: rs_driver_last_raw_launches (rs_driver_run without forcing windows); 7: rs_compat_* (module RoadSurf's per-step procedures) */
+#define RS_ABI_VERSION 8 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles; 4: RsPointParams::horizon_index, rs_hip_step_knots; 5: RS_SUN_COLS 6, RsPointParams::horizons_by_point; 6: rs_driver_last_raw_launches (rs_driver_run without forcing windows); 7: rs_compat_* (module RoadSurf's per-step procedures); 8: RsPreview::prec */
 int rs_abi_version(void);
 /* sizeof of the boundary structs as the C side / the Fortran side see them
  * (0 InputPointers, 1 OutputPointers, 2 InputSettings, 3 InputParameters,

@@ -384,7 +384,8 @@ int rs_hip_recluster_forecast(RsPlan *pl, const RsPreview *pv) {
   a.slots = pl->sort_keys + 2 * pl->np_pad;
   /* a key of at most 12 bits is sorted by the plan's own counting pass (3 kernels), a longer one by
    * the library (ROADSURF_HIP_LIBRARY_SORT=1 forces the library: A/B) */
-  const int bits = rs_forecast_key_bits(pv->mode);
+  const int wet_bit = pv->prec[0] ? 1 : 0; /* RsPreview::prec: one more bit, the most significant */
+  const int bits = rs_forecast_key_bits(pv->mode) + wet_bit;
   const bool lib_sort = getenv("ROADSURF_HIP_LIBRARY_SORT") != nullptr; /* read per call: the tests switch it */
   a.compact = (bits >= 1 && bits <= 12 && !lib_sort) ? 1 : 0;
   /* the ground digit (field 9 of the mode): below the others - a pass of its own in the plan's counting
@@ -401,7 +402,7 @@ int rs_hip_recluster_forecast(RsPlan *pl, const RsPreview *pv) {
      * 1..6 sets the bits (tuning; classes hold at least 64 bins of the key). */
     int cb = 5;
     if (const char *e = getenv("ROADSURF_HIP_WAVE_CLASS_BITS")) cb = atoi(e);
-    const bool table = cb >= 1 && cb <= 6 && bits - cb >= 6 && !pl->f32;
+    const bool table = cb >= 1 && cb <= 6 && bits - wet_bit - cb >= 6 && !pl->f32;
     uint32_t *class_total = nullptr;
     int32_t maxw = 0;
     if (table) {

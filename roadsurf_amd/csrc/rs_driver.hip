@@ -533,7 +533,7 @@ __global__ void __launch_bounds__(RS_BLOCK) blank_rejected_kernel(double *out, i
  * ROWS once the step kernel makes its own forcing from the raw series (rs_step_raw): air temperature and
  * road-temperature observation of index 1 for the initial profile (src/Initialization.f90:256-259), air
  * temperature and wind speed at the three preview indices of the forecast sort key.  Shared time axes. */
-constexpr int RAWROWS_MAX = 8;
+constexpr int RAWROWS_MAX = 12;
 struct RawRowsArgs {
   SrcSet S;
   const int32_t *status, *order; /* as ExpandRawArgs */
@@ -1781,7 +1781,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
         if (rs_hip_recluster(pg.p) != 0) return -14;
         return gather_params();
       }
-      if (!d_prev.p) HOK(d_prev.alloc((size_t)6 * mp * sizeof(double)));
+      if (!d_prev.p) HOK(d_prev.alloc((size_t)9 * mp * sizeof(double)));
       const int idx[3] = {t_next, t_next + len_next / 2, t_next + len_next - 1};
       ExpandRawArgs pe = ea; /* current order, same sources and decisions */
       RsPreview pv;
@@ -1793,7 +1793,9 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
         ra.S = S_full;
         ra.status = ea.status;
         ra.order = ea.order;
-        ra.nrows = 6;
+        /* ... nine with the precipitation of the three indices (RsPreview::prec: the key's precipitation bit) */
+        static const bool wet_bit = !(getenv("ROADSURF_HIP_PRECIP_BIT") && atoi(getenv("ROADSURF_HIP_PRECIP_BIT")) == 0);
+        ra.nrows = wet_bit ? 9 : 6;
         for (int q = 0; q < 3; ++q) {
           ra.fld[2 * q] = R_TAIR;
           ra.fld[2 * q + 1] = R_VZ;
@@ -1803,8 +1805,14 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
           pv.tair[q] = ra.out[2 * q];
           pv.vz[q] = ra.out[2 * q + 1];
           pv.hour[q] = in->hour[idx[q] - 1];
+          if (wet_bit) {
+            ra.fld[6 + q] = R_PREC;
+            ra.idx[6 + q] = idx[q] - 1;
+            ra.out[6 + q] = d_prev.as<double>() + (size_t)(6 + q) * mp;
+            pv.prec[q] = ra.out[6 + q];
+          }
         }
-        hipLaunchKernelGGL(raw_rows_kernel, dim3((unsigned)(mp / RS_BLOCK), 6), dim3(RS_BLOCK), 0, stream, ra);
+        hipLaunchKernelGGL(raw_rows_kernel, dim3((unsigned)(mp / RS_BLOCK), (unsigned)ra.nrows), dim3(RS_BLOCK), 0, stream, ra);
         HOK(hipGetLastError());
       } else
       for (int q = 0; q < 3; ++q) {

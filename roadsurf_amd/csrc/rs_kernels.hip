@@ -2604,6 +2604,17 @@ __global__ void __launch_bounds__(kBlock) forecast_key_kernel(const ForecastArgs
     else if (d == 7) { key = (key << 2) | (uint32_t)(unst > 3 ? 3 : unst); bits += 2; }
     else if (d == 8) { key = (key << 2) | (uint32_t)(farc > 3 ? 3 : farc); bits += 2; }
   }
+  /* RsPreview::prec (ABI 8): the most significant bit - some preview has precipitation.  Points with
+   * precipitation are a few per cent of a batch at any time, but in an order that ignores it they sit in four
+   * wavefronts out of five, and every such wavefront runs PrecipitationToStorage / CalcPrecType (the logistic
+   * exp where the phase is missing) for all of its lanes; gathered, they fill one wavefront in thirty. */
+  if (a.pv.prec[0]) {
+    uint32_t wet = 0u;
+    for (int q = 0; q < a.pv.n; ++q)
+      if (a.pv.prec[q] && a.pv.prec[q][pq] > 0.0) wet = 1u;
+    key |= wet << bits;
+    bits += 1;
+  }
   /* descending: the expensive points get the low slots (longest job first, rs_cluster.hip) */
   if (a.compact) { /* right-aligned in its own bits: the plan's counting sort */
     const int low = a.low_bits; /* the ground digit below them, if the mode has one */

@@ -286,7 +286,7 @@ class Plan:
         lib.check(self.L.rs_hip_plan_reset_order(self._h), "rs_hip_plan_reset_order")
 
     def recluster_forecast(self, tair_rows, vz_rows, hours, tair_now, alpha: float = 0.5,
-                           mode: int = 1, point_order: bool = False) -> None:
+                           mode: int = 1, point_order: bool = False, prec_rows=None) -> None:
         """Sort the slots by a forecast of the next launch (rs_hip_recluster_forecast): rows are
         tensors [np_pad] at the preview times, hours the hour of day.  Rows in the CURRENT slot order,
         or - ``point_order`` - in point order, read through the plan's order row."""
@@ -295,6 +295,9 @@ class Plan:
         pv.n = len(tair_rows)
         for q, (ta, vz, h) in enumerate(zip(tair_rows, vz_rows, hours)):
             pv.tair[q] = ta.data_ptr(); pv.vz[q] = vz.data_ptr(); pv.hour[q] = int(h)
+        if prec_rows is not None:  # one more key bit: precipitation somewhere in the next window
+            for q, pr in enumerate(prec_rows):
+                pv.prec[q] = pr.data_ptr()
         pv.tair_now = tair_now.data_ptr()
         pv.alpha = alpha
         pv.mode = mode

@@ -17,6 +17,8 @@ inside the timed region) before the slots are re-sorted for the next launch.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import device, lib
@@ -56,6 +58,8 @@ class SyntheticRun:
         # sort key of the re-sort: forecast of the next window (rs_hip_recluster_forecast) or the
         # history of the last one (rs_hip_recluster)
         self.forecast, self.forecast_alpha, self.forecast_mode = forecast, forecast_alpha, forecast_mode
+        # round 5: one more key bit for "precipitation in the next window" (ROADSURF_HIP_PRECIP_BIT=0: A/B)
+        self.precip_bit = os.environ.get("ROADSURF_HIP_PRECIP_BIT", "1") != "0"
         plan.set_history_score(not (plan_order and forecast))  # nobody reads it then
         dev, npad = plan.device, plan.np_pad
         wdtype = torch.float32 if f32 else torch.float64
@@ -144,8 +148,11 @@ class SyntheticRun:
         nk = min(k1 - k0 + 1, 8)
         hours = [(self.spec.start_hour + k0 + q) % 24 for q in range(nk)]
         kn = self.knots
+        # ... field 4 the precipitation: a window has precipitation at some index iff one of its knots has
+        prec = [kn[k0 + q, 4] for q in range(nk)] if self.precip_bit else None
         plan.recluster_forecast([kn[k0 + q, 0] for q in range(nk)], [kn[k0 + q, 2] for q in range(nk)],
-                                hours, kn[k0, 0], self.forecast_alpha, self.forecast_mode, point_order=True)
+                                hours, kn[k0, 0], self.forecast_alpha, self.forecast_mode, point_order=True,
+                                prec_rows=prec)
 
     def slots_of(self, c: int, points: torch.Tensor) -> torch.Tensor:
         """Columns of launch ``c``'s output window that hold the given local points."""
