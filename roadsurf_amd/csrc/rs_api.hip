@@ -552,7 +552,7 @@ int rs_hip_init_state(RsPlan *pl, const RsForcing *f, const RsPointParams *pp) {
  * the final index, no sky view: the rounds run the lock-step loop over the list (time_loop<REPLAY>:
  * scalar row arithmetic, coalesced outputs of the first pass' quality) instead of the general
  * kernel, which carries a time index per lane. */
-static int cpl_replay_rounds(RsPlan *pl, rs::StepArgs a, bool lockstep = false) {
+static int cpl_replay_rounds(RsPlan *pl, rs::StepArgs a, bool lockstep = false, bool raw = false) {
   if (!pl->cpl_list) {
     HIP_OK(plan_malloc(pl, &pl->cpl_flags, (size_t)2 * pl->np_pad * sizeof(int32_t)));
     HIP_OK(plan_malloc(pl, &pl->cpl_list, (size_t)pl->np_pad * sizeof(int32_t)));
@@ -583,12 +583,14 @@ static int cpl_replay_rounds(RsPlan *pl, rs::StepArgs a, bool lockstep = false) 
      * take issue slots from the other blocks' launches).  So it is done only for the tail of the tail:
      * once the list is down to 1/64 of the plan's points.  ROADSURF_HIP_CPL_COLLAPSE=r collapses from
      * round r on instead (tests; 0 = never). */
-    bool collapse = lockstep && (int64_t)n_again * 64 <= pl->npoints;
+    bool collapse = lockstep && !raw && (int64_t)n_again * 64 <= pl->npoints;
     if (const char *e = getenv("ROADSURF_HIP_CPL_COLLAPSE"))
-      collapse = lockstep && atoi(e) > 0 && round + 1 >= atoi(e);
+      collapse = lockstep && !raw && atoi(e) > 0 && round + 1 >= atoi(e);
     a.cpl_inner = collapse ? 64 : 1;
     a.cpl_prio = ((int64_t)n_again * 4 <= pl->npoints) ? 1 : 0;
-    if (lockstep)
+    if (raw) /* two wavefronts per 64 listed points, forcing from the raw series (one replay per round) */
+      HIP_OK(rs_launch_step_duo_raw_replay(a, pl->stream));
+    else if (lockstep)
       HIP_OK(rs_launch_step_cpl_replay(a, pl->c.NLayers, pl->stream));
     else
       HIP_OK(rs_launch_step_coupled(a, pl->c.NLayers, pl->stream));
@@ -886,6 +888,62 @@ int rs_step_raw(RsPlan *pl, const rs::RawForcing *raw, const double *sun, const 
   a.out_index = (out_by_point && pl->order) ? pl->order : nullptr;
   const hipError_t le = rs_launch_step_duo_raw(a, pl->history_score, sky, coupled, pl->stream);
   if (le != hipSuccess) return set_err("rs_step_raw: kernel launch failed: %s", hipGetErrorString(le));
+  return 0;
+}
+
+/* The replay rounds over the raw series (internal, rs_kernels.h): what rs_hip_cpl_replay does with a forcing
+ * window, with step_kernel_duo<..., CPL, REPLAY> making its forcing itself.  The block [t0, t0 + nsteps) must
+ * cover every parked point's [couplingStartI, couplingEndI + 1] and end before SimLen; no sky view. */
+int rs_cpl_replay_raw(RsPlan *pl, const rs::RawForcing *raw, const RsOutputs *o, const RsPointParams *pp,
+                      int32_t t0, int32_t nsteps, bool out_by_point, int32_t *rounds) {
+  if (!pl || !raw || raw->nsrc < 1 || raw->nsrc > RS_MAX_SOURCES || !raw->segs || !raw->hour)
+    return set_err("rs_cpl_replay_raw: bad arguments");
+  if (!pp || !pp->tbottom || !pp->initlen || !pp->coupling_index || !pp->coupling_tsurf)
+    return set_err("rs_cpl_replay_raw: tbottom, initlen, coupling_index and coupling_tsurf are required");
+  if (!pl->c.use_coupling || !rs_step_raw_ok(pl) || pp->sky_view)
+    return set_err("rs_cpl_replay_raw: a coupled plan with NLayers = 15, fp64, no output depth, no sky view only");
+  if (!o || !o->tsurf || !o->snow || !o->water || !o->ice || !o->deposit || !o->ice2 || o->decimate < 1)
+    return set_err("rs_cpl_replay_raw: all six output streams are required");
+  if (t0 < 1 || nsteps < 1 || (int64_t)t0 + nsteps - 1 >= pl->c.SimLen)
+    return set_err("rs_cpl_replay_raw: the block [%d,%d] must lie inside [1, SimLen - 1]", t0, t0 + nsteps - 1);
+  const int64_t out_rows = ((int64_t)t0 + nsteps - 2) / o->decimate - o->row0 + 1;
+  if ((uint64_t)o->t_stride * (uint64_t)(out_rows > 0 ? out_rows : 1) >= (1ull << 29))
+    return set_err("rs_cpl_replay_raw: output window of 4 GiB per stream or more");
+  if (raw->seg0 < 0 || raw->seg0 >= raw->nseg) return set_err("rs_cpl_replay_raw: seg0 outside the segment table");
+  HIP_OK(hipSetDevice(pl->device));
+  rs::StepArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.consts = pl->consts_dev;
+  a.f.t_stride = pl->np_pad;
+  a.o = *o;
+  a.pp = *pp;
+  a.state = pl->state;
+  a.npoints = pl->npoints;
+  a.np_pad = pl->np_pad;
+  a.t0 = t0;
+  a.nsteps = nsteps;
+  a.duo_full_ok = 3;
+  a.raw = *raw;
+  a.out_index = (out_by_point && pl->order) ? pl->order : nullptr;
+  { /* the block must cover the coupling windows of the points that replay (as rs_hip_cpl_replay checks) */
+    if (!pl->cpl_list) {
+      HIP_OK(plan_malloc(pl, &pl->cpl_flags, (size_t)2 * pl->np_pad * sizeof(int32_t)));
+      HIP_OK(plan_malloc(pl, &pl->cpl_list, (size_t)pl->np_pad * sizeof(int32_t)));
+      HIP_OK(plan_malloc(pl, &pl->cpl_count, sizeof(int32_t)));
+      pl->cpl_tmp_bytes = rs_cpl_select_scratch_bytes(pl->npoints);
+      HIP_OK(plan_malloc(pl, &pl->cpl_tmp, pl->cpl_tmp_bytes ? pl->cpl_tmp_bytes : 8));
+    }
+    int32_t b[2] = {INT32_MAX, 0};
+    HIP_OK(hipMemcpyAsync(pl->cpl_flags, b, sizeof(b), hipMemcpyHostToDevice, pl->stream));
+    HIP_OK(rs_launch_cpl_window_bounds(a, pl->cpl_flags, pl->stream));
+    HIP_OK(hipMemcpyAsync(b, pl->cpl_flags, sizeof(b), hipMemcpyDeviceToHost, pl->stream));
+    HIP_OK(hipStreamSynchronize(pl->stream));
+    if (b[1] > 0 && (b[0] < t0 || b[1] + 1 > t0 + nsteps - 1))
+      return set_err("rs_cpl_replay_raw: the block [%d,%d] does not cover the coupling windows of the points that "
+                     "replay, [%d,%d]", t0, t0 + nsteps - 1, b[0], b[1] + 1);
+  }
+  if (cpl_replay_rounds(pl, a, true, true)) return -1;
+  if (rounds) *rounds = pl->cpl_rounds_last;
   return 0;
 }
 

@@ -1358,8 +1358,13 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
   HOK(hipSetDevice(device));
   StreamGuard sg, sg_copy;
   HOK(hipStreamCreate(&sg.s));
-  HOK(hipStreamCreate(&sg_copy.s)); /* the uploads of a tile: TileLanding */
-  hipStream_t stream = sg.s, copy_stream = sg_copy.s;
+  /* ROADSURF_HIP_UPLOAD_STREAM=1: the uploads of a tile on a stream of their own, the transposes behind their
+   * pieces (TileLanding).  Off by default: a process has four hardware queues, and with two streams per worker
+   * two blocks' compute streams can land on one queue - their step kernels then take turns (measured: one queue
+   * with 102 of a call's 204 step launches, the call 0.64 s instead of 0.58 s) */
+  static const bool upload_stream = getenv("ROADSURF_HIP_UPLOAD_STREAM") != nullptr;
+  if (upload_stream) HOK(hipStreamCreate(&sg_copy.s));
+  hipStream_t stream = sg.s, copy_stream = upload_stream ? sg_copy.s : sg.s;
 
   const int L = c.L;
   const bool coupled = st->use_coupling == 1;
@@ -1490,8 +1495,8 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
       const double tg0 = PhaseTimer::now();
       std::lock_guard<std::mutex> turn(rsu::copy_gate(device)); /* rs_devices.hpp: uploads take turns */
       const double tg1 = PhaseTimer::now();
-      /* ROADSURF_HIP_UPLOAD_INLINE=1 (A/B): copies and transposes one after the other on the worker's stream */
-      static const bool inline_upload = getenv("ROADSURF_HIP_UPLOAD_INLINE") != nullptr;
+      /* default: copies and transposes one after the other on the worker's stream */
+      const bool inline_upload = !upload_stream;
       landing.async = !inline_upload;
       hipStream_t cs = inline_upload ? stream : copy_stream;
       if (!inline_upload) { /* the landing block comes out of the arena the last tile's kernels may still be reading */
@@ -1591,7 +1596,11 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
       }
     }
     const int r_lo = cs_min, r_hi = std::min(ce_max + 1, L); /* replay block, 1-based inclusive */
-    const bool need_win = !use_raw || (cpl_chunked && any_on); /* raw-series stepping: windows for the replays only */
+    /* the replay rounds read the raw series too (rs_cpl_replay_raw) where the block ends before SimLen and
+     * there is no sky view; ROADSURF_HIP_CPL_REPLAY_WINDOWS=1: a window + the one-point-per-lane kernels (A/B) */
+    const bool replay_raw = use_raw && cpl_chunked && any_on && !skyview && std::min(ce_max + 1, L) < L &&
+                            !getenv("ROADSURF_HIP_CPL_REPLAY_WINDOWS");
+    const bool need_win = !use_raw || (cpl_chunked && any_on && !replay_raw); /* raw-series stepping: windows for such replays only */
     const int WR = (cpl_chunked && any_on) ? (use_raw ? r_hi - r_lo + 1 : std::max(TC, r_hi - r_lo + 1)) : TC;
     if (cpl_chunked && WR > TC && (size_t)nwin * mp * WR * sizeof(double) > win_budget && m > 4096) {
       Pcur = std::max(4096, (m / 2 + 4095) / 4096 * 4096);
@@ -1916,9 +1925,17 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
           if (int rc = resort(t_next)) return rc;
       }
       if (any_on) {
-        if (int rc = expand_window(r_lo, r_hi - r_lo + 1, fo)) return rc;
         int32_t rounds = 0;
-        if (rs_hip_cpl_replay(pg.p, &fo, &oo, &ppx, r_lo, r_hi - r_lo + 1, &rounds) != 0) return -13;
+        if (replay_raw) {
+          while (seg > 0 && c.segs[seg].i0 > r_lo - 1) --seg;
+          while (seg + 1 < c.segs.size() && c.segs[seg].i1 <= r_lo - 1) ++seg;
+          rf.seg0 = (int32_t)seg;
+          rf.col = cluster ? ea.order : nullptr;
+          if (rs_cpl_replay_raw(pg.p, &rf, &oo, &ppx, r_lo, r_hi - r_lo + 1, cluster, &rounds) != 0) return -13;
+        } else {
+          if (int rc = expand_window(r_lo, r_hi - r_lo + 1, fo)) return rc;
+          if (rs_hip_cpl_replay(pg.p, &fo, &oo, &ppx, r_lo, r_hi - r_lo + 1, &rounds) != 0) return -13;
+        }
         /* every window is behind the plan: stage 3's re-sorts need not move the saved state */
         if (rs_hip_coupling_windows_closed(pg.p, 1) != 0) return -14;
         for (int t0 = ce_min + 1; t0 <= L; t0 += TC) {

@@ -131,7 +131,12 @@ hipError_t rs_launch_step_duo_raw(const rs::StepArgs &a, bool score, bool sky, b
 /* the step of rs_driver_run's blocks (rs_api.hip): NLayers = 15, fp64, no output depth; pp in SLOT order, raw
  * series in point order behind raw.col.  A coupled plan (use_coupling, pp->coupling_index): a LOCK-STEP chunk as
  * rs_hip_step_cpl runs it - points park behind their coupling window until rs_hip_cpl_replay has run. */
+hipError_t rs_launch_step_duo_raw_replay(const rs::StepArgs &a, hipStream_t stream);
 struct RsPlan;
+/* the replay rounds of a coupled plan whose lock-step chunks run through rs_step_raw: as rs_hip_cpl_replay, the
+ * forcing of the block [t0, t0 + nsteps) from the raw series (no sky view; the block must end before SimLen) */
+int rs_cpl_replay_raw(RsPlan *pl, const rs::RawForcing *raw, const RsOutputs *o, const RsPointParams *pp,
+                      int32_t t0, int32_t nsteps, bool out_by_point, int32_t *rounds);
 bool rs_step_raw_ok(const RsPlan *pl); /* a plan whose settings rs_step_raw can run */
 int rs_step_raw(RsPlan *pl, const rs::RawForcing *raw, const double *sun, const RsOutputs *o,
                 const RsPointParams *pp, int32_t t0, int32_t nsteps, bool out_by_point);

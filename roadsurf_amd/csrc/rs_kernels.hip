@@ -1242,7 +1242,7 @@ __device__ __forceinline__ void duo_put_prep(DuoMail &mail, int buf, uint32_t la
     w[10][lane] = q.lw;
   }
   if (FULL) w[11][lane] = q.tsurfobs;
-  mail.prep_bad[buf][lane] = (q.bad ? 1u : 0u) | (q.night ? 2u : 0u);
+  mail.prep_bad[buf][lane] = (q.bad ? 1u : 0u) | (q.night ? 2u : 0u) | (q.bad_rw ? 8u : 0u);
 }
 template <bool FULL, bool SKYG = false, class C>
 __device__ __forceinline__ ForcingPrep duo_get_prep(const C &c, const DuoMail &mail, int buf, uint32_t lane,
@@ -1267,6 +1267,7 @@ __device__ __forceinline__ ForcingPrep duo_get_prep(const C &c, const DuoMail &m
   q.avk = AirVCap * c.VK_Const;
   q.bad = (flags & 1u) != 0u;
   q.stop = SKYG && (flags & 4u) != 0u; /* only an instance with a sky wave raises it */
+  q.bad_rw = (flags & 8u) != 0u;       /* (only a replay instance's ground wave raises it) */
   return q;
 }
 
@@ -1287,19 +1288,32 @@ __device__ __forceinline__ void duo_meet() { asm volatile("s_waitcnt lgkmcnt(0)\
  * phase, Coupling_control at the window end - a point that has to replay PARKS -, the decaying corrections
  * behind the window.  A lane steps index i only if it is the index it is due for (RS_ST_CPL_RESUME); parked or
  * ahead, it is frozen for that index in both wavefronts (DuoMail::failed is rewritten before every meeting). */
+/* REPLAY (with CPL): one replay ROUND of the coupling windows in lock step, as time_loop<REPLAY> has it, for the
+ * points of the compacted list that asked for another replay (StepArgs::cpl_list): the launch covers [first
+ * window start, last window end + 1]; a lane waits for its window start, rewinds there - CheckValues of the
+ * index behind its window end, as the reference's loop does before CouplingOperations1 takes it back
+ * (examples/example1/src/Simulation.f90:62-71: the forcing's verdict comes from the ground wave, ForcingPrep::
+ * bad_rw), then uploadDataForCoupling (src/Coupling.f90:213-255) and the radiation coefficient (:61-78) -, runs
+ * its window in the coupling phase and lets Coupling_control decide again at the end.  The list breaks the tie
+ * between lane and point: `lane` below is the POINT (row0 = 0), `ml` the lane of the mailbox. */
 template <int NL, bool SCORE, bool FULL = false, bool SKY = false, bool SKYG = false, bool OUTIDX = false,
-          bool CPL = false>
+          bool CPL = false, bool REPLAY = false>
 __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, const StepArgs &a,
                                             const uint32_t *skyfl = nullptr) {
   static_assert(FULL || !SKY, "sky view belongs to the FULL feature set");
   static_assert(!(SKY && SKYG), "the sky view is this wave's or the ground wave's");
   static_assert(FULL || !CPL, "coupling belongs to the FULL feature set");
+  static_assert(CPL || !REPLAY, "replays belong to coupling");
   KernArgs ka = kernargs();
-  const uint32_t lane = threadIdx.x & 63u;
-  /* the workgroup's slots: 64 from 64 * blockIdx.x, or what the wave table says (rs_cluster_wave_table) */
-  const int64_t row0 = a.wave_start ? (int64_t)a.wave_start[blockIdx.x] : (int64_t)blockIdx.x * 64;
+  const uint32_t ml = threadIdx.x & 63u;
+  /* the workgroup's slots: 64 from 64 * blockIdx.x, or what the wave table says (rs_cluster_wave_table);
+   * REPLAY: entries 64 * blockIdx.x ... of the list */
+  const int64_t listed = REPLAY ? (int64_t)blockIdx.x * 64 + ml : 0;
+  const int64_t row0 = REPLAY ? 0 : a.wave_start ? (int64_t)a.wave_start[blockIdx.x] : (int64_t)blockIdx.x * 64;
+  const uint32_t lane = REPLAY ? (listed < a.cpl_nlist ? (uint32_t)a.cpl_list[listed] : 0u) : ml;
   const int64_t p = row0 + lane;
-  const bool live = a.wave_start ? (int32_t)lane < a.wave_cnt[blockIdx.x] : p < a.npoints; /* a dead lane still walks to every barrier */
+  const bool live = REPLAY ? listed < a.cpl_nlist
+                           : a.wave_start ? (int32_t)lane < a.wave_cnt[blockIdx.x] : p < a.npoints; /* a dead lane still walks to every barrier */
   RegProfile<2> T;
   Scalars s;
   {
@@ -1350,10 +1364,16 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
     cpl_lwcorr = st[(int64_t)RS_ST_CPL_LWCORR * np + p];
     parked = (((int32_t)st[(int64_t)RS_ST_CPL_FLAGS * np + p]) & 1) != 0;
     next_i = (int32_t)st[(int64_t)RS_ST_CPL_RESUME * np + p];
+    if (REPLAY) { /* a listed point: parked behind its window, wanting it again */
+      parked = false;
+      next_i = cpl_cs;
+    }
   }
-  mail.v[0][0][lane] = T.get(2);
+  /* REPLAY: SWRadCof / LWRadCof of the window being replayed */
+  double r_swcof = R4(1.0), r_lwcof = R4(1.0);
+  mail.v[0][0][ml] = T.get(2);
   /* arrives failed (or a dead lane): frozen from the first index; CPL: or not due for it */
-  mail.failed[lane] = (s.failed || (CPL && (parked || t0 != next_i))) ? 1u : 0u;
+  mail.failed[ml] = (s.failed || (CPL && (parked || t0 != next_i))) ? 1u : 0u;
   duo_meet();
   auto blank_rows = [&](int32_t i_from) { /* as in time_loop */
     for (int32_t ii = i_from; ii < t0 + nsteps; ++ii) {
@@ -1366,7 +1386,7 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
   };
   /* (CPL: from the index the point is due for - rows before it were written when it was stepped there, by a
    * replay launch that ran ahead of this chunk) */
-  if (live && s.failed) blank_rows(CPL && next_i > t0 ? next_i : t0);
+  if (live && s.failed && !REPLAY) blank_rows(CPL && next_i > t0 ? next_i : t0);
   int32_t score = 0; /* scheduling hint of rs_hip_recluster, as in time_loop */
   /* (the forcing windows are the ground wave's to read: this wave gets what a step needs of them
    * through the mailbox, worked out one index ahead - ForcingPrep) */
@@ -1377,25 +1397,28 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
     const int32_t i = t0 + k;
     int64_t orow = 0;
     const bool owrite = output_row<true>(ka, i, orow);
-    const double t3 = mail.v[k & 1][1][lane]; /* Tmp(3) as the last step left it */
+    double t3 = mail.v[k & 1][1][ml]; /* Tmp(3) as the last step left it */
     bool go = true; /* CPL: the lane is due for this index (a failed lane keeps counting: its rows are blanked) */
     if (CPL) {
       go = !(parked || i != next_i);
       if (go) next_i = i + 1;
     }
     if (go && !s.failed) {
-      const ForcingPrep q = duo_get_prep<FULL, SKYG>(c, mail, k & 1, lane, skyfl);
+      const ForcingPrep q = duo_get_prep<FULL, SKYG>(c, mail, k & 1, ml, skyfl);
       if (i < c.SimLen) { /* CheckValues: the forcing's verdict | the surface temperature's */
-        if (q.bad | check_values_tsurf(c, s.tsurf)) {
+        /* REPLAY, at the rewind: the index CheckValues has just seen is the one behind the window end - with
+         * the surface temperature of the end of the window */
+        const bool rewind = REPLAY && i == cpl_cs;
+        if ((rewind ? q.bad_rw : q.bad) | check_values_tsurf(c, s.tsurf)) {
           s.failed = true;
-          ka->state[(int64_t)RS_ST_FAILED * ka->np_pad + row0 + lane] = (double)i;
-          mail.failed[lane] = 1u; /* this index still steps (the ground wave is in it already); the next does not */
+          ka->state[(int64_t)RS_ST_FAILED * ka->np_pad + row0 + lane] = (double)(rewind ? cpl_ce + 1 : i);
+          mail.failed[ml] = 1u; /* this index still steps (the ground wave is in it already); the next does not */
         }
       }
       if (SKYG && q.stop) { /* as duo_surface<SKY> flags it: at any index */
         s.failed = true;
         ka->state[(int64_t)RS_ST_FAILED * ka->np_pad + row0 + lane] = (double)i;
-        mail.failed[lane] = 1u;
+        mail.failed[ml] = 1u;
       }
       s.tnw1 = T.get(1);
       s.tnw2 = T.get(2);
@@ -1403,7 +1426,39 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
       if (CPL && cpl_on) { /* CouplingOperations1, src/Coupling.f90:10-96, first pass of the window: time_loop<CPL> */
         if (i < c.SimLen) {
           cp.in_phase = (i >= cpl_cs && i <= cpl_ce);
-          if (i == cpl_cs) { /* saveDataForCoupling :172-210 - this wave's share (the ground wave saves layers 3..N) */
+          if (REPLAY && i == cpl_cs) {
+            /* inCouplingPhase is set from the loop index BEFORE a rewind takes it back (:22-27 against :61-66):
+             * the step at the window start of a replay runs outside the coupling phase.  uploadDataForCoupling
+             * :213-255: SrfIcemms, Q2Melt, T4Melt and TmpNw are NOT restored - s.tnw1/2 above hold the
+             * end-of-window values CalcHCapHCond sees in this step (the ground wave does the same for 3..N) */
+            cp.in_phase = false;
+            double *st = ka->state;
+            const int64_t np = ka->np_pad, pp_ = row0 + lane;
+            s.tsurf = st[(int64_t)RS_ST_CPL_SAVE_TSURF * np + pp_];
+            s.wat = st[(int64_t)RS_ST_CPL_SAVE_WAT * np + pp_];
+            s.ice2 = st[(int64_t)RS_ST_CPL_SAVE_ICE2 * np + pp_];
+            s.dep = st[(int64_t)RS_ST_CPL_SAVE_DEP * np + pp_];
+            s.snow = st[(int64_t)RS_ST_CPL_SAVE_SNOW * np + pp_];
+            s.albedo = st[(int64_t)RS_ST_CPL_SAVE_ALBEDO * np + pp_];
+            const int32_t fl = (int32_t)st[(int64_t)RS_ST_CPL_FLAGS * np + pp_];
+            s.verycold = (fl & 4) != 0;
+            st[(int64_t)RS_ST_CPL_FLAGS * np + pp_] = (double)(fl & ~1); /* start_coupling_again = .false. */
+            T.set(1, st[(int64_t)(RS_ST_CPL_SAVE_TMP0 + 0) * np + pp_]);
+            T.set(2, st[(int64_t)(RS_ST_CPL_SAVE_TMP0 + 1) * np + pp_]);
+            t3 = st[(int64_t)(RS_ST_CPL_SAVE_TMP0 + 2) * np + pp_]; /* layer 2's lower boundary: the restored Tmp(3) */
+            /* short-wave scaling by day, long-wave by night (:68-76; no sky view in this instance) */
+            const double radcoeff = st[(int64_t)RS_ST_CPL_RADCOEFF * np + pp_];
+            if (q.sw > q.lw) {
+              r_swcof = radcoeff;
+              r_lwcof = R4(1.0);
+            } else {
+              r_swcof = R4(1.0);
+              r_lwcof = radcoeff;
+            }
+            st[(int64_t)RS_ST_CPL_SWCOF * np + pp_] = r_swcof; /* Coupling_control reads them at the end */
+            st[(int64_t)RS_ST_CPL_LWCOF * np + pp_] = r_lwcof;
+          }
+          if (!REPLAY && i == cpl_cs) { /* saveDataForCoupling :172-210 - this wave's share (the ground wave saves layers 3..N) */
             double *st = ka->state;
             const int64_t np = ka->np_pad, pp_ = row0 + lane;
             st[(int64_t)RS_ST_CPL_SAVE_TSURF * np + pp_] = s.tsurf;
@@ -1421,6 +1476,10 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
             const double e = cpl_decay(c, mt, i, cpl_ce);
             cp.sw_cof = R4(1.0) + cpl_swcorr * e;
             cp.lw_cof = R4(1.0) + cpl_lwcorr * e;
+          }
+          if (REPLAY && i >= cpl_cs && i <= cpl_ce) {
+            cp.sw_cof = r_swcof;
+            cp.lw_cof = r_lwcof;
           }
           if (cp.in_phase) { /* snowIceCheck :259-289 */
             if (cpl_lastobs > c.TLimMeltSnow && s.snow > R4(0.00)) { s.wat = s.wat + s.snow; s.snow = R4(0.00); }
@@ -1467,7 +1526,7 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
           if (sky_on && (sw_dir < R4(-0.1) || sw_dir > R4(4000.0) || lw_net < R4(-1000.0) || lw_net > R4(1000.0))) {
             s.failed = true; /* src/InputOutput.f90:68-74 */
             ka->state[(int64_t)RS_ST_FAILED * ka->np_pad + row0 + lane] = (double)i;
-            mail.failed[lane] = 1u;
+            mail.failed[ml] = 1u;
           }
           if (sw_dir > q.sw) sw_dir = q.sw; /* :75-77 */
         }
@@ -1478,7 +1537,7 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
                                   ka->pp.horizons_by_point ? (int64_t)1 : ka->np_pad, qs.sw, sw_dir, qs.lw, lw_net)) {
             s.failed = true; /* the reference would `stop` the process here */
             ka->state[(int64_t)RS_ST_FAILED * ka->np_pad + row0 + lane] = (double)i;
-            mail.failed[lane] = 1u;
+            mail.failed[ml] = 1u;
           }
         }
         if (ka->wb.sw_dir) { /* the caller's arrays as the reference leaves them (time_loop<SKY>) */
@@ -1501,7 +1560,9 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
         if (OUTIDX && ka->out_index) store_outputs<true, false>(ka, orow, row0, lane, s, true);
         else store_outputs<false, true>(ka, orow, row0, lane, s, true);
       }
-      if (s.failed) blank_rows(i + 1);
+      /* (REPLAY: a point that fails in the middle of a replay keeps, up to its window end, what the earlier
+       * passes saved there: src/InputOutput.f90:151-165 only ever overwrites) */
+      if (s.failed) blank_rows(REPLAY && cpl_ce + 1 > i + 1 ? cpl_ce + 1 : i + 1);
       if (CPL && cpl_on && i < c.SimLen && i == cpl_ce) {
         /* CheckEndCoupling + CouplingOperations2, src/Coupling.f90:98-141: as time_loop<CPL> */
         double *st = ka->state;
@@ -1523,8 +1584,8 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
       }
     }
     /* CPL: frozen at the NEXT index? (failed, parked, or not due for it) */
-    if (CPL) mail.failed[lane] = (s.failed || parked || (i + 1) != next_i) ? 1u : 0u;
-    mail.v[(k & 1) ^ 1][0][lane] = T.get(2);
+    if (CPL) mail.failed[ml] = (s.failed || parked || (i + 1) != next_i) ? 1u : 0u;
+    mail.v[(k & 1) ^ 1][0][ml] = T.get(2);
     duo_meet();
   }
   if (CPL && live) a.state[(int64_t)RS_ST_CPL_RESUME * a.np_pad + p] = (double)next_i;
@@ -1809,22 +1870,29 @@ enum { SRC_WINDOW = 0, SRC_KNOTS = 1, SRC_RAW = 2 }; /* where the ground wave's 
 /* SKYG (with SRC_RAW): the launch has per-point sky view and a THIRD wavefront for it (duo_sky): the short- and
  * long-wave radiation, their share of CheckValues and ModRadiationBySurroundings are that wave's; this one
  * makes the other six variables. */
-template <int NL, int SRC = SRC_WINDOW, bool FULL = false, bool SKYG = false, bool CPL = false>
+/* REPLAY (with CPL, SRC_RAW): see duo_surface - this wave restores layers 3..N at the rewind and computes the
+ * flux and heat capacities of that step from the restored profile and the end-of-window one (the stale TmpNw),
+ * and hands over CheckValues' verdict on the forcing of the index behind the window (ForcingPrep::bad_rw). */
+template <int NL, int SRC = SRC_WINDOW, bool FULL = false, bool SKYG = false, bool CPL = false, bool REPLAY = false>
 __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, const StepArgs &a) {
   constexpr bool KNOTS = SRC == SRC_KNOTS, RAW = SRC == SRC_RAW;
   static_assert(FULL || !CPL, "coupling belongs to the FULL feature set");
   static_assert(!RAW || FULL, "the driver's series carry the FULL feature set");
   static_assert(!SKYG || RAW, "a sky wave exists only where the forcing is made from the raw series");
+  static_assert(!REPLAY || (CPL && RAW && !SKYG), "replay rounds in this flavour: raw series, no sky view");
   KernArgs ka = kernargs();
-  const uint32_t lane = threadIdx.x & 63u;
-  const int64_t row0 = a.wave_start ? (int64_t)a.wave_start[blockIdx.x] : (int64_t)blockIdx.x * 64;
+  const uint32_t ml = threadIdx.x & 63u; /* lane of the mailbox; `lane` + row0 = the point (REPLAY: through the list) */
+  const int64_t listed = REPLAY ? (int64_t)blockIdx.x * 64 + ml : 0;
+  const int64_t row0 = REPLAY ? 0 : a.wave_start ? (int64_t)a.wave_start[blockIdx.x] : (int64_t)blockIdx.x * 64;
+  const uint32_t lane = REPLAY ? (listed < a.cpl_nlist ? (uint32_t)a.cpl_list[listed] : 0u) : ml;
   const int64_t p = row0 + lane;
-  const bool live = a.wave_start ? (int32_t)lane < a.wave_cnt[blockIdx.x] : p < a.npoints;
+  const bool live = REPLAY ? listed < a.cpl_nlist
+                           : a.wave_start ? (int32_t)lane < a.wave_cnt[blockIdx.x] : p < a.npoints;
   double Tg[NL - 2]; /* Tmp(3..NL) */
 #pragma unroll
   for (int j = 3; j <= NL; ++j) Tg[j - 3] = live ? a.state[(int64_t)(RS_ST_TMP0 + j - 1) * a.np_pad + p] : 0.0;
   const double tbot = live ? ka->pp.tbottom[p] : 0.0;
-  mail.v[0][1][lane] = Tg[0];
+  mail.v[0][1][ml] = Tg[0];
   const int32_t nsteps = ka->nsteps, t0 = ka->t0;
   /* FULL: as time_loop sets them up */
   int32_t initlen = 0;
@@ -1849,12 +1917,15 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
   }
   /* CPL: where the point's coupling window starts - from there on the observation is no longer forced on the
    * two top layers (src/InputOutput.f90:120-121), and at that index the layers are saved (src/Coupling.f90:172-210) */
-  int32_t cpl_cs = 0x7fffffff;
+  int32_t cpl_cs = 0x7fffffff, cpl_ce = 0x7ffffff0;
   if (CPL && live) {
     const int32_t cidx = ka->pp.coupling_index ? ka->pp.coupling_index[p] : 0;
-    if (consts_of(ka).use_coupling && ka->pp.coupling_index && !(ka->pp.coupling_tsurf[p] < -100 || cidx < 1))
+    if (consts_of(ka).use_coupling && ka->pp.coupling_index && !(ka->pp.coupling_tsurf[p] < -100 || cidx < 1)) {
       cpl_cs = ((double)cidx <= consts_of(ka).cplLenR) ? 1 : cidx - consts_of(ka).cplLenI;
+      cpl_ce = cidx;
+    }
   }
+  const int64_t rcol_ = (RAW && live) ? (ka->raw.col ? (int64_t)ka->raw.col[p] : p) : 0; /* the point's column of the raw series */
   /* the anchors of an index are stored at the START of that index's step, when the surface wave's
    * verdict on the index before is in the mailbox (a point that has failed never reaches it) */
   bool anchor_due = false;
@@ -1900,6 +1971,20 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
     }
     ForcingPrep q = forcing_prep_tail(c, mt, f, tair, vz, rhz, bad);
     q.tsurfobs = obs;
+    if (REPLAY && live && in == cpl_cs && in < c.SimLen) {
+      /* the rewind: CheckValues has just seen the index behind the window end (0-based: cpl_ce) - its forcing
+       * the long way, once per replay */
+      Forcing g = Forcing();
+      const int32_t tb = cpl_ce;
+      g.tair = ka->raw.status && ka->raw.status[rcol_] != 0 ? raw_miss() : raw_slow_value(ka, RAW_TAIR, rcol_, tb);
+      g.vz = raw_slow_value(ka, RAW_VZ, rcol_, tb);
+      g.rhz = raw_slow_value(ka, RAW_RHZ, rcol_, tb);
+      g.prec = raw_slow_value(ka, RAW_PREC, rcol_, tb);
+      g.sw = raw_slow_value(ka, RAW_SW, rcol_, tb);
+      g.lw = raw_slow_value(ka, RAW_LW, rcol_, tb);
+      g.tdew = raw_slow_value(ka, RAW_TDEW, rcol_, tb);
+      q.bad_rw = check_values_forcing(c, g) | (g.tdew < -90) | (g.tdew > R4(100.0));
+    }
     return q;
   };
   /* the forcing of the launch's first index, prepared before the first meeting (a lane beyond npoints
@@ -1911,7 +1996,7 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
   /* RAW: the point's column of the raw series, read_input's verdict on it, the segment of the first index */
   constexpr int FSET = SKYG ? FSET_GROUND : FSET_ALL;
   RawLerp<raw_nfields(FSET)> rlerp;
-  const int64_t rcol = (RAW && live) ? (ka->raw.col ? (int64_t)ka->raw.col[p] : p) : 0;
+  const int64_t rcol = rcol_;
   const bool rejected = RAW && live && ka->raw.status && ka->raw.status[rcol] != 0;
   /* the observation can act at index `in`: SetCurrentValues' own condition (src/InputOutput.f90:116-121),
    * for the whole wavefront */
@@ -1927,7 +2012,7 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
     if (KNOTS) nxt = knot_forcing<FULL>(ka, kcol, live, klerp, kcur, t0);
     else if (RAW) nxt = raw_forcing<FSET>(ka, rcol, live, rejected, rlerp, t0, obs_wanted(c0, t0));
     else if (live) nxt = load_forcing<FULL, true>(ka, row0, lane, 0);
-    duo_put_prep<FULL, SKYG>(mail, 0, lane, prep(c0, nxt, t0, obs_cur));
+    duo_put_prep<FULL, SKYG>(mail, 0, ml, prep(c0, nxt, t0, obs_cur));
   }
   duo_meet();
   for (int32_t kv = 0; kv < nsteps; ++kv) {
@@ -1936,11 +2021,26 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
     const int32_t k = __builtin_amdgcn_readfirstlane(kv);
     /* next index's forcing: fetched here, used behind the layers */
     if (!KNOTS && !RAW && k + 1 < nsteps && live) nxt = load_forcing<FULL, true>(ka, row0, lane, k + 1);
-    double t2 = mail.v[k & 1][0][lane]; /* Tmp(2) as the last step left it (melting included) */
+    double t2 = mail.v[k & 1][0][ml]; /* Tmp(2) as the last step left it (melting included) */
     /* a failed point takes no further step in any flavour: its Tmp(3..N) stay as the failing index left
      * them (the flag was raised before the barrier that ended that index) */
-    if (!mail.failed[lane]) {
-      if (CPL && t0 + k == cpl_cs && t0 + k < c.SimLen && live) { /* saveDataForCoupling: layers 3..N as they stand */
+    if (REPLAY && !mail.failed[ml] && t0 + k == cpl_cs && t0 + k < c.SimLen && live) {
+      /* the rewind (uploadDataForCoupling, src/Coupling.f90:245-247): Tmp is restored, TmpNw is not - this
+       * step's heat capacities see the end-of-window profile (Tg as it stands), its fluxes the restored one */
+      const double *sv = ka->state + (int64_t)RS_ST_CPL_SAVE_TMP0 * ka->np_pad + p;
+      const int64_t np = ka->np_pad;
+      double cur = sv[(int64_t)2 * np]; /* restored Tmp(3) */
+      double Gprev = c.lk[2].condDZ * (cur - sv[np]); /* ... against the restored Tmp(2) */
+#pragma unroll
+      for (int j = 3; j <= NL; ++j) {
+        const double tnext = (j == NL) ? tbot : sv[(int64_t)j * np];
+        const double stale = Tg[j - 3];
+        Tg[j - 3] = layer_step(c, j, cur, stale, tnext, Gprev, nullptr);
+        cur = tnext;
+      }
+    } else
+    if (!mail.failed[ml]) {
+      if (CPL && !REPLAY && t0 + k == cpl_cs && t0 + k < c.SimLen && live) { /* saveDataForCoupling: layers 3..N as they stand */
 #pragma unroll
         for (int j = 3; j <= NL; ++j) ka->state[(int64_t)(RS_ST_CPL_SAVE_TMP0 + j - 1) * ka->np_pad + p] = Tg[j - 3];
       }
@@ -1962,12 +2062,12 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
       }
     }
     if (FULL) anchor_due = false;
-    mail.v[(k & 1) ^ 1][1][lane] = Tg[0];
+    mail.v[(k & 1) ^ 1][1][ml] = Tg[0];
     if (k + 1 < nsteps) {
       const int32_t in = t0 + k + 1;
       if (KNOTS) nxt = knot_forcing<FULL>(ka, kcol, live, klerp, kcur, in);
       if (RAW) nxt = raw_forcing<FSET>(ka, rcol, live, rejected, rlerp, in, obs_wanted(c, in));
-      duo_put_prep<FULL, SKYG>(mail, (k & 1) ^ 1, lane, prep(c, nxt, in, obs_cur));
+      duo_put_prep<FULL, SKYG>(mail, (k & 1) ^ 1, ml, prep(c, nxt, in, obs_cur));
     }
     duo_meet();
   }
@@ -2048,8 +2148,10 @@ __device__ __forceinline__ void duo_sky(DuoMail &mail, uint32_t *skyfl, const St
 
 /* SRC: SRC_WINDOW / SRC_KNOTS / SRC_RAW.  SKY: per-point sky view - on the surface wave (forcing windows)
  * or, with SRC_RAW, on a third wavefront (duo_sky). */
-template <int NL, bool SCORE, int SRC = SRC_WINDOW, bool FULL = false, bool SKY = false, bool CPL = false>
-__global__ void __launch_bounds__((SKY && SRC == SRC_RAW) ? 192 : 128, 4) step_kernel_duo(const StepArgs a) {
+template <int NL, bool SCORE, int SRC = SRC_WINDOW, bool FULL = false, bool SKY = false, bool CPL = false,
+          bool REPLAY = false>
+__global__ void __launch_bounds__((SKY && SRC == SRC_RAW) ? 192 : 128, REPLAY ? 3 : 4) step_kernel_duo(const StepArgs a) {
+  /* (REPLAY at three waves per SIMD: with the rewind's code the instance spilled 50 registers at four) */
   static_assert(!CPL || SRC == SRC_RAW, "coupling in the two-wavefront flavour: the driver path's lock-step chunks");
   constexpr bool SKYG = SKY && SRC == SRC_RAW;
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
@@ -2064,9 +2166,9 @@ __global__ void __launch_bounds__((SKY && SRC == SRC_RAW) ? 192 : 128, 4) step_k
   if (a.wave_start && a.wave_cnt[blockIdx.x] == 0) return; /* a spare workgroup of the wave table: all wavefronts leave */
   if (threadIdx.x < 64) {
     if (a.surface_prio) __builtin_amdgcn_s_setprio(1); /* the longer chain of the two issues first (StepArgs::surface_prio) */
-    duo_surface<NL, SCORE, FULL, SKY && !SKYG, SKYG, SRC == SRC_RAW, CPL>(mt, mail, a, skyfl);
+    duo_surface<NL, SCORE, FULL, SKY && !SKYG, SKYG, SRC == SRC_RAW, CPL, REPLAY>(mt, mail, a, skyfl);
   } else if (!SKYG || threadIdx.x < 128) {
-    duo_ground<NL, SRC, FULL, SKYG, CPL>(mt, mail, a);
+    duo_ground<NL, SRC, FULL, SKYG, CPL, REPLAY>(mt, mail, a);
   } else {
     duo_sky(mail, skyfl, a);
   }
@@ -2756,6 +2858,14 @@ hipError_t rs_launch_step_duo_raw(const rs::StepArgs &a, bool score, bool sky, b
   else if (sky) hipLaunchKernelGGL((rs::step_kernel_duo<15, false, rs::SRC_RAW, true, true>), gd, dim3(192), 0, stream, a);
   else if (score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, rs::SRC_RAW, true>), gd, dim3(128), 0, stream, a);
   else hipLaunchKernelGGL((rs::step_kernel_duo<15, false, rs::SRC_RAW, true>), gd, dim3(128), 0, stream, a);
+  return hipGetLastError();
+}
+
+/* one replay round of the coupling windows over the listed points, forcing from the raw series */
+hipError_t rs_launch_step_duo_raw_replay(const rs::StepArgs &a, hipStream_t stream) {
+  if (!a.cpl_list || a.cpl_nlist < 1) return hipSuccess;
+  const dim3 gd((unsigned)((a.cpl_nlist + 63) / 64));
+  hipLaunchKernelGGL((rs::step_kernel_duo<15, true, rs::SRC_RAW, true, false, true, true>), gd, dim3(128), 0, stream, a);
   return hipGetLastError();
 }
 
