@@ -91,6 +91,9 @@ struct Shard {
   int device;
   int64_t off, cnt;
 };
+#ifndef RS_BLOCK_TAPER_PCT_DEFAULT
+#define RS_BLOCK_TAPER_PCT_DEFAULT 0
+#endif
 
 /* contiguous block partition of n points over the listed devices, remainders to the first
  * blocks (roadsurf_amd/sharding.py strong_shard is the same rule) */
@@ -123,6 +126,26 @@ inline std::vector<Shard> make_shards(int64_t n, const std::vector<int> &devs) {
     const int64_t base = (n - first) / (k - 1), rem = (n - first) % (k - 1);
     for (int64_t i = 1; i < k; ++i) {
       const int64_t cnt = base + (i - 1 < rem ? 1 : 0);
+      s.push_back(Shard{devs[(size_t)i], off, cnt});
+      off += cnt;
+    }
+    return s;
+  }
+  /* Blocks that share ONE device take turns on the link, so they start staggered by an upload each and - of
+   * equal size - end staggered too, the last ones alone on the GPU.  ROADSURF_HIP_BLOCK_TAPER_PCT = t: the
+   * blocks shrink linearly, the last one to (100 - t) % of the first (default below; 0: equal blocks). */
+  bool one_device = true;
+  for (int64_t i = 1; i < k; ++i) one_device = one_device && devs[(size_t)i] == devs[0];
+  int taper = RS_BLOCK_TAPER_PCT_DEFAULT;
+  if (const char *e = getenv("ROADSURF_HIP_BLOCK_TAPER_PCT")) taper = atoi(e);
+  if (one_device && k > 1 && taper > 0 && taper < 90 && n / k >= 4 * min_shard) {
+    double wsum = 0.0;
+    std::vector<double> w((size_t)k);
+    for (int64_t i = 0; i < k; ++i) wsum += (w[(size_t)i] = 1.0 - (taper / 100.0) * (double)i / (double)(k - 1));
+    for (int64_t i = 0; i < k; ++i) {
+      int64_t cnt = (i + 1 == k) ? n - off : (int64_t)((double)n * w[(size_t)i] / wsum) / 256 * 256;
+      if (cnt < min_shard) cnt = min_shard;
+      if (cnt > n - off) cnt = n - off;
       s.push_back(Shard{devs[(size_t)i], off, cnt});
       off += cnt;
     }
