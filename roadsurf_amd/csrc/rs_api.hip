@@ -1184,9 +1184,9 @@ int rs_hip_div_samples(RsPlan *pl, double *out) {
 int rs_hip_bl_stats(RsPlan *pl, int64_t *out) {
   if (!pl || !out) return set_err("rs_hip_bl_stats: bad arguments");
   HIP_OK(hipSetDevice(pl->device));
-  unsigned long long v[8];
+  unsigned long long v[24];
   HIP_OK(rs_read_bl_stats(v, pl->stream));
-  for (int k = 0; k < 8; ++k) out[k] = (int64_t)v[k];
+  for (int k = 0; k < 24; ++k) out[k] = (int64_t)v[k];
   return 0;
 }
 

@@ -2745,8 +2745,8 @@ hipError_t rs_read_div_mismatch(unsigned long long *out /*[3]*/, hipStream_t str
   return hipStreamSynchronize(stream);
 }
 
-hipError_t rs_read_bl_stats(unsigned long long *out /*[8]*/, hipStream_t stream) {
-  hipError_t e = hipMemcpyFromSymbolAsync(out, HIP_SYMBOL(rs::g_bl_stats), 8 * sizeof(*out), 0,
+hipError_t rs_read_bl_stats(unsigned long long *out /*[RS_BL_NSTATS]*/, hipStream_t stream) {
+  hipError_t e = hipMemcpyFromSymbolAsync(out, HIP_SYMBOL(rs::g_bl_stats), RS_BL_NSTATS * sizeof(*out), 0,
                                           hipMemcpyDeviceToHost, stream);
   if (e != hipSuccess) return e;
   return hipStreamSynchronize(stream);

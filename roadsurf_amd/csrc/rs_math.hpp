@@ -125,7 +125,12 @@ static __device__ unsigned long long g_div_mismatch[3] = {0ull, 0ull, 0ull};
 /* -DRS_BL_STATS (an experiment build, `make blstats`): how often the boundary-layer fixed point repeats its
  * bits before the fifth pass - [0] wave-steps, [1] lane-steps, [2..4] wave-steps in which EVERY active lane's
  * (PSIM, PSIH) came out of pass 2 / 3 / 4 as they went in, [5..7] the same counted per lane */
-static __device__ unsigned long long g_bl_stats[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+/* [8] sum over wave-steps of the loop's trip count (the wavefront's: its slowest lane's), [9] the same summed
+ * per lane; road_condition: [10] wave-steps, [11] the bare-road shortcut taken, every lane with [12] no snow,
+ * [13] no ice of either kind, [14] no deposit and no condensation, [15] no water, [16] none of snow / ice / deposit;
+ * forcing_prep_tail: [17] wave-steps, [18] the precipitation branch taken */
+#define RS_BL_NSTATS 24
+static __device__ unsigned long long g_bl_stats[RS_BL_NSTATS];
 /* the first RS_DIV_SAMPLES finite mismatches: {numerator (or sqrt argument), denominator (0 for
  * sqrt), IEEE result, bare result} */
 #define RS_DIV_SAMPLES 64
