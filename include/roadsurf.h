@@ -492,7 +492,7 @@ int rs_hip_set_precision(RsPlan *plan, int32_t bits);
  * rs_hip_div_mismatch_count returns how many call-site evaluations disagreed
  * with two finite results since the library was loaded (0 in the other modes). */
 int rs_hip_division_mode(void);
-/* Experiment builds (-DRS_BL_STATS): out[24] = {wave-steps, lane-steps, wave-steps in which every active lane's
+/* Experiment builds (-DRS_BL_STATS): out[48] = {wave-steps, lane-steps, wave-steps in which every active lane's
  * boundary-layer fixed point repeated its bits at pass 2, 3, 4, the same per lane, trip counts and which
  * wave-uniform shortcuts applied (rs_math.hpp g_bl_stats)}; zeros in the product. */
 int rs_hip_bl_stats(RsPlan *plan, int64_t *out);
@@ -564,8 +564,11 @@ typedef struct RsPreview {
   int32_t mode;                          /* key fields in priority order as decimal digits: 1 unstable
                                             previews, 2 table-path previews, 3 cover, 4 predicted extra
                                             passes (e.g. 1234); 0..3 = 14, 124, 134, 1234; 5 storage
-                                            class, 6/7/8 = 4/1/2 in fewer bits, 0 (inside a list) = 4 in
-                                            three bits; 9 (anywhere in the list)
+                                            class, 6/7/8 = 4/1/2 in fewer bits, 0 (inside a list) = three
+                                            bits for the LONGEST loop expected in the window - over the previews,
+                                            the last index stepped and a passage through the loop's slow band -
+                                            in classes 5, 6, 7, 8, 9-12, 13-20, 21-30, 31+ passes (round 4, and
+                                            ROADSURF_HIP_EXTRA_CLASSES=0: field 4 saturating at 7); 9 (anywhere in the list)
                                             = the ground digit, which layers are frozen, always the LEAST
                                             significant field, honoured for keys of at most 12 bits without
                                             it (the plan's counting sort; 378059 is what bench.py and

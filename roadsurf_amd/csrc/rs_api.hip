@@ -393,6 +393,10 @@ int rs_hip_recluster_forecast(RsPlan *pl, const RsPreview *pv) {
   const int lowb = rs_forecast_key_low_bits(pv->mode);
   const int low = (a.compact || (bits >= 1 && bits + lowb <= RS_SORT_KEY_BITS)) ? lowb : 0;
   a.low_bits = low;
+  /* field 0 of the mode in classes of the longest expected loop (default), or - ROADSURF_HIP_EXTRA_CLASSES=0,
+   * round 4's form, A/B - the previews' extra passes summed and saturating at 7 */
+  static const int extra_log = getenv("ROADSURF_HIP_EXTRA_CLASSES") ? atoi(getenv("ROADSURF_HIP_EXTRA_CLASSES")) : 1;
+  a.extra_log = extra_log ? 1 : 0;
   HIP_OK(rs_launch_forecast_keys(a, pl->stream));
   pl->wave_tab_valid = false;
   if (a.compact) {
@@ -1184,9 +1188,9 @@ int rs_hip_div_samples(RsPlan *pl, double *out) {
 int rs_hip_bl_stats(RsPlan *pl, int64_t *out) {
   if (!pl || !out) return set_err("rs_hip_bl_stats: bad arguments");
   HIP_OK(hipSetDevice(pl->device));
-  unsigned long long v[24];
+  unsigned long long v[48];
   HIP_OK(rs_read_bl_stats(v, pl->stream));
-  for (int k = 0; k < 24; ++k) out[k] = (int64_t)v[k];
+  for (int k = 0; k < 48; ++k) out[k] = (int64_t)v[k];
   return 0;
 }
 

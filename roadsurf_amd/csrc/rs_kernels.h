@@ -92,6 +92,9 @@ struct ForecastArgs {
   int32_t compact; /* 1: the key is stored right-aligned in its own bits (counting sort), 0: left-aligned
                       in RS_SORT_KEY_BITS (library sort) */
   int32_t low_bits; /* compact keys: bits of the ground digit below the others (rs_forecast_key_low_bits) */
+  int32_t extra_log; /* field 0 of the mode: 0 = the previews' extra passes summed, saturating at 7; 1 = the
+                        LONGEST loop expected in the window (previews, the last index stepped, a passage through
+                        the loop's slow band) in classes 5, 6, 7, 8, 9-12, 13-20, 21-30, 31+ */
 };
 
 struct KnotArgs {
@@ -115,7 +118,7 @@ struct ExpandArgs {
 
 hipError_t rs_read_div_mismatch(unsigned long long *out /*[3]*/, hipStream_t stream);
 hipError_t rs_read_div_samples(double *out /*[64][4]*/, hipStream_t stream);
-hipError_t rs_read_bl_stats(unsigned long long *out /*[24]*/, hipStream_t stream);
+hipError_t rs_read_bl_stats(unsigned long long *out /*[48]*/, hipStream_t stream);
 hipError_t rs_launch_math_test(int fn, int64_t n, const double *x, double *y, hipStream_t stream);
 /* raw-series Tdew<->RH completion (needs the math tables: create a plan first) */
 hipError_t rs_launch_humidity_fill(const double *tair, double *tdew, double *rhz, int64_t n,

@@ -1549,10 +1549,12 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
           }
         }
       }
-      const Fluxes fx = model_step_fluxes_prepped<SCORE>(c, mt, s, qs, cp);
+      const Fluxes fx = model_step_fluxes_prepped<SCORE ? 1 : 2>(c, mt, s, qs, cp);
       if (SCORE) {
         score += (fx.trips & 63) - 5;
         if ((fx.trips & 64) && k >= nsteps - RS_REGIME_WINDOW) score |= 1 << 30;
+      } else if (k == nsteps - 1) {
+        score = fx.trips; /* the launch's last index: what forecast_key_kernel takes as one more preview */
       }
       /* layers 1-2 with Tmp(3) where a two-layer column has its lower boundary */
       model_step_ground<RegProfile<2>, RegProfile<2>, false>(c, s, T, t3, tair, fx, R4(-9999.9), cp);
@@ -1606,7 +1608,7 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
     st[(int64_t)RS_ST_T4MELT * np + p] = s.t4melt;
     st[(int64_t)RS_ST_ALBEDO * np + p] = s.albedo;
     st[(int64_t)RS_ST_VERYCOLD * np + p] = s.verycold ? 1.0 : 0.0;
-    if (SCORE) st[(int64_t)RS_ST_BLSCORE * np + p] = bl_score_key(score, s);
+    st[(int64_t)RS_ST_BLSCORE * np + p] = SCORE ? bl_score_key(score, s) : (double)score;
   }
 }
 
@@ -2613,7 +2615,8 @@ __global__ void __launch_bounds__(kBlock) forecast_key_kernel(const ForecastArgs
   const int64_t pq = a.pv.index ? (int64_t)a.pv.index[s] : s; /* preview rows in point order */
   const double ta_now = a.pv.tair_now[pq];
   const double stab_num = -c.VK_Const * c.ZRefT * c.Grav;
-  int32_t unst = 0, farc = 0, extra = 0;
+  int32_t unst = 0, farc = 0, extra = 0, maxtrip = 5;
+  float stab_lo = 2.f, stab_hi = -2.f; /* the converged stability parameter of the previews, after its clamp */
   for (int q = 0; q < a.pv.n; ++q) {
     const double ta = a.pv.tair[q][pq];
     double vz = a.pv.vz[q][pq];
@@ -2631,7 +2634,7 @@ __global__ void __launch_bounds__(kBlock) forecast_key_kernel(const ForecastArgs
     const float dT = (float)(ts - ta), den0 = (float)(avc * TaK), vkvz = (float)(c.VK_Const * vz),
                 avk = (float)(avc * c.VK_Const), snum = (float)stab_num, lU = (float)c.logUstar,
                 lC = (float)c.logCond;
-    float psim = 0.f, psih = 0.f, bl = 0.f;
+    float psim = 0.f, psih = 0.f, bl = 0.f, stab_last = 0.f;
     int32_t nnear = 0, nfar = 0, j = 1;
     for (; j <= RS_BL_MAXIT; ++j) {
       const float old = bl;
@@ -2639,6 +2642,7 @@ __global__ void __launch_bounds__(kBlock) forecast_key_kernel(const ForecastArgs
       bl = avk * us * __builtin_amdgcn_rcpf(lC + psih);
       float stab = snum * bl * dT * __builtin_amdgcn_rcpf(den0 * (us * us * us));
       if (stab > 1.f) stab = 1.f;
+      stab_last = stab;
       if (stab > 0.f) {
         psih = 4.7f * stab;
         psim = psih;
@@ -2654,9 +2658,28 @@ __global__ void __launch_bounds__(kBlock) forecast_key_kernel(const ForecastArgs
     }
     if (j > RS_BL_MAXIT) j = RS_BL_MAXIT;
     extra += j - 5;
+    maxtrip = j > maxtrip ? j : maxtrip;
+    stab_lo = stab_last < stab_lo ? stab_last : stab_lo;
+    stab_hi = stab_last > stab_hi ? stab_last : stab_hi;
     if (nnear + nfar > 0) {
       ++unst;
       if (nfar >= nnear) ++farc;
+    }
+  }
+  /* Field 0 in classes (ForecastArgs::extra_log): the LONGEST loop the point is expected to run in the window.
+   * The loop's slow band is a narrow curve in the stable regime (Tsurf - Tair about -2.6 VZ^2 for the default
+   * heights: the fixed point's slope goes through 1 there, 20-39 passes; profiles/r05_wave_stats.txt: 0.2 % of
+   * the lane-steps, but a wavefront runs as many passes as its slowest lane).  On one side of it the stability
+   * parameter sits at its clamp (PSI = 4.7, two passes and it stands), on the other below: a point whose
+   * previews lie on both sides passes through the band inside the window ... */
+  if (a.extra_log && stab_hi >= 1.f && stab_lo < 1.f) maxtrip = 31;
+  if (a.extra_log) { /* ... and the pass count of the last index stepped is one more preview (the two-wavefront
+                        flavour without the history score leaves it in the score's slot; other flavours leave 0
+                        or a score there: ignored unless 5..RS_BL_MAXIT) */
+    const double last = st(RS_ST_BLSCORE);
+    if (last >= 5.0 && last <= (double)RS_BL_MAXIT) {
+      const int32_t lt = (int32_t)last;
+      maxtrip = lt > maxtrip ? lt : maxtrip;
     }
   }
   if (extra > 4095) extra = 4095;
@@ -2702,7 +2725,12 @@ __global__ void __launch_bounds__(kBlock) forecast_key_kernel(const ForecastArgs
     else if (d == 5) { key = (key << 2) | (uint32_t)sclass; bits += 2; }
     /* compact forms: extra passes saturating at 31 (5 bits), the two preview counts at 3 (2 bits) */
     else if (d == 6) { key = (key << 5) | (uint32_t)(extra > 31 ? 31 : extra); bits += 5; }
-    else if (d == 0) { key = (key << 3) | (uint32_t)(extra > 7 ? 7 : extra); bits += 3; } /* (inside a list) extra passes saturating at 7 */
+    else if (d == 0) { /* (inside a list) extra passes saturating at 7, or the longest preview in classes */
+      const int32_t t = maxtrip;
+      const uint32_t cls = (uint32_t)(t <= 8 ? t - 5 : t <= 12 ? 4 : t <= 20 ? 5 : t <= 30 ? 6 : 7);
+      key = (key << 3) | (a.extra_log ? cls : (uint32_t)(extra > 7 ? 7 : extra));
+      bits += 3;
+    }
     else if (d == 7) { key = (key << 2) | (uint32_t)(unst > 3 ? 3 : unst); bits += 2; }
     else if (d == 8) { key = (key << 2) | (uint32_t)(farc > 3 ? 3 : farc); bits += 2; }
   }
