@@ -51,7 +51,7 @@ using rsu::Dev;
 using rsu::transpose;
 
 #ifndef RS_DRIVER_RAW_CHUNK
-#define RS_DRIVER_RAW_CHUNK 240 /* indices per launch of a block whose step kernel reads the raw series */
+#define RS_DRIVER_RAW_CHUNK 120 /* indices per launch of a block whose step kernel reads the raw series (round 5, with the class key: 120 beats 240 by 1 % without coupling, 3-4 % with; 60 and 180 between) */
 #endif
 constexpr int NFLD = rs::RAW_NFLD;
 /* order of `merged` in rs_driver_expand and of the window buffers (rs_raw.hpp) */
