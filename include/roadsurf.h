@@ -567,7 +567,8 @@ typedef struct RsPreview {
                                             class, 6/7/8 = 4/1/2 in fewer bits, 0 (inside a list) = three
                                             bits for the LONGEST loop expected in the window - over the previews,
                                             the last index stepped and a passage through the loop's slow band -
-                                            in classes 5, 6, 7, 8, 9-12, 13-20, 21-30, 31+ passes (round 4, and
+                                            in classes 5, 6, 7, 8, 9-12, 13-20, 21-30, 31+ passes (round 4, a
+                                            device whose live plans hold at most 131 072 points, and
                                             ROADSURF_HIP_EXTRA_CLASSES=0: field 4 saturating at 7); 9 (anywhere in the list)
                                             = the ground digit, which layers are frozen, always the LEAST
                                             significant field, honoured for keys of at most 12 bits without

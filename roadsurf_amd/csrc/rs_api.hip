@@ -395,8 +395,11 @@ int rs_hip_recluster_forecast(RsPlan *pl, const RsPreview *pv) {
   a.low_bits = low;
   /* field 0 of the mode in classes of the longest expected loop (default), or - ROADSURF_HIP_EXTRA_CLASSES=0,
    * round 4's form, A/B - the previews' extra passes summed and saturating at 7 */
-  static const int extra_log = getenv("ROADSURF_HIP_EXTRA_CLASSES") ? atoi(getenv("ROADSURF_HIP_EXTRA_CLASSES")) : 1;
-  a.extra_log = extra_log ? 1 : 0;
+  static const int extra_log = getenv("ROADSURF_HIP_EXTRA_CLASSES") ? atoi(getenv("ROADSURF_HIP_EXTRA_CLASSES")) : -1;
+  /* ... which stays the form of an underfilled device: there a launch is as long as its slowest wavefront, and
+   * gathering the points of the slow band makes that wavefront slower (125 000 points: 1.40e10 against 1.37e10;
+   * 500 000: 2.39e10 against 2.44e10, profiles/r05_ab_extra_pass_classes_small_shards.txt) */
+  a.extra_log = extra_log >= 0 ? (extra_log ? 1 : 0) : underfilled(pl) ? 0 : 1;
   HIP_OK(rs_launch_forecast_keys(a, pl->stream));
   pl->wave_tab_valid = false;
   if (a.compact) {
