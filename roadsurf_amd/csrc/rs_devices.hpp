@@ -97,7 +97,7 @@ struct Shard {
 
 /* contiguous block partition of n points over the listed devices, remainders to the first
  * blocks (roadsurf_amd/sharding.py strong_shard is the same rule) */
-inline std::vector<Shard> make_shards(int64_t n, const std::vector<int> &devs) {
+inline std::vector<Shard> make_shards(int64_t n, const std::vector<int> &devs, int default_taper = RS_BLOCK_TAPER_PCT_DEFAULT) {
   std::vector<Shard> s;
   if (n < 1 || devs.empty()) return s;
   int64_t min_shard = 4096;
@@ -136,7 +136,7 @@ inline std::vector<Shard> make_shards(int64_t n, const std::vector<int> &devs) {
    * blocks shrink linearly, the last one to (100 - t) % of the first (default below; 0: equal blocks). */
   bool one_device = true;
   for (int64_t i = 1; i < k; ++i) one_device = one_device && devs[(size_t)i] == devs[0];
-  int taper = RS_BLOCK_TAPER_PCT_DEFAULT;
+  int taper = default_taper;
   if (const char *e = getenv("ROADSURF_HIP_BLOCK_TAPER_PCT")) taper = atoi(e);
   if (one_device && k > 1 && taper > 0 && taper < 90 && n / k >= 4 * min_shard) {
     double wsum = 0.0;

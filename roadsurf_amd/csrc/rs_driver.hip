@@ -1323,7 +1323,11 @@ int rs_driver_run(const RsDriverInput *in, const InputSettings *st, const InputP
    * was transposed on the device, tools/experiments/r4_blocks.sh; with the table left in the caller's layout
    * - RsPointParams::horizons_by_point - four and six are level: 1.047e10 / 1.046e10 over three alternating
    * runs each.) */
-  const std::vector<rsu::Shard> shards = rsu::make_shards(in->n_points, rsu::device_list());
+  /* With local horizons a block uploads twice the bytes, the blocks start 38 instead of 19 ms apart and - of equal
+   * size - end that far apart too: there the blocks shrink, the last to 70 % of the first (+1.4 % over three
+   * tapers, profiles/r05_ab_block_taper.txt; without horizons equal blocks are as good). */
+  const std::vector<rsu::Shard> shards =
+      rsu::make_shards(in->n_points, rsu::device_list(), in->horizons ? 30 : RS_BLOCK_TAPER_PCT_DEFAULT);
   return rsu::fan_out(shards, [&](const rsu::Shard &sh, int) {
     return driver_run_range(in, st, params, local, out, sh.device, sh.off, sh.off + sh.cnt);
   });
