@@ -492,7 +492,7 @@ int rs_hip_set_precision(RsPlan *plan, int32_t bits);
  * rs_hip_div_mismatch_count returns how many call-site evaluations disagreed
  * with two finite results since the library was loaded (0 in the other modes). */
 int rs_hip_division_mode(void);
-/* Experiment builds (-DRS_BL_STATS): out[48] = {wave-steps, lane-steps, wave-steps in which every active lane's
+/* Experiment builds (-DRS_BL_STATS): out[56] = {wave-steps, lane-steps, wave-steps in which every active lane's
  * boundary-layer fixed point repeated its bits at pass 2, 3, 4, the same per lane, trip counts and which
  * wave-uniform shortcuts applied (rs_math.hpp g_bl_stats)}; zeros in the product. */
 int rs_hip_bl_stats(RsPlan *plan, int64_t *out);

@@ -1191,9 +1191,9 @@ int rs_hip_div_samples(RsPlan *pl, double *out) {
 int rs_hip_bl_stats(RsPlan *pl, int64_t *out) {
   if (!pl || !out) return set_err("rs_hip_bl_stats: bad arguments");
   HIP_OK(hipSetDevice(pl->device));
-  unsigned long long v[48];
+  unsigned long long v[56];
   HIP_OK(rs_read_bl_stats(v, pl->stream));
-  for (int k = 0; k < 48; ++k) out[k] = (int64_t)v[k];
+  for (int k = 0; k < 56; ++k) out[k] = (int64_t)v[k];
   return 0;
 }
 

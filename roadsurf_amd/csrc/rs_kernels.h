@@ -118,7 +118,7 @@ struct ExpandArgs {
 
 hipError_t rs_read_div_mismatch(unsigned long long *out /*[3]*/, hipStream_t stream);
 hipError_t rs_read_div_samples(double *out /*[64][4]*/, hipStream_t stream);
-hipError_t rs_read_bl_stats(unsigned long long *out /*[48]*/, hipStream_t stream);
+hipError_t rs_read_bl_stats(unsigned long long *out /*[56]*/, hipStream_t stream);
 hipError_t rs_launch_math_test(int fn, int64_t n, const double *x, double *y, hipStream_t stream);
 /* raw-series Tdew<->RH completion (needs the math tables: create a plan first) */
 hipError_t rs_launch_humidity_fill(const double *tair, double *tdew, double *rhz, int64_t n,

@@ -128,8 +128,11 @@ static __device__ unsigned long long g_div_mismatch[3] = {0ull, 0ull, 0ull};
 /* [8] sum over wave-steps of the loop's trip count (the wavefront's: its slowest lane's), [9] the same summed
  * per lane; road_condition: [10] wave-steps, [11] the bare-road shortcut taken, every lane with [12] no snow,
  * [13] no ice of either kind, [14] no deposit and no condensation, [15] no water, [16] none of snow / ice / deposit;
- * forcing_prep_tail: [17] wave-steps, [18] the precipitation branch taken */
-#define RS_BL_NSTATS 48 /* [24..31] wave-steps by the wavefront's trip count 5, 6, 7, 8, 9-12, 13-20, 21-39, 40; [32..39] lane-steps likewise; [40..45] wave-steps with 1, 2-3, 4-7, 8-15, 16-31, 32-64 lanes of more than 20 passes */
+ * forcing_prep_tail: [17] wave-steps, [18] the precipitation branch taken; boundary-layer passes as wavefronts issue
+ * them: [19] all, [20] with a lane on the unstable arm, [21] with lanes on both paths of its log, [22] with lanes on
+ * both arms, [23] with a lane on log's table path; [48] lane-passes, [46] of them on the unstable arm, [47] on log's
+ * table path */
+#define RS_BL_NSTATS 56 /* [24..31] wave-steps by the wavefront's trip count 5, 6, 7, 8, 9-12, 13-20, 21-39, 40; [32..39] lane-steps likewise; [40..45] wave-steps with 1, 2-3, 4-7, 8-15, 16-31, 32-64 lanes of more than 20 passes */
 static __device__ unsigned long long g_bl_stats[RS_BL_NSTATS];
 /* the first RS_DIV_SAMPLES finite mismatches: {numerator (or sqrt argument), denominator (0 for
  * sqrt), IEEE result, bare result} */

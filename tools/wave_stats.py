@@ -30,7 +30,7 @@ else:
     run.run_pass(None)
 torch.cuda.synchronize()
 L = lib.load()
-out = (C.c_int64 * 48)()
+out = (C.c_int64 * 56)()
 L.rs_hip_bl_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
 assert L.rs_hip_bl_stats(plan._h, out) == 0
 ws, ls = max(out[0], 1), max(out[1], 1)
@@ -40,6 +40,11 @@ names = ["5", "6", "7", "8", "9-12", "13-20", "21-39", "40"]
 print("  wave-steps by trip count: " + ", ".join(f"{k}: {out[24 + i] / ws:.4f}" for i, k in enumerate(names)))
 print("  lane-steps by trip count: " + ", ".join(f"{k}: {out[32 + i] / ls:.4f}" for i, k in enumerate(names)))
 print("  wave-steps with lanes of more than 20 passes, by how many: " + ", ".join(f"{k}: {out[40 + i] / ws:.4f}" for i, k in enumerate(["1", "2-3", "4-7", "8-15", "16-31", "32-64"])))
+wp = max(out[19], 1)
+print(f"  passes as issued: {out[19]} ({out[19] / ws:.3f} per wave-step); with a lane on the unstable arm {out[20] / wp:.4f}, on both arms {out[22] / wp:.4f}, "
+      f"on log's table path {out[23] / wp:.4f}, on both paths of log {out[21] / wp:.4f}")
+lp = max(out[48], 1)
+print(f"  lane-passes: {out[48]}; on the unstable arm {out[46] / lp:.4f}, on log's table path {out[47] / lp:.4f}")
 rc = max(out[10], 1)
 print(f"  road_condition: {out[10]} wave-steps; bare-road shortcut {out[11] / rc:.4f}; every lane without snow {out[12] / rc:.4f}, "
       f"without ice {out[13] / rc:.4f}, without deposit or condensation {out[14] / rc:.4f}, without water {out[15] / rc:.4f}, "
