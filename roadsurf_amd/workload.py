@@ -150,6 +150,22 @@ class SyntheticRun:
         kn = self.knots
         # ... field 4 the precipitation: a window has precipitation at some index iff one of its knots has
         prec = [kn[k0 + q, 4] for q in range(nk)] if self.precip_bit else None
+        if os.environ.get("ROADSURF_HIP_PREVIEW_LERP") == "1" and k0 + 1 < kn.shape[0]:
+            # (experiment, tools/wave_stats.py only: synchronises) previews AT the window's first, middle and last
+            # index - the knots' straight line, as the forcing itself - instead of at the knots around it
+            torch.cuda.synchronize()
+            idx = [t_next - 1, t_next - 1 + ns // 2, t_next + ns - 2]
+            ta, vz, hh = [], [], []
+            for i in idx:
+                k = min(i // SPK, kn.shape[0] - 2)
+                w = (i - k * SPK) / SPK
+                ta.append(torch.lerp(kn[k, 0], kn[k + 1, 0], w)); vz.append(torch.lerp(kn[k, 2], kn[k + 1, 2], w))
+                hh.append((self.spec.start_hour + i // SPK) % 24)
+            torch.cuda.synchronize()
+            plan.recluster_forecast(ta, vz, hh, ta[0], self.forecast_alpha, self.forecast_mode, point_order=True,
+                                    prec_rows=prec[:3] if prec and len(prec) >= 3 else (prec + [prec[-1]] * (3 - len(prec)) if prec else None))
+            self._keep = (ta, vz)
+            return
         plan.recluster_forecast([kn[k0 + q, 0] for q in range(nk)], [kn[k0 + q, 2] for q in range(nk)],
                                 hours, kn[k0, 0], self.forecast_alpha, self.forecast_mode, point_order=True,
                                 prec_rows=prec)
