@@ -583,7 +583,15 @@ typedef struct RsPreview {
                                             none of whose points has precipitation at an index skips
                                             PrecipitationToStorage / CalcPrecType there (exact: they add zeros);
                                             precipitating points are a few per cent of a batch at any time but, in
-                                            arbitrary order, sit in most wavefronts */
+                                            arbitrary order, sit in most wavefronts.  Read for every q < RS_PREVIEW_MAX
+                                            with a row, whatever n says (the rows need not be at the preview times) */
+  const double *tair_b[RS_PREVIEW_MAX];  /* ABI 9.  Previews BETWEEN two rows: where tair_b[q] is not NULL, preview q is */
+  const double *vz_b[RS_PREVIEW_MAX];    /* tair[q] + w[q] * (tair_b[q] - tair[q]), likewise vz - the straight line the */
+  double w[RS_PREVIEW_MAX];              /* forcing itself follows between two hourly knots: a caller whose rows are the
+                                            knots places its previews AT the first, middle and last index of the next
+                                            window instead of at the knots around it (bench.py's workload: a wavefront's
+                                            boundary-layer passes per step 6.50 -> 6.21).  tair_now may then be NULL: the
+                                            air temperature of preview 0 */
 } RsPreview;
 int rs_hip_recluster_forecast(RsPlan *plan, const RsPreview *preview);
 /* A plan that is only ever sorted by forecast can tell the step kernels not to keep the history
@@ -762,7 +770,7 @@ int rs_compat_outputs(const RsCompat *ctx, int32_t i, double *out6);
 int32_t rs_compat_failed_index(const RsCompat *ctx);
 void rs_compat_end(RsCompat *ctx);
 
-#define RS_ABI_VERSION 8 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles; 4: RsPointParams::horizon_index, rs_hip_step_knots; 5: RS_SUN_COLS 6, RsPointParams::horizons_by_point; 6: rs_driver_last_raw_launches (rs_driver_run without forcing windows); 7: rs_compat_* (module RoadSurf's per-step procedures); 8: RsPreview::prec */
+#define RS_ABI_VERSION 9 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles; 4: RsPointParams::horizon_index, rs_hip_step_knots; 5: RS_SUN_COLS 6, RsPointParams::horizons_by_point; 6: rs_driver_last_raw_launches (rs_driver_run without forcing windows); 7: rs_compat_* (module RoadSurf's per-step procedures); 8: RsPreview::prec; 9: RsPreview::tair_b / vz_b / w */
 int rs_abi_version(void);
 /* sizeof of the boundary structs as the C side / the Fortran side see them
  * (0 InputPointers, 1 OutputPointers, 2 InputSettings, 3 InputParameters,

@@ -365,11 +365,14 @@ static int recluster_apply(RsPlan *pl) {
 
 int rs_hip_recluster_forecast(RsPlan *pl, const RsPreview *pv) {
   if (!pl || !pv) return set_err("rs_hip_recluster_forecast: bad arguments");
-  if (pv->n < 1 || pv->n > RS_PREVIEW_MAX || !pv->tair_now)
-    return set_err("rs_hip_recluster_forecast: 1 <= n <= %d previews and tair_now are required",
+  if (pv->n < 1 || pv->n > RS_PREVIEW_MAX || (!pv->tair_now && !pv->tair_b[0]))
+    return set_err("rs_hip_recluster_forecast: 1 <= n <= %d previews and tair_now (or a preview 0 between two rows) are required",
                    RS_PREVIEW_MAX);
-  for (int q = 0; q < pv->n; ++q)
+  for (int q = 0; q < pv->n; ++q) {
     if (!pv->tair[q] || !pv->vz[q]) return set_err("rs_hip_recluster_forecast: preview row %d is null", q);
+    if ((pv->tair_b[q] != nullptr) != (pv->vz_b[q] != nullptr) || (pv->tair_b[q] && !(pv->w[q] >= 0.0 && pv->w[q] <= 1.0)))
+      return set_err("rs_hip_recluster_forecast: preview %d: tair_b and vz_b come together, with 0 <= w <= 1", q);
+  }
   if (!rs_hip_plan_order(pl)) return -1;
   HIP_OK(hipSetDevice(pl->device));
   if (recluster_buffers(pl)) return -1;

@@ -2613,13 +2613,17 @@ __global__ void __launch_bounds__(kBlock) forecast_key_kernel(const ForecastArgs
   /* which storage branches the point will take (src/Storage.f90): snow is the longest chain */
   const int32_t sclass = has_snow ? 3 : has_ice ? 2 : has_wet ? 1 : 0;
   const int64_t pq = a.pv.index ? (int64_t)a.pv.index[s] : s; /* preview rows in point order */
-  const double ta_now = a.pv.tair_now[pq];
+  auto preview = [&](const double *const *row, const double *const *row_b, int q) -> double {
+    const double v = row[q][pq];
+    return row_b[q] ? v + a.pv.w[q] * (row_b[q][pq] - v) : v; /* RsPreview::tair_b: between two rows */
+  };
+  const double ta_now = a.pv.tair_now ? a.pv.tair_now[pq] : preview(a.pv.tair, a.pv.tair_b, 0);
   const double stab_num = -c.VK_Const * c.ZRefT * c.Grav;
   int32_t unst = 0, farc = 0, extra = 0, maxtrip = 5;
   float stab_lo = 2.f, stab_hi = -2.f; /* the converged stability parameter of the previews, after its clamp */
   for (int q = 0; q < a.pv.n; ++q) {
-    const double ta = a.pv.tair[q][pq];
-    double vz = a.pv.vz[q][pq];
+    const double ta = preview(a.pv.tair, a.pv.tair_b, q);
+    double vz = preview(a.pv.vz, a.pv.vz_b, q);
     const double hour = (double)a.pv.hour[q];
     const double calm = (hour >= c.NightOn || hour <= c.NightOff) ? c.CalmLimNgt : c.CalmLimDay;
     if (vz < calm) vz = calm;
@@ -2740,7 +2744,7 @@ __global__ void __launch_bounds__(kBlock) forecast_key_kernel(const ForecastArgs
    * exp where the phase is missing) for all of its lanes; gathered, they fill one wavefront in thirty. */
   if (a.pv.prec[0]) {
     uint32_t wet = 0u;
-    for (int q = 0; q < a.pv.n; ++q)
+    for (int q = 0; q < RS_PREVIEW_MAX; ++q)
       if (a.pv.prec[q] && a.pv.prec[q][pq] > 0.0) wet = 1u;
     key |= wet << bits;
     bits += 1;

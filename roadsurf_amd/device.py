@@ -286,11 +286,16 @@ class Plan:
         lib.check(self.L.rs_hip_plan_reset_order(self._h), "rs_hip_plan_reset_order")
 
     def recluster_forecast(self, tair_rows, vz_rows, hours, tair_now, alpha: float = 0.5,
-                           mode: int = 1, point_order: bool = False, prec_rows=None) -> None:
+                           mode: int = 1, point_order: bool = False, prec_rows=None, between=None) -> None:
         """Sort the slots by a forecast of the next launch (rs_hip_recluster_forecast): rows are
         tensors [np_pad] at the preview times, hours the hour of day.  Rows in the CURRENT slot order,
-        or - ``point_order`` - in point order, read through the plan's order row."""
+        or - ``point_order`` - in point order, read through the plan's order row.  ``between``: per preview
+        (tair_b, vz_b, w) - the preview lies between its row and that one (RsPreview::tair_b); tair_now may
+        then be None."""
         pv = lib.RsPreview()
+        if between is not None:
+            for q, (tb, vb, w) in enumerate(between):
+                pv.tair_b[q] = tb.data_ptr(); pv.vz_b[q] = vb.data_ptr(); pv.w[q] = float(w)
         pv.index = self.L.rs_hip_plan_order(self._h) if point_order else None
         pv.n = len(tair_rows)
         for q, (ta, vz, h) in enumerate(zip(tair_rows, vz_rows, hours)):
@@ -298,7 +303,7 @@ class Plan:
         if prec_rows is not None:  # one more key bit: precipitation somewhere in the next window
             for q, pr in enumerate(prec_rows):
                 pv.prec[q] = pr.data_ptr()
-        pv.tair_now = tair_now.data_ptr()
+        pv.tair_now = tair_now.data_ptr() if tair_now is not None else None
         pv.alpha = alpha
         pv.mode = mode
         lib.check(self.L.rs_hip_recluster_forecast(self._h, C.byref(pv)), "rs_hip_recluster_forecast")

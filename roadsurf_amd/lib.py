@@ -80,7 +80,9 @@ RS_PREVIEW_MAX = 8
 class RsPreview(C.Structure):
     _fields_ = [("n", C.c_int32), ("tair", C.c_void_p * RS_PREVIEW_MAX), ("vz", C.c_void_p * RS_PREVIEW_MAX),
                 ("hour", C.c_int32 * RS_PREVIEW_MAX), ("tair_now", C.c_void_p), ("alpha", C.c_double),
-                ("mode", C.c_int32), ("index", C.c_void_p), ("prec", C.c_void_p * RS_PREVIEW_MAX)]
+                ("mode", C.c_int32), ("index", C.c_void_p), ("prec", C.c_void_p * RS_PREVIEW_MAX),
+                ("tair_b", C.c_void_p * RS_PREVIEW_MAX), ("vz_b", C.c_void_p * RS_PREVIEW_MAX),
+                ("w", C.c_double * RS_PREVIEW_MAX)]
 
 
 class RsSynthSpec(C.Structure):

@@ -60,6 +60,8 @@ class SyntheticRun:
         self.forecast, self.forecast_alpha, self.forecast_mode = forecast, forecast_alpha, forecast_mode
         # round 5: one more key bit for "precipitation in the next window" (ROADSURF_HIP_PRECIP_BIT=0: A/B)
         self.precip_bit = os.environ.get("ROADSURF_HIP_PRECIP_BIT", "1") != "0"
+        # ... and previews placed inside the window (ROADSURF_HIP_PREVIEWS_AT_KNOTS=1: round 4's, A/B)
+        self.previews_in_window = os.environ.get("ROADSURF_HIP_PREVIEWS_AT_KNOTS", "0") != "1"
         plan.set_history_score(not (plan_order and forecast))  # nobody reads it then
         dev, npad = plan.device, plan.np_pad
         wdtype = torch.float32 if f32 else torch.float64
@@ -150,21 +152,17 @@ class SyntheticRun:
         kn = self.knots
         # ... field 4 the precipitation: a window has precipitation at some index iff one of its knots has
         prec = [kn[k0 + q, 4] for q in range(nk)] if self.precip_bit else None
-        if os.environ.get("ROADSURF_HIP_PREVIEW_LERP") == "1" and k0 + 1 < kn.shape[0]:
-            # (experiment, tools/wave_stats.py only: synchronises) previews AT the window's first, middle and last
-            # index - the knots' straight line, as the forcing itself - instead of at the knots around it
-            torch.cuda.synchronize()
+        if self.previews_in_window and kn.shape[0] >= 2 and ((t_next - 1) % SPK != 0 or ns % SPK != 0):
+            # a window that does not start and end on knots: previews AT its first, middle and last index, on the
+            # knots' straight line as the forcing itself (RsPreview::tair_b), instead of at the knots around it - a
+            # half-hour window is not forecast from a knot half an hour old.  (Windows of whole hours keep their
+            # knots: measured level or 0.5 % better, profiles/r05_ab_previews_in_window.txt)
             idx = [t_next - 1, t_next - 1 + ns // 2, t_next + ns - 2]
-            ta, vz, hh = [], [], []
-            for i in idx:
-                k = min(i // SPK, kn.shape[0] - 2)
-                w = (i - k * SPK) / SPK
-                ta.append(torch.lerp(kn[k, 0], kn[k + 1, 0], w)); vz.append(torch.lerp(kn[k, 2], kn[k + 1, 2], w))
-                hh.append((self.spec.start_hour + i // SPK) % 24)
-            torch.cuda.synchronize()
-            plan.recluster_forecast(ta, vz, hh, ta[0], self.forecast_alpha, self.forecast_mode, point_order=True,
-                                    prec_rows=prec[:3] if prec and len(prec) >= 3 else (prec + [prec[-1]] * (3 - len(prec)) if prec else None))
-            self._keep = (ta, vz)
+            ks = [min(i // SPK, kn.shape[0] - 2) for i in idx]
+            plan.recluster_forecast([kn[k, 0] for k in ks], [kn[k, 2] for k in ks],
+                                    [(self.spec.start_hour + i // SPK) % 24 for i in idx], None, self.forecast_alpha,
+                                    self.forecast_mode, point_order=True, prec_rows=prec,
+                                    between=[(kn[k + 1, 0], kn[k + 1, 2], min(1.0, (i - k * SPK) / SPK)) for i, k in zip(idx, ks)])
             return
         plan.recluster_forecast([kn[k0 + q, 0] for q in range(nk)], [kn[k0 + q, 2] for q in range(nk)],
                                 hours, kn[k0, 0], self.forecast_alpha, self.forecast_mode, point_order=True,
