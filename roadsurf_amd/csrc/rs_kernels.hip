@@ -2735,8 +2735,9 @@ __global__ void __launch_bounds__(kBlock) forecast_key_kernel(const ForecastArgs
       key = (key << 3) | (a.extra_log ? cls : (uint32_t)(extra > 7 ? 7 : extra));
       bits += 3;
     }
-    else if (d == 7) { key = (key << 2) | (uint32_t)(unst > 3 ? 3 : unst); bits += 2; }
-    else if (d == 8) { key = (key << 2) | (uint32_t)(farc > 3 ? 3 : farc); bits += 2; }
+    /* (more than three previews: the counts scaled to 0..3) */
+    else if (d == 7) { key = (key << 2) | (uint32_t)(a.pv.n > 3 ? (unst * 3 + a.pv.n / 2) / a.pv.n : unst > 3 ? 3 : unst); bits += 2; }
+    else if (d == 8) { key = (key << 2) | (uint32_t)(a.pv.n > 3 ? (farc * 3 + a.pv.n / 2) / a.pv.n : farc > 3 ? 3 : farc); bits += 2; }
   }
   /* RsPreview::prec (ABI 8): the most significant bit - some preview has precipitation.  Points with
    * precipitation are a few per cent of a batch at any time, but in an order that ignores it they sit in four

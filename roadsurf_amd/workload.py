@@ -157,6 +157,7 @@ class SyntheticRun:
             # knots' straight line as the forcing itself (RsPreview::tair_b), instead of at the knots around it - a
             # half-hour window is not forecast from a knot half an hour old.  (Windows of whole hours keep their
             # knots: measured level or 0.5 % better, profiles/r05_ab_previews_in_window.txt)
+            # (three: five and seven previews sort no better and cost more, profiles/r05_sweep_previews.txt)
             idx = [t_next - 1, t_next - 1 + ns // 2, t_next + ns - 2]
             ks = [min(i // SPK, kn.shape[0] - 2) for i in idx]
             plan.recluster_forecast([kn[k, 0] for k in ks], [kn[k, 2] for k in ks],
