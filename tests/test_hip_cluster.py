@@ -213,3 +213,40 @@ def test_the_plans_own_sort_equals_the_library_sort(n, monkeypatch):
     assert np.array_equal(rows["own"], rows["library"])
     for r in rows["own"]:
         assert np.array_equal(np.sort(r), np.arange(n))
+
+
+def test_previews_between_two_rows_sort_like_the_blended_rows():
+    """RsPreview::tair_b / vz_b / w (ABI 9): a preview between two rows - the caller's hourly knots - is the
+    straight line between them, so the slots must come out in the order that rows blended by the caller give;
+    and that order differs from the one the knots themselves give (the previews really moved)."""
+    import torch
+    from roadsurf_amd import abi, device, workload
+    n, hours = 5000, 3
+    L = hours * 120 + 1
+    s = abi.default_settings(L); p = abi.default_parameters()
+    orders = {}
+    for tag in ("between", "blended", "knots"):
+        plan = device.Plan(n, s, p, 0)
+        run = workload.SyntheticRun(plan, 7, hours, 60, plan_order=True, forecast=True)
+        run.run_pass()  # some history in the state, and an order that is not the identity (the same for all three)
+        plan.sync()
+        kn = run.knots
+        ws = (0.0, 0.25, 0.4916666666666667)
+        hrs = [3, 3, 3]
+        if tag == "between":
+            plan.recluster_forecast([kn[1, 0]] * 3, [kn[1, 2]] * 3, hrs, None, 0.5, workload.DEFAULT_FORECAST_MODE,
+                                    point_order=True, between=[(kn[2, 0], kn[2, 2], w) for w in ws])
+        elif tag == "blended":
+            ta = [kn[1, 0] + w * (kn[2, 0] - kn[1, 0]) for w in ws]
+            vz = [kn[1, 2] + w * (kn[2, 2] - kn[1, 2]) for w in ws]
+            torch.cuda.synchronize()
+            plan.recluster_forecast(ta, vz, hrs, ta[0], 0.5, workload.DEFAULT_FORECAST_MODE, point_order=True)
+        else:
+            plan.recluster_forecast([kn[1, 0], kn[2, 0]], [kn[1, 2], kn[2, 2]], hrs[:2], kn[1, 0], 0.5,
+                                    workload.DEFAULT_FORECAST_MODE, point_order=True)
+        plan.sync()
+        orders[tag] = plan.order()[:n].cpu().numpy().copy()
+        plan.close()
+    assert np.array_equal(np.sort(orders["between"]), np.arange(n))
+    assert np.array_equal(orders["between"], orders["blended"])
+    assert not np.array_equal(orders["between"], orders["knots"])
