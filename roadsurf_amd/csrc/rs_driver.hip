@@ -1400,7 +1400,13 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     Pdef = std::max<int64_t>(4096, std::min<int64_t>(262144, Pdef / 4096 * 4096));
   }
   const int P = (int)std::min<int64_t>(pend - pbeg, ep ? std::max(1, atoi(ep)) : Pdef);
-  const int TC = (coupled && !cpl_chunked) ? L : std::min(L, et ? std::max(1, atoi(et)) : use_raw ? RS_DRIVER_RAW_CHUNK : 256);
+  /* A block of a few wavefronts (the reference's operational example: 401 stations) is the latency of its
+   * dependent steps whatever the order of its points: no re-sorts, and launches of eight hours (154 against 165 ms
+   * per call of that example, profiles/r05_operational_shape.txt) */
+  const bool small_block = pend - pbeg < 4096;
+  const char *ec = getenv("ROADSURF_HIP_CLUSTER"); /* 0 / 1: natural / plan order whatever the size */
+  const bool want_cluster = ec ? atoi(ec) != 0 : !small_block;
+  const int TC = (coupled && !cpl_chunked) ? L : std::min(L, et ? std::max(1, atoi(et)) : use_raw ? (want_cluster ? RS_DRIVER_RAW_CHUNK : 960) : 256);
 
   /* Every buffer of a tile other than the forcing windows comes out of one block this worker keeps
    * across calls (rs_devutil.hpp: Arena): no hipMalloc / hipFree inside the tile loop.  The size is
@@ -1602,7 +1608,12 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     const int r_lo = cs_min, r_hi = std::min(ce_max + 1, L); /* replay block, 1-based inclusive */
     /* the replay rounds read the raw series too (rs_cpl_replay_raw) where the block ends before SimLen and
      * there is no sky view; ROADSURF_HIP_CPL_REPLAY_WINDOWS=1: a window + the one-point-per-lane kernels (A/B) */
+    /* ... and is COMPACT - not much longer than one coupling window, rs_hip_cpl_replay's own rule: stations whose
+     * observations end hours apart (the reference's operational example) make a block in which a lock-step
+     * replay would step every listed point through all of it, round after round - those keep the forcing window
+     * and the per-lane replay kernel */
     const bool replay_raw = use_raw && cpl_chunked && any_on && !skyview && std::min(ce_max + 1, L) < L &&
+                            (int64_t)(r_hi - r_lo + 1) * 4 <= ((int64_t)c.cplLen + 2) * 5 &&
                             !getenv("ROADSURF_HIP_CPL_REPLAY_WINDOWS");
     const bool need_win = !use_raw || (cpl_chunked && any_on && !replay_raw); /* raw-series stepping: windows for such replays only */
     const int WR = (cpl_chunked && any_on) ? (use_raw ? r_hi - r_lo + 1 : std::max(TC, r_hi - r_lo + 1)) : TC;
@@ -1665,8 +1676,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
      * kernel), see DESIGN.md 6 for the forecast key.  ROADSURF_HIP_CLUSTER=0 switches the order
      * off.  Sky view (round 4): the four geometry scalars are gathered like the other per-point
      * parameters, the local-horizon table is read through the order row. */
-    const char *ec = getenv("ROADSURF_HIP_CLUSTER");
-    const bool cluster = (!coupled || cpl_chunked) && TC < L && !(ec && atoi(ec) == 0);
+    const bool cluster = (!coupled || cpl_chunked) && TC < L && want_cluster;
     const int rows_c = TC / step + 2; /* output rows one launch can produce */
     Dev d_outc, d_pp_s, d_geo_s;
     RsOutputs oc = oo;

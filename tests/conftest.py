@@ -38,3 +38,14 @@ def pytest_sessionstart(session):
 def hip_lib():
     from roadsurf_amd import lib
     return lib.load()
+
+
+@pytest.fixture(autouse=True)
+def _plan_order_for_small_batches(monkeypatch):
+    """rs_driver_run leaves blocks of fewer than 4 096 points in natural order with launches of eight hours (they
+    are a handful of wavefronts: the latency of their dependent steps whatever the order).  The suite's batches
+    are that small, and it is the plan-order path with its re-sorts that they are there to hold to the
+    reference's bits: ask for it.  Tests that want natural order set the variable to 0 themselves;
+    tests/test_hip_operational.py removes it to run the library's own default."""
+    if "ROADSURF_HIP_CLUSTER" not in os.environ:
+        monkeypatch.setenv("ROADSURF_HIP_CLUSTER", "1")

@@ -25,7 +25,9 @@ def _bits(a, b):
 
 
 @pytest.mark.parametrize("case", ["files", "sky"])
-def test_operational_shape_through_rs_driver_run(case):
+def test_operational_shape_through_rs_driver_run(case, monkeypatch):
+    monkeypatch.delenv("ROADSURF_HIP_CLUSTER", raising=False)  # the library's own default for a block of 401 points:
+    #                                                            natural order, launches of eight hours
     z = gh.load("e2e_operational.npz")
     src, s, p, t0, tf, local, hz = dh.operational_case(z, case)
     assert s.SimLen == 8881

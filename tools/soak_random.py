@@ -19,6 +19,7 @@ class MP:  # the two monkeypatch methods the tests use
         self.saved = {}
 
 
+os.environ.setdefault("ROADSURF_HIP_CLUSTER", "1")  # (as tests/conftest.py: the plan-order path also for small batches)
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 bad = 0
