@@ -1705,6 +1705,12 @@ struct RawLerp {
    * +0, as in the general form.  The rule outside the hours in which observations overlay the forecast. */
   int32_t single;
   int32_t seg, seg_end; /* current segment and its end (0-based, exclusive) */
+  /* MIXED variables (uniform mask): the lanes disagree on the supplying source - stations without a sensor, gaps
+   * in an observation series - but every lane's ends allow the short form: each interpolating source's line is
+   * evaluated with that source's scalars and the lane keeps its own (`wsel`, per lane: three bits per variable,
+   * the source or 4).  `imask`: the sources that interpolate in this segment. */
+  uint32_t mixed, imask;
+  uint32_t wsel;
 };
 
 /* one variable of one point at 0-based index i, the long way: every source, every test */
@@ -1735,6 +1741,9 @@ __device__ __forceinline__ void raw_resolve(KernArgs ka, int64_t col, bool live,
   const int nsrc = ka->raw.nsrc;
   const int64_t np = ka->raw.np_pad;
   uint64_t mode = 0;
+  uint32_t mixed = 0u, imask = 0u, wsel = 0u;
+  for (int s = 0; s < nsrc; ++s)
+    if (sg->kind[s] == RAW_INTERP) imask |= 1u << s;
 #pragma unroll
   for (int q = 0; q < NF; ++q) {
     const int fld = raw_field_of(FSET, q);
@@ -1772,13 +1781,20 @@ __device__ __forceinline__ void raw_resolve(KernArgs ka, int64_t col, bool live,
       }
     }
     const int32_t w0 = __builtin_amdgcn_readfirstlane(wl); /* lane 0 is never a dead lane */
-    const bool uni = __builtin_amdgcn_ballot_w64(live && (wl != w0 || !okl)) == 0ull;
-    mode |= uni ? (1ull << (10 * w0 + q)) : (1ull << (50 + q));
+    const bool all_ok = __builtin_amdgcn_ballot_w64(live && !okl) == 0ull;
+    const bool same = __builtin_amdgcn_ballot_w64(live && wl != w0) == 0ull;
+    if (all_ok && same) mode |= 1ull << (10 * w0 + q);
+    else if (all_ok) mixed |= 1u << q;
+    else mode |= 1ull << (50 + q);
+    wsel |= (uint32_t)wl << (3 * q);
     R.v0[q] = a_w;
     R.dv[q] = d_w;
   }
   R.mode = mode;
-  int32_t single = ((mode >> 50) & 1023ull) ? -1 : 4;
+  R.mixed = mixed;
+  R.imask = imask;
+  R.wsel = wsel;
+  int32_t single = (((mode >> 50) & 1023ull) || mixed) ? -1 : 4;
   for (int s = 0; s < RS_MAX_SOURCES; ++s)
     if ((mode >> (10 * s)) & 1023ull) single = (single == 4) ? s : -1;
   R.single = single;
@@ -1832,6 +1848,30 @@ __device__ __forceinline__ void raw_values(KernArgs ka, int64_t col, bool live, 
 #pragma unroll
     for (int q = 0; q < NF; ++q)
       if (m & (1u << q)) val[q] = R.v0[q] + 0.0; /* a copy, or missing: what the short form gives for dv = 0 */
+  }
+  uint32_t mix = R.mixed & keep;
+  if (mix) { /* uniform */
+    for (int s = 0; s < RS_MAX_SOURCES; ++s) /* an entry that promises nothing: the long way for this index */
+      if ((R.imask & (1u << s)) && raw_plan_at(ka->raw.src[s].plan, t).rden == 0.0) {
+        slow |= mix;
+        mix = 0u;
+      }
+  }
+  if (mix) {
+#pragma unroll
+    for (int q = 0; q < NF; ++q)
+      if (mix & (1u << q)) val[q] = R.v0[q] + 0.0; /* the lanes that copy, or have nobody: dv = 0 */
+#pragma nounroll
+    for (int s = 0; s < RS_MAX_SOURCES; ++s) {
+      if (!(R.imask & (1u << s))) continue;
+      const RawPlanStep st = raw_plan_at(ka->raw.src[s].plan, t);
+#pragma unroll
+      for (int q = 0; q < NF; ++q)
+        if (mix & (1u << q)) {
+          const double cand = R.v0[q] + raw_quot(st.num * R.dv[q], st.den, st.rden);
+          if (((R.wsel >> (3 * q)) & 7u) == (uint32_t)s) val[q] = cand;
+        }
+    }
   }
   if (slow) {
 #pragma unroll

@@ -40,7 +40,8 @@ class DriverWorkload:
     to ``n`` (bounds the host time spent making inputs; the regimes inside a tile are what a batch
     of that size has)."""
 
-    def __init__(self, n: int, hours: int = 48, seed: int = 1, unique: int | None = None, pinned: bool = False):
+    def __init__(self, n: int, hours: int = 48, seed: int = 1, unique: int | None = None, pinned: bool = False,
+                 missing: float = 0.0):
         self.n, self.hours, self.pinned = n, hours, pinned
         self.simlen = hours * 120 + 1
         u = n if unique is None else min(unique, n)
@@ -69,6 +70,14 @@ class DriverWorkload:
         self.ob_t = START + np.arange(nt_ob, dtype=np.int64) * 600
         ob = dict(tair=series(nt_ob, 600, -12, 6, 1.0), rhz=np.clip(series(nt_ob, 600, 70, 95, 5.0), 5, 100),
                   vz=np.abs(series(nt_ob, 600, 1, 8, 1.0)) + 0.2, tsurfobs=series(nt_ob, 600, -10, 4, 1.0))
+        if missing > 0.0:
+            # stations as real networks have them: some without an air-temperature / humidity / wind sensor (no
+            # value of that variable in the observation source at all), and gaps in the road-temperature series -
+            # the lanes of a wavefront then disagree on which source supplies a variable
+            for name in ("tair", "rhz", "vz"):
+                ob[name][rs.rand(u) < missing] = -9999.9
+            ob["tsurfobs"][rs.rand(u, nt_ob) < missing] = -9999.9
+            ob["tsurfobs"][:, -1] = np.where(ob["tsurfobs"][:, -1] < -9000, -3.0, ob["tsurfobs"][:, -1])  # (coupling needs the last one)
         self.fc = {k: tile(v) for k, v in fc.items()}
         self.ob = {k: tile(v) for k, v in ob.items()}
         self.sky_view = tile(rs.uniform(0.3, 1.0, (u, 1)))[:, 0]
