@@ -41,7 +41,7 @@ class DriverWorkload:
     of that size has)."""
 
     def __init__(self, n: int, hours: int = 48, seed: int = 1, unique: int | None = None, pinned: bool = False,
-                 missing: float = 0.0):
+                 missing: float = 0.0, ragged: float = 0.0):
         self.n, self.hours, self.pinned = n, hours, pinned
         self.simlen = hours * 120 + 1
         u = n if unique is None else min(unique, n)
@@ -78,6 +78,12 @@ class DriverWorkload:
                 ob[name][rs.rand(u) < missing] = -9999.9
             ob["tsurfobs"][rs.rand(u, nt_ob) < missing] = -9999.9
             ob["tsurfobs"][:, -1] = np.where(ob["tsurfobs"][:, -1] < -9000, -3.0, ob["tsurfobs"][:, -1])  # (coupling needs the last one)
+        if ragged > 0.0:
+            # ... and some whose road-temperature observations end one to three hours before the others': their
+            # coupling windows end that much earlier (the reference's operational example has such stations)
+            late = rs.rand(u) < ragged
+            cut = nt_ob - 6 * rs.randint(1, 4, u)
+            ob["tsurfobs"][late[:, None] & (np.arange(nt_ob)[None, :] >= cut[:, None])] = -9999.9
         self.fc = {k: tile(v) for k, v in fc.items()}
         self.ob = {k: tile(v) for k, v in ob.items()}
         self.sky_view = tile(rs.uniform(0.3, 1.0, (u, 1)))[:, 0]
