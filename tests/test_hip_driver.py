@@ -412,3 +412,25 @@ def test_driver_run_fans_out_over_the_device_list(monkeypatch):
     for q in range(n):
         for f in LP_FIELDS:
             assert getattr(a["local"][q], f) == getattr(b["local"][q], f), (q, f)
+
+
+@pytest.mark.parametrize("mode", ["relax", "coupling", "skyview"])
+def test_observations_with_holes_on_the_benchmark_workload(mode):
+    """The raw-series benchmark workload (roadsurf_amd/driver_workload.py) with observation series as real
+    networks have them: stations without an air-temperature / humidity / wind sensor, gaps in the road
+    temperature, series that end hours apart.  The lanes of a wavefront then disagree on the source that
+    supplies a variable and the step kernel's ground wave keeps every interpolating source's line per lane
+    (rs_kernels.hip raw_values, MIXED).  Same bits as the checker, in plan order, several wavefronts per class."""
+    from roadsurf_amd import driver_workload
+    n, hours = 3000, 8
+    w = driver_workload.DriverWorkload(n, hours, seed=11, missing=0.15, ragged=0.2)
+    src, s, p = w.sources(mode), w.settings(mode), abi.default_parameters()
+    loc = w.local(mode)
+    hz = w.horizons() if mode == "skyview" else None
+    t0, tf = driver_workload.START, driver_workload.START + driver_workload.OBS_HOURS * 3600
+    o = dh.oracle_run(_kind(mode == "coupling"), src, s, p, t0, tf, local=loc, cal=w.cal, horizons=hz)
+    g = driver.run(src, s, p, t0, tf, cal=w.cal, local=w.local(mode), horizons=hz)
+    assert np.array_equal(g["status"], o["status"]) and (o["status"] == 0).sum() > n // 2
+    for k in driver.OUT_FIELDS:
+        assert _same_bits(g[k], o[k]), (mode, k, int((g[k] != o[k]).sum()))
+    assert lib.load().rs_driver_last_raw_launches() > 0
