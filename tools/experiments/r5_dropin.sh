@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# the literal drop-in under the C++ harness (tools/dropin_harness.cpp): threads x coalescing mode
+# the literal drop-in under the C++ harness (tools/dropin_harness.cpp; `make -C roadsurf_amd harness`): threads x coalescing mode
 H="timeout -k 5 120 tools/bin/dropin_harness"
 export ROADSURF_HIP_DEVICE=0
 echo "default (automatic): $($H 1 48)"
