@@ -588,7 +588,7 @@ typedef struct RsPreview {
   const double *tair_b[RS_PREVIEW_MAX];  /* ABI 9.  Previews BETWEEN two rows: where tair_b[q] is not NULL, preview q is */
   const double *vz_b[RS_PREVIEW_MAX];    /* tair[q] + w[q] * (tair_b[q] - tair[q]), likewise vz - the straight line the */
   double w[RS_PREVIEW_MAX];              /* forcing itself follows between two hourly knots: a caller whose rows are the
-                                            knots places its previews AT the first, middle and last index of the next
+                                            knots places its previews AT the first and last index of the next
                                             window instead of at the knots around it (bench.py's workload: a wavefront's
                                             boundary-layer passes per step 6.50 -> 6.21).  tair_now may then be NULL: the
                                             air temperature of preview 0 */

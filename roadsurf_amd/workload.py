@@ -153,12 +153,14 @@ class SyntheticRun:
         # ... field 4 the precipitation: a window has precipitation at some index iff one of its knots has
         prec = [kn[k0 + q, 4] for q in range(nk)] if self.precip_bit else None
         if self.previews_in_window and kn.shape[0] >= 2 and ((t_next - 1) % SPK != 0 or ns % SPK != 0):
-            # a window that does not start and end on knots: previews AT its first, middle and last index, on the
+            # a window that does not start and end on knots: previews AT its first and last index, on the
             # knots' straight line as the forcing itself (RsPreview::tair_b), instead of at the knots around it - a
             # half-hour window is not forecast from a knot half an hour old.  (Windows of whole hours keep their
             # knots: measured level or 0.5 % better, profiles/r05_ab_previews_in_window.txt)
-            # (three: five and seven previews sort no better and cost more, profiles/r05_sweep_previews.txt)
-            idx = [t_next - 1, t_next - 1 + ns // 2, t_next + ns - 2]
+            # (two: the middle index, and five or seven previews, sort no better, profiles/r05_sweep_previews.txt)
+            idx = [t_next - 1, t_next + ns - 2]
+            if os.environ.get("ROADSURF_HIP_PREVIEWS") == "3":  # (tuning) with the middle index: 0.4 % slower
+                idx = [idx[0], t_next - 1 + ns // 2, idx[1]]
             ks = [min(i // SPK, kn.shape[0] - 2) for i in idx]
             plan.recluster_forecast([kn[k, 0] for k in ks], [kn[k, 2] for k in ks],
                                     [(self.spec.start_hour + i // SPK) % 24 for i in idx], None, self.forecast_alpha,
