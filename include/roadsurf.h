@@ -598,6 +598,18 @@ int rs_hip_recluster_forecast(RsPlan *plan, const RsPreview *preview);
  * score (a few vector instructions per boundary-layer pass); rs_hip_recluster then refuses. */
 int rs_hip_set_history_score(RsPlan *plan, int32_t on);
 int rs_hip_plan_order_copy(RsPlan *plan, int32_t *dst_device);
+/* ABI 10.  The output rows of a launch in POINT order at every index, for a consumer that keeps one series per
+ * point (SaveOutput fills a point's arrays, src/InputOutput.f90:151-165; OutputData.cpp:5-13): the first
+ * `nrows` rows of the window `src` ([row][slot], fp64) are written into point-major arrays
+ *     dst[stream][point * dst_rows + dst_row0 + row],   stream = Tsurf, Snow, Water, Ice, Deposit, Ice2,
+ * point = order[slot] (`order`: a device row kept with rs_hip_plan_order_copy, or NULL = the plan's current
+ * order: then call it between the step launch and the next re-sort).  Asynchronous on the plan's stream.  One
+ * pass over the rows (read once, written once in whole lines), and not a cheap one - the outputs are most of
+ * the bytes this path moves: at 1 M points the pass with it after every launch runs at 1.48e10 point-timesteps/s
+ * against 2.5e10 without; natural order, whose rows are [row][point], not per-point series, runs at 1.46e10
+ * (tools/bench_point_order_outputs.py). */
+int rs_hip_outputs_by_point(RsPlan *plan, const RsOutputs *src, int32_t nrows, const int32_t *order_device,
+                            double *const *dst_device, int64_t dst_rows, int64_t dst_row0);
 int rs_hip_plan_reset_order(RsPlan *plan);
 
 /* Device timing of the step kernel with HIP events recorded on the plan's
@@ -770,7 +782,7 @@ int rs_compat_outputs(const RsCompat *ctx, int32_t i, double *out6);
 int32_t rs_compat_failed_index(const RsCompat *ctx);
 void rs_compat_end(RsCompat *ctx);
 
-#define RS_ABI_VERSION 9 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles; 4: RsPointParams::horizon_index, rs_hip_step_knots; 5: RS_SUN_COLS 6, RsPointParams::horizons_by_point; 6: rs_driver_last_raw_launches (rs_driver_run without forcing windows); 7: rs_compat_* (module RoadSurf's per-step procedures); 8: RsPreview::prec; 9: RsPreview::tair_b / vz_b / w */
+#define RS_ABI_VERSION 10 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles; 4: RsPointParams::horizon_index, rs_hip_step_knots; 5: RS_SUN_COLS 6, RsPointParams::horizons_by_point; 6: rs_driver_last_raw_launches (rs_driver_run without forcing windows); 7: rs_compat_* (module RoadSurf's per-step procedures); 8: RsPreview::prec; 9: RsPreview::tair_b / vz_b / w; 10: rs_hip_outputs_by_point */
 int rs_abi_version(void);
 /* sizeof of the boundary structs as the C side / the Fortran side see them
  * (0 InputPointers, 1 OutputPointers, 2 InputSettings, 3 InputParameters,

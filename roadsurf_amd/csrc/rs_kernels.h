@@ -169,6 +169,9 @@ hipError_t rs_launch_forecast_keys(const rs::ForecastArgs &a, hipStream_t stream
 /* plan order (rs_cluster.hip) */
 #define RS_SORT_KEY_BITS 24
 hipError_t rs_cluster_identity(int32_t *order, int64_t np_pad, hipStream_t stream);
+hipError_t rs_cluster_outputs_by_point(const double *const src[6], double *const dst[6], const int32_t *order,
+                                       int64_t npoints, int64_t src_stride, int32_t nrows, int64_t dst_rows,
+                                       int64_t dst_row0, hipStream_t stream);
 size_t rs_cluster_scratch_bytes(int64_t npoints);
 hipError_t rs_cluster_sort(const double *state, bool f32, int64_t np_pad, int64_t npoints,
                            uint32_t *scratch, void *tmp, size_t tmp_bytes, hipStream_t stream);

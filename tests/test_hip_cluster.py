@@ -250,3 +250,36 @@ def test_previews_between_two_rows_sort_like_the_blended_rows():
     assert np.array_equal(np.sort(orders["between"]), np.arange(n))
     assert np.array_equal(orders["between"], orders["blended"])
     assert not np.array_equal(orders["between"], orders["knots"])
+
+
+def test_outputs_by_point_are_the_slot_rows_in_point_major_order():
+    """rs_hip_outputs_by_point (ABI 10): the rows of a launch, [row][slot] in plan order, as per-point series
+    [point][row] - every value where its point's series has it, ragged sizes (a last partial wavefront, more
+    rows than one tile of 32), rows placed at an offset of the series, a kept order row or the plan's own."""
+    import torch
+    from roadsurf_amd import abi, device, workload
+    n, hours, chunk = 2500, 3, 90
+    L = hours * 120 + 1
+    s = abi.default_settings(L); p = abi.default_parameters()
+    plan = device.Plan(n, s, p, 0)
+    run = workload.SyntheticRun(plan, 3, hours, chunk, plan_order=True, forecast=True)
+    series = {k: torch.full((plan.np_pad, L + 7), -1.0, dtype=torch.float64, device=plan.device) for k in device.OUT_FIELDS}
+    kept = {}
+
+    def on_launch(c, t0, ns):
+        # the plan's current order is still the launch's; every second launch through the kept row instead
+        order = run.orders[c] if c % 2 else None
+        plan.outputs_by_point(run.out, ns, series, dst_row0=t0 - 1 + 7, order=order)
+        kept[c] = {k: run.out.tensors[k][:ns, :n].clone() for k in device.OUT_FIELDS}
+    run.run_pass(on_launch)
+    plan.sync()
+    assert len(kept) > 3
+    for c, t0 in enumerate(run.starts):
+        order = run.orders[c][:n].long()
+        ns = min(chunk, L - t0 + 1)
+        for k in device.OUT_FIELDS:
+            got = series[k][order, t0 - 1 + 7:t0 - 1 + 7 + ns].T
+            assert torch.equal(got.contiguous(), kept[c][k]), (c, k)
+    for k in device.OUT_FIELDS:
+        assert bool((series[k][:n, :7] == -1.0).all()) and bool((series[k][n:] == -1.0).all())  # nothing else was touched
+    plan.close()
