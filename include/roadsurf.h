@@ -603,13 +603,15 @@ int rs_hip_plan_order_copy(RsPlan *plan, int32_t *dst_device);
  * `nrows` rows of the window `src` ([row][slot], fp64) are written into point-major arrays
  *     dst[stream][point * dst_rows + dst_row0 + row],   stream = Tsurf, Snow, Water, Ice, Deposit, Ice2,
  * point = order[slot] (`order`: a device row kept with rs_hip_plan_order_copy, or NULL = the plan's current
- * order: then call it between the step launch and the next re-sort).  Asynchronous on the plan's stream.  One
+ * order: then call it between the step launch and the next re-sort).  Asynchronous on the plan's stream, or - with
+ * a kept order row - on `stream` (a hipStream_t of the caller's, who orders it behind the launch and in front of
+ * the window's next use: with two windows in turn the pass overlaps the next launch).  One
  * pass over the rows (read once, written once in whole lines), and not a cheap one - the outputs are most of
- * the bytes this path moves: at 1 M points the pass with it after every launch runs at 1.48e10 point-timesteps/s
+ * the bytes this path moves: at 1 M points the pass with it after every launch runs at 1.4-1.5e10 point-timesteps/s
  * against 2.5e10 without; natural order, whose rows are [row][point], not per-point series, runs at 1.46e10
  * (tools/bench_point_order_outputs.py). */
 int rs_hip_outputs_by_point(RsPlan *plan, const RsOutputs *src, int32_t nrows, const int32_t *order_device,
-                            double *const *dst_device, int64_t dst_rows, int64_t dst_row0);
+                            double *const *dst_device, int64_t dst_rows, int64_t dst_row0, void *stream);
 int rs_hip_plan_reset_order(RsPlan *plan);
 
 /* Device timing of the step kernel with HIP events recorded on the plan's

@@ -459,7 +459,7 @@ int rs_hip_plan_order_copy(RsPlan *pl, int32_t *dst) {
 }
 
 int rs_hip_outputs_by_point(RsPlan *pl, const RsOutputs *src, int32_t nrows, const int32_t *order,
-                            double *const *dst, int64_t dst_rows, int64_t dst_row0) {
+                            double *const *dst, int64_t dst_rows, int64_t dst_row0, void *stream) {
   if (!pl || !src || !dst || nrows < 1 || dst_rows < 1 || dst_row0 < 0 || dst_row0 + nrows > dst_rows)
     return set_err("rs_hip_outputs_by_point: bad arguments (rows [dst_row0, dst_row0 + nrows) must lie inside a point's dst_rows)");
   if (pl->f32) return set_err("rs_hip_outputs_by_point: fp64 output windows only");
@@ -470,10 +470,11 @@ int rs_hip_outputs_by_point(RsPlan *pl, const RsOutputs *src, int32_t nrows, con
     out[f] = dst[f];
   }
   if (src->t_stride < pl->npoints) return set_err("rs_hip_outputs_by_point: t_stride below the plan's points");
+  if (!order && stream) return set_err("rs_hip_outputs_by_point: on a stream of the caller's the order row must be a kept one");
   if (!order && !rs_hip_plan_order(pl)) return -1;
   HIP_OK(hipSetDevice(pl->device));
   HIP_OK(rs_cluster_outputs_by_point(in, out, order ? order : pl->order, pl->npoints, src->t_stride, nrows, dst_rows,
-                                     dst_row0, pl->stream));
+                                     dst_row0, stream ? (hipStream_t)stream : pl->stream));
   return 0;
 }
 

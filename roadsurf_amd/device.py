@@ -282,7 +282,8 @@ class Plan:
         lib.check(self.L.rs_hip_plan_order_copy(self._h, C.c_void_p(dst.data_ptr())),
                   "rs_hip_plan_order_copy")
 
-    def outputs_by_point(self, out: "OutputWindow", nrows: int, dst: dict, dst_row0: int = 0, order=None) -> None:
+    def outputs_by_point(self, out: "OutputWindow", nrows: int, dst: dict, dst_row0: int = 0, order=None,
+                         stream: torch.cuda.Stream | None = None) -> None:
         """The first ``nrows`` rows of the output window, [row][slot], into point-major tensors
         ``dst[name][npoints, dst_rows]`` at columns ``dst_row0 ...`` (rs_hip_outputs_by_point); ``order``: a kept
         order row, default the plan's current order (call between the launch and the next re-sort)."""
@@ -291,7 +292,9 @@ class Plan:
         ptrs = (C.c_void_p * 6)(*[dst[n].data_ptr() for n in OUT_FIELDS])
         lib.check(self.L.rs_hip_outputs_by_point(self._h, C.byref(o), int(nrows),
                                                  C.c_void_p(order.data_ptr()) if order is not None else None,
-                                                 ptrs, C.c_int64(rows), C.c_int64(dst_row0)), "rs_hip_outputs_by_point")
+                                                 ptrs, C.c_int64(rows), C.c_int64(dst_row0),
+                                                 C.c_void_p(stream.cuda_stream) if stream is not None else None),
+                  "rs_hip_outputs_by_point")
 
     def reset_order(self) -> None:
         lib.check(self.L.rs_hip_plan_reset_order(self._h), "rs_hip_plan_reset_order")

@@ -189,7 +189,7 @@ def load() -> C.CDLL:
     L.rs_hip_coupling_windows_closed.argtypes = [C.c_void_p, C.c_int32]
     L.rs_hip_set_writeback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.rs_hip_plan_order_copy.argtypes = [C.c_void_p, C.c_void_p]
-    L.rs_hip_outputs_by_point.argtypes = [C.c_void_p, P(RsOutputs), C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
+    L.rs_hip_outputs_by_point.argtypes = [C.c_void_p, P(RsOutputs), C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     L.rs_hip_plan_reset_order.argtypes = [C.c_void_p]
     L.rs_hip_set_variant.argtypes = [C.c_void_p, C.c_int32]
     L.rs_hip_set_precision.argtypes = [C.c_void_p, C.c_int32]

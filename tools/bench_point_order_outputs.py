@@ -26,23 +26,43 @@ for j in range(K):
     runs.append(workload.SyntheticRun(pl, 20240110, hours, chunk, point_offset=off, plan_order=True, forecast=True,
                                       forecast_mode=workload.DEFAULT_FORECAST_MODE))
 dst = [{k: torch.empty((r.plan.np_pad, chunk), dtype=torch.float64, device=dev) for k in device.OUT_FIELDS} for r in runs]
+# second mode: the transposition on a stream of its own, two output windows in turn - it runs beside the next launch
+side = [torch.cuda.Stream(dev) for _ in runs]
+wins = [[r.out, device.OutputWindow.empty(chunk, r.plan.np_pad, dev)] for r in runs]
+done = [[None, None] for _ in runs]
 
 
-def gather(j):
+def gather(j, overlapped):
     r = runs[j]
-    def on_launch(c, t0, ns):  # between the launch and its re-sort: the plan's current order is the launch's
-        r.plan.outputs_by_point(r.out, ns, dst[j])
+    def on_launch(c, t0, ns):
+        if not overlapped:  # between the launch and its re-sort: the plan's current order is the launch's
+            r.plan.outputs_by_point(r.out, ns, dst[j])
+            return
+        w = c & 1
+        ev = torch.cuda.Event()
+        ev.record(r.plan.stream)
+        side[j].wait_event(ev)                      # behind the launch that filled window w
+        r.plan.outputs_by_point(wins[j][w], ns, dst[j], order=r.orders[c], stream=side[j])
+        done[j][w] = torch.cuda.Event()
+        done[j][w].record(side[j])
+        r.out = wins[j][w ^ 1]                      # the next launch writes the other window ...
+        if done[j][w ^ 1] is not None:
+            r.plan.stream.wait_event(done[j][w ^ 1])  # ... once its last reader is through
     return on_launch
 
 
-def one_pass(point_order):
-    its = [r.iter_pass(gather(j) if point_order else None) for j, r in enumerate(runs)]
+def one_pass(mode):
+    for j, r in enumerate(runs):
+        r.out = wins[j][0]
+        done[j][0] = done[j][1] = None
+    its = [r.iter_pass(gather(j, mode == 2) if mode else None) for j, r in enumerate(runs)]
     while its:
         its = [it for it in its if next(it, None) is not None]
 
 
 res = {}
-for tag, po in (("slot order + order rows (bench.py)", False), ("point-major arrays in point order (rs_hip_outputs_by_point)", True), ("slot order + order rows (bench.py)", False), ("point-major arrays in point order (rs_hip_outputs_by_point)", True)):
+for tag, po in (("slot order + order rows (bench.py)", 0), ("per-point series behind every launch (rs_hip_outputs_by_point)", 1),
+                ("per-point series, on a second stream with two output windows in turn", 2)) * 2:
     one_pass(po)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -51,10 +71,11 @@ for tag, po in (("slot order + order rows (bench.py)", False), ("point-major arr
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / passes
     print(f"{tag}: {dt * 1e3:.1f} ms per pass -> {n * simlen / dt:.3e} point-timesteps/s", flush=True)
-# the point-major rows are the slot rows, permuted and transposed
+# the point-major rows are the slot rows, permuted and transposed (last launch of plan 0, last mode)
 r = runs[0]
 c = len(r.starts) - 1
 order = r.orders[c][:r.plan.npoints].long()
 ns = min(chunk, simlen - r.starts[c] + 1)
-ok = all(torch.equal(dst[0][k][order, :ns].T.contiguous(), r.out.tensors[k][:ns, :r.plan.npoints].contiguous()) for k in device.OUT_FIELDS)
+src = wins[0][c & 1]
+ok = all(torch.equal(dst[0][k][order, :ns].T.contiguous(), src.tensors[k][:ns, :r.plan.npoints].contiguous()) for k in device.OUT_FIELDS)
 print("last launch of plan 0: dst[order[slot], row] == src[row, slot]:", ok)
