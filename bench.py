@@ -32,7 +32,9 @@ sharded over the GPUs); `--points N` gives every GPU N points (weak scaling).
 The default run (N = 1) adds short extra legs under the same clock, reported as extra keys of the
 one JSON line: `full_feature_value` (the FULL feature set on the same points) and
 `driver_path_{relax,coupling,sky}_value` (rs_driver_run from raw series in host arrays, PCIe
-inclusive); `--no-extra-legs` skips them.
+inclusive), `driver_path_relax_holes_value` (the same on observation series with missing sensors,
+gaps and early ends), `host_batch_value` (runsimulation_batch from step-resolution host arrays);
+`--no-extra-legs` skips them.
 
 Prints ONE JSON line on rank 0.
 """
@@ -519,13 +521,30 @@ def main() -> None:
                            "series": "distinct for every point (generated once, before the timed calls)",
                            "value_is": "mean of the timed calls",
                            "pcie_inclusive": True, "raw_input_bytes": dw.raw_bytes(mode),
-                           "forcing_window": "with coupling only" if mode == "coupling" else
-                                             "none: the step kernel's ground wavefront interpolates and overlays the "
-                                             "raw series itself (rs_step_raw)",
+                           "forcing_window": "none: the step kernel's ground wavefront interpolates and overlays the "
+                                             "raw series itself (rs_step_raw), coupling's replay rounds included",
                            "blocks_per_device": int(os.environ.get("ROADSURF_HIP_PLANS_PER_DEVICE", "4"))},
             }
             del r
         del dw
+        # ... and the same call on observation series as real networks have them (round 5): 10 % of the stations
+        # without an air-temperature / humidity / wind sensor each, 10 % of the road-temperature observations
+        # missing, 20 % of the series ending one to three hours early - the lanes of a wavefront then disagree on
+        # the source that supplies a variable
+        dw = driver_workload.DriverWorkload(args.extra_points, args.hours, unique=None, missing=0.1, ragged=0.2)
+        best, times, r = dw.time_calls("relax", reps=3, warm=1, device=-1)
+        mean = sum(times) / len(times)
+        extra["driver_path_relax_holes"] = {
+            "value": dw.n * dw.simlen / mean, "unit": "point-timesteps/s", "seconds_per_call": mean,
+            "seconds_per_call_all": times, "best_call_value": dw.n * dw.simlen / best,
+            "calls_timed": len(times), "calls_warm": 1, "points_ok": int((r["status"] == 0).sum()),
+            "config": {"workload": f"rs_driver_run as driver_path_relax, {dw.n} points x {args.hours} h, on observation "
+                                   "series with holes: 10 % of the stations without an air-temperature / humidity / "
+                                   "wind sensor each, 10 % of the road-temperature observations missing, 20 % of the "
+                                   "series ending 1-3 h early",
+                       "series": "distinct for every point", "value_is": "mean of the timed calls", "pcie_inclusive": True},
+        }
+        del r, dw
         # (3) the drop-in batch entry from STEP-RESOLUTION host arrays (runsimulation_batch: 11 f64 + 2 i32 in,
         # 6 f64 out per point and index over the boundary): PCIe-bound by construction
         extra["host_batch"] = host_batch_leg(args.host_batch_points, simlen, args.seed)
