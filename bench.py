@@ -76,15 +76,15 @@ def cpu_baseline(sample_points: int, simlen: int, seed: int):
     """Reference Fortran (oracle/_ref, kind 'reference') or, if absent, the C port,
     OpenMP over points on this box's host cores, on a bounded sample of the workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_helpers as oh
-    from roadsurf_amd import abi
+    import oracle_helpers as oh  # the checker: timed here as the CPU baseline, nothing else of it is used
+    from roadsurf_amd import abi, synth
 
     kind = "ref" if os.path.exists(oh.REF_SO) else "port"
     s = abi.default_settings(simlen)
     p = abi.default_parameters()
     l = abi.default_local()
     l.InitLenI = 1
-    f = oh.synth_forcing(sample_points, simlen, seed=seed)
+    f = synth.synth_forcing(sample_points, simlen, seed=seed)
     oh.run_oracle(kind, {k: (v[:64] if v.ndim == 2 else v) for k, v in f.items()}, s, p, l,
                   nthreads=effective_cpus())  # warm
     t = time.perf_counter()
@@ -125,13 +125,11 @@ def host_batch_leg(n: int, simlen: int, seed: int) -> dict:
     import ctypes as C
     import numpy as np
 
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_helpers as oh
-    from roadsurf_amd import abi, lib as rslib
+    from roadsurf_amd import abi, lib as rslib, synth
 
     L = rslib.load()
-    f = oh.synth_forcing(n, simlen, seed=seed)
-    out = {k: np.empty((n, simlen)) for k in oh.F64_OUT}
+    f = synth.synth_forcing(n, simlen, seed=seed)  # the product's own host generator (rs_synth_fill_points)
+    out = {k: np.empty((n, simlen)) for k in synth.F64_OUT}
     s = abi.default_settings(simlen)
     p = abi.default_parameters()
     l = abi.default_local()
@@ -140,7 +138,7 @@ def host_batch_leg(n: int, simlen: int, seed: int) -> dict:
     ops = (abi.OutputPointers * n)()
     keep = []
     for pt in range(n):
-        ips[pt], ops[pt], kp = oh.point_pointers(f, pt, out)
+        ips[pt], ops[pt], kp = synth.point_pointers(f, pt, out)
         keep.append(kp)
     larr = (abi.LocalParameters * n)(*([l] * n))
     st = C.c_int32(0)

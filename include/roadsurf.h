@@ -154,6 +154,11 @@ int32_t rs_coalesce_run(OutputPointers *outPointers, const InputPointers *inPoin
                         const InputSettings *inSettings, const InputParameters *inputParam,
                         const LocalParameters *localParam);
 void rs_coalesce_stats(int64_t *batches, int64_t *points);
+/* What rs_coalesce_run hands its gathered points to: runsimulation_batch with the reference's in-place input
+ * edits written back by default (below).  Exported for that caller only. */
+void rs_runsimulation_gathered(int32_t n, OutputPointers *outPointers, const InputPointers *inPointers,
+                               const InputSettings *inSettings, const InputParameters *inputParam,
+                               const LocalParameters *localParam, int32_t *status);
 
 /* Extension: n independent points with shared settings/parameters, one
  * OutputPointers/InputPointers/LocalParameters per point (exactly what the
@@ -167,10 +172,14 @@ void runsimulation_batch(int32_t n, OutputPointers *outPointers,
 /* Same, plus what the reference only prints: first_failed[n] (or NULL) receives per point 0, or the
  * 1-based time index at which CheckValues failed it ("BAD input value!" / "Abnormal surface
  * temperature", src/InputOutput.f90:63-65,80-81); outputs after that index read -9999.0.
- * Environment ROADSURF_HIP_WRITEBACK=1 makes both entries (and runsimulation) write the
- * reference's in-place edits of the INPUT arrays back to the caller: the SW_dir clamp of
- * CheckValues and, with sky view, SW / SW_dir / LW as ModRadiationBySurroundings leaves them
- * (the VZ(1) >= 0.4 edit of src/Initialization.f90:121-123 is always written). */
+ * In-place edits of the INPUT arrays (Ownership): the reference clamps SW_dir to SW at
+ * every checked index (src/InputOutput.f90:75-77) and, with sky view, rewrites SW / SW_dir / LW
+ * (src/ModRadiation.f90:57-71) in the CALLER's arrays.  Who writes them back:
+ *   runsimulation                      by default (it is the reference's entry and leaves the caller's
+ *                                      arrays as the reference does); ROADSURF_HIP_WRITEBACK=0 opts out
+ *   runsimulation_batch / _batch_ex    only with ROADSURF_HIP_WRITEBACK=1: three more arrays per point
+ *                                      back over PCIe, which a batch caller rarely reads
+ * The VZ(1) >= 0.4 edit of src/Initialization.f90:121-123 is always written, by every entry. */
 void runsimulation_batch_ex(int32_t n, OutputPointers *outPointers,
                             const InputPointers *inPointers,
                             const InputSettings *inSettings,
@@ -437,6 +446,17 @@ typedef struct RsSynthSpec {
 
 /* Number of doubles per point and knot in a knot buffer. */
 #define RS_KNOT_FIELDS 9
+/* The same generator on the host, in the layout the reference driver hands runsimulation: per-point
+ * [n][simlen] series (InputPointers' eleven f64 arrays + PrecPhase) and the hour of every index (the shared
+ * calendar; examples/example1/src/InputData.cpp:5-26).  Host code, no device call: bench.py's host-array leg,
+ * __graft_entry__.smoke() and the parity tests take their inputs from it, so that the CPU checker and the GPU
+ * path see bit-identical forcing (csrc/rs_synth_host.hip). */
+void rs_synth_fill_points(uint64_t seed, int64_t point_offset, int32_t n, int32_t simlen,
+                          int32_t steps_per_knot, int32_t start_hour, double *tair, double *tdew,
+                          double *vz, double *rhz, double *prec, double *sw, double *lw,
+                          double *sw_dir, double *lw_net, double *tsurfobs, double *depth,
+                          int32_t *precphase, int32_t *hour);
+
 /* Generate hourly knots k0..k0+nknots-1 into `knots` (device,
  * [nknots][RS_KNOT_FIELDS][npoints_padded] doubles; npoints_padded from
  * rs_hip_plan_npoints_padded). */
@@ -784,6 +804,9 @@ int rs_compat_outputs(const RsCompat *ctx, int32_t i, double *out6);
 int32_t rs_compat_failed_index(const RsCompat *ctx);
 void rs_compat_end(RsCompat *ctx);
 
+/* Hash of the sources this library was built from (16 hex digits; roadsurf_amd/provenance.py build_sha16()):
+ * tests/conftest.py rebuilds a prebuilt library whose stamp is not the hash of the sources beside it. */
+const char *rs_build_sha16(void);
 #define RS_ABI_VERSION 10 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles; 4: RsPointParams::horizon_index, rs_hip_step_knots; 5: RS_SUN_COLS 6, RsPointParams::horizons_by_point; 6: rs_driver_last_raw_launches (rs_driver_run without forcing windows); 7: rs_compat_* (module RoadSurf's per-step procedures); 8: RsPreview::prec; 9: RsPreview::tair_b / vz_b / w; 10: rs_hip_outputs_by_point */
 int rs_abi_version(void);
 /* sizeof of the boundary structs as the C side / the Fortran side see them

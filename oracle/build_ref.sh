@@ -103,6 +103,8 @@ if [ -f "$PROD/build/roadsurf.mod" ] && [ -f "$PROD/lib/libroadsurf_hip.so" ]; t
   $FC -shared -o "$OUT/libsimulation_over_hip.so" "$TMP/over/Simulation.o" -L"$PROD/lib" -lroadsurf_hip \
       -Wl,-rpath,'$ORIGIN/../../roadsurf_amd/lib'
   echo "built $OUT/libsimulation_over_hip.so"
+  # which product sources its module files came from (tests/conftest.py rebuilds when they have moved on)
+  python3 "$PROD/provenance.py" --build > "$OUT/over_hip.stamp"
 fi
 
 # ---- the driver's one self-contained C++ file -----------------------------------------

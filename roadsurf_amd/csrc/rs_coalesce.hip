@@ -30,9 +30,12 @@
 
 #include "../../include/roadsurf.h"
 
-extern "C" void runsimulation_batch(int32_t n, OutputPointers *out, const InputPointers *in,
-                                    const InputSettings *settings, const InputParameters *params,
-                                    const LocalParameters *local, int32_t *status);
+/* runsimulation_batch for the points of `runsimulation` callers (RoadSurfHip.f90): as that entry is the
+ * reference's own, the reference's in-place edits of the input arrays are written back by default
+ * (src/InputOutput.f90:75-77, src/ModRadiation.f90:57-71; ROADSURF_HIP_WRITEBACK=0 opts out) */
+extern "C" void rs_runsimulation_gathered(int32_t n, OutputPointers *out, const InputPointers *in,
+                                          const InputSettings *settings, const InputParameters *params,
+                                          const LocalParameters *local, int32_t *status);
 
 namespace {
 
@@ -102,7 +105,7 @@ struct Runner {
       cv.wait(lk, [&] { return has_job; });
       lk.unlock();
       int32_t st = 0;
-      runsimulation_batch(n, o, i, s, p, l, &st);
+      rs_runsimulation_gathered(n, o, i, s, p, l, &st);
       lk.lock();
       status = st;
       has_job = false;
@@ -152,7 +155,7 @@ int32_t rs_coalesce_run(OutputPointers *out, const InputPointers *in, const Inpu
   int w = window_us();
   if (w == 0) {
     int32_t st = 0;
-    runsimulation_batch(1, out, in, settings, params, local, &st);
+    rs_runsimulation_gathered(1, out, in, settings, params, local, &st);
     return st;
   }
   Request me;
@@ -173,7 +176,7 @@ int32_t rs_coalesce_run(OutputPointers *out, const InputPointers *in, const Inpu
       lk.unlock();
       const auto t0 = std::chrono::steady_clock::now();
       int32_t st = 0;
-      runsimulation_batch(1, out, in, settings, params, local, &st);
+      rs_runsimulation_gathered(1, out, in, settings, params, local, &st);
       const long us = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
       lk.lock();
       g_last_batch_us = us;
@@ -235,7 +238,7 @@ int32_t rs_coalesce_run(OutputPointers *out, const InputPointers *in, const Inpu
       int32_t st = 0;
       const auto tb0 = std::chrono::steady_clock::now();
       if (n > 1) st = runner().run(n, o.data(), i.data(), me.settings, me.params, l.data());
-      else runsimulation_batch(n, o.data(), i.data(), me.settings, me.params, l.data(), &st);
+      else rs_runsimulation_gathered(n, o.data(), i.data(), me.settings, me.params, l.data(), &st);
       const long batch_us = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tb0).count();
       /* a batch-level error is some ONE caller's (an array shorter than SimLen, ...): the header promises
        * every caller the bits and the status of a call of its own, so the members run again one by one */
@@ -243,7 +246,7 @@ int32_t rs_coalesce_run(OutputPointers *out, const InputPointers *in, const Inpu
       if (st != 0 && n > 1)
         for (int32_t k = 0; k < n; ++k) {
           each[k] = 0;
-          runsimulation_batch(1, &o[k], &i[k], me.settings, me.params, &l[k], &each[k]);
+          rs_runsimulation_gathered(1, &o[k], &i[k], me.settings, me.params, &l[k], &each[k]);
         }
       lk.lock();
       g_inflight -= 1;

@@ -453,7 +453,7 @@ module RoadSurfHipEntry
       end function rs_coalesce_run
    end interface
 
-   public :: runsimulation, runsimulation_batch, runsimulation_batch_ex
+   public :: runsimulation, runsimulation_batch, runsimulation_batch_ex, rs_runsimulation_gathered
 
 contains
 
@@ -506,8 +506,11 @@ contains
    end function same_axis
 
    !> Same; first_failed (int32[n] or NULL) receives per point 0 or the 1-based time index at which
-   !! CheckValues failed it.  ROADSURF_HIP_WRITEBACK=1: the reference's in-place edits of the input
-   !! arrays (SW_dir clamp, sky-view SW/SW_dir/LW) are written back to the caller.
+   !! CheckValues failed it.  The reference's in-place edits of the input arrays beyond VZ(1) (SW_dir
+   !! clamp, src/InputOutput.f90:75-77; sky-view SW/SW_dir/LW, src/ModRadiation.f90:57-71) are written
+   !! back to the caller with ROADSURF_HIP_WRITEBACK=1 only: for a batch they are three more arrays per
+   !! point over PCIe that a batch caller rarely reads.  (The one-point entry `runsimulation` writes them
+   !! back by default, as the reference does.)
    subroutine runsimulation_batch_ex(n, outPointers, inPointers, inSettings, inputParam, localParam, status, &
                                      first_failed_arg) bind(C, name='runsimulation_batch_ex')
       integer(c_int), value :: n
@@ -518,6 +521,39 @@ contains
       type(LocalParameters), intent(in) :: localParam(n)
       integer(c_int), intent(out) :: status
       type(c_ptr), value :: first_failed_arg
+      call rs_batch_core(n, outPointers, inPointers, inSettings, inputParam, localParam, status, &
+                         first_failed_arg, 0_c_int)
+   end subroutine runsimulation_batch_ex
+
+   !> The points that concurrent callers of the one-point entry `runsimulation` brought (rs_coalesce.hip):
+   !! a batch like any other, except that the reference's in-place input edits are written back by
+   !! default - `runsimulation` is the reference's own entry and leaves the caller's arrays as the
+   !! reference does (ROADSURF_HIP_WRITEBACK=0 opts out).
+   subroutine rs_runsimulation_gathered(n, outPointers, inPointers, inSettings, inputParam, localParam, status) &
+      bind(C, name='rs_runsimulation_gathered')
+      integer(c_int), value :: n
+      type(OutputPointers), intent(inout) :: outPointers(n)
+      type(InputPointers), intent(in) :: inPointers(n)
+      type(InputSettings), intent(in) :: inSettings
+      type(InputParameters), intent(in) :: inputParam
+      type(LocalParameters), intent(in) :: localParam(n)
+      integer(c_int), intent(out) :: status
+      call rs_batch_core(n, outPointers, inPointers, inSettings, inputParam, localParam, status, &
+                         c_null_ptr, 1_c_int)
+   end subroutine rs_runsimulation_gathered
+
+   !> wb_default: whether the in-place input edits are written back when ROADSURF_HIP_WRITEBACK is unset.
+   subroutine rs_batch_core(n, outPointers, inPointers, inSettings, inputParam, localParam, status, &
+                            first_failed_arg, wb_default)
+      integer(c_int), value :: n
+      type(OutputPointers), intent(inout) :: outPointers(n)
+      type(InputPointers), intent(in) :: inPointers(n)
+      type(InputSettings), intent(in) :: inSettings
+      type(InputParameters), intent(in) :: inputParam
+      type(LocalParameters), intent(in) :: localParam(n)
+      integer(c_int), intent(out) :: status
+      type(c_ptr), value :: first_failed_arg
+      integer(c_int), value :: wb_default
       type(c_ptr) :: first_failed
       integer(c_int), allocatable, target :: ffdiag(:)
       logical :: diag
@@ -584,10 +620,10 @@ contains
       extras%sun = c_null_ptr; extras%sin_lat = c_null_ptr; extras%cos_lat = c_null_ptr
       extras%lon_rad = c_null_ptr; extras%albedo_surroundings = inputParam%Albedo_surroundings
       extras%first_failed = first_failed
-      extras%writeback = 0
+      extras%writeback = wb_default
       call get_environment_variable('ROADSURF_HIP_WRITEBACK', envv, envl, envs)
       if (envs == 0 .and. envl >= 1) then
-         if (envv(1:1) /= '0') extras%writeback = 1
+         extras%writeback = merge(0_c_int, 1_c_int, envv(1:1) == '0')
       end if
       if (any_sky) then
          ! The solar quantities that depend on time only (src/SunPosition.f90:196-260 and :70-125)
@@ -658,7 +694,7 @@ contains
       end if
       deallocate (tbottom)
       if (diag .and. status == 0) call print_diagnostics(n, outPointers, inPointers, localParam, first_failed)
-   end subroutine runsimulation_batch_ex
+   end subroutine rs_batch_core
 
    !> The reference's diagnostics for the points CheckValues failed (src/InputOutput.f90:55-82): the
    !! same three messages on standard output, from the caller's arrays at the failing index.  The

@@ -93,7 +93,7 @@ class RsSynthSpec(C.Structure):
 #: every symbol ``include/roadsurf.h`` declares
 EXPORTS = (
     "rs_default_parameters", "rs_default_settings", "rs_default_local",
-    "runsimulation", "runsimulation_batch", "runsimulation_batch_ex", "rs_coalesce_run", "rs_coalesce_stats", "rs_build_constants", "rs_bottom_temperature",
+    "runsimulation", "runsimulation_batch", "runsimulation_batch_ex", "rs_coalesce_run", "rs_coalesce_stats", "rs_runsimulation_gathered", "rs_synth_fill_points", "rs_build_sha16", "rs_build_constants", "rs_bottom_temperature",
     "rs_sun_table", "rs_point_geometry",
     "rs_last_error", "rs_hip_device_count", "rs_hip_plan_create", "rs_hip_plan_destroy",
     "rs_hip_plan_npoints", "rs_hip_plan_npoints_padded", "rs_hip_plan_state_bytes",

@@ -14,20 +14,42 @@ def pytest_configure(config):
 
 
 def _ensure_built():
-    """Build the in-tree libraries when they are missing (fresh checkout): the product library
-    cross-compiles without a GPU; on the GPU box the prebuilt .so files travel with the snapshot."""
+    """Build the in-tree libraries when they are missing OR STALE: every product library carries the hash of
+    the sources it was built from (roadsurf_amd/Makefile, provenance.build_sha16()); one whose stamp is not the
+    hash of the sources beside it is rebuilt before any test maps it (round 5 ran a suite against a
+    libroadsurf_hip_divcheck.so older than csrc/).  The product library cross-compiles without a GPU; on the GPU
+    box the prebuilt .so files travel with the snapshot together with their sources, so the stamps match and
+    nothing is rebuilt there."""
     import subprocess
-    lib_so = os.path.join(ROOT, "roadsurf_amd", "lib", "libroadsurf_hip.so")
-    if not os.path.exists(lib_so):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "roadsurf_amd")], stdout=subprocess.DEVNULL)
-    chk = os.path.join(ROOT, "roadsurf_amd", "lib", "libroadsurf_hip_divcheck.so")
-    if not os.path.exists(chk):
-        subprocess.call(["make", "-C", os.path.join(ROOT, "roadsurf_amd"), "divcheck"], stdout=subprocess.DEVNULL)
+    from roadsurf_amd import provenance
+    amd = os.path.join(ROOT, "roadsurf_amd")
+    want = provenance.build_sha16()
+    rebuilt = False
+    for so, target in (("libroadsurf_hip.so", []), ("libroadsurf_hip_divcheck.so", ["divcheck"])):
+        path = os.path.join(amd, "lib", so)
+        if provenance.stamp_of(path) == want:
+            continue
+        subprocess.check_call(["make", "-C", amd, "-j4"] + target, stdout=subprocess.DEVNULL)
+        if provenance.stamp_of(path) != want:  # (make saw nothing to do: time stamps that lie) - from scratch
+            subprocess.check_call(["make", "-C", amd, "-j4", "-B"] + target, stdout=subprocess.DEVNULL)
+        if provenance.stamp_of(path) != want:
+            raise RuntimeError(f"{so}: build stamp {provenance.stamp_of(path)} != sources {want} after a rebuild")
+        rebuilt = True
     if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"], stdout=subprocess.DEVNULL)
-    if os.path.isdir("/root/reference/src") and not os.path.exists(
-            os.path.join(ROOT, "oracle", "_ref", "libroadrunner_tools_ref.so")):
-        subprocess.check_call(["bash", os.path.join(ROOT, "oracle", "build_ref.sh")], stdout=subprocess.DEVNULL)
+    else:  # the checker's own sources are three C files: let make compare the time stamps
+        subprocess.call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"], stdout=subprocess.DEVNULL,
+                        stderr=subprocess.DEVNULL)
+    # oracle/_ref: the reference's libraries, and the reference's Simulation.f90 over THIS library's module
+    # surface (libsimulation_over_hip.so: stale when the product's modules have changed since - build_ref.sh
+    # leaves the product's stamp beside it).  Only where the reference's sources exist.
+    if os.path.isdir("/root/reference/src"):
+        ref_dir = os.path.join(ROOT, "oracle", "_ref")
+        over_stamp = os.path.join(ref_dir, "over_hip.stamp")
+        have = open(over_stamp).read().strip() if os.path.exists(over_stamp) else None
+        if (rebuilt or have != want or not os.path.exists(os.path.join(ref_dir, "libroadrunner_tools_ref.so"))
+                or not os.path.exists(os.path.join(ref_dir, "libsimulation_over_hip.so"))):
+            subprocess.check_call(["bash", os.path.join(ROOT, "oracle", "build_ref.sh")], stdout=subprocess.DEVNULL)
 
 
 def pytest_sessionstart(session):

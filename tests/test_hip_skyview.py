@@ -204,6 +204,51 @@ def test_writeback_of_the_sw_dir_clamp_without_sky_view(monkeypatch):
     assert np.array_equal(ff, first_missing.astype(np.int32))
 
 
+def test_writeback_is_the_default_of_the_one_point_entry(monkeypatch):
+    """`runsimulation` is the reference's own entry: with NO environment variable set it leaves the caller's
+    input arrays as the reference's run leaves them - the SW_dir clamp (src/InputOutput.f90:75-77), the sky
+    view's SW / SW_dir / LW (src/ModRadiation.f90:57-71), VZ(1) - for a point with sky view, one without, and
+    one that fails half way (its arrays stay as they were from there on).  ROADSURF_HIP_WRITEBACK=0 opts out;
+    the batch entries keep them out unless asked (test_writeback_of_the_in_place_input_edits)."""
+    L_ = lib.load()
+    n, SL = 6, 1441
+    f, ls = _sky_case(n, SL, 33, summer=True)
+    ls[0].sky_view = 0.5
+    ls[1].sky_view = 1.0                # no sky view: only the SW_dir clamp
+    ls[2].sky_view = 0.75
+    f["tair"][2, 500] = -200.0          # fails at index 501
+    f["vz"][3, 0] = 0.1
+    s = abi.default_settings(SL); p = abi.default_parameters()
+    ora, fmut, _ = oh.run_oracle("ref" if oh.have_ref() else "port", f, s, p, ls)
+    assert (fmut["sw"] != f["sw"]).any() and (fmut["sw_dir"] != f["sw_dir"]).any() and (fmut["lw"] != f["lw"]).any()
+
+    def run():
+        g = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in f.items()}
+        out = {k: np.full((n, SL), np.nan) for k in oh.F64_OUT}
+        for pt in range(n):
+            ip, op, kp = oh.point_pointers(g, pt, out)
+            hzrow = np.ascontiguousarray(g["local_horizons"][pt])
+            ip.c_local_horizons = hzrow.ctypes.data_as(abi.c_double_p)
+            L_.runsimulation(C.byref(op), C.byref(ip), C.byref(s), C.byref(p), C.byref(ls[pt]))
+        return g, out
+
+    monkeypatch.delenv("ROADSURF_HIP_WRITEBACK", raising=False)
+    g, out = run()
+    for k in oh.F64_OUT:
+        assert np.array_equal(out[k], ora[k]), k
+    for k in ("sw", "sw_dir", "lw", "vz"):
+        assert np.array_equal(g[k], fmut[k]), (k, int((g[k] != fmut[k]).sum()))
+    for k in ("tair", "rhz", "prec", "lw_net", "tsurfobs"):
+        assert np.array_equal(g[k], f[k]), k
+    monkeypatch.setenv("ROADSURF_HIP_WRITEBACK", "0")
+    g, out = run()
+    for k in oh.F64_OUT:
+        assert np.array_equal(out[k], ora[k]), k
+    for k in ("sw", "sw_dir", "lw"):
+        assert np.array_equal(g[k], f[k]), k
+    assert np.array_equal(g["vz"], fmut["vz"])  # VZ(1): always
+
+
 def test_sky_view_with_two_time_axes_in_one_batch():
     """The reference takes the solar position from each point's OWN year(i)..second(i)
     (src/SunPosition.f90:196-260): a batch may mix points whose series start on different dates.
