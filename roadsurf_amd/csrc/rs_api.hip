@@ -118,6 +118,15 @@ static hipError_t plan_malloc(RsPlan *pl, T **p, size_t bytes) {
   return e;
 }
 
+uint64_t rs_a32_limit(void) {
+  /* (read per call: a test lowers it for one case) */
+  const char *e = getenv("ROADSURF_HIP_A32_LIMIT");
+  const uint64_t hard = 1ull << 29;
+  if (!e) return hard;
+  const unsigned long long v = strtoull(e, nullptr, 10);
+  return (v >= 1024 && v < hard) ? (uint64_t)v : hard;
+}
+
 extern "C" {
 
 const char *rs_last_error(void) { return g_err; }
@@ -711,9 +720,9 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
     /* bit 2: a sky-view launch the two-wavefront flavour can take (rs_launch_step_sky): no output depth, and
      * every stream of the windows within 32-bit offsets */
     const int64_t orows = ((int64_t)t0 + nsteps - 2) / o->decimate - o->row0 + 1;
-    const bool a32 = (uint64_t)f->t_stride * (uint64_t)nsteps < (1ull << 29) &&
-                     (uint64_t)o->t_stride * (uint64_t)(orows > 0 ? orows : 1) < (1ull << 29) &&
-                     (!pl->wb.sw_dir || (uint64_t)pl->wb.t_stride * (uint64_t)nsteps < (1ull << 29));
+    const bool a32 = (uint64_t)f->t_stride * (uint64_t)nsteps < rs_a32_limit() &&
+                     (uint64_t)o->t_stride * (uint64_t)(orows > 0 ? orows : 1) < rs_a32_limit() &&
+                     (!pl->wb.sw_dir || (uint64_t)pl->wb.t_stride * (uint64_t)nsteps < rs_a32_limit());
     if (skyview && !coupled && !f->depth && !(pl->c.tsurfOutputDepth >= 0.0) && a32) a.duo_full_ok |= 4;
   }
   a.surface_prio = underfilled(pl);
@@ -740,7 +749,7 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
   }
   hipError_t le;
   if (pl->f32)
-    le = rs32_launch_step(a, pl->c.NLayers, pl->variant, pl->stream);
+    le = rs32_launch_step(a, pl->c.NLayers, pl->variant, pl->history_score, pl->stream);
   else if (skyview && !coupled)
     le = rs_launch_step_sky(a, pl->c.NLayers, pl->history_score, pl->stream); /* lock-step FULL + sky view */
   else if (coupled) {
@@ -798,10 +807,10 @@ int rs_hip_step_knots(RsPlan *pl, const RsSynthSpec *spec, const double *knots, 
     if (first < o->row0) return set_err("rs_hip_step_knots: output row0 beyond first row");
   }
   const int64_t out_rows = ((int64_t)t0 + nsteps - 2) / o->decimate - o->row0 + 1;
-  if (pl->f32 || pl->c.NLayers != 15 || pl->c.tsurfOutputDepth >= 0.0 || pp->sky_view ||
+  if (pl->c.NLayers != 15 || pl->c.tsurfOutputDepth >= 0.0 || pp->sky_view ||
       (pl->c.use_coupling && pp->coupling_index) ||
-      (uint64_t)o->t_stride * (uint64_t)(out_rows > 0 ? out_rows : 1) >= (1ull << 29))
-    return set_err("rs_hip_step_knots: NLayers = 15, fp64, no output depth, sky view or coupling and an output "
+      (!pl->f32 && (uint64_t)o->t_stride * (uint64_t)(out_rows > 0 ? out_rows : 1) >= rs_a32_limit()))
+    return set_err("rs_hip_step_knots: NLayers = 15, no output depth, sky view or coupling and (fp64) an output "
                    "window below 4 GiB per stream only - use rs_hip_expand_forcing_ordered + rs_hip_step");
   /* the FULL feature set as far as the knots carry it: the dew point (CheckValues' test), the observation
    * of index 1, an initialization phase, relaxation - what rs_hip_step calls `full` for a window with the
@@ -809,12 +818,15 @@ int rs_hip_step_knots(RsPlan *pl, const RsSynthSpec *spec, const double *knots, 
   const bool full = (pp->initlen != nullptr) || pl->c.force_tsurf || (pl->c.use_relaxation && pp->tair_relax != nullptr);
   if (pl->c.use_relaxation && pp->tair_relax && (!pp->vz_relax || !pp->rh_relax || !pp->initlen))
     return set_err("rs_hip_step_knots: relaxation needs tair_relax, vz_relax, rh_relax and initlen");
+  if (pl->f32 && full)
+    return set_err("rs_hip_step_knots: the fp32 flavour supports the LEAN feature set only (no initialization "
+                   "phase, observation forcing or relaxation)");
   const int32_t *order = rs_hip_plan_order(pl);
   if (!order) return -1;
   HIP_OK(hipSetDevice(pl->device));
   rs::StepArgs a;
   std::memset(&a, 0, sizeof(a));
-  a.consts = pl->consts_dev;
+  a.consts = pl->f32 ? pl->consts32_dev : pl->consts_dev;
   a.f.t_stride = pl->np_pad; /* no window: nothing of `f` is read */
   a.o = *o;
   a.pp = *pp;
@@ -851,7 +863,9 @@ int rs_hip_step_knots(RsPlan *pl, const RsSynthSpec *spec, const double *knots, 
     e1 = pl->ev[pl->ev_used + 1];
     HIP_OK(hipEventRecord(e0, pl->stream));
   }
-  const hipError_t le = rs_launch_step_duo_knots(a, pl->history_score, pl->stream);
+  /* fp32: two points per lane, each lane interpolating its own forcing (rs_kernels_f32.hip) */
+  const hipError_t le = pl->f32 ? rs32_launch_step_knots(a, pl->history_score, pl->stream)
+                                : rs_launch_step_duo_knots(a, pl->history_score, pl->stream);
   if (le != hipSuccess) return set_err("rs_hip_step_knots: kernel launch failed: %s", hipGetErrorString(le));
   if (pl->timing) {
     HIP_OK(hipEventRecord(e1, pl->stream));
@@ -884,7 +898,7 @@ int rs_step_raw(RsPlan *pl, const rs::RawForcing *raw, const double *sun, const 
   const int64_t first = ((int64_t)t0 - 1 + o->decimate - 1) / o->decimate;
   if (first < o->row0) return set_err("rs_step_raw: output row0 beyond first row");
   const int64_t out_rows = ((int64_t)t0 + nsteps - 2) / o->decimate - o->row0 + 1;
-  if (!rs_step_raw_ok(pl) || (uint64_t)o->t_stride * (uint64_t)(out_rows > 0 ? out_rows : 1) >= (1ull << 29))
+  if (!rs_step_raw_ok(pl) || (uint64_t)o->t_stride * (uint64_t)(out_rows > 0 ? out_rows : 1) >= rs_a32_limit())
     return set_err("rs_step_raw: NLayers = 15, fp64, no output depth and an output window below 4 GiB per stream only");
   const bool coupled = pl->c.use_coupling != 0;
   if (coupled && (!pp->coupling_index || !pp->coupling_tsurf))
@@ -937,7 +951,7 @@ int rs_cpl_replay_raw(RsPlan *pl, const rs::RawForcing *raw, const RsOutputs *o,
   if (t0 < 1 || nsteps < 1 || (int64_t)t0 + nsteps - 1 >= pl->c.SimLen)
     return set_err("rs_cpl_replay_raw: the block [%d,%d] must lie inside [1, SimLen - 1]", t0, t0 + nsteps - 1);
   const int64_t out_rows = ((int64_t)t0 + nsteps - 2) / o->decimate - o->row0 + 1;
-  if ((uint64_t)o->t_stride * (uint64_t)(out_rows > 0 ? out_rows : 1) >= (1ull << 29))
+  if ((uint64_t)o->t_stride * (uint64_t)(out_rows > 0 ? out_rows : 1) >= rs_a32_limit())
     return set_err("rs_cpl_replay_raw: output window of 4 GiB per stream or more");
   if (raw->seg0 < 0 || raw->seg0 >= raw->nseg) return set_err("rs_cpl_replay_raw: seg0 outside the segment table");
   HIP_OK(hipSetDevice(pl->device));

@@ -21,6 +21,10 @@ struct RsConstantsF {
 #define X(n) float n;
   RS_CONST_SCALARS(X)
 #undef X
+  /* made ON THE DEVICE from the members above, by the expressions the lanes evaluate (prepare_constants_f32,
+   * rs_kernels_f32.hip): capDZ of a frozen layer and HS(1) of a frozen top layer (src/BalanceModel.f90:132-155,
+   * 215-241: the heat capacity of a layer below 0 C is a constant), 1 / twoDT */
+  float capDZF[RS_MAX_LAYERS + 2], hs1F, r_twoDT;
 };
 
 static inline void rs_constants_to_f32(const RsConstants &c, RsConstantsF &f) {
@@ -33,4 +37,7 @@ static inline void rs_constants_to_f32(const RsConstants &c, RsConstantsF &f) {
 #define X(n) f.n = (float)c.n;
   RS_CONST_SCALARS(X)
 #undef X
+  for (int i = 0; i < RS_MAX_LAYERS + 2; ++i) f.capDZF[i] = 0.f;
+  f.hs1F = 0.f;
+  f.r_twoDT = 0.f;
 }

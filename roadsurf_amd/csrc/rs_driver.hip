@@ -1399,7 +1399,15 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     Pdef = (int64_t)(64e9 / ((double)L * NFLD * sizeof(double)));
     Pdef = std::max<int64_t>(4096, std::min<int64_t>(262144, Pdef / 4096 * 4096));
   }
-  const int P = (int)std::min<int64_t>(pend - pbeg, ep ? std::max(1, atoi(ep)) : Pdef);
+  int64_t Pcap = INT64_MAX;
+  if (use_raw) {
+    /* the raw-series step kernels address a tile's whole output window (every decimated row of the series,
+     * padded stride) with 32-bit offsets: rs_step_raw / rs_cpl_replay_raw refuse a window of rs_a32_limit()
+     * elements per stream or more (e.g. 250 000 points x 48 h with outputStep = 1 min: 7.2e8), so the tile is
+     * cut to fit - whatever ROADSURF_HIP_TILE_POINTS asks for */
+    Pcap = std::max<int64_t>(RS_BLOCK, (int64_t)((rs_a32_limit() - 1) / (uint64_t)n_out) / RS_BLOCK * RS_BLOCK);
+  }
+  const int P = (int)std::min<int64_t>(std::min<int64_t>(pend - pbeg, Pcap), ep ? std::max(1, atoi(ep)) : Pdef);
   /* A block of a few wavefronts (the reference's operational example: 401 stations) is the latency of its
    * dependent steps whatever the order of its points: no re-sorts, and launches of eight hours (154 against 165 ms
    * per call of that example, profiles/r05_operational_shape.txt) */

@@ -140,6 +140,11 @@ struct RsPlan;
  * forcing of the block [t0, t0 + nsteps) from the raw series (no sky view; the block must end before SimLen) */
 int rs_cpl_replay_raw(RsPlan *pl, const rs::RawForcing *raw, const RsOutputs *o, const RsPointParams *pp,
                       int32_t t0, int32_t nsteps, bool out_by_point, int32_t *rounds);
+/* Elements per stream of a window that the kernels with 32-bit byte offsets can address (2^29 doubles = 4 GiB).
+ * The launchers that need it refuse larger windows; rs_driver_run cuts its point tiles so that a tile's output
+ * window stays below it.  ROADSURF_HIP_A32_LIMIT (elements) can only LOWER it: the tests reach the limit with
+ * windows of megabytes instead of gigabytes. */
+uint64_t rs_a32_limit(void);
 bool rs_step_raw_ok(const RsPlan *pl); /* a plan whose settings rs_step_raw can run */
 int rs_step_raw(RsPlan *pl, const rs::RawForcing *raw, const double *sun, const RsOutputs *o,
                 const RsPointParams *pp, int32_t t0, int32_t nsteps, bool out_by_point);
@@ -198,6 +203,7 @@ hipError_t rs_cluster_apply(const double *state_src, double *state_dst, bool f32
 /* single-precision mirror of the constants: fills *dst (device, rs32_constants_bytes() bytes) */
 size_t rs32_constants_bytes(void);
 hipError_t rs32_upload_constants(void *dst, const RsConstants *c, hipStream_t stream);
-hipError_t rs32_launch_step(const rs::StepArgs &a, int NL, int variant, hipStream_t stream);
+hipError_t rs32_launch_step(const rs::StepArgs &a, int NL, int variant, bool score, hipStream_t stream);
+hipError_t rs32_launch_step_knots(const rs::StepArgs &a, bool score, hipStream_t stream);
 hipError_t rs32_launch_init(const rs::InitArgs &a, hipStream_t stream);
 hipError_t rs32_launch_expand(const rs::ExpandArgs &a, int32_t nintervals, hipStream_t stream);

@@ -55,6 +55,10 @@ class SyntheticRun:
         # between two step launches of a plan, and a small shard has nothing to hide it behind.
         self.fused = bool(plan_order and not f32 and not (full and depth_stream) and getattr(plan, "variant", 0) == 3
                           and plan.consts.NLayers == 15)
+        # fp32 (round 6): the two-points-per-lane kernel reads the knots itself too, in either order (variants 1
+        # and 2 keep round 2-5's one point per lane with a forcing window, for A/B)
+        if f32 and not full and plan.consts.NLayers == 15 and getattr(plan, "variant", 0) % 10 not in (1, 2):
+            self.fused = True
         # sort key of the re-sort: forecast of the next window (rs_hip_recluster_forecast) or the
         # history of the last one (rs_hip_recluster)
         self.forecast, self.forecast_alpha, self.forecast_mode = forecast, forecast_alpha, forecast_mode

@@ -206,6 +206,32 @@ def test_tiling_does_not_change_results(monkeypatch):
     assert np.array_equal(a["status"], b["status"])
 
 
+@pytest.mark.parametrize("coupled", [False, True], ids=["relaxation", "coupling"])
+def test_tiles_are_cut_to_what_32_bit_offsets_address(coupled, monkeypatch):
+    """The raw-series step kernels address a tile's whole output window with 32-bit offsets and refuse a window of
+    2^29 elements per stream or more (250 000 points x 48 h with outputStep = 1 min would be 7.2e8): rs_driver_run
+    cuts its tiles to fit.  The limit lowered to megabytes (ROADSURF_HIP_A32_LIMIT), a block that fitted one tile
+    takes several, with the same bits; before round 6 the call failed with -13."""
+    n = 1500
+    src, L, t0, tf = dh.scenario(n, hours=6, seed=8, obs_hours=3)
+    s = _settings(L, outputStep=1, use_relaxation=1, use_coupling=1 if coupled else 0)
+    p = abi.default_parameters()
+    monkeypatch.setenv("ROADSURF_HIP_DEVICES", "0")  # one block: the tiles are what is counted
+    a = driver.run(src, s, p, t0, tf)
+    assert lib.load().rs_driver_last_raw_launches() > 0 and lib.load().rs_driver_last_tiles() == 1
+    n_out = a["tsurf"].shape[1]
+    assert n_out == (L + 1) // 2
+    monkeypatch.setenv("ROADSURF_HIP_A32_LIMIT", str(600 * n_out))  # tiles of 512 points at most
+    b = driver.run(src, s, p, t0, tf)
+    assert lib.load().rs_driver_last_tiles() == 3 and lib.load().rs_driver_last_raw_launches() > 0
+    for k in driver.OUT_FIELDS:
+        assert _same_bits(a[k], b[k]), k
+    assert np.array_equal(a["status"], b["status"])
+    o = dh.oracle_run(_kind(coupled), src, s, p, t0, tf)
+    for k in driver.OUT_FIELDS:
+        assert _same_bits(b[k], o[k]), k
+
+
 def test_argument_errors_are_reported():
     src, L, t0, tf = dh.scenario(4, hours=1, seed=1, obs_hours=1)
     with pytest.raises(ValueError, match="outputStep"):
