@@ -540,7 +540,8 @@ int rs_hip_set_history_score(RsPlan *pl, int32_t on) {
 }
 
 int rs_hip_set_variant(RsPlan *pl, int32_t variant) {
-  if (!pl || variant < 0 || variant % 10 > 4 || variant / 10 > 4)
+  /* (5: fp32 plans only - two points per lane in ONE wavefront, the A/B partner of the two-wavefront default) */
+  if (!pl || variant < 0 || variant % 10 > 5 || variant / 10 > 4 || (variant % 10 == 5 && variant != 5))
     return set_err("rs_hip_set_variant: bad arguments");
   if (variant % 10 == RS_VARIANT_REG && pl->c.NLayers != 15)
     return set_err("register-profile kernel is built for NLayers == 15 only (got %d)",
@@ -864,7 +865,7 @@ int rs_hip_step_knots(RsPlan *pl, const RsSynthSpec *spec, const double *knots, 
     HIP_OK(hipEventRecord(e0, pl->stream));
   }
   /* fp32: two points per lane, each lane interpolating its own forcing (rs_kernels_f32.hip) */
-  const hipError_t le = pl->f32 ? rs32_launch_step_knots(a, pl->history_score, pl->stream)
+  const hipError_t le = pl->f32 ? rs32_launch_step_knots(a, pl->variant, pl->history_score, pl->stream)
                                 : rs_launch_step_duo_knots(a, pl->history_score, pl->stream);
   if (le != hipSuccess) return set_err("rs_hip_step_knots: kernel launch failed: %s", hipGetErrorString(le));
   if (pl->timing) {

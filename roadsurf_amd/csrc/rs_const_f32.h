@@ -25,6 +25,9 @@ struct RsConstantsF {
    * rs_kernels_f32.hip): capDZ of a frozen layer and HS(1) of a frozen top layer (src/BalanceModel.f90:132-155,
    * 215-241: the heat capacity of a layer below 0 C is a constant), 1 / twoDT */
   float capDZF[RS_MAX_LAYERS + 2], hs1F, r_twoDT;
+  /* ... and per layer, side by side (one scalar load per layer): A = DyC WCont, B = DyC dryCap - capDZ =
+   * -1 / (A chwt + B) -, condDZ, capDZ of the frozen layer */
+  float lk4[RS_MAX_LAYERS + 2][4];
 };
 
 static inline void rs_constants_to_f32(const RsConstants &c, RsConstantsF &f) {
@@ -40,4 +43,6 @@ static inline void rs_constants_to_f32(const RsConstants &c, RsConstantsF &f) {
   for (int i = 0; i < RS_MAX_LAYERS + 2; ++i) f.capDZF[i] = 0.f;
   f.hs1F = 0.f;
   f.r_twoDT = 0.f;
+  for (int i = 0; i < RS_MAX_LAYERS + 2; ++i)
+    for (int q = 0; q < 4; ++q) f.lk4[i][q] = 0.f;
 }

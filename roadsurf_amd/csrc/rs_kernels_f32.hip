@@ -321,21 +321,25 @@ constexpr int kX2Lanes = 64; /* one wavefront per workgroup: 128 points, no LDS,
 enum { X2_WINDOW = 0, X2_KNOTS = 1 };
 constexpr float kCHF = 920.0f * 2100.0f; /* density x specific heat of ice: the frozen branch of CalcHCapHCond */
 
-/* capDZ of a layer from the volumetric heat capacity of its water: ONE definition for the lanes and for the
- * frozen-layer constants (prepare_constants_f32).  src/BalanceModel.f90:239,146. */
+/* capDZ of a layer from the heat capacity of its water (src/BalanceModel.f90:239,146: VSH = dryCap + WCont CHWT,
+ * capDZ = -1 / (DyC VSH)) with DyC multiplied in beforehand: -1 / (A chwt + B), A = DyC WCont, B = DyC dryCap.
+ * ONE definition for the lanes and for the frozen-layer constants (prepare_constants_f32). */
 __device__ __forceinline__ float x2_vsh(float wcont, float drycap, float chwt) { return __builtin_fmaf(wcont, chwt, drycap); }
-__device__ __forceinline__ float x2_capdz(float dyc, float vsh) { return -__builtin_amdgcn_rcpf(dyc * vsh); }
+__device__ __forceinline__ float x2_capdz(float A, float B, float chwt) { return -__builtin_amdgcn_rcpf(__builtin_fmaf(A, chwt, B)); }
 __device__ __forceinline__ float x2_hs1(float vsh, float hsfac1, float r_twodt) { return (vsh * hsfac1) * r_twodt; }
 
-/* fills RsConstantsF::capDZF / hs1F / r_twoDT on the device, by the lanes' own expressions */
+/* fills the device-made members of RsConstantsF, by the lanes' own expressions */
 __global__ void prepare_constants_f32(RsConstantsF *c) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const float r_twodt = __builtin_amdgcn_rcpf(c->twoDT);
   c->r_twoDT = r_twodt;
   for (int j = 1; j <= c->NLayers; ++j) {
-    const float vsh = x2_vsh(c->WCont[j], c->dryCap[j], kCHF);
-    c->capDZF[j] = x2_capdz(c->DyC[j], vsh);
-    if (j == 1) c->hs1F = x2_hs1(vsh, c->HSfac1, r_twodt);
+    const float A = c->DyC[j] * c->WCont[j], B = c->DyC[j] * c->dryCap[j];
+    c->lk4[j][0] = A;
+    c->lk4[j][1] = B;
+    c->lk4[j][2] = c->condDZ[j];
+    c->lk4[j][3] = c->capDZF[j] = x2_capdz(A, B, kCHF);
+    if (j == 1) c->hs1F = x2_hs1(x2_vsh(c->WCont[1], c->dryCap[1], kCHF), c->HSfac1, r_twodt);
   }
 }
 
@@ -356,6 +360,25 @@ __device__ __forceinline__ Scalars x2_scalars(const X2State &s, int comp, float 
   q.verycold = comp ? s.verycold.y : s.verycold.x;
   q.failed = false;
   return q;
+}
+
+/* capDZ of layer j for the lane's two points from their (stale) temperatures tj (CalcHCapHCond + calcCapDZCondDZ,
+ * src/BalanceModel.f90:189-251,132-155); hs1: where to leave HS(1) (layer 1 only).  A wavefront all of whose 128
+ * points have the layer frozen takes the plan's constant - the same bits, by construction. */
+__device__ __forceinline__ f2 x2_layer_capdz(const ConstsAS &c, int j, f2 tj, f2 *hs1) {
+  const b2 thawed = ge2(tj, S2(0.f));
+  if (!wave_any2(thawed)) {
+    if (hs1) *hs1 = S2(c.hs1F);
+    return S2(c.lk4[j][3]);
+  }
+  const f2 t2 = tj * tj;
+  const f2 roow = fma2(S2(-0.0050f), t2, fma2(S2(0.0079f), tj, S2(1000.0028f)));
+  const f2 cw = fma2(S2(0.0000102f), t2 * t2,
+                     fma2(S2(-0.0017169f), t2 * tj, fma2(S2(0.11516f), t2, fma2(S2(-3.4739f), tj, S2(4217.2f)))));
+  const f2 chwt = sel2(thawed, roow * cw, S2(kCHF));
+  /* x2_vsh / x2_hs1 / x2_capdz, packed: the operations prepare_constants_f32 runs for a frozen layer */
+  if (hs1) *hs1 = (fma2(S2(c.WCont[1]), chwt, S2(c.dryCap[1])) * S2(c.HSfac1)) * S2(c.r_twoDT);
+  return -rcp2(fma2(S2(c.lk4[j][0]), chwt, S2(c.lk4[j][1])));
 }
 
 /* src/BoundaryLayer.f90:3-190 for two points: air properties, the fixed point, calcRaero, CalcLE.
@@ -637,22 +660,8 @@ __global__ void __launch_bounds__(kX2Lanes, RS_X2_WAVES) step_kernel_f32x2(const
         const f2 tj = T[j - 1];
         const f2 tnext = (j == 15) ? tbot : T[j];
         const b2 thawed = ge2(tj, S2(0.f));
-        f2 capDZ;
-        if (!wave_any2(thawed)) { /* all 128 points have the layer frozen: the plan's constants */
-          capDZ = S2(c.capDZF[j]);
-          if (j == 1) hs1 = S2(c.hs1F);
-        } else {
-          const f2 t2 = tj * tj;
-          const f2 roow = fma2(S2(-0.0050f), t2, fma2(S2(0.0079f), tj, S2(1000.0028f)));
-          const f2 cw = fma2(S2(0.0000102f), t2 * t2,
-                             fma2(S2(-0.0017169f), t2 * tj, fma2(S2(0.11516f), t2, fma2(S2(-3.4739f), tj, S2(4217.2f)))));
-          const f2 chwt = sel2(thawed, roow * cw, S2(kCHF));
-          /* x2_vsh / x2_hs1 / x2_capdz, packed: the operations prepare_constants_f32 runs for a frozen layer */
-          const f2 vsh = fma2(S2(c.WCont[j]), chwt, S2(c.dryCap[j]));
-          if (j == 1) hs1 = (vsh * S2(c.HSfac1)) * S2(c.r_twoDT);
-          capDZ = -rcp2(S2(c.DyC[j]) * vsh);
-        }
-        const f2 G = S2(c.condDZ[j]) * (tnext - tj);
+        const f2 capDZ = x2_layer_capdz(c, j, tj, j == 1 ? &hs1 : nullptr);
+        const f2 G = S2(c.lk4[j][2]) * (tnext - tj);
         T[j - 1] = fma2(dts, capDZ * (G - Gprev), tj);
         Gprev = G;
         /* the update belongs HERE: left alone, the compiler sinks the fifteen updates behind the last layer's
@@ -724,6 +733,443 @@ __global__ void __launch_bounds__(kX2Lanes, RS_X2_WAVES) step_kernel_f32x2(const
   }
 }
 
+
+/* ==== two points per lane, two wavefronts per 128 points (step_kernel_f32duo) ==========================
+ * The single-wavefront organisation above keeps a point's whole state, the knots of its forcing and every
+ * temporary of a time step in one wavefront's registers: 168-250 of them, two or three wavefronts per SIMD, each
+ * of which offers the vector unit work only about half of the time it is resident (scalar loads, branches,
+ * waits) - 4.1e10 point-timesteps/s, what one point per lane gave (profiles/r06_f32_single_wave_*).  As in the
+ * fp64 flavour (rs_kernels.hip step_kernel_duo) a workgroup is therefore TWO wavefronts that share 128 points
+ * and meet once per time index:
+ *   ground wave:  layers 3..15 of the explicit update (they read only OLD neighbours) and everything a step
+ *                 needs of its forcing alone, one index AHEAD - the interpolation from the knots (or the window
+ *                 row), SetCurrentValues' VZ(1) floor, CheckValues' forcing tests, PrecipitationToStorage's
+ *                 amounts, SetDayDependendVariables, the air properties and loop invariants of CalcBLCondAndLE,
+ *                 the vapour pressure of the air: eleven floats per point through the LDS mailbox;
+ *   surface wave: the chain that starts at the surface state - boundary-layer loop, CalcLE, CalcRNet, layers
+ *                 1-2, melting, the storages, the outputs.  It never touches the forcing.
+ * Half the registers per wavefront, twice the wavefronts for the same points, two different instruction
+ * streams per SIMD. */
+#define RS_X2D_NPREP 11
+enum { XP_TAIR = 0, XP_C1, XP_K3, XP_RRA, XP_AVCAP, XP_PSYCH, XP_EAIR, XP_SW, XP_ELW, XP_RAIN, XP_SNOW };
+struct X2Mail {
+  float v[2][2][128];              /* [buffer][0: Tmp(2) from the surface wave, 1: Tmp(3) from the ground wave][point] */
+  float prep[2][RS_X2D_NPREP][128]; /* [buffer = index parity][value][point] */
+  uint32_t flags[2][128];          /* bit 0: CheckValues' verdict on the forcing; bit 1: night (SetDayDependendVariables) */
+};
+#ifndef RS_X2D_WAVES
+#define RS_X2D_WAVES 5 /* wavefronts per SIMD: 96 registers; the mailbox (14.3 KB per workgroup) allows ten workgroups per CU */
+#endif
+__device__ __forceinline__ void x2_meet() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ f2 lds_ld2(const float *row, uint32_t lane) { return *reinterpret_cast<const f2 *>(row + 2 * lane); }
+__device__ __forceinline__ void lds_st2(float *row, uint32_t lane, f2 v) { *reinterpret_cast<f2 *>(row + 2 * lane) = v; }
+
+template <int SRC>
+__device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) {
+  KernArgs ka = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  const uint32_t lane = threadIdx.x & 63u;
+  const int64_t p = 2 * ((int64_t)blockIdx.x * 64 + lane); /* < np_pad: every array below has np_pad columns */
+  const bool liveX = p < a.npoints, liveY = p + 1 < a.npoints;
+  const int64_t np = a.np_pad;
+  const float *st = reinterpret_cast<const float *>(a.state);
+  f2 T[13]; /* Tmp(3..15) */
+#pragma unroll
+  for (int j = 3; j <= 15; ++j) T[j - 3] = *reinterpret_cast<const f2 *>(st + (int64_t)(RS_ST_TMP0 + j - 1) * np + p);
+  const f2 tbot = f2{(float)ka->pp.tbottom[p], (float)ka->pp.tbottom[p + 1]};
+  const int32_t nsteps = ka->nsteps, t0 = ka->t0;
+  rs::MathTab mt{nullptr, nullptr, nullptr};
+  f2 kv0[6], kdv[6];
+  i2 kph0 = i2{0, 0}, kph1 = i2{0, 0};
+  int32_t kcur = -1;
+  int64_t kcolx = p, kcoly = p + 1;
+  if (SRC == X2_KNOTS && ka->knot_gather) {
+    kcolx = ka->knot_gather[p];
+    kcoly = ka->knot_gather[p + 1];
+  }
+  const bool fvec = SRC == X2_WINDOW && !(ka->f.t_stride & 1) && liveY;
+  /* the forcing's share of index `in` -> mailbox buffer `buf` */
+  auto prep = [&](int buf, int32_t in) {
+    const ConstsAS &c = consts_of(ka);
+    f2 tair, vz, rhz, prec, sw, lw;
+    i2 phase;
+    int32_t hour_u = 0;
+    i2 hour_p = i2{0, 0};
+    bool hour_per_point = false;
+    if (SRC == X2_KNOTS) {
+      const int32_t spk = ka->spk;
+      const int32_t t = in - 1;
+      const int32_t kk = __builtin_amdgcn_readfirstlane(t / spk);
+      const int32_t rr = t - kk * spk;
+      if (kk != kcur) { /* uniform: a new knot interval - expand_kernel_f32's loads and differences */
+        kcur = kk;
+        const int fld[6] = {0, 2, 3, 4, 5, 6};
+        const double *ka_ = ka->knots + ((int64_t)(kk - ka->knot_k0) * RS_KNOT_FIELDS) * np;
+        const bool has_b = (kk + 1 - ka->knot_k0) < ka->knot_n;
+        const double *kb_ = ka_ + (int64_t)RS_KNOT_FIELDS * np;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const double ax = ka_[(int64_t)fld[q] * np + kcolx], ay = ka_[(int64_t)fld[q] * np + kcoly];
+          const double bx = has_b ? kb_[(int64_t)fld[q] * np + kcolx] : ax, by = has_b ? kb_[(int64_t)fld[q] * np + kcoly] : ay;
+          kv0[q] = f2{(float)ax, (float)ay};
+          kdv[q] = f2{(float)(bx - ax), (float)(by - ay)};
+        }
+        kph0 = i2{(int32_t)ka_[8 * np + kcolx], (int32_t)ka_[8 * np + kcoly]};
+        kph1 = has_b ? i2{(int32_t)kb_[8 * np + kcolx], (int32_t)kb_[8 * np + kcoly]} : kph0;
+      }
+      const f2 w = S2(rs32_lerp_weight(rr, ka->r_spk));
+      tair = fma2(w, kdv[0], kv0[0]); vz = fma2(w, kdv[1], kv0[1]); rhz = fma2(w, kdv[2], kv0[2]);
+      prec = fma2(w, kdv[3], kv0[3]); sw = fma2(w, kdv[4], kv0[4]); lw = fma2(w, kdv[5], kv0[5]);
+      phase = (rr == 0) ? kph0 : kph1;
+      hour_u = rs_sy_hour(in, spk, ka->start_hour);
+    } else {
+      const int64_t row = (int64_t)(in - t0) * ka->f.t_stride + p;
+      auto in2 = [&](const void *base) -> f2 {
+        const float *q = reinterpret_cast<const float *>(base) + row;
+        if (fvec) return *reinterpret_cast<const f2 *>(q);
+        return f2{liveX ? q[0] : 0.f, liveY ? q[1] : 0.f};
+      };
+      tair = in2(ka->f.tair); vz = in2(ka->f.vz); rhz = in2(ka->f.rhz);
+      prec = in2(ka->f.prec); sw = in2(ka->f.sw); lw = in2(ka->f.lw);
+      phase = i2{liveX ? (ka->f.precphase + row)[0] : 0, liveY ? (ka->f.precphase + row)[1] : 0};
+      hour_per_point = ka->f.hour_pstride != 0;
+      if (hour_per_point) hour_p = i2{liveX ? (ka->f.hour + row)[0] : 0, liveY ? (ka->f.hour + row)[1] : 0};
+      else hour_u = ka->f.hour[in - t0];
+    }
+    if (in == 1) vz = sel2(lt2(vz, S2(0.4f)), S2(0.4f), vz); /* src/Initialization.f90:121-123 */
+    uint32_t flx = 0u, fly = 0u;
+    if (in < c.SimLen) { /* CheckValues' forcing tests (src/InputOutput.f90:45-84); the surface temperature's are the surface wave's */
+      Forcing fa, fb;
+      fa.tair = tair.x; fa.vz = vz.x; fa.rhz = rhz.x; fa.prec = prec.x; fa.sw = sw.x; fa.lw = lw.x;
+      fb.tair = tair.y; fb.vz = vz.y; fb.rhz = rhz.y; fb.prec = prec.y; fb.sw = sw.y; fb.lw = lw.y;
+      fa.tdew = fb.tdew = 0.f; fa.tsurfobs = fb.tsurfobs = -9999.9f; fa.depth = fb.depth = -9999.9f;
+      fa.phase = phase.x; fb.phase = phase.y; fa.hour = fb.hour = 0;
+      flx = check_values_forcing(c, fa) ? 1u : 0u;
+      fly = check_values_forcing(c, fb) ? 1u : 0u;
+    }
+    /* PrecipitationToStorage without the storages (src/Storage.f90:9-29, src/Cond.f90:143-249): the amounts */
+    const f2 prec_ts = (prec * S2(__builtin_amdgcn_rcpf(3600.0f))) * S2(c.DTSecs);
+    f2 rain = S2(0.f), snowfall = S2(0.f);
+    if (!(RS_PREC_FAST(c) && wave_all2(b2{prec_ts.x == 0.f, prec_ts.y == 0.f}))) {
+      Scalars z;
+      float pt = prec_ts.x;
+      z.wat = 0.f; z.snow = 0.f;
+      precipitation_to_storage(c, mt, z, phase.x, pt, tair.x, rhz.x);
+      rain.x = z.wat; snowfall.x = z.snow;
+      pt = prec_ts.y;
+      z.wat = 0.f; z.snow = 0.f;
+      precipitation_to_storage(c, mt, z, phase.y, pt, tair.y, rhz.y);
+      rain.y = z.wat; snowfall.y = z.snow;
+    }
+    /* SetDayDependendVariables (src/BalanceModel.f90:354-387): the calm limit here, the traffic friction from the
+     * night bit on the surface wave */
+    {
+      const float calmN = c.CalmLimNgt, calmD = c.CalmLimDay;
+      f2 calm;
+      if (hour_per_point) {
+        const b2 night = b2{((float)hour_p.x >= c.NightOn) || ((float)hour_p.x <= c.NightOff),
+                            ((float)hour_p.y >= c.NightOn) || ((float)hour_p.y <= c.NightOff)};
+        calm = sel2(night, S2(calmN), S2(calmD));
+        flx |= night.x ? 2u : 0u;
+        fly |= night.y ? 2u : 0u;
+      } else {
+        const bool night = ((float)hour_u >= c.NightOn) || ((float)hour_u <= c.NightOff);
+        calm = S2(night ? calmN : calmD);
+        flx |= night ? 2u : 0u;
+        fly |= night ? 2u : 0u;
+      }
+      vz = sel2(lt2(vz, calm), calm, vz);
+    }
+    /* air properties and the loop's invariants (src/BoundaryLayer.f90:50-62,78-79; x2_boundary_layer has the algebra) */
+    const f2 TaK = tair + S2(273.15f);
+    const f2 AirDens = S2(100000.0f) * rcp2(S2(287.05f) * TaK);
+    const f2 dK = (TaK - S2(250.0f)) * (TaK - S2(250.0f));
+    const f2 AirHCap = fma2(dK, S2(1.0f / 3364.0f), S2(1005.0f));
+    const f2 AirVCap = AirHCap * AirDens;
+    const f2 PsychC = S2(0.1f) * fma2(S2(0.00063f), TaK, S2(0.47496f));
+    const f2 vkvz = S2(c.VK_Const) * vz;
+    const f2 C1 = (AirVCap * S2(c.VK_Const)) * vkvz;
+    const float stab_num = -c.VK_Const * c.ZRefT * c.Grav;
+    const f2 K3 = S2(stab_num) * rcp2((AirVCap * TaK) * (vkvz * vkvz * vkvz));
+    const f2 rRA = rcp2(S2(c.VK_Const * c.VK_Const) * vz);
+    /* the vapour pressure of the air (CalcLE, :160-170) */
+    const b2 aneg = lt2(tair, S2(0.f));
+    const f2 aa = sel2(aneg, S2(21.875f), S2(17.269f)), ba = sel2(aneg, S2(265.5f), S2(237.3f));
+    const f2 ESat = S2(0.61078f) * exp2v((aa * tair) * rcp2(tair + ba));
+    f2 hum = S2(0.01f) * rhz;
+    hum = sel2(gt2(hum, S2(1.0f)), S2(1.0f), hum);
+    float (*w)[128] = mail.prep[buf];
+    lds_st2(w[XP_TAIR], lane, tair); lds_st2(w[XP_C1], lane, C1); lds_st2(w[XP_K3], lane, K3);
+    lds_st2(w[XP_RRA], lane, rRA); lds_st2(w[XP_AVCAP], lane, AirVCap); lds_st2(w[XP_PSYCH], lane, PsychC);
+    lds_st2(w[XP_EAIR], lane, hum * ESat); lds_st2(w[XP_SW], lane, sw); lds_st2(w[XP_ELW], lane, S2(c.Emiss) * lw);
+    lds_st2(w[XP_RAIN], lane, rain); lds_st2(w[XP_SNOW], lane, snowfall);
+    *reinterpret_cast<uint2 *>(&mail.flags[buf][2 * lane]) = uint2{flx, fly};
+  };
+  lds_st2(mail.v[0][1], lane, T[0]);
+  prep(0, t0);
+  x2_meet();
+  for (int32_t kv = 0; kv < nsteps; ++kv) {
+    asm volatile("" : "+s"(ka));
+    const ConstsAS &c = consts_of(ka);
+    const int32_t k = __builtin_amdgcn_readfirstlane(kv);
+    const f2 t2 = lds_ld2(mail.v[k & 1][0], lane); /* Tmp(2) as the last step left it (melting included) */
+    /* (a point that has failed keeps stepping here: its layers are never read again) */
+    f2 Gprev = S2(c.lk4[2][2]) * (T[0] - t2); /* G(2), the expression layer 2 itself evaluates */
+    const f2 dts = S2(c.DTSecs);
+#pragma unroll
+    for (int j = 3; j <= 15; ++j) {
+      const f2 tj = T[j - 3];
+      const f2 tnext = (j == 15) ? tbot : T[j - 2];
+      const f2 capDZ = x2_layer_capdz(c, j, tj, nullptr);
+      const f2 G = S2(c.lk4[j][2]) * (tnext - tj);
+      T[j - 3] = fma2(dts, capDZ * (G - Gprev), tj);
+      Gprev = G;
+      asm volatile("" : "+v"(T[j - 3]), "+v"(Gprev)); /* the update belongs HERE (see step_kernel_f32x2) */
+    }
+    lds_st2(mail.v[(k & 1) ^ 1][1], lane, T[0]);
+    if (k + 1 < nsteps) prep((k & 1) ^ 1, t0 + k + 1);
+    x2_meet();
+  }
+  if (liveX) {
+    float *sw_ = reinterpret_cast<float *>(a.state);
+#pragma unroll
+    for (int j = 3; j <= 15; ++j) {
+      float *q = sw_ + (int64_t)(RS_ST_TMP0 + j - 1) * np + p;
+      if (liveY) *reinterpret_cast<f2 *>(q) = T[j - 3];
+      else q[0] = T[j - 3].x;
+    }
+  }
+}
+
+template <bool SCORE>
+__device__ __forceinline__ void x2d_surface(X2Mail &mail, const rs::StepArgs &a) {
+  KernArgs ka = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  const uint32_t lane = threadIdx.x & 63u;
+  const int64_t p = 2 * ((int64_t)blockIdx.x * 64 + lane);
+  const bool liveX = p < a.npoints, liveY = p + 1 < a.npoints;
+  const int64_t np = a.np_pad;
+  float *st = reinterpret_cast<float *>(a.state);
+  auto ldst = [&](int slot) -> f2 { return *reinterpret_cast<const f2 *>(st + (int64_t)slot * np + p); };
+  auto stst = [&](int slot, f2 v) {
+    float *q = st + (int64_t)slot * np + p;
+    if (liveY) *reinterpret_cast<f2 *>(q) = v;
+    else if (liveX) q[0] = v.x;
+  };
+  f2 T1 = ldst(RS_ST_TMP0), T2 = ldst(RS_ST_TMP0 + 1);
+  X2State s;
+  s.tsurf = ldst(RS_ST_TSURF);
+  s.wat = ldst(RS_ST_WAT); s.snow = ldst(RS_ST_SNOW); s.ice = ldst(RS_ST_ICE); s.ice2 = ldst(RS_ST_ICE2);
+  s.dep = ldst(RS_ST_DEP); s.q2melt = ldst(RS_ST_Q2MELT); s.t4melt = ldst(RS_ST_T4MELT);
+  s.albedo = ldst(RS_ST_ALBEDO);
+  {
+    const f2 vc = ldst(RS_ST_VERYCOLD), fl = ldst(RS_ST_FAILED);
+    s.verycold = b2{vc.x != 0.f, vc.y != 0.f};
+    s.failed = b2{fl.x != 0.f || !liveX, fl.y != 0.f || !liveY}; /* a point beyond npoints never steps */
+  }
+  const int32_t nsteps = ka->nsteps, t0 = ka->t0;
+  i2 score = i2{0, 0}, regime = i2{0, 0}, last_trips = i2{0, 0};
+  const bool ovec = !(ka->o.t_stride & 1) && liveY;
+  lds_st2(mail.v[0][0], lane, T2);
+  x2_meet();
+  for (int32_t kv = 0; kv < nsteps; ++kv) {
+    asm volatile("" : "+s"(ka));
+    const ConstsAS &c = consts_of(ka);
+    const int32_t k = __builtin_amdgcn_readfirstlane(kv);
+    const int32_t i = t0 + k;
+    int64_t r = (int64_t)(i - 1);
+    const int32_t dec = ka->o.decimate;
+    bool write = true;
+    if (dec > 1) {
+      write = (r % dec == 0);
+      r /= dec;
+    }
+    const int64_t orow = (r - ka->o.row0) * ka->o.t_stride + p;
+    auto out2 = [&](void *base, f2 v) {
+      float *q = reinterpret_cast<float *>(base) + orow;
+      if (ovec) {
+        *reinterpret_cast<f2 *>(q) = v;
+      } else {
+        if (liveX) q[0] = v.x;
+        if (liveY) q[1] = v.y;
+      }
+    };
+    const b2 was_failed = s.failed;
+    const f2 t3 = lds_ld2(mail.v[k & 1][1], lane); /* Tmp(3) as the last step left it */
+    const float (*w)[128] = mail.prep[k & 1];
+    const uint2 fl = *reinterpret_cast<const uint2 *>(&mail.flags[k & 1][2 * lane]);
+    if (!wave_all2(was_failed)) {
+      const f2 tair = lds_ld2(w[XP_TAIR], lane);
+      if (i < c.SimLen) { /* CheckValues: the forcing's verdict | the surface temperature's ("Abnormal surface temperature") */
+        const bool badx = !was_failed.x && ((fl.x & 1u) || check_values_tsurf(c, s.tsurf.x));
+        const bool bady = !was_failed.y && ((fl.y & 1u) || check_values_tsurf(c, s.tsurf.y));
+        if (badx) { s.failed.x = true; st[(int64_t)RS_ST_FAILED * np + p] = (float)i; }
+        if (bady) { s.failed.y = true; st[(int64_t)RS_ST_FAILED * np + p + 1] = (float)i; }
+      }
+      const b2 live = not2(was_failed);
+      s.wat = s.wat + lds_ld2(w[XP_RAIN], lane);
+      s.snow = s.snow + lds_ld2(w[XP_SNOW], lane);
+      const f2 trffric = f2{(fl.x & 2u) ? c.TrfFricNgt : c.TrFfricDay, (fl.y & 2u) ? c.TrfFricNgt : c.TrFfricDay};
+      /* ---- the boundary-layer fixed point (x2_boundary_layer's algebra) from the handed-over invariants ---- */
+      f2 blcond, le, evap;
+      i2 trips;
+      b2 unst = b2{false, false};
+      {
+        const f2 C1 = lds_ld2(w[XP_C1], lane);
+        const f2 C2 = lds_ld2(w[XP_K3], lane) * (s.tsurf - tair);
+        f2 PSIM = S2(0.f), PSIH = S2(0.f), BL = S2(0.f);
+        const f2 lU = S2(c.logUstar), lC = S2(c.logCond);
+        auto pass = [&](f2 &psim, f2 &psih, f2 &bl, b2 act) {
+          const f2 av = lU + psim, bv = lC + psih;
+          bl = C1 * rcp2(av * bv);
+          f2 Stab = (C2 * bl) * (av * av * av);
+          Stab = sel2(gt2(Stab, S2(1.0f)), S2(1.0f), Stab);
+          const b2 stable = gt2(Stab, S2(0.f));
+          const f2 ps = S2(4.7f) * Stab;
+          const b2 uns = and2(not2(stable), act);
+          if (wave_any2(uns)) {
+            const f2 arg = (S2(1.0f) + sqrt2(fma2(S2(-16.0f), Stab, S2(1.0f)))) * S2(0.5f);
+            const f2 pu = S2(-2.0f * 0.69314718056f) * f2{__builtin_amdgcn_logf(arg.x), __builtin_amdgcn_logf(arg.y)};
+            psih = sel2(stable, ps, pu);
+            psim = sel2(stable, ps, S2(0.6f) * pu);
+            if (SCORE) unst = or2(unst, uns);
+          } else {
+            psih = ps;
+            psim = ps;
+          }
+        };
+#pragma unroll 1
+        for (int j = 1; j <= 4; ++j) pass(PSIM, PSIH, BL, live);
+        b2 act;
+        {
+          const f2 old = BL;
+          pass(PSIM, PSIH, BL, live);
+          act = and2(live, not2(lt2(abs2(BL - old), S2(0.001f))));
+        }
+        trips = i2{5, 5};
+        for (int j = 6; j <= RS_BL_MAXIT && wave_any2(act); ++j) {
+          f2 pm = PSIM, ph = PSIH, bl = BL;
+          pass(pm, ph, bl, act);
+          const b2 done = lt2(abs2(bl - BL), S2(0.001f));
+          PSIM = sel2(act, pm, PSIM);
+          PSIH = sel2(act, ph, PSIH);
+          BL = sel2(act, bl, BL);
+          trips = i2{trips.x + (act.x ? 1 : 0), trips.y + (act.y ? 1 : 0)};
+          act = and2(act, not2(done));
+        }
+        blcond = BL;
+        /* calcRaero (:112-131), CalcLE (:134-190) */
+        f2 RAero = ((S2(c.logMom) + PSIM) * (S2(c.logHeat) + PSIH)) * lds_ld2(w[XP_RRA], lane);
+        RAero = sel2(gt2(RAero, S2(30.0f)), S2(30.0f), RAero);
+        const b2 sneg = lt2(s.tsurf, S2(0.f));
+        const f2 as = sel2(sneg, S2(21.875f), S2(17.269f)), bs = sel2(sneg, S2(265.5f), S2(237.3f));
+        const f2 ESurf = S2(0.61078f) * exp2v((as * s.tsurf) * rcp2(s.tsurf + bs));
+        const f2 WatDen = fma2(S2(-0.0050f) * s.tsurf, s.tsurf, fma2(S2(0.0079f), s.tsurf, S2(1000.0028f)));
+        f2 le_ = (lds_ld2(w[XP_AVCAP], lane) * (ESurf - lds_ld2(w[XP_EAIR], lane))) * rcp2(lds_ld2(w[XP_PSYCH], lane) * RAero);
+        const f2 lat = sel2(ge2(s.tsurf, S2(0.f)), S2(c.LVap), S2(c.LFus));
+        const f2 ev = ((le_ * rcp2(lat * WatDen)) * S2(1000.0f)) * S2(c.DTSecs);
+        const b2 nowater = and2(gt2(le_, S2(0.f)), le2(s.wat, S2(0.f)));
+        le = sel2(nowater, S2(0.f), le_);
+        evap = sel2(nowater, S2(0.f), ev);
+      }
+      if (SCORE) {
+        score = i2{score.x + trips.x - 5, score.y + trips.y - 5};
+        if (k >= nsteps - 30) regime = i2{regime.x | (unst.x ? 1 : 0), regime.y | (unst.y ? 1 : 0)};
+      } else {
+        last_trips = trips;
+      }
+      /* CalcRNet (src/BalanceModel.f90:282-307) */
+      f2 rnet;
+      {
+        const f2 TK = s.tsurf + S2(273.15f);
+        const f2 TK2 = TK * TK;
+        const f2 RBB = S2(c.Emiss * c.SB_Const) * (TK2 * TK2);
+        rnet = fma2(S2(1.0f) - s.albedo, lds_ld2(w[XP_SW], lane), lds_ld2(w[XP_ELW], lane) - RBB);
+      }
+      /* layers 1-2 with Tmp(3) where a two-layer column has its lower boundary */
+      const f2 t1old = T1, t2old = T2;
+      f2 hs1 = S2(0.f);
+      {
+        const f2 dts = S2(c.DTSecs);
+        f2 Gprev = ((rnet - le) + trffric) + blcond * (tair - t1old);
+        const f2 cap1 = x2_layer_capdz(c, 1, t1old, &hs1);
+        const f2 G1 = S2(c.lk4[1][2]) * (t2old - t1old);
+        T1 = fma2(dts, cap1 * (G1 - Gprev), t1old);
+        const f2 cap2 = x2_layer_capdz(c, 2, t2old, nullptr);
+        const f2 G2 = S2(c.lk4[2][2]) * (t3 - t2old);
+        T2 = fma2(dts, cap2 * (G2 - G1), t2old);
+      }
+      /* calcHStor, melting, the new surface temperature, RoadCond ... CalcAlbedo: per point (see step_kernel_f32x2) */
+      {
+        const f2 T1Ave = (t1old + S2(3.f) * t2old) * S2(0.25f);
+        const f2 TN1Ave = (T1 + S2(3.f) * T2) * S2(0.25f);
+        const f2 hstor = hs1 * (TN1Ave - T1Ave);
+        const b2 frozen_cover = b2{(s.snow.x > 0.f) || (s.ice.x > 0.f) || (s.ice2.x > 0.f),
+                                   (s.snow.y > 0.f) || (s.ice.y > 0.f) || (s.ice2.y > 0.f)};
+        const bool melt_here = wave_any2(frozen_cover);
+#pragma unroll
+        for (int comp = 0; comp < 2; ++comp) {
+          RegProfile<2> TT;
+          TT.set(1, comp ? T1.y : T1.x);
+          TT.set(2, comp ? T2.y : T2.x);
+          Scalars q = x2_scalars(s, comp, TT.get(1), TT.get(2));
+          if (melt_here) melting(q, TT, comp ? hstor.y : hstor.x, comp ? hs1.y : hs1.x, false, 0.f);
+          else q.q2melt = 0.f;
+          q.tsurf = (TT.get(1) + TT.get(2)) / 2.0f;
+          road_condition(c, q, comp ? evap.y : evap.x);
+          if (comp) {
+            T1.y = TT.get(1); T2.y = TT.get(2);
+            s.tsurf.y = q.tsurf; s.wat.y = q.wat; s.snow.y = q.snow; s.ice.y = q.ice; s.ice2.y = q.ice2; s.dep.y = q.dep;
+            s.q2melt.y = q.q2melt; s.t4melt.y = q.t4melt; s.albedo.y = q.albedo; s.verycold.y = q.verycold;
+          } else {
+            T1.x = TT.get(1); T2.x = TT.get(2);
+            s.tsurf.x = q.tsurf; s.wat.x = q.wat; s.snow.x = q.snow; s.ice.x = q.ice; s.ice2.x = q.ice2; s.dep.x = q.dep;
+            s.q2melt.x = q.q2melt; s.t4melt.x = q.t4melt; s.albedo.x = q.albedo; s.verycold.x = q.verycold;
+          }
+        }
+      }
+    }
+    /* SaveOutput (src/InputOutput.f90:151-165); -9999.0 for a point that failed before this index */
+    if (write) {
+      if (wave_any2(was_failed)) {
+        const f2 m = S2(-9999.0f);
+        out2(ka->o.tsurf, sel2(was_failed, m, s.tsurf)); out2(ka->o.snow, sel2(was_failed, m, s.snow));
+        out2(ka->o.water, sel2(was_failed, m, s.wat)); out2(ka->o.ice, sel2(was_failed, m, s.ice));
+        out2(ka->o.deposit, sel2(was_failed, m, s.dep)); out2(ka->o.ice2, sel2(was_failed, m, s.ice2));
+      } else {
+        out2(ka->o.tsurf, s.tsurf); out2(ka->o.snow, s.snow); out2(ka->o.water, s.wat);
+        out2(ka->o.ice, s.ice); out2(ka->o.deposit, s.dep); out2(ka->o.ice2, s.ice2);
+      }
+    }
+    lds_st2(mail.v[(k & 1) ^ 1][0], lane, T2);
+    x2_meet();
+  }
+  stst(RS_ST_TMP0, T1);
+  stst(RS_ST_TMP0 + 1, T2);
+  stst(RS_ST_TSURF, s.tsurf);
+  stst(RS_ST_WAT, s.wat); stst(RS_ST_SNOW, s.snow); stst(RS_ST_ICE, s.ice); stst(RS_ST_ICE2, s.ice2);
+  stst(RS_ST_DEP, s.dep); stst(RS_ST_Q2MELT, s.q2melt); stst(RS_ST_T4MELT, s.t4melt);
+  stst(RS_ST_ALBEDO, s.albedo);
+  stst(RS_ST_VERYCOLD, f2{s.verycold.x ? 1.f : 0.f, s.verycold.y ? 1.f : 0.f});
+  if (SCORE) { /* sort key of rs_hip_recluster, as in the other flavours (rs_kernels.hip, bl_score_key) */
+    auto key = [&](int32_t sc, int32_t rg, float w_, float sn, float ic, float i2_, float dp) -> float {
+      const int32_t lo = sc > 0x7ffff ? 0x7ffff : (sc < 0 ? 0 : sc);
+      const int32_t covered = (w_ > 0.f || sn > 0.f || ic > 0.f || i2_ > 0.f || dp > 0.f) ? 1 : 0;
+      return (float)(lo | (covered << 19) | (rg << 20));
+    };
+    stst(RS_ST_BLSCORE, f2{key(score.x, regime.x, s.wat.x, s.snow.x, s.ice.x, s.ice2.x, s.dep.x),
+                           key(score.y, regime.y, s.wat.y, s.snow.y, s.ice.y, s.ice2.y, s.dep.y)});
+  } else { /* the pass count of the launch's last index: one more preview for forecast_key_kernel */
+    stst(RS_ST_BLSCORE, f2{(float)last_trips.x, (float)last_trips.y});
+  }
+}
+
+template <int SRC, bool SCORE>
+__global__ void __launch_bounds__(128, RS_X2D_WAVES) step_kernel_f32duo(const rs::StepArgs a) {
+  __shared__ X2Mail mail;
+  /* no early return: both wavefronts walk to every barrier; points beyond npoints are dead weight */
+  if (threadIdx.x < 64) x2d_surface<SCORE>(mail, a);
+  else x2d_ground<SRC>(mail, a);
+}
+
 }  // namespace rs32
 
 static inline dim3 grid_for32(int64_t n) { return dim3((unsigned)((n + RS_BLOCK - 1) / RS_BLOCK)); }
@@ -747,10 +1193,14 @@ static inline dim3 grid_x2(int64_t n) { return dim3((unsigned)((n + 2 * rs32::kX
 hipError_t rs32_launch_step(const rs::StepArgs &a, int NL, int variant, bool score, hipStream_t stream) {
   const dim3 g = grid_for32(a.npoints), b(RS_BLOCK);
   const int v = variant % 10;
-  if (NL == 15 && v != RS_VARIANT_REG && v != RS_VARIANT_LDS) {
-    /* two points per lane (round 6); RS_VARIANT_REG / _LDS: round 2-5's one point per lane, for A/B */
+  if (NL == 15 && v == 5) { /* (A/B) two points per lane in ONE wavefront */
     if (score) hipLaunchKernelGGL((rs32::step_kernel_f32x2<rs32::X2_WINDOW, true>), grid_x2(a.npoints), dim3(rs32::kX2Lanes), 0, stream, a);
     else hipLaunchKernelGGL((rs32::step_kernel_f32x2<rs32::X2_WINDOW, false>), grid_x2(a.npoints), dim3(rs32::kX2Lanes), 0, stream, a);
+  } else if (NL == 15 && v != RS_VARIANT_REG && v != RS_VARIANT_LDS) {
+    /* two points per lane, two wavefronts per 128 points (round 6); RS_VARIANT_REG / _LDS: round 2-5's one point
+     * per lane, for A/B */
+    if (score) hipLaunchKernelGGL((rs32::step_kernel_f32duo<rs32::X2_WINDOW, true>), grid_x2(a.npoints), dim3(128), 0, stream, a);
+    else hipLaunchKernelGGL((rs32::step_kernel_f32duo<rs32::X2_WINDOW, false>), grid_x2(a.npoints), dim3(128), 0, stream, a);
   } else if (v == RS_VARIANT_REG) {
     if (NL != 15) return hipErrorInvalidValue;
     hipLaunchKernelGGL(rs32::step_kernel_f32_reg15, g, b, 0, stream, a);
@@ -761,7 +1211,12 @@ hipError_t rs32_launch_step(const rs::StepArgs &a, int NL, int variant, bool sco
 }
 
 /* the two-points-per-lane kernel reading the hourly knots itself (StepArgs::knots): no forcing window */
-hipError_t rs32_launch_step_knots(const rs::StepArgs &a, bool score, hipStream_t stream) {
+hipError_t rs32_launch_step_knots(const rs::StepArgs &a, int variant, bool score, hipStream_t stream) {
+  if (variant % 10 != 5) {
+    if (score) hipLaunchKernelGGL((rs32::step_kernel_f32duo<rs32::X2_KNOTS, true>), grid_x2(a.npoints), dim3(128), 0, stream, a);
+    else hipLaunchKernelGGL((rs32::step_kernel_f32duo<rs32::X2_KNOTS, false>), grid_x2(a.npoints), dim3(128), 0, stream, a);
+    return hipGetLastError();
+  }
   if (score) hipLaunchKernelGGL((rs32::step_kernel_f32x2<rs32::X2_KNOTS, true>), grid_x2(a.npoints), dim3(rs32::kX2Lanes), 0, stream, a);
   else hipLaunchKernelGGL((rs32::step_kernel_f32x2<rs32::X2_KNOTS, false>), grid_x2(a.npoints), dim3(rs32::kX2Lanes), 0, stream, a);
   return hipGetLastError();
