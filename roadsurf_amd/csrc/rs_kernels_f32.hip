@@ -311,8 +311,27 @@ __device__ __forceinline__ b2 or2(b2 a, b2 b) { return b2{a.x || b.x, a.y || b.y
 __device__ __forceinline__ b2 not2(b2 a) { return b2{!a.x, !a.y}; }
 __device__ __forceinline__ f2 sel2(b2 m, f2 a, f2 b) { return f2{m.x ? a.x : b.x, m.y ? a.y : b.y}; }
 /* over the wavefront's active lanes, both points of each */
-__device__ __forceinline__ bool wave_any2(b2 m) { return __builtin_amdgcn_ballot_w64(m.x || m.y) != 0ull; }
-__device__ __forceinline__ bool wave_all2(b2 m) { return __builtin_amdgcn_ballot_w64(!(m.x && m.y)) == 0ull; }
+/* (one ballot per point of the pair, OR-ed on the scalar unit: a compare's mask is a ballot already; `m.x || m.y`
+ * as one ballot makes the compiler materialise the OR in a vector register first) */
+__device__ __forceinline__ bool wave_any2(b2 m) {
+  return (__builtin_amdgcn_ballot_w64(m.x) | __builtin_amdgcn_ballot_w64(m.y)) != 0ull;
+}
+__device__ __forceinline__ bool wave_all2(b2 m) {
+  return (__builtin_amdgcn_ballot_w64(!m.x) | __builtin_amdgcn_ballot_w64(!m.y)) == 0ull;
+}
+
+/* a select whose condition is a wavefront mask held on the scalar unit (a loop-carried per-point flag kept as a
+ * lane-bool costs a v_cndmask + v_cmp_ne to turn it back into a mask at every vote) */
+__device__ __forceinline__ float selm(uint64_t mask, float a, float b) {
+  float r;
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+  return r;
+}
+__device__ __forceinline__ int32_t addm(uint64_t mask, int32_t t) { /* t + 1 in the lanes of the mask */
+  int32_t r;
+  asm("v_addc_co_u32 %0, vcc, 0, %1, %2" : "=v"(r) : "v"(t), "s"(mask) : "vcc");
+  return r;
+}
 
 constexpr int kX2Lanes = 64; /* one wavefront per workgroup: 128 points, no LDS, no barrier */
 #ifndef RS_X2_WAVES
@@ -325,7 +344,7 @@ constexpr float kCHF = 920.0f * 2100.0f; /* density x specific heat of ice: the 
  * capDZ = -1 / (DyC VSH)) with DyC multiplied in beforehand: -1 / (A chwt + B), A = DyC WCont, B = DyC dryCap.
  * ONE definition for the lanes and for the frozen-layer constants (prepare_constants_f32). */
 __device__ __forceinline__ float x2_vsh(float wcont, float drycap, float chwt) { return __builtin_fmaf(wcont, chwt, drycap); }
-__device__ __forceinline__ float x2_capdz(float A, float B, float chwt) { return -__builtin_amdgcn_rcpf(__builtin_fmaf(A, chwt, B)); }
+__device__ __forceinline__ float x2_rcap(float A, float B, float chwt) { return __builtin_amdgcn_rcpf(__builtin_fmaf(A, chwt, B)); }
 __device__ __forceinline__ float x2_hs1(float vsh, float hsfac1, float r_twodt) { return (vsh * hsfac1) * r_twodt; }
 
 /* fills the device-made members of RsConstantsF, by the lanes' own expressions */
@@ -338,7 +357,8 @@ __global__ void prepare_constants_f32(RsConstantsF *c) {
     c->lk4[j][0] = A;
     c->lk4[j][1] = B;
     c->lk4[j][2] = c->condDZ[j];
-    c->lk4[j][3] = c->capDZF[j] = x2_capdz(A, B, kCHF);
+    c->lk4[j][3] = x2_rcap(A, B, kCHF); /* without capDZ's sign: the update subtracts */
+    c->capDZF[j] = -c->lk4[j][3];
     if (j == 1) c->hs1F = x2_hs1(x2_vsh(c->WCont[1], c->dryCap[1], kCHF), c->HSfac1, r_twodt);
   }
 }
@@ -362,24 +382,55 @@ __device__ __forceinline__ Scalars x2_scalars(const X2State &s, int comp, float 
   return q;
 }
 
-/* capDZ of layer j for the lane's two points from their (stale) temperatures tj (CalcHCapHCond + calcCapDZCondDZ,
- * src/BalanceModel.f90:189-251,132-155); hs1: where to leave HS(1) (layer 1 only).  A wavefront all of whose 128
- * points have the layer frozen takes the plan's constant - the same bits, by construction. */
-__device__ __forceinline__ f2 x2_layer_capdz(const ConstsAS &c, int j, f2 tj, f2 *hs1) {
+/* The three literals of a layer update that cannot ride on an instruction as its one scalar operand, kept in vector
+ * registers for a whole time step (left to itself the compiler re-materialises them in every layer) */
+struct X2Lit {
+  float a1, c3, chf;
+  __device__ __forceinline__ void make() {
+    a1 = 0.0079f;
+    c3 = -0.0017169f;
+    chf = kCHF;
+    asm volatile("" : "+v"(a1), "+v"(c3), "+v"(chf));
+  }
+};
+
+/* 1 / (DyC VSH) of layer j for the lane's two points from their (stale) temperatures tj - capDZ without its sign
+ * (CalcHCapHCond + calcCapDZCondDZ, src/BalanceModel.f90:189-251,132-155; the water polynomials in Horner form);
+ * hs1: where to leave HS(1) (layer 1 only).  A wavefront all of whose 128 points have the layer frozen takes the
+ * plan's constant - the same bits, by construction (prepare_constants_f32). */
+__device__ __forceinline__ f2 x2_layer_rcap(const ConstsAS &c, const X2Lit &L, float kA, float kB, float kF, f2 tj, f2 *hs1) {
   const b2 thawed = ge2(tj, S2(0.f));
+#ifndef RS_ABL_NOFROZEN
   if (!wave_any2(thawed)) {
     if (hs1) *hs1 = S2(c.hs1F);
-    return S2(c.lk4[j][3]);
+    return S2(kF);
   }
-  const f2 t2 = tj * tj;
-  const f2 roow = fma2(S2(-0.0050f), t2, fma2(S2(0.0079f), tj, S2(1000.0028f)));
-  const f2 cw = fma2(S2(0.0000102f), t2 * t2,
-                     fma2(S2(-0.0017169f), t2 * tj, fma2(S2(0.11516f), t2, fma2(S2(-3.4739f), tj, S2(4217.2f)))));
-  const f2 chwt = sel2(thawed, roow * cw, S2(kCHF));
-  /* x2_vsh / x2_hs1 / x2_capdz, packed: the operations prepare_constants_f32 runs for a frozen layer */
+#endif
+  const f2 roow = fma2(fma2(tj, S2(-0.0050f), S2(L.a1)), tj, S2(1000.0028f));
+  f2 cw = fma2(tj, S2(0.0000102f), S2(L.c3));
+  cw = fma2(cw, tj, S2(0.11516f));
+  cw = fma2(cw, tj, S2(-3.4739f));
+  cw = fma2(cw, tj, S2(4217.2f));
+  const f2 chwt = sel2(thawed, roow * cw, S2(L.chf));
+  /* x2_vsh / x2_hs1 / x2_rcap, packed: the operations prepare_constants_f32 runs for a frozen layer */
   if (hs1) *hs1 = (fma2(S2(c.WCont[1]), chwt, S2(c.dryCap[1])) * S2(c.HSfac1)) * S2(c.r_twoDT);
-  return -rcp2(fma2(S2(c.lk4[j][0]), chwt, S2(c.lk4[j][1])));
+  return rcp2(fma2(S2(kA), chwt, S2(kB)));
 }
+__device__ __forceinline__ f2 x2_layer_rcap(const ConstsAS &c, const X2Lit &L, int j, f2 tj, f2 *hs1) {
+  return x2_layer_rcap(c, L, c.lk4[j][0], c.lk4[j][1], c.lk4[j][3], tj, hs1);
+}
+
+/* A layer's four constants (RsConstantsF::lk4 row) by ONE scalar load issued a layer AHEAD: the compiler loads each
+ * member where it is first used, behind the frozen / thawed branch, and waits for it on the spot - thirteen layers,
+ * three exposed scalar-cache round trips each.  (The wait takes the value as an operand, so nothing that reads it
+ * can move above it.) */
+typedef float f4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4s x2_sload4(const ConstsAS *c, uint32_t byte_off) {
+  f4s r;
+  asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(r) : "s"(c), "s"(byte_off));
+  return r;
+}
+__device__ __forceinline__ void x2_swait(f4s &r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r)); }
 
 /* src/BoundaryLayer.f90:3-190 for two points: air properties, the fixed point, calcRaero, CalcLE.
  * active: the points that take part (not failed before this index); trips: passes per point (5 + the tail);
@@ -411,7 +462,7 @@ __device__ __forceinline__ void x2_boundary_layer(const ConstsAS &c, f2 tsurf, f
     const f2 av = lU + psim, bv = lC + psih;
     bl = C1 * rcp2(av * bv);
     f2 Stab = (C2 * bl) * (av * av * av);
-    Stab = sel2(gt2(Stab, S2(1.0f)), S2(1.0f), Stab);
+    Stab = min2(Stab, S2(1.0f)); /* (`if (Stab > 1) Stab = 1`; v_min_f32 differs for a NaN only) */
     const b2 stable = gt2(Stab, S2(0.f));
     const f2 ps = S2(4.7f) * Stab;
     const b2 uns = and2(not2(stable), act);
@@ -450,14 +501,14 @@ __device__ __forceinline__ void x2_boundary_layer(const ConstsAS &c, f2 tsurf, f
   blcond = BL;
   /* calcRaero (:112-131), CalcLE (:134-190) */
   f2 RAero = ((S2(c.logMom) + PSIM) * (S2(c.logHeat) + PSIH)) * rcp2(S2(c.VK_Const * c.VK_Const) * vz);
-  RAero = sel2(gt2(RAero, S2(30.0f)), S2(30.0f), RAero);
+  RAero = min2(RAero, S2(30.0f));
   const b2 sneg = lt2(tsurf, S2(0.f)), aneg = lt2(tair, S2(0.f));
   const f2 as = sel2(sneg, S2(21.875f), S2(17.269f)), bs = sel2(sneg, S2(265.5f), S2(237.3f));
   const f2 ESurf = S2(0.61078f) * exp2v((as * tsurf) * rcp2(tsurf + bs));
   const f2 aa = sel2(aneg, S2(21.875f), S2(17.269f)), ba = sel2(aneg, S2(265.5f), S2(237.3f));
   const f2 ESat = S2(0.61078f) * exp2v((aa * tair) * rcp2(tair + ba));
   f2 hum = S2(0.01f) * rhz;
-  hum = sel2(gt2(hum, S2(1.0f)), S2(1.0f), hum);
+  hum = min2(hum, S2(1.0f));
   const f2 EAir = hum * ESat;
   f2 le_ = ((AirDens * AirHCap) * (ESurf - EAir)) * rcp2(PsychC * RAero);
   const f2 lat = sel2(ge2(tsurf, S2(0.f)), S2(c.LVap), S2(c.LFus));
@@ -586,7 +637,7 @@ __global__ void __launch_bounds__(kX2Lanes, RS_X2_WAVES) step_kernel_f32x2(const
       if (hour_per_point) hour_p = i2{(ka->f.hour + row)[0], liveY ? (ka->f.hour + row)[1] : 0};
       else hour_u = ka->f.hour[k];
     }
-    if (i == 1) vz = sel2(lt2(vz, S2(0.4f)), S2(0.4f), vz); /* src/Initialization.f90:121-123 */
+    if (i == 1) vz = max2(vz, S2(0.4f)); /* src/Initialization.f90:121-123 */
     const f2 prec_ts = (prec * S2(__builtin_amdgcn_rcpf(3600.0f))) * S2(c.DTSecs);
     /* CheckValues (src/InputOutput.f90:45-84): a point that fails still takes this step, and no other */
     if (i < c.SimLen) {
@@ -628,7 +679,7 @@ __global__ void __launch_bounds__(kX2Lanes, RS_X2_WAVES) step_kernel_f32x2(const
         calm = S2(night ? calmN : calmD);
         trffric = S2(night ? fricN : fricD);
       }
-      vz = sel2(lt2(vz, calm), calm, vz);
+      vz = max2(vz, calm);
     }
     f2 blcond, le, evap;
     i2 trips;
@@ -655,14 +706,15 @@ __global__ void __launch_bounds__(kX2Lanes, RS_X2_WAVES) step_kernel_f32x2(const
     {
       f2 Gprev = ((rnet - le) + trffric) + blcond * (tair - t1old);
       const f2 dts = S2(c.DTSecs);
+      X2Lit lit;
+      lit.make();
 #pragma unroll
       for (int j = 1; j <= 15; ++j) {
         const f2 tj = T[j - 1];
         const f2 tnext = (j == 15) ? tbot : T[j];
-        const b2 thawed = ge2(tj, S2(0.f));
-        const f2 capDZ = x2_layer_capdz(c, j, tj, j == 1 ? &hs1 : nullptr);
+        const f2 rcap = x2_layer_rcap(c, lit, j, tj, j == 1 ? &hs1 : nullptr);
         const f2 G = S2(c.lk4[j][2]) * (tnext - tj);
-        T[j - 1] = fma2(dts, capDZ * (G - Gprev), tj);
+        T[j - 1] = fma2(dts, rcap * (Gprev - G), tj);
         Gprev = G;
         /* the update belongs HERE: left alone, the compiler sinks the fifteen updates behind the last layer's
          * branch and keeps fifteen capDZ pairs alive until then (30 registers, all of them spilled) */
@@ -835,7 +887,7 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
       if (hour_per_point) hour_p = i2{liveX ? (ka->f.hour + row)[0] : 0, liveY ? (ka->f.hour + row)[1] : 0};
       else hour_u = ka->f.hour[in - t0];
     }
-    if (in == 1) vz = sel2(lt2(vz, S2(0.4f)), S2(0.4f), vz); /* src/Initialization.f90:121-123 */
+    if (in == 1) vz = max2(vz, S2(0.4f)); /* src/Initialization.f90:121-123 */
     uint32_t flx = 0u, fly = 0u;
     if (in < c.SimLen) { /* CheckValues' forcing tests (src/InputOutput.f90:45-84); the surface temperature's are the surface wave's */
       Forcing fa, fb;
@@ -877,7 +929,7 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
         flx |= night ? 2u : 0u;
         fly |= night ? 2u : 0u;
       }
-      vz = sel2(lt2(vz, calm), calm, vz);
+      vz = max2(vz, calm);
     }
     /* air properties and the loop's invariants (src/BoundaryLayer.f90:50-62,78-79; x2_boundary_layer has the algebra) */
     const f2 TaK = tair + S2(273.15f);
@@ -896,7 +948,7 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
     const f2 aa = sel2(aneg, S2(21.875f), S2(17.269f)), ba = sel2(aneg, S2(265.5f), S2(237.3f));
     const f2 ESat = S2(0.61078f) * exp2v((aa * tair) * rcp2(tair + ba));
     f2 hum = S2(0.01f) * rhz;
-    hum = sel2(gt2(hum, S2(1.0f)), S2(1.0f), hum);
+    hum = min2(hum, S2(1.0f));
     float (*w)[128] = mail.prep[buf];
     lds_st2(w[XP_TAIR], lane, tair); lds_st2(w[XP_C1], lane, C1); lds_st2(w[XP_K3], lane, K3);
     lds_st2(w[XP_RRA], lane, rRA); lds_st2(w[XP_AVCAP], lane, AirVCap); lds_st2(w[XP_PSYCH], lane, PsychC);
@@ -915,13 +967,25 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
     /* (a point that has failed keeps stepping here: its layers are never read again) */
     f2 Gprev = S2(c.lk4[2][2]) * (T[0] - t2); /* G(2), the expression layer 2 itself evaluates */
     const f2 dts = S2(c.DTSecs);
+    X2Lit lit;
+    lit.make();
+    constexpr uint32_t lk0 = (uint32_t)offsetof(RsConstantsF, lk4);
+    f4s kn = x2_sload4(&c, lk0 + 3u * 16u);
+#ifdef RS_ABL_NOLAYERS
+#pragma unroll
+    for (int j = 3; j <= 3; ++j) {
+#else
 #pragma unroll
     for (int j = 3; j <= 15; ++j) {
+#endif
+      f4s kc = kn;
+      x2_swait(kc);
+      if (j < 15) kn = x2_sload4(&c, lk0 + (uint32_t)(j + 1) * 16u);
       const f2 tj = T[j - 3];
       const f2 tnext = (j == 15) ? tbot : T[j - 2];
-      const f2 capDZ = x2_layer_capdz(c, j, tj, nullptr);
-      const f2 G = S2(c.lk4[j][2]) * (tnext - tj);
-      T[j - 3] = fma2(dts, capDZ * (G - Gprev), tj);
+      const f2 rcap = x2_layer_rcap(c, lit, kc.x, kc.y, kc.w, tj, nullptr);
+      const f2 G = S2(kc.z) * (tnext - tj);
+      T[j - 3] = fma2(dts, rcap * (Gprev - G), tj);
       Gprev = G;
       asm volatile("" : "+v"(T[j - 3]), "+v"(Gprev)); /* the update belongs HERE (see step_kernel_f32x2) */
     }
@@ -1004,61 +1068,79 @@ __device__ __forceinline__ void x2d_surface(X2Mail &mail, const rs::StepArgs &a)
         if (badx) { s.failed.x = true; st[(int64_t)RS_ST_FAILED * np + p] = (float)i; }
         if (bady) { s.failed.y = true; st[(int64_t)RS_ST_FAILED * np + p + 1] = (float)i; }
       }
-      const b2 live = not2(was_failed);
       s.wat = s.wat + lds_ld2(w[XP_RAIN], lane);
       s.snow = s.snow + lds_ld2(w[XP_SNOW], lane);
       const f2 trffric = f2{(fl.x & 2u) ? c.TrfFricNgt : c.TrFfricDay, (fl.y & 2u) ? c.TrfFricNgt : c.TrFfricDay};
-      /* ---- the boundary-layer fixed point (x2_boundary_layer's algebra) from the handed-over invariants ---- */
+      /* ---- the boundary-layer fixed point (x2_boundary_layer's algebra) from the handed-over invariants ----
+       * which points are still in the loop is kept as two wavefront masks on the scalar unit */
       f2 blcond, le, evap;
-      i2 trips;
-      b2 unst = b2{false, false};
+      i2 trips = i2{5, 5};
+      uint64_t unsx = 0ull, unsy = 0ull; /* (SCORE) some pass of the point took the unstable arm */
       {
         const f2 C1 = lds_ld2(w[XP_C1], lane);
         const f2 C2 = lds_ld2(w[XP_K3], lane) * (s.tsurf - tair);
         f2 PSIM = S2(0.f), PSIH = S2(0.f), BL = S2(0.f);
         const f2 lU = S2(c.logUstar), lC = S2(c.logCond);
-        auto pass = [&](f2 &psim, f2 &psih, f2 &bl, b2 act) {
+        const uint64_t livex = __builtin_amdgcn_ballot_w64(!was_failed.x), livey = __builtin_amdgcn_ballot_w64(!was_failed.y);
+        auto pass = [&](f2 &psim, f2 &psih, f2 &bl, uint64_t actx, uint64_t acty) {
           const f2 av = lU + psim, bv = lC + psih;
           bl = C1 * rcp2(av * bv);
           f2 Stab = (C2 * bl) * (av * av * av);
-          Stab = sel2(gt2(Stab, S2(1.0f)), S2(1.0f), Stab);
-          const b2 stable = gt2(Stab, S2(0.f));
+          Stab = min2(Stab, S2(1.0f)); /* (`if (Stab > 1) Stab = 1`; v_min_f32 differs for a NaN only) */
+          const bool stx = Stab.x > 0.f, sty = Stab.y > 0.f;
           const f2 ps = S2(4.7f) * Stab;
-          const b2 uns = and2(not2(stable), act);
-          if (wave_any2(uns)) {
+          const uint64_t ux = __builtin_amdgcn_ballot_w64(!stx) & actx, uy = __builtin_amdgcn_ballot_w64(!sty) & acty;
+          if ((ux | uy) != 0ull) { /* (the plan order keeps the regimes together) */
             const f2 arg = (S2(1.0f) + sqrt2(fma2(S2(-16.0f), Stab, S2(1.0f)))) * S2(0.5f);
             const f2 pu = S2(-2.0f * 0.69314718056f) * f2{__builtin_amdgcn_logf(arg.x), __builtin_amdgcn_logf(arg.y)};
-            psih = sel2(stable, ps, pu);
-            psim = sel2(stable, ps, S2(0.6f) * pu);
-            if (SCORE) unst = or2(unst, uns);
+            const f2 pm = S2(0.6f) * pu;
+            psih = f2{stx ? ps.x : pu.x, sty ? ps.y : pu.y};
+            psim = f2{stx ? ps.x : pm.x, sty ? ps.y : pm.y};
+            if (SCORE) {
+              unsx |= ux;
+              unsy |= uy;
+            }
           } else {
             psih = ps;
             psim = ps;
           }
         };
+#ifdef RS_ABL_NOBL
+        const int npre = 1;
+#else
+        const int npre = 4;
+#endif
+        /* passes 1-4 never test (j >= 5 in the exit condition), the fifth is the first that may end the loop */
 #pragma unroll 1
-        for (int j = 1; j <= 4; ++j) pass(PSIM, PSIH, BL, live);
-        b2 act;
+        for (int j = 1; j <= npre; ++j) pass(PSIM, PSIH, BL, livex, livey);
+        uint64_t actx, acty;
         {
           const f2 old = BL;
-          pass(PSIM, PSIH, BL, live);
-          act = and2(live, not2(lt2(abs2(BL - old), S2(0.001f))));
+          pass(PSIM, PSIH, BL, livex, livey);
+          const f2 d = abs2(BL - old);
+          actx = livex & ~__builtin_amdgcn_ballot_w64(d.x < 0.001f);
+          acty = livey & ~__builtin_amdgcn_ballot_w64(d.y < 0.001f);
+#ifdef RS_ABL_NOBL
+          actx = acty = 0ull;
+#endif
         }
-        trips = i2{5, 5};
-        for (int j = 6; j <= RS_BL_MAXIT && wave_any2(act); ++j) {
+        /* the tail: a point that has left the loop keeps its values (what a lane's exit does in the one-point flavours) */
+        const bool count = SCORE || k == nsteps - 1;
+        for (int j = 6; j <= RS_BL_MAXIT && (actx | acty) != 0ull; ++j) {
           f2 pm = PSIM, ph = PSIH, bl = BL;
-          pass(pm, ph, bl, act);
-          const b2 done = lt2(abs2(bl - BL), S2(0.001f));
-          PSIM = sel2(act, pm, PSIM);
-          PSIH = sel2(act, ph, PSIH);
-          BL = sel2(act, bl, BL);
-          trips = i2{trips.x + (act.x ? 1 : 0), trips.y + (act.y ? 1 : 0)};
-          act = and2(act, not2(done));
+          pass(pm, ph, bl, actx, acty);
+          const f2 d = abs2(bl - BL);
+          PSIM = f2{selm(actx, pm.x, PSIM.x), selm(acty, pm.y, PSIM.y)};
+          PSIH = f2{selm(actx, ph.x, PSIH.x), selm(acty, ph.y, PSIH.y)};
+          BL = f2{selm(actx, bl.x, BL.x), selm(acty, bl.y, BL.y)};
+          if (count) trips = i2{addm(actx, trips.x), addm(acty, trips.y)};
+          actx &= ~__builtin_amdgcn_ballot_w64(d.x < 0.001f);
+          acty &= ~__builtin_amdgcn_ballot_w64(d.y < 0.001f);
         }
         blcond = BL;
         /* calcRaero (:112-131), CalcLE (:134-190) */
         f2 RAero = ((S2(c.logMom) + PSIM) * (S2(c.logHeat) + PSIH)) * lds_ld2(w[XP_RRA], lane);
-        RAero = sel2(gt2(RAero, S2(30.0f)), S2(30.0f), RAero);
+        RAero = min2(RAero, S2(30.0f));
         const b2 sneg = lt2(s.tsurf, S2(0.f));
         const f2 as = sel2(sneg, S2(21.875f), S2(17.269f)), bs = sel2(sneg, S2(265.5f), S2(237.3f));
         const f2 ESurf = S2(0.61078f) * exp2v((as * s.tsurf) * rcp2(s.tsurf + bs));
@@ -1072,7 +1154,7 @@ __device__ __forceinline__ void x2d_surface(X2Mail &mail, const rs::StepArgs &a)
       }
       if (SCORE) {
         score = i2{score.x + trips.x - 5, score.y + trips.y - 5};
-        if (k >= nsteps - 30) regime = i2{regime.x | (unst.x ? 1 : 0), regime.y | (unst.y ? 1 : 0)};
+        if (k >= nsteps - 30) regime = i2{regime.x | (int32_t)selm(unsx, 1.f, 0.f), regime.y | (int32_t)selm(unsy, 1.f, 0.f)};
       } else {
         last_trips = trips;
       }
@@ -1090,12 +1172,14 @@ __device__ __forceinline__ void x2d_surface(X2Mail &mail, const rs::StepArgs &a)
       {
         const f2 dts = S2(c.DTSecs);
         f2 Gprev = ((rnet - le) + trffric) + blcond * (tair - t1old);
-        const f2 cap1 = x2_layer_capdz(c, 1, t1old, &hs1);
+        X2Lit lit;
+        lit.make();
+        const f2 rcap1 = x2_layer_rcap(c, lit, 1, t1old, &hs1);
         const f2 G1 = S2(c.lk4[1][2]) * (t2old - t1old);
-        T1 = fma2(dts, cap1 * (G1 - Gprev), t1old);
-        const f2 cap2 = x2_layer_capdz(c, 2, t2old, nullptr);
+        T1 = fma2(dts, rcap1 * (Gprev - G1), t1old);
+        const f2 rcap2 = x2_layer_rcap(c, lit, 2, t2old, nullptr);
         const f2 G2 = S2(c.lk4[2][2]) * (t3 - t2old);
-        T2 = fma2(dts, cap2 * (G2 - G1), t2old);
+        T2 = fma2(dts, rcap2 * (G1 - G2), t2old);
       }
       /* calcHStor, melting, the new surface temperature, RoadCond ... CalcAlbedo: per point (see step_kernel_f32x2) */
       {
@@ -1111,10 +1195,14 @@ __device__ __forceinline__ void x2d_surface(X2Mail &mail, const rs::StepArgs &a)
           TT.set(1, comp ? T1.y : T1.x);
           TT.set(2, comp ? T2.y : T2.x);
           Scalars q = x2_scalars(s, comp, TT.get(1), TT.get(2));
+#ifndef RS_ABL_NOROAD /* (ablation builds, tools/experiments/r6_ablate.sh: what a part costs) */
           if (melt_here) melting(q, TT, comp ? hstor.y : hstor.x, comp ? hs1.y : hs1.x, false, 0.f);
           else q.q2melt = 0.f;
+#endif
           q.tsurf = (TT.get(1) + TT.get(2)) / 2.0f;
+#ifndef RS_ABL_NOROAD
           road_condition(c, q, comp ? evap.y : evap.x);
+#endif
           if (comp) {
             T1.y = TT.get(1); T2.y = TT.get(2);
             s.tsurf.y = q.tsurf; s.wat.y = q.wat; s.snow.y = q.snow; s.ice.y = q.ice; s.ice2.y = q.ice2; s.dep.y = q.dep;
