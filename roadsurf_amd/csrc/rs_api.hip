@@ -321,6 +321,10 @@ RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints, const RsConstants *c
 }
 
 static inline int32_t underfilled(const RsPlan *pl) {
+  if (pl->f32) { /* (tuning, fp32 flavour) ROADSURF_HIP_F32_SURFACE_PRIO: 0 / 1 whatever the size */
+    static const int forced = [] { const char *e = getenv("ROADSURF_HIP_F32_SURFACE_PRIO"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return forced;
+  }
   return g_live_points[pl->device & 63].load() <= 131072 ? 1 : 0;
 }
 
@@ -540,8 +544,7 @@ int rs_hip_set_history_score(RsPlan *pl, int32_t on) {
 }
 
 int rs_hip_set_variant(RsPlan *pl, int32_t variant) {
-  /* (5: fp32 plans only - two points per lane in ONE wavefront, the A/B partner of the two-wavefront default) */
-  if (!pl || variant < 0 || variant % 10 > 5 || variant / 10 > 4 || (variant % 10 == 5 && variant != 5))
+  if (!pl || variant < 0 || variant % 10 > 4 || variant / 10 > 4)
     return set_err("rs_hip_set_variant: bad arguments");
   if (variant % 10 == RS_VARIANT_REG && pl->c.NLayers != 15)
     return set_err("register-profile kernel is built for NLayers == 15 only (got %d)",
@@ -865,7 +868,7 @@ int rs_hip_step_knots(RsPlan *pl, const RsSynthSpec *spec, const double *knots, 
     HIP_OK(hipEventRecord(e0, pl->stream));
   }
   /* fp32: two points per lane, each lane interpolating its own forcing (rs_kernels_f32.hip) */
-  const hipError_t le = pl->f32 ? rs32_launch_step_knots(a, pl->variant, pl->history_score, pl->stream)
+  const hipError_t le = pl->f32 ? rs32_launch_step_knots(a, pl->history_score, pl->stream)
                                 : rs_launch_step_duo_knots(a, pl->history_score, pl->stream);
   if (le != hipSuccess) return set_err("rs_hip_step_knots: kernel launch failed: %s", hipGetErrorString(le));
   if (pl->timing) {
@@ -1169,6 +1172,15 @@ int64_t rs_hip_failed_count(RsPlan *pl) {
   if (!pl) return -1;
   if (hipSetDevice(pl->device) != hipSuccess) return -1;
   unsigned long long h = 0;
+  if (pl->f32) { /* the state block holds floats: the row is counted on the host (a diagnostic, not a hot path) */
+    std::vector<float> row((size_t)pl->np_pad);
+    if (hipMemcpyAsync(row.data(), (const char *)pl->state + (size_t)RS_ST_FAILED * pl->np_pad * sizeof(float),
+                       row.size() * sizeof(float), hipMemcpyDeviceToHost, pl->stream) != hipSuccess)
+      return -1;
+    if (hipStreamSynchronize(pl->stream) != hipSuccess) return -1;
+    for (int64_t q = 0; q < pl->npoints; ++q) h += row[(size_t)q] != 0.f ? 1 : 0;
+    return (int64_t)h;
+  }
   if (hipMemsetAsync(pl->counter, 0, sizeof(h), pl->stream) != hipSuccess) return -1;
   if (rs_launch_count_failed(pl->state, pl->np_pad, pl->npoints, pl->counter, pl->stream) !=
       hipSuccess)

@@ -7,31 +7,38 @@
  * with the tolerance written there.  LEAN feature set only (no observation forcing after index 1,
  * output depth, relaxation, coupling, sky view).
  *
- * Round 6: step_kernel_f32x2, TWO POINTS PER LANE (NLayers = 15).  What decides the organisation is how a
- * gfx950 SIMD issues fp32 (tools/f32_issue.hip, profiles/r06_f32_issue_rates.txt): a wavefront's DEPENDENT
- * v_fma_f32 chain gets one instruction per 4.3-4.6 cycles however many wavefronts share the SIMD - the
- * rate of fp64 - and only a second INDEPENDENT instruction right behind it uses the other half of the slot
- * (2.35 cycles each); v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do two points in the one slot (4.1-4.7
- * cycles).  The model is a dependent chain, so one point per lane in fp32 issues at the fp64 rate (round
- * 2-5's flavour: 885 vector instructions per 64 point-steps, 1.6 x the fp64 rate only because rcp/exp/log
- * are single instructions).  Here a lane owns the points 2l and 2l+1 of its wavefront's 128 slots: state,
- * forcing and every temporary are float2 (ext_vector_type), the arithmetic is packed, compares, selects and
- * transcendentals come in independent pairs; the 15-layer update measured 1.52 x per point this way
- * (tools/f32_layer_probe.hip, profiles/r06_f32_layer_probe.txt).  Beside that:
- *   - no forcing window and no expansion kernel: the lane interpolates its two points' forcing from the
- *     resident hourly knots (rs_hip_step_knots on an fp32 plan; a window is still read by rs_hip_step);
- *   - explicit fused multiply-adds (the translation unit is still compiled with -ffp-contract=off: what
- *     is contracted is what is written, so a point's bits cannot depend on how the compiler scheduled the
- *     wavefront it sits in - tests/test_hip_f32.py::test_fp32_plan_order_changes_no_value);
+ * Round 6: step_kernel_f32duo, TWO POINTS PER LANE and two wavefronts per 128 points (NLayers = 15).
+ * What decides the organisation is how a gfx950 SIMD issues fp32 (tools/f32_issue.hip,
+ * profiles/r06_f32_issue_rates.txt): every vector instruction of a wavefront's DEPENDENT stream takes a
+ * four-cycle issue slot, fp32 or fp64, packed or not (v_fma_f32 4.3-4.6 cycles each however many wavefronts
+ * share the SIMD; 2.35 only behind an independent twin; v_pk_fma_f32 4.1-4.7).  The model is a dependent
+ * chain, so one point per lane in fp32 issues at the fp64 rate (round 2-5's flavour: 885 vector instructions
+ * per 64 point-steps, 1.6 x the fp64 rate only because rcp / exp / log are single instructions).  Here a lane
+ * owns the points 2l and 2l+1 of its workgroup's 128: state, forcing and temporaries are float2
+ * (ext_vector_type), the arithmetic is v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 - two points per slot -,
+ * compares, selects and transcendentals come in pairs (the 15-layer update alone: 1.52 x per point,
+ * tools/f32_layer_probe.hip, profiles/r06_f32_layer_probe.txt).  Beside that:
+ *   - two wavefronts per 128 points as in the fp64 flavour (ground wave: layers 3-15 and the forcing's share
+ *     of a step one index ahead; surface wave: the chain from the surface state), 96 registers each, five
+ *     wavefronts per SIMD.  One wavefront holding everything needed 168-250 registers, two or three per SIMD,
+ *     and ran at 4.1e10 - what one point per lane had given;
+ *   - no forcing window and no expansion kernel: the ground wave interpolates its points' forcing from the
+ *     resident hourly knots (rs_hip_step_knots on an fp32 plan; rs_hip_step still reads a window);
+ *   - explicit fused multiply-adds (the translation unit is still compiled with -ffp-contract=off: what is
+ *     contracted is what is written, so a point's bits cannot depend on how the compiler scheduled the wavefront
+ *     it sits in - tests/test_hip_f32.py::test_fp32_plan_order_changes_no_value);
  *   - the boundary-layer fixed point (src/BoundaryLayer.f90:64-96) with ONE reciprocal per pass instead of
  *     three: UStar = VK VZ / a and BLCond = avk UStar / b give BLCond = (avk VK VZ) / (a b) and
  *     1 / (den0 UStar^3) = a^3 / (den0 (VK VZ)^3), whose constant part leaves the loop - the same iteration,
- *     the same exit test, other roundings (this flavour is gated by a distribution, not by bits);
- *   - frozen layers from constants where all 128 points of the wavefront have the layer frozen, made ON THE
+ *     the same exit test, other roundings (this flavour is gated by a distribution, not by bits); which points
+ *     are still iterating is two wavefront masks on the scalar unit;
+ *   - frozen layers from constants where all 128 points of the workgroup have the layer frozen, made ON THE
  *     DEVICE by the lanes' own expression (prepare_constants_f32: a host-made constant differs in the last
- *     bit from v_rcp_f32's, and a point's bits would depend on its wavefront);
+ *     bit from v_rcp_f32's, and a point's bits would depend on its wavefront); the water polynomials in Horner
+ *     form; a layer's four constants by one scalar load issued a layer ahead;
+ *   - CheckValues' forcing tests an hour at a time where both knots keep a margin to the limits;
  *   - the storages' state machine (src/Storage.f90, src/Cond.f90: compares and selects, nothing to pack)
- *     per point through the one-point physics source, behind the wavefront-uniform shortcuts.
+ *     per point through the one-point physics source, behind its wavefront-uniform shortcuts.
  * Other layer counts keep one point per lane with the profile in LDS (step_kernel_f32_lds).
  */
 #include <hip/hip_runtime.h>
@@ -265,7 +272,7 @@ __global__ void __launch_bounds__(kBlock) expand_kernel_f32(const rs::ExpandArgs
     uint32_t b4; /* the lane's byte offset, formed in this block (rs_kernels.hip, LaneOff) */
     asm volatile("v_lshlrev_b32 %0, 2, %1" : "=v"(b4) : "v"(threadIdx.x));
     auto st = [&](const void *base, float v) { *(float *)((char *)((float *)base + row) + b4) = v; };
-    /* rs32_lerp: the arithmetic step_kernel_f32x2 uses when it reads the knots itself - a window and the
+    /* rs32_lerp: the arithmetic step_kernel_f32duo's ground wave uses when it reads the knots itself - a window and the
      * knot-reading launch hand the model the same bits */
     float v[7];
     const float w = rs32_lerp_weight(r, a.r_spk);
@@ -333,10 +340,6 @@ __device__ __forceinline__ int32_t addm(uint64_t mask, int32_t t) { /* t + 1 in 
   return r;
 }
 
-constexpr int kX2Lanes = 64; /* one wavefront per workgroup: 128 points, no LDS, no barrier */
-#ifndef RS_X2_WAVES
-#define RS_X2_WAVES 3 /* wavefronts per SIMD the register budget is cut for (512 / 3 = 168 VGPRs) */
-#endif
 enum { X2_WINDOW = 0, X2_KNOTS = 1 };
 constexpr float kCHF = 920.0f * 2100.0f; /* density x specific heat of ice: the frozen branch of CalcHCapHCond */
 
@@ -432,367 +435,13 @@ __device__ __forceinline__ f4s x2_sload4(const ConstsAS *c, uint32_t byte_off) {
 }
 __device__ __forceinline__ void x2_swait(f4s &r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r)); }
 
-/* src/BoundaryLayer.f90:3-190 for two points: air properties, the fixed point, calcRaero, CalcLE.
- * active: the points that take part (not failed before this index); trips: passes per point (5 + the tail);
- * unst (SCORE): some pass of the point took the unstable arm. */
-template <bool SCORE>
-__device__ __forceinline__ void x2_boundary_layer(const ConstsAS &c, f2 tsurf, f2 tair, f2 vz, f2 rhz, f2 wat,
-                                                  b2 live, f2 &blcond, f2 &le, f2 &evap, i2 &trips, b2 &unst) {
-  /* bl_setup (:50-62) */
-  const f2 TaK = tair + S2(273.15f);
-  const f2 AirDens = S2(100000.0f) * rcp2(S2(287.05f) * TaK);
-  const f2 dK = (TaK - S2(250.0f)) * (TaK - S2(250.0f));
-  const f2 AirHCap = fma2(dK, S2(1.0f / 3364.0f), S2(1005.0f));
-  const f2 AirVCap = AirHCap * AirDens;
-  const f2 PsychC = S2(0.1f) * fma2(S2(0.00063f), TaK, S2(0.47496f));
-  const f2 WatDen = fma2(S2(-0.0050f) * tsurf, tsurf, fma2(S2(0.0079f), tsurf, S2(1000.0028f)));
-  const f2 dT = tsurf - tair;
-  const f2 den0 = AirVCap * TaK;
-  const f2 vkvz = S2(c.VK_Const) * vz;
-  /* the loop (:64-96) with one reciprocal per pass: with a = logUstar + PSIM, b = logCond + PSIH
-   *   UStar = vkvz / a,  BLCond = avk UStar / b = (avk vkvz) / (a b),
-   *   Stab  = stab_num BLCond dT / (den0 UStar^3) = [stab_num dT / (den0 vkvz^3)] BLCond a^3 */
-  const f2 C1 = (AirVCap * S2(c.VK_Const)) * vkvz;
-  const float stab_num = -c.VK_Const * c.ZRefT * c.Grav;
-  const f2 C2 = (S2(stab_num) * dT) * rcp2(den0 * (vkvz * vkvz * vkvz));
-  f2 PSIM = S2(0.f), PSIH = S2(0.f), BL = S2(0.f);
-  const f2 lU = S2(c.logUstar), lC = S2(c.logCond);
-  b2 u = b2{false, false};
-  auto pass = [&](f2 &psim, f2 &psih, f2 &bl, b2 act) {
-    const f2 av = lU + psim, bv = lC + psih;
-    bl = C1 * rcp2(av * bv);
-    f2 Stab = (C2 * bl) * (av * av * av);
-    Stab = min2(Stab, S2(1.0f)); /* (`if (Stab > 1) Stab = 1`; v_min_f32 differs for a NaN only) */
-    const b2 stable = gt2(Stab, S2(0.f));
-    const f2 ps = S2(4.7f) * Stab;
-    const b2 uns = and2(not2(stable), act);
-    if (wave_any2(uns)) { /* (the plan order keeps the regimes together: most wavefronts are stable throughout) */
-      const f2 pu = S2(-2.0f) * log2v((S2(1.0f) + sqrt2(fma2(S2(-16.0f), Stab, S2(1.0f)))) * S2(0.5f));
-      psih = sel2(stable, ps, pu);
-      psim = sel2(stable, ps, S2(0.6f) * pu);
-      if (SCORE) u = or2(u, uns);
-    } else {
-      psih = ps;
-      psim = ps;
-    }
-  };
-  /* passes 1-4 never test (j >= 5 in the exit condition), the fifth is the first that may end the loop */
-#pragma unroll 1
-  for (int j = 1; j <= 4; ++j) pass(PSIM, PSIH, BL, live);
-  b2 act;
-  {
-    const f2 old = BL;
-    pass(PSIM, PSIH, BL, live);
-    act = and2(live, not2(lt2(abs2(BL - old), S2(0.001f))));
-  }
-  trips = i2{5, 5};
-  /* the tail: a point that has left the loop keeps its values (what a lane's exit does in the one-point flavours) */
-  for (int j = 6; j <= RS_BL_MAXIT && wave_any2(act); ++j) {
-    f2 pm = PSIM, ph = PSIH, bl = BL;
-    pass(pm, ph, bl, act);
-    const b2 done = lt2(abs2(bl - BL), S2(0.001f));
-    PSIM = sel2(act, pm, PSIM);
-    PSIH = sel2(act, ph, PSIH);
-    BL = sel2(act, bl, BL);
-    trips = i2{trips.x + (act.x ? 1 : 0), trips.y + (act.y ? 1 : 0)};
-    act = and2(act, not2(done));
-  }
-  unst = u;
-  blcond = BL;
-  /* calcRaero (:112-131), CalcLE (:134-190) */
-  f2 RAero = ((S2(c.logMom) + PSIM) * (S2(c.logHeat) + PSIH)) * rcp2(S2(c.VK_Const * c.VK_Const) * vz);
-  RAero = min2(RAero, S2(30.0f));
-  const b2 sneg = lt2(tsurf, S2(0.f)), aneg = lt2(tair, S2(0.f));
-  const f2 as = sel2(sneg, S2(21.875f), S2(17.269f)), bs = sel2(sneg, S2(265.5f), S2(237.3f));
-  const f2 ESurf = S2(0.61078f) * exp2v((as * tsurf) * rcp2(tsurf + bs));
-  const f2 aa = sel2(aneg, S2(21.875f), S2(17.269f)), ba = sel2(aneg, S2(265.5f), S2(237.3f));
-  const f2 ESat = S2(0.61078f) * exp2v((aa * tair) * rcp2(tair + ba));
-  f2 hum = S2(0.01f) * rhz;
-  hum = min2(hum, S2(1.0f));
-  const f2 EAir = hum * ESat;
-  f2 le_ = ((AirDens * AirHCap) * (ESurf - EAir)) * rcp2(PsychC * RAero);
-  const f2 lat = sel2(ge2(tsurf, S2(0.f)), S2(c.LVap), S2(c.LFus));
-  f2 ev = ((le_ * rcp2(lat * WatDen)) * S2(1000.0f)) * S2(c.DTSecs);
-  const b2 nowater = and2(gt2(le_, S2(0.f)), le2(wat, S2(0.f)));
-  le = sel2(nowater, S2(0.f), le_);
-  evap = sel2(nowater, S2(0.f), ev);
-}
-
-template <int SRC, bool SCORE>
-__global__ void __launch_bounds__(kX2Lanes, RS_X2_WAVES) step_kernel_f32x2(const rs::StepArgs a) {
-  KernArgs ka = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
-  const uint32_t lane = threadIdx.x;
-  const int64_t p = 2 * ((int64_t)blockIdx.x * kX2Lanes + lane); /* the lane's points: p, p + 1 */
-  if (p >= a.npoints) return;
-  const bool liveY = p + 1 < a.npoints;
-  const int64_t np = a.np_pad;
-  float *st = reinterpret_cast<float *>(a.state);
-  auto ldst = [&](int slot) -> f2 { return *reinterpret_cast<const f2 *>(st + (int64_t)slot * np + p); };
-  auto stst = [&](int slot, f2 v) { *reinterpret_cast<f2 *>(st + (int64_t)slot * np + p) = v; };
-  f2 T[15];
-#pragma unroll
-  for (int j = 0; j < 15; ++j) T[j] = ldst(RS_ST_TMP0 + j);
-  X2State s;
-  s.tsurf = ldst(RS_ST_TSURF);
-  s.wat = ldst(RS_ST_WAT); s.snow = ldst(RS_ST_SNOW); s.ice = ldst(RS_ST_ICE); s.ice2 = ldst(RS_ST_ICE2);
-  s.dep = ldst(RS_ST_DEP); s.q2melt = ldst(RS_ST_Q2MELT); s.t4melt = ldst(RS_ST_T4MELT);
-  s.albedo = ldst(RS_ST_ALBEDO);
-  {
-    const f2 vc = ldst(RS_ST_VERYCOLD), fl = ldst(RS_ST_FAILED);
-    s.verycold = b2{vc.x != 0.f, vc.y != 0.f};
-    s.failed = b2{fl.x != 0.f, fl.y != 0.f || !liveY}; /* the second point of the last lane may not exist: it never steps */
-  }
-  const f2 tbot = f2{(float)ka->pp.tbottom[p], liveY ? (float)ka->pp.tbottom[p + 1] : 0.f};
-  const int32_t nsteps = ka->nsteps, t0 = ka->t0;
-  rs::MathTab mt{nullptr, nullptr, nullptr}; /* fp32 exp/log take no tables */
-  i2 score = i2{0, 0}, regime = i2{0, 0}, last_trips = i2{0, 0};
-  /* knots: the lane's two columns of the resident knot block, the current interval's values and differences */
-  f2 kv0[6], kdv[6];
-  i2 kph0 = i2{0, 0}, kph1 = i2{0, 0};
-  int32_t kcur = -1;
-  int64_t kcolx = p, kcoly = p + 1;
-  if (SRC == X2_KNOTS && ka->knot_gather) {
-    kcolx = ka->knot_gather[p];
-    kcoly = liveY ? ka->knot_gather[p + 1] : kcolx;
-  } else if (!liveY) {
-    kcoly = kcolx;
-  }
-  /* windows: rows of floats; a pair is one 8-byte access where the stride keeps it aligned */
-  const bool fvec = SRC == X2_WINDOW && !(ka->f.t_stride & 1) && liveY;
-  const bool ovec = !(ka->o.t_stride & 1) && liveY;
-
-  for (int32_t k = 0; k < nsteps; ++k) {
-    asm volatile("" : "+s"(ka));
-    const ConstsAS &c = consts_of(ka);
-    const int32_t i = t0 + k;
-    int64_t r = (int64_t)(i - 1);
-    const int32_t dec = ka->o.decimate;
-    bool write = true;
-    if (dec > 1) {
-      write = (r % dec == 0);
-      r /= dec;
-    }
-    const int64_t orow = (r - ka->o.row0) * ka->o.t_stride + p;
-    const b2 was_failed = s.failed;
-    auto out2 = [&](void *base, f2 v) {
-      float *q = reinterpret_cast<float *>(base) + orow;
-      if (ovec) {
-        *reinterpret_cast<f2 *>(q) = v;
-      } else {
-        q[0] = v.x;
-        if (liveY) q[1] = v.y;
-      }
-    };
-    if (wave_all2(was_failed)) { /* nothing left to step in this wavefront */
-      if (write) {
-        const f2 m = S2(-9999.0f);
-        out2(ka->o.tsurf, m); out2(ka->o.snow, m); out2(ka->o.water, m);
-        out2(ka->o.ice, m); out2(ka->o.deposit, m); out2(ka->o.ice2, m);
-      }
-      continue;
-    }
-    /* ---- the forcing of index i ---- */
-    f2 tair, vz, rhz, prec, sw, lw;
-    i2 phase;
-    int32_t hour_u = 0;
-    i2 hour_p = i2{0, 0};
-    bool hour_per_point = false;
-    if (SRC == X2_KNOTS) {
-      const int32_t spk = ka->spk;
-      const int32_t t = i - 1;
-      const int32_t kk = __builtin_amdgcn_readfirstlane(t / spk);
-      const int32_t rr = t - kk * spk;
-      if (kk != kcur) { /* uniform: a new knot interval - expand_kernel_f32's loads and differences */
-        kcur = kk;
-        const int fld[6] = {0, 2, 3, 4, 5, 6};
-        const double *ka_ = ka->knots + ((int64_t)(kk - ka->knot_k0) * RS_KNOT_FIELDS) * np;
-        const bool has_b = (kk + 1 - ka->knot_k0) < ka->knot_n;
-        const double *kb_ = ka_ + (int64_t)RS_KNOT_FIELDS * np;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          const double ax = ka_[(int64_t)fld[q] * np + kcolx], ay = ka_[(int64_t)fld[q] * np + kcoly];
-          const double bx = has_b ? kb_[(int64_t)fld[q] * np + kcolx] : ax, by = has_b ? kb_[(int64_t)fld[q] * np + kcoly] : ay;
-          kv0[q] = f2{(float)ax, (float)ay};
-          kdv[q] = f2{(float)(bx - ax), (float)(by - ay)};
-        }
-        kph0 = i2{(int32_t)ka_[8 * np + kcolx], (int32_t)ka_[8 * np + kcoly]};
-        kph1 = has_b ? i2{(int32_t)kb_[8 * np + kcolx], (int32_t)kb_[8 * np + kcoly]} : kph0;
-      }
-      const f2 w = S2(rs32_lerp_weight(rr, ka->r_spk));
-      tair = fma2(w, kdv[0], kv0[0]); vz = fma2(w, kdv[1], kv0[1]); rhz = fma2(w, kdv[2], kv0[2]);
-      prec = fma2(w, kdv[3], kv0[3]); sw = fma2(w, kdv[4], kv0[4]); lw = fma2(w, kdv[5], kv0[5]);
-      phase = (rr == 0) ? kph0 : kph1;
-      hour_u = rs_sy_hour(i, spk, ka->start_hour);
-    } else {
-      const int64_t row = (int64_t)k * ka->f.t_stride + p;
-      auto in2 = [&](const void *base) -> f2 {
-        const float *q = reinterpret_cast<const float *>(base) + row;
-        if (fvec) return *reinterpret_cast<const f2 *>(q);
-        return f2{q[0], liveY ? q[1] : 0.f};
-      };
-      tair = in2(ka->f.tair); vz = in2(ka->f.vz); rhz = in2(ka->f.rhz);
-      prec = in2(ka->f.prec); sw = in2(ka->f.sw); lw = in2(ka->f.lw);
-      phase = i2{(ka->f.precphase + row)[0], liveY ? (ka->f.precphase + row)[1] : 0};
-      hour_per_point = ka->f.hour_pstride != 0;
-      if (hour_per_point) hour_p = i2{(ka->f.hour + row)[0], liveY ? (ka->f.hour + row)[1] : 0};
-      else hour_u = ka->f.hour[k];
-    }
-    if (i == 1) vz = max2(vz, S2(0.4f)); /* src/Initialization.f90:121-123 */
-    const f2 prec_ts = (prec * S2(__builtin_amdgcn_rcpf(3600.0f))) * S2(c.DTSecs);
-    /* CheckValues (src/InputOutput.f90:45-84): a point that fails still takes this step, and no other */
-    if (i < c.SimLen) {
-      Forcing fa, fb;
-      fa.tair = tair.x; fa.vz = vz.x; fa.rhz = rhz.x; fa.prec = prec.x; fa.sw = sw.x; fa.lw = lw.x;
-      fb.tair = tair.y; fb.vz = vz.y; fb.rhz = rhz.y; fb.prec = prec.y; fb.sw = sw.y; fb.lw = lw.y;
-      fa.tdew = fb.tdew = 0.f; fa.tsurfobs = fb.tsurfobs = -9999.9f; fa.depth = fb.depth = -9999.9f;
-      fa.phase = phase.x; fb.phase = phase.y; fa.hour = fb.hour = 0;
-      const bool badx = !was_failed.x && check_values(c, fa, s.tsurf.x, false);
-      const bool bady = !was_failed.y && check_values(c, fb, s.tsurf.y, false);
-      if (badx) { s.failed.x = true; st[(int64_t)RS_ST_FAILED * np + p] = (float)i; }
-      if (bady) { s.failed.y = true; st[(int64_t)RS_ST_FAILED * np + p + 1] = (float)i; }
-    }
-    const b2 live = not2(was_failed);
-    /* PrecipitationToStorage (src/Storage.f90:9-29, src/Cond.f90:143-249): rare, per point */
-    if (!(RS_PREC_FAST(c) && wave_all2(b2{prec_ts.x == 0.f, prec_ts.y == 0.f}))) {
-      Scalars z;
-      float pt = prec_ts.x;
-      z.wat = s.wat.x; z.snow = s.snow.x;
-      precipitation_to_storage(c, mt, z, phase.x, pt, tair.x, rhz.x);
-      s.wat.x = z.wat; s.snow.x = z.snow;
-      pt = prec_ts.y;
-      z.wat = s.wat.y; z.snow = s.snow.y;
-      precipitation_to_storage(c, mt, z, phase.y, pt, tair.y, rhz.y);
-      s.wat.y = z.wat; s.snow.y = z.snow;
-    }
-    /* SetDayDependendVariables (src/BalanceModel.f90:354-387) */
-    f2 trffric;
-    {
-      const float calmN = c.CalmLimNgt, calmD = c.CalmLimDay, fricN = c.TrfFricNgt, fricD = c.TrFfricDay;
-      f2 calm;
-      if (hour_per_point) {
-        const b2 night = b2{((float)hour_p.x >= c.NightOn) || ((float)hour_p.x <= c.NightOff),
-                            ((float)hour_p.y >= c.NightOn) || ((float)hour_p.y <= c.NightOff)};
-        calm = sel2(night, S2(calmN), S2(calmD));
-        trffric = sel2(night, S2(fricN), S2(fricD));
-      } else {
-        const bool night = ((float)hour_u >= c.NightOn) || ((float)hour_u <= c.NightOff);
-        calm = S2(night ? calmN : calmD);
-        trffric = S2(night ? fricN : fricD);
-      }
-      vz = max2(vz, calm);
-    }
-    f2 blcond, le, evap;
-    i2 trips;
-    b2 unst;
-    x2_boundary_layer<SCORE>(c, s.tsurf, tair, vz, rhz, s.wat, live, blcond, le, evap, trips, unst);
-    if (SCORE) {
-      score = i2{score.x + trips.x - 5, score.y + trips.y - 5};
-      if (k >= nsteps - 30) regime = i2{regime.x | (unst.x ? 1 : 0), regime.y | (unst.y ? 1 : 0)};
-    } else {
-      last_trips = trips;
-    }
-    /* CalcRNet (src/BalanceModel.f90:282-307) */
-    f2 rnet;
-    {
-      const f2 TK = s.tsurf + S2(273.15f);
-      const f2 TK2 = TK * TK;
-      const f2 RBB = S2(c.Emiss * c.SB_Const) * (TK2 * TK2);
-      rnet = fma2(S2(1.0f) - s.albedo, sw, fma2(S2(c.Emiss), lw, -RBB));
-    }
-    /* CalcHCapHCond + calcCapDZCondDZ + calcProfile, one fused pass over the layers (src/BalanceModel.f90:
-     * 189-251, 132-155, 90-129) */
-    const f2 t1old = T[0], t2old = T[1];
-    f2 hs1 = S2(0.f);
-    {
-      f2 Gprev = ((rnet - le) + trffric) + blcond * (tair - t1old);
-      const f2 dts = S2(c.DTSecs);
-      X2Lit lit;
-      lit.make();
-#pragma unroll
-      for (int j = 1; j <= 15; ++j) {
-        const f2 tj = T[j - 1];
-        const f2 tnext = (j == 15) ? tbot : T[j];
-        const f2 rcap = x2_layer_rcap(c, lit, j, tj, j == 1 ? &hs1 : nullptr);
-        const f2 G = S2(c.lk4[j][2]) * (tnext - tj);
-        T[j - 1] = fma2(dts, rcap * (Gprev - G), tj);
-        Gprev = G;
-        /* the update belongs HERE: left alone, the compiler sinks the fifteen updates behind the last layer's
-         * branch and keeps fifteen capDZ pairs alive until then (30 registers, all of them spilled) */
-        asm volatile("" : "+v"(T[j - 1]), "+v"(Gprev));
-      }
-    }
-    /* calcHStor (src/BalanceModel.f90:311-322), melting (src/Storage.f90:319-402), the new surface temperature,
-     * RoadCond with the four storages, NewMeltFreezeHeat, CalcAlbedo (src/Cond.f90:9-139): per point through the
-     * one-point source (compares and selects: nothing to pack), behind its wavefront-uniform shortcuts */
-    {
-      const f2 T1Ave = (t1old + S2(3.f) * t2old) * S2(0.25f);
-      const f2 TN1Ave = (T[0] + S2(3.f) * T[1]) * S2(0.25f);
-      const f2 hstor = hs1 * (TN1Ave - T1Ave);
-      const b2 frozen_cover = b2{(s.snow.x > 0.f) || (s.ice.x > 0.f) || (s.ice2.x > 0.f),
-                                 (s.snow.y > 0.f) || (s.ice.y > 0.f) || (s.ice2.y > 0.f)};
-      const bool melt_here = wave_any2(frozen_cover);
-#pragma unroll
-      for (int comp = 0; comp < 2; ++comp) {
-        RegProfile<2> TT;
-        TT.set(1, comp ? T[0].y : T[0].x);
-        TT.set(2, comp ? T[1].y : T[1].x);
-        Scalars q = x2_scalars(s, comp, TT.get(1), TT.get(2));
-        if (melt_here) melting(q, TT, comp ? hstor.y : hstor.x, comp ? hs1.y : hs1.x, false, 0.f);
-        else q.q2melt = 0.f; /* no snow or ice on any road of the wavefront: melting's else-branch */
-        q.tsurf = (TT.get(1) + TT.get(2)) / 2.0f;
-        road_condition(c, q, comp ? evap.y : evap.x);
-        if (comp) {
-          T[0].y = TT.get(1); T[1].y = TT.get(2);
-          s.tsurf.y = q.tsurf; s.wat.y = q.wat; s.snow.y = q.snow; s.ice.y = q.ice; s.ice2.y = q.ice2; s.dep.y = q.dep;
-          s.q2melt.y = q.q2melt; s.t4melt.y = q.t4melt; s.albedo.y = q.albedo; s.verycold.y = q.verycold;
-        } else {
-          T[0].x = TT.get(1); T[1].x = TT.get(2);
-          s.tsurf.x = q.tsurf; s.wat.x = q.wat; s.snow.x = q.snow; s.ice.x = q.ice; s.ice2.x = q.ice2; s.dep.x = q.dep;
-          s.q2melt.x = q.q2melt; s.t4melt.x = q.t4melt; s.albedo.x = q.albedo; s.verycold.x = q.verycold;
-        }
-      }
-    }
-    /* SaveOutput (src/InputOutput.f90:151-165); -9999.0 for a point that failed before this index */
-    if (write) {
-      if (wave_any2(was_failed)) {
-        const f2 m = S2(-9999.0f);
-        out2(ka->o.tsurf, sel2(was_failed, m, s.tsurf)); out2(ka->o.snow, sel2(was_failed, m, s.snow));
-        out2(ka->o.water, sel2(was_failed, m, s.wat)); out2(ka->o.ice, sel2(was_failed, m, s.ice));
-        out2(ka->o.deposit, sel2(was_failed, m, s.dep)); out2(ka->o.ice2, sel2(was_failed, m, s.ice2));
-      } else {
-        out2(ka->o.tsurf, s.tsurf); out2(ka->o.snow, s.snow); out2(ka->o.water, s.wat);
-        out2(ka->o.ice, s.ice); out2(ka->o.deposit, s.dep); out2(ka->o.ice2, s.ice2);
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 15; ++j) stst(RS_ST_TMP0 + j, T[j]);
-  stst(RS_ST_TSURF, s.tsurf);
-  stst(RS_ST_WAT, s.wat); stst(RS_ST_SNOW, s.snow); stst(RS_ST_ICE, s.ice); stst(RS_ST_ICE2, s.ice2);
-  stst(RS_ST_DEP, s.dep); stst(RS_ST_Q2MELT, s.q2melt); stst(RS_ST_T4MELT, s.t4melt);
-  stst(RS_ST_ALBEDO, s.albedo);
-  stst(RS_ST_VERYCOLD, f2{s.verycold.x ? 1.f : 0.f, s.verycold.y ? 1.f : 0.f});
-  if (SCORE) { /* sort key of rs_hip_recluster, as in the other flavours (rs_kernels.hip, bl_score_key) */
-    auto key = [&](int32_t sc, int32_t rg, float w_, float sn, float ic, float i2_, float dp) -> float {
-      const int32_t lo = sc > 0x7ffff ? 0x7ffff : (sc < 0 ? 0 : sc);
-      const int32_t covered = (w_ > 0.f || sn > 0.f || ic > 0.f || i2_ > 0.f || dp > 0.f) ? 1 : 0;
-      return (float)(lo | (covered << 19) | (rg << 20));
-    };
-    stst(RS_ST_BLSCORE, f2{key(score.x, regime.x, s.wat.x, s.snow.x, s.ice.x, s.ice2.x, s.dep.x),
-                           key(score.y, regime.y, s.wat.y, s.snow.y, s.ice.y, s.ice2.y, s.dep.y)});
-  } else { /* the pass count of the launch's last index: one more preview for forecast_key_kernel */
-    stst(RS_ST_BLSCORE, f2{(float)last_trips.x, (float)last_trips.y});
-  }
-}
-
-
 /* ==== two points per lane, two wavefronts per 128 points (step_kernel_f32duo) ==========================
- * The single-wavefront organisation above keeps a point's whole state, the knots of its forcing and every
- * temporary of a time step in one wavefront's registers: 168-250 of them, two or three wavefronts per SIMD, each
- * of which offers the vector unit work only about half of the time it is resident (scalar loads, branches,
- * waits) - 4.1e10 point-timesteps/s, what one point per lane gave (profiles/r06_f32_single_wave_*).  As in the
- * fp64 flavour (rs_kernels.hip step_kernel_duo) a workgroup is therefore TWO wavefronts that share 128 points
- * and meet once per time index:
+ * One wavefront that keeps a point's whole state, the knots of its forcing and every temporary of a time step in
+ * its registers needs 168-250 of them: two or three wavefronts per SIMD, each of which offers the vector unit work
+ * only about half of the time it is resident (scalar loads, branches, waits) - measured 4.1e10 point-timesteps/s,
+ * what one point per lane gave (the kernel is in the history, commit "fp32 flavour: two points per
+ * lane").  As in the fp64 flavour (rs_kernels.hip step_kernel_duo) a workgroup is therefore TWO wavefronts that
+ * share 128 points and meet once per time index:
  *   ground wave:  layers 3..15 of the explicit update (they read only OLD neighbours) and everything a step
  *                 needs of its forcing alone, one index AHEAD - the interpolation from the knots (or the window
  *                 row), SetCurrentValues' VZ(1) floor, CheckValues' forcing tests, PrecipitationToStorage's
@@ -833,6 +482,7 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
   f2 kv0[6], kdv[6];
   i2 kph0 = i2{0, 0}, kph1 = i2{0, 0};
   int32_t kcur = -1;
+  bool knots_safe = false; /* uniform: no index of the current knot interval can fail CheckValues' forcing tests */
   int64_t kcolx = p, kcoly = p + 1;
   if (SRC == X2_KNOTS && ka->knot_gather) {
     kcolx = ka->knot_gather[p];
@@ -867,6 +517,25 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
         }
         kph0 = i2{(int32_t)ka_[8 * np + kcolx], (int32_t)ka_[8 * np + kcoly]};
         kph1 = has_b ? i2{(int32_t)kb_[8 * np + kcolx], (int32_t)kb_[8 * np + kcoly]} : kph0;
+        /* CheckValues' forcing tests for the whole interval at once: a value between two knots lies between them
+         * (to a rounding), so where both ends of every variable keep a margin of 0.01 to its limits (src/InputOutput.f90:
+         * 55-66) no index of the interval can fail them - for all 128 points, or the tests run index by index as
+         * before (a NaN end compares false: index by index) */
+        {
+          auto inside = [&](int comp) -> bool {
+            auto v0 = [&](int q) { return comp ? kv0[q].y : kv0[q].x; };
+            auto v1 = [&](int q) { return comp ? kv0[q].y + kdv[q].y : kv0[q].x + kdv[q].x; };
+            const float m = 0.01f;
+            bool ok = v0(0) > -90.f + m && v1(0) > -90.f + m && v0(0) < 100.f - m && v1(0) < 100.f - m;   /* tair */
+            ok = ok && v0(1) > -1.f + m && v1(1) > -1.f + m && v0(1) < 100.f - m && v1(1) < 100.f - m;     /* vz */
+            ok = ok && v0(2) > -0.1f + m && v1(2) > -0.1f + m && v0(2) < 120.f - m && v1(2) < 120.f - m;   /* rhz */
+            ok = ok && v0(3) > -0.1f + m && v1(3) > -0.1f + m && v0(3) < 500.f - m && v1(3) < 500.f - m;   /* prec */
+            ok = ok && v0(4) > -0.1f + m && v1(4) > -0.1f + m && v0(4) < 4000.f - m && v1(4) < 4000.f - m; /* sw */
+            ok = ok && v0(5) > -0.1f + m && v1(5) > -0.1f + m && v0(5) < 1000.f - m && v1(5) < 1000.f - m; /* lw */
+            return ok;
+          };
+          knots_safe = wave_all2(b2{inside(0), inside(1)});
+        }
       }
       const f2 w = S2(rs32_lerp_weight(rr, ka->r_spk));
       tair = fma2(w, kdv[0], kv0[0]); vz = fma2(w, kdv[1], kv0[1]); rhz = fma2(w, kdv[2], kv0[2]);
@@ -889,7 +558,7 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
     }
     if (in == 1) vz = max2(vz, S2(0.4f)); /* src/Initialization.f90:121-123 */
     uint32_t flx = 0u, fly = 0u;
-    if (in < c.SimLen) { /* CheckValues' forcing tests (src/InputOutput.f90:45-84); the surface temperature's are the surface wave's */
+    if (in < c.SimLen && !(SRC == X2_KNOTS && knots_safe)) { /* CheckValues' forcing tests (src/InputOutput.f90:45-84); the surface temperature's are the surface wave's */
       Forcing fa, fb;
       fa.tair = tair.x; fa.vz = vz.x; fa.rhz = rhz.x; fa.prec = prec.x; fa.sw = sw.x; fa.lw = lw.x;
       fb.tair = tair.y; fb.vz = vz.y; fb.rhz = rhz.y; fb.prec = prec.y; fb.sw = sw.y; fb.lw = lw.y;
@@ -931,7 +600,7 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
       }
       vz = max2(vz, calm);
     }
-    /* air properties and the loop's invariants (src/BoundaryLayer.f90:50-62,78-79; x2_boundary_layer has the algebra) */
+    /* air properties and the loop's invariants (src/BoundaryLayer.f90:50-62,78-79; the algebra: x2d_surface) */
     const f2 TaK = tair + S2(273.15f);
     const f2 AirDens = S2(100000.0f) * rcp2(S2(287.05f) * TaK);
     const f2 dK = (TaK - S2(250.0f)) * (TaK - S2(250.0f));
@@ -987,7 +656,9 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
       const f2 G = S2(kc.z) * (tnext - tj);
       T[j - 3] = fma2(dts, rcap * (Gprev - G), tj);
       Gprev = G;
-      asm volatile("" : "+v"(T[j - 3]), "+v"(Gprev)); /* the update belongs HERE (see step_kernel_f32x2) */
+      /* the update belongs HERE: left alone, the compiler sinks the thirteen updates behind the last layer's branch and
+       * keeps thirteen reciprocals alive until then (26 registers) */
+      asm volatile("" : "+v"(T[j - 3]), "+v"(Gprev));
     }
     lds_st2(mail.v[(k & 1) ^ 1][1], lane, T[0]);
     if (k + 1 < nsteps) prep((k & 1) ^ 1, t0 + k + 1);
@@ -1071,8 +742,11 @@ __device__ __forceinline__ void x2d_surface(X2Mail &mail, const rs::StepArgs &a)
       s.wat = s.wat + lds_ld2(w[XP_RAIN], lane);
       s.snow = s.snow + lds_ld2(w[XP_SNOW], lane);
       const f2 trffric = f2{(fl.x & 2u) ? c.TrfFricNgt : c.TrFfricDay, (fl.y & 2u) ? c.TrfFricNgt : c.TrFfricDay};
-      /* ---- the boundary-layer fixed point (x2_boundary_layer's algebra) from the handed-over invariants ----
-       * which points are still in the loop is kept as two wavefront masks on the scalar unit */
+      /* ---- the boundary-layer fixed point (src/BoundaryLayer.f90:64-96) from the handed-over invariants, with one
+       * reciprocal per pass: with a = logUstar + PSIM, b = logCond + PSIH
+       *   UStar = vkvz / a,  BLCond = avk UStar / b = C1 / (a b),                       C1 = avk vkvz
+       *   Stab  = stab_num BLCond dT / (den0 UStar^3) = C2 BLCond a^3,                  C2 = dT stab_num / (den0 vkvz^3)
+       * Which points are still in the loop is kept as two wavefront masks on the scalar unit. */
       f2 blcond, le, evap;
       i2 trips = i2{5, 5};
       uint64_t unsx = 0ull, unsy = 0ull; /* (SCORE) some pass of the point took the unstable arm */
@@ -1082,10 +756,19 @@ __device__ __forceinline__ void x2d_surface(X2Mail &mail, const rs::StepArgs &a)
         f2 PSIM = S2(0.f), PSIH = S2(0.f), BL = S2(0.f);
         const f2 lU = S2(c.logUstar), lC = S2(c.logCond);
         const uint64_t livex = __builtin_amdgcn_ballot_w64(!was_failed.x), livey = __builtin_amdgcn_ballot_w64(!was_failed.y);
-        auto pass = [&](f2 &psim, f2 &psih, f2 &bl, uint64_t actx, uint64_t acty) {
-          const f2 av = lU + psim, bv = lC + psih;
-          bl = C1 * rcp2(av * bv);
-          f2 Stab = (C2 * bl) * (av * av * av);
+        /* the first pass starts from PSIM = PSIH = 0 (:62): a = logUstar and b = logCond for every point - the
+         * reciprocal and the cube once per wavefront, by the general pass's own operations on the same values */
+        const float K0 = __builtin_amdgcn_rcpf(c.logUstar * c.logCond), U3 = (c.logUstar * c.logUstar) * c.logUstar;
+        auto pass = [&](f2 &psim, f2 &psih, f2 &bl, uint64_t actx, uint64_t acty, bool first = false) {
+          f2 Stab;
+          if (first) {
+            bl = C1 * S2(K0);
+            Stab = (C2 * bl) * S2(U3);
+          } else {
+            const f2 av = lU + psim, bv = lC + psih;
+            bl = C1 * rcp2(av * bv);
+            Stab = (C2 * bl) * (av * av * av);
+          }
           Stab = min2(Stab, S2(1.0f)); /* (`if (Stab > 1) Stab = 1`; v_min_f32 differs for a NaN only) */
           const bool stx = Stab.x > 0.f, sty = Stab.y > 0.f;
           const f2 ps = S2(4.7f) * Stab;
@@ -1111,8 +794,9 @@ __device__ __forceinline__ void x2d_surface(X2Mail &mail, const rs::StepArgs &a)
         const int npre = 4;
 #endif
         /* passes 1-4 never test (j >= 5 in the exit condition), the fifth is the first that may end the loop */
+        pass(PSIM, PSIH, BL, livex, livey, true);
 #pragma unroll 1
-        for (int j = 1; j <= npre; ++j) pass(PSIM, PSIH, BL, livex, livey);
+        for (int j = 2; j <= npre; ++j) pass(PSIM, PSIH, BL, livex, livey);
         uint64_t actx, acty;
         {
           const f2 old = BL;
@@ -1181,7 +865,9 @@ __device__ __forceinline__ void x2d_surface(X2Mail &mail, const rs::StepArgs &a)
         const f2 G2 = S2(c.lk4[2][2]) * (t3 - t2old);
         T2 = fma2(dts, rcap2 * (G1 - G2), t2old);
       }
-      /* calcHStor, melting, the new surface temperature, RoadCond ... CalcAlbedo: per point (see step_kernel_f32x2) */
+      /* calcHStor (src/BalanceModel.f90:311-322), melting (src/Storage.f90:319-402), the new surface temperature, RoadCond
+       * with the four storages, NewMeltFreezeHeat, CalcAlbedo (src/Cond.f90:9-139): per point through the one-point source
+       * (compares and selects: nothing to pack), behind its wavefront-uniform shortcuts */
       {
         const f2 T1Ave = (t1old + S2(3.f) * t2old) * S2(0.25f);
         const f2 TN1Ave = (T1 + S2(3.f) * T2) * S2(0.25f);
@@ -1254,8 +940,12 @@ template <int SRC, bool SCORE>
 __global__ void __launch_bounds__(128, RS_X2D_WAVES) step_kernel_f32duo(const rs::StepArgs a) {
   __shared__ X2Mail mail;
   /* no early return: both wavefronts walk to every barrier; points beyond npoints are dead weight */
-  if (threadIdx.x < 64) x2d_surface<SCORE>(mail, a);
-  else x2d_ground<SRC>(mail, a);
+  if (threadIdx.x < 64) {
+    if (a.surface_prio) __builtin_amdgcn_s_setprio(1); /* the longer chain of the two issues first (StepArgs::surface_prio) */
+    x2d_surface<SCORE>(mail, a);
+  } else {
+    x2d_ground<SRC>(mail, a);
+  }
 }
 
 }  // namespace rs32
@@ -1276,15 +966,12 @@ hipError_t rs32_upload_constants(void *dst, const RsConstants *c, hipStream_t st
   return hipStreamSynchronize(stream); /* f is stack scratch */
 }
 
-static inline dim3 grid_x2(int64_t n) { return dim3((unsigned)((n + 2 * rs32::kX2Lanes - 1) / (2 * rs32::kX2Lanes))); }
+static inline dim3 grid_x2(int64_t n) { return dim3((unsigned)((n + 127) / 128)); } /* a workgroup steps 128 points */
 
 hipError_t rs32_launch_step(const rs::StepArgs &a, int NL, int variant, bool score, hipStream_t stream) {
   const dim3 g = grid_for32(a.npoints), b(RS_BLOCK);
   const int v = variant % 10;
-  if (NL == 15 && v == 5) { /* (A/B) two points per lane in ONE wavefront */
-    if (score) hipLaunchKernelGGL((rs32::step_kernel_f32x2<rs32::X2_WINDOW, true>), grid_x2(a.npoints), dim3(rs32::kX2Lanes), 0, stream, a);
-    else hipLaunchKernelGGL((rs32::step_kernel_f32x2<rs32::X2_WINDOW, false>), grid_x2(a.npoints), dim3(rs32::kX2Lanes), 0, stream, a);
-  } else if (NL == 15 && v != RS_VARIANT_REG && v != RS_VARIANT_LDS) {
+  if (NL == 15 && v != RS_VARIANT_REG && v != RS_VARIANT_LDS) {
     /* two points per lane, two wavefronts per 128 points (round 6); RS_VARIANT_REG / _LDS: round 2-5's one point
      * per lane, for A/B */
     if (score) hipLaunchKernelGGL((rs32::step_kernel_f32duo<rs32::X2_WINDOW, true>), grid_x2(a.npoints), dim3(128), 0, stream, a);
@@ -1299,14 +986,9 @@ hipError_t rs32_launch_step(const rs::StepArgs &a, int NL, int variant, bool sco
 }
 
 /* the two-points-per-lane kernel reading the hourly knots itself (StepArgs::knots): no forcing window */
-hipError_t rs32_launch_step_knots(const rs::StepArgs &a, int variant, bool score, hipStream_t stream) {
-  if (variant % 10 != 5) {
-    if (score) hipLaunchKernelGGL((rs32::step_kernel_f32duo<rs32::X2_KNOTS, true>), grid_x2(a.npoints), dim3(128), 0, stream, a);
-    else hipLaunchKernelGGL((rs32::step_kernel_f32duo<rs32::X2_KNOTS, false>), grid_x2(a.npoints), dim3(128), 0, stream, a);
-    return hipGetLastError();
-  }
-  if (score) hipLaunchKernelGGL((rs32::step_kernel_f32x2<rs32::X2_KNOTS, true>), grid_x2(a.npoints), dim3(rs32::kX2Lanes), 0, stream, a);
-  else hipLaunchKernelGGL((rs32::step_kernel_f32x2<rs32::X2_KNOTS, false>), grid_x2(a.npoints), dim3(rs32::kX2Lanes), 0, stream, a);
+hipError_t rs32_launch_step_knots(const rs::StepArgs &a, bool score, hipStream_t stream) {
+  if (score) hipLaunchKernelGGL((rs32::step_kernel_f32duo<rs32::X2_KNOTS, true>), grid_x2(a.npoints), dim3(128), 0, stream, a);
+  else hipLaunchKernelGGL((rs32::step_kernel_f32duo<rs32::X2_KNOTS, false>), grid_x2(a.npoints), dim3(128), 0, stream, a);
   return hipGetLastError();
 }
 

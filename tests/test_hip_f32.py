@@ -141,3 +141,58 @@ def test_fp32_config5_shape_properties_1250000_points_7_days():
     ora, _, _ = oh.run_oracle("ref" if oh.have_ref() else "port", f, s, p, l)
     d = np.abs(samp1["tsurf"][:, 64:128].T.astype(np.float64) - ora["tsurf"])
     assert (d > 0.05).mean() < 1e-4 and d.max() < 0.5
+
+
+# ---- round 6: two points per lane, two wavefronts per 128 points (step_kernel_f32duo) ----------------
+
+@pytest.mark.parametrize("n", [1000, 1001, 129])
+def test_fp32_knot_reading_launch_equals_window_launch(n):
+    """The fp32 step kernel interpolates its forcing from the resident hourly knots itself (rs_hip_step_knots on an
+    fp32 plan: no forcing window, no expansion kernel) with the arithmetic expand_kernel_f32 writes a window with
+    (rs32_lerp): the two launches hand the model the same bits - in natural order and in plan order, for a point
+    count that leaves the last lane one point (a lane owns two) and the last workgroup mostly empty, with launch
+    boundaries on, before and between knots."""
+    from f32_experiment import run_f32
+    L, seed = 1441, 5
+    for chunk, cluster in ((97, False), (120, True), (250, True)):
+        a = run_f32(n, L, seed, chunk=chunk, cluster=cluster)
+        b = run_f32(n, L, seed, chunk=chunk, cluster=cluster, fused=True)
+        for k in ("tsurf", "snow", "water", "ice", "deposit", "ice2"):
+            assert np.array_equal(a[k], b[k]), (n, chunk, cluster, k, int((a[k] != b[k]).sum()))
+        assert np.isfinite(a["tsurf"]).all() and (a["tsurf"] > -9000).all()
+
+
+def test_fp32_failed_points_leave_the_loop_at_the_reference_index():
+    """CheckValues in the fp32 flavour (src/InputOutput.f90:45-84): a point whose forcing leaves the limits fails at
+    the first such index - that index is still stepped and saved, every later row reads -9999.0 - and its lane
+    partner and its neighbours are untouched.  The knot-reading launch tests an hour at a time where both knots
+    keep a margin to the limits and index by index otherwise: same indices, same bits as the window launch."""
+    from f32_experiment import run_f32
+    n, L, seed, spk = 300, 1441, 9, 120
+    bad = {7: (5, 0, 150.0),      # air temperature above 100 from some index before knot 5 on
+           8: (0, 3, 130.0),      # relative humidity above 120 at index 1 (the lane partner of point 9)
+           200: (9, 2, 101.0),    # wind speed
+           299: (3, 4, -5.0)}     # precipitation below -0.1 (last point: the last lane's second point)
+
+    def edit(knots):
+        for pnt, (k, fld, v) in bad.items():
+            knots[k, fld, pnt] = v
+
+    clean = run_f32(n, L, seed, chunk=120)
+    win, iw = run_f32(n, L, seed, chunk=120, edit_knots=edit, return_plan_info=True)
+    kn, ik = run_f32(n, L, seed, chunk=120, edit_knots=edit, fused=True, return_plan_info=True)
+    srt, isr = run_f32(n, L, seed, chunk=120, edit_knots=edit, fused=True, cluster=True, return_plan_info=True)
+    assert iw["failed"] == ik["failed"] == isr["failed"] == len(bad)
+    assert np.array_equal(iw["first_failed"], ik["first_failed"]) and np.array_equal(iw["first_failed"], isr["first_failed"])
+    ff = iw["first_failed"]
+    assert ff[8] == 1 and (ff[[p for p in range(n) if p not in bad]] == 0).all()
+    assert 4 * spk + 1 < ff[7] <= 5 * spk + 1 and 8 * spk + 1 < ff[200] <= 9 * spk + 1 and 2 * spk + 1 < ff[299] <= 3 * spk + 1
+    for k in ("tsurf", "snow", "water", "ice", "deposit", "ice2"):
+        assert np.array_equal(win[k], kn[k]) and np.array_equal(win[k], srt[k]), k
+        for pnt in bad:
+            f = int(ff[pnt])                       # rows [0, f) saved (index f included), the rest blank
+            assert (win[k][pnt, f:] == -9999.0).all() and (win[k][pnt, :f] > -9000).all(), (k, pnt)
+        ok = [p for p in range(n) if p not in bad]
+        assert np.array_equal(win[k][ok], clean[k][ok]), k
+    # up to the hour in which its forcing starts to differ a failing point follows the clean run
+    assert np.array_equal(win["tsurf"][7, :4 * spk], clean["tsurf"][7, :4 * spk])
