@@ -163,6 +163,45 @@ def host_batch_leg(n: int, simlen: int, seed: int) -> dict:
                        "bytes_over_the_boundary_per_unit": bytes_per_unit}}
 
 
+F32_POINTS, F32_HOURS, F32_PLANS, F32_CHUNK = 1_250_000, 168, 2, 360
+
+
+def f32_config5_leg(make_plans, timed_leg, params, args) -> dict:
+    """BASELINE config 5's per-GPU share through the fp32 flavour (rs_kernels_f32.hip step_kernel_f32duo: two
+    points per lane, two wavefronts per 128 points, forcing interpolated from the resident knots)."""
+    from roadsurf_amd import abi, workload
+
+    simlen = F32_HOURS * workload.SPK + 1
+    s32 = abi.default_settings(simlen)
+    plans, offs = make_plans(F32_PLANS, s32, 0, npoints=F32_POINTS, f32=True)
+    steps = 3
+    el, step_ms, nl, chunk, busy = timed_leg(True, plans, offs, F32_CHUNK, False, steps=steps, warmup=1,
+                                             hours=F32_HOURS, f32=True)
+    nfail = sum(pl.failed_count() for pl in plans)
+    for pl in plans:
+        pl.close()
+    units = F32_POINTS * simlen
+    achieved = 52.0 * units * steps / (busy / 1e3) / 1e9
+    return {
+        "value": units * steps / el, "unit": "point-timesteps/s", "ms_per_step": el / steps * 1e3, "steps": steps,
+        "warmup": 1, "dtype": "f32", "failed_points": int(nfail),
+        "config": {"workload": f"{F32_POINTS} synthetic points x {F32_HOURS} h (SimLen {simlen}, DTSecs 30, NLayers 15), "
+                               "fp32 state / forcing / outputs / arithmetic, LEAN feature set, outputs every time "
+                               "index, attributable to points; hourly knots of every point resident in HBM",
+                   "plans_per_gpu": F32_PLANS, "chunk_steps": chunk, "plan_order": True,
+                   "gate": "distribution of |fp32 - fp64 oracle| (tests/test_hip_f32.py): 99.999 % of the point-steps "
+                           "within 0.05 K over 7 days, rms < 5e-4 K"},
+        "roofline": {"bound": "hbm", "kernel": "rs32::step_kernel_f32duo", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_unit": 52.0, "avg_launch_ms": step_ms / max(nl, 1), "launches": nl,
+                     "busy_ms": busy, "concurrent_launches": step_ms / busy,
+                     "step_kernel_only_value": units * steps / (busy / 1e3),
+                     "note": "the kernel neither reads nor writes a forcing window (the ground wavefront interpolates "
+                             "the knots): what HBM moves is the 24 B of outputs per point-timestep; the binding "
+                             "roofline is vector issue (DESIGN.md 3.9)"},
+    }
+
+
 class ClockProbe:
     """Engine clock of the GPU while the timed passes run: rs_hip_clock_probe kernels (one wavefront
     that reads the shader-clock counter and the constant 100 MHz counter about 0.2 ms apart) enqueued
@@ -318,6 +357,10 @@ def main() -> None:
         # 250 000 / 125 000 points; with the 10-bit key, r4_key10_sweep.sh: 3 x 60 2.39e10 / 2.37e10 at 1 M / 500 000,
         # 3 x 90 2.38e10 / 2.36e10)
         K, ch = (3, 60) if n >= 400_000 else (4, 120) if n >= 200_000 else (2, 240) if n >= 100_000 else (1, 240)
+    elif args.f32 and args.variant % 10 not in (1, 2):
+        # round 6 (tools/experiments/r6_f32_sweep.sh): with two points per lane a step launch costs half as much
+        # against the same re-sort chain - two plans, launches of three hours
+        K, ch = (2 if n >= 100_000 else 1), 360
     else:
         # measured on MI355X (tools/experiments/exp_plans.sh, r3_small2.sh; DESIGN_HISTORY.md 6)
         K, ch = (4 if n >= 200_000 else 2 if n >= 100_000 else 1), (120 if n >= 400_000 else 240)
@@ -333,15 +376,15 @@ def main() -> None:
         K = args.plans_per_gpu if args.plans_per_gpu > 0 else 3
         if chunk_auto:
             args.chunk = 120 if fused else 240
-    def make_plans(K, settings, variant):
+    def make_plans(K, settings, variant, npoints=None, f32=None):
         plans, offsets = [], []
         for j in range(K):
-            off_j, n_j = sharding.strong_shard(n, K, j)
+            off_j, n_j = sharding.strong_shard(n if npoints is None else npoints, K, j)
             st = torch.cuda.current_stream(dev) if K == 1 else torch.cuda.Stream(dev)
             pl = device.Plan(n_j, settings, params, dev_index, stream=st)
             if variant:
                 pl.set_variant(variant)
-            if args.f32:
+            if args.f32 if f32 is None else f32:
                 pl.set_precision(32)
             plans.append(pl)
             offsets.append(offset + off_j)
@@ -357,7 +400,7 @@ def main() -> None:
         torch.cuda.synchronize(dev)
 
     def timed_leg(plan_order: bool, plans=None, offsets=None, chunk_steps=None, full=None, steps=None,
-                  warmup=None):
+                  warmup=None, hours=None, f32=None):
         """W untimed + exactly K timed passes, barrier + synchronize on both sides, MAX over ranks."""
         plans = plans_main if plans is None else plans
         offsets = offsets_main if offsets is None else offsets
@@ -365,8 +408,8 @@ def main() -> None:
         full = args.full if full is None else full
         steps = args.steps if steps is None else steps
         warmup = args.warmup if warmup is None else warmup
-        runs = [workload.SyntheticRun(pl, args.seed, args.hours, chunk_steps, point_offset=o,
-                                      plan_order=plan_order, f32=args.f32,
+        runs = [workload.SyntheticRun(pl, args.seed, args.hours if hours is None else hours, chunk_steps, point_offset=o,
+                                      plan_order=plan_order, f32=args.f32 if f32 is None else f32,
                                       forecast=args.sort_key == "forecast",
                                       forecast_alpha=args.forecast_alpha, forecast_mode=args.forecast_mode,
                                       full=full)
@@ -469,6 +512,10 @@ def main() -> None:
     extra = {}
     if world == 1 and not (args.no_extra_legs or args.f32 or args.full) and cluster:
         t_x = time.perf_counter()
+        # the headline's plans are done (its timing events and failure counts are read): every leg below has the
+        # GPU to itself, as the headline had (the library counts a device's live plans: rs_api.hip `underfilled`)
+        for pl in plans:
+            pl.close()
         # (1) the FULL feature set (Tdew / TsurfObs / depth streams, 6 h initialization phase, relaxation
         # behind it) on the same synthetic points: what `bench.py --full` reports as its headline
         s_full = abi.default_settings(simlen)
@@ -546,6 +593,30 @@ def main() -> None:
         # (3) the drop-in batch entry from STEP-RESOLUTION host arrays (runsimulation_batch: 11 f64 + 2 i32 in,
         # 6 f64 out per point and index over the boundary): PCIe-bound by construction
         extra["host_batch"] = host_batch_leg(args.host_batch_points, simlen, args.seed)
+        # (4) BASELINE config 4's per-GPU shards on this one GPU (1 M points over 8 / 4 GPUs: 125 000 / 250 000
+        # points, the headline's flavour and launch shapes for those sizes): what DESIGN.md 3.2's projection of the
+        # strong-scaling curve rests on, under the driver's clock
+        for pts in (125_000, 250_000):
+            Ks, chs = (4, 120) if pts >= 200_000 else (2, 240)
+            splans, soffs = make_plans(Ks, settings, args.variant, npoints=pts)
+            s_steps = 3
+            s_el, s_step_ms, s_nl, s_chunk, s_busy = timed_leg(True, splans, soffs, chs, False, steps=s_steps, warmup=1)
+            extra["shard_%dk" % (pts // 1000)] = {
+                "value": pts * simlen * s_steps / s_el, "unit": "point-timesteps/s", "ms_per_step": s_el / s_steps * 1e3,
+                "steps": s_steps, "warmup": 1, "avg_launch_ms": s_step_ms / max(s_nl, 1),
+                "concurrent_launches": s_step_ms / s_busy,
+                "config": {"workload": f"{pts} synthetic points x {args.hours} h (SimLen {simlen}), fp64, LEAN: the shard "
+                                       f"one GPU holds when config 4's 1 000 000 points are cut over {1_000_000 // pts} GPUs",
+                           "plans_per_gpu": Ks, "chunk_steps": s_chunk, "kernel_variant": args.variant, "plan_order": True},
+            }
+            for pl in splans:
+                pl.close()
+            del splans
+            torch.cuda.empty_cache()
+        # (5) BASELINE config 5 at its per-GPU shape: fp32, 1.25 M points (10 M over 8 GPUs) x 7 days (SimLen 20 161),
+        # tolerance-gated against the fp64 oracle (tests/test_hip_f32.py), its own roofline block (52 algorithmic
+        # bytes per point-timestep: 6 x 4 + 4 read, 6 x 4 written)
+        extra["f32_config5"] = f32_config5_leg(make_plans, timed_leg, params, args)
         extra["seconds"] = time.perf_counter() - t_x
     # dominant kernel: step kernel, HIP events on its own stream around every launch (this rank).
     # achieved = algorithmic bytes of the launches / time the device spent in them.  With one plan
@@ -655,6 +726,8 @@ def main() -> None:
                 line[k + "_value"] = v["value"]
         if extra:
             line["extra_legs"] = extra
+            if "f32_config5" in extra:
+                line["f32_config5_roofline"] = extra["f32_config5"]["roofline"]
         if natural is not None:
             n_elapsed, n_step_ms, n_nlaunch, n_chunk, n_busy, n_K = natural
             line["natural_order_value"] = units_per_pass_job * args.steps / n_elapsed

@@ -71,3 +71,25 @@ def _plan_order_for_small_batches(monkeypatch):
     tests/test_hip_operational.py removes it to run the library's own default."""
     if "ROADSURF_HIP_CLUSTER" not in os.environ:
         monkeypatch.setenv("ROADSURF_HIP_CLUSTER", "1")
+
+
+# ---- kernel reachability map (tools/kernel_reachability.py): with RS_TEST_WINDOWS=<file> every test's wall-clock
+# window is appended to the file (CLOCK_MONOTONIC, the clock rocprofv3 stamps kernel dispatches with), so that a
+# `rocprofv3 --kernel-trace -- python3 -m pytest tests -m gpu` run can be reduced to "kernel -> tests that launched it"
+@pytest.fixture(autouse=True)
+def _test_window(request):
+    path = os.environ.get("RS_TEST_WINDOWS")
+    if not path:
+        yield
+        return
+    import time
+    t0 = time.monotonic_ns()
+    yield
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
+    with open(path, "a") as f:
+        f.write("%s,%d,%d\n" % (request.node.nodeid.replace(",", ";"), t0, time.monotonic_ns()))
