@@ -357,7 +357,7 @@ def main() -> None:
         # 250 000 / 125 000 points; with the 10-bit key, r4_key10_sweep.sh: 3 x 60 2.39e10 / 2.37e10 at 1 M / 500 000,
         # 3 x 90 2.38e10 / 2.36e10)
         K, ch = (3, 60) if n >= 400_000 else (4, 120) if n >= 200_000 else (2, 240) if n >= 100_000 else (1, 240)
-    elif args.f32 and args.variant % 10 not in (1, 2):
+    elif args.f32 and args.variant not in (1, 2):
         # round 6 (tools/experiments/r6_f32_sweep.sh): with two points per lane a step launch costs half as much
         # against the same re-sort chain - two plans, launches of three hours
         K, ch = (2 if n >= 100_000 else 1), 360
@@ -544,8 +544,9 @@ def main() -> None:
         # comparable with `value`, whose inputs are resident in HBM)
         from roadsurf_amd import driver_workload
 
-        if not (os.environ.get("ROADSURF_HIP_DEVICES") or os.environ.get("ROADSURF_HIP_DEVICE")):
-            os.environ["ROADSURF_HIP_DEVICE"] = str(dev_index)  # the library's fan-out stays on THIS GPU
+        if not os.environ.get("ROADSURF_HIP_DEVICES"):
+            # the library's fan-out stays on THIS GPU, four blocks on it (the default of a one-GPU process)
+            os.environ["ROADSURF_HIP_DEVICES"] = ",".join([str(dev_index)] * int(os.environ.get("ROADSURF_HIP_PLANS_PER_DEVICE", "4")))
         # distinct series for every point (tiles of 65 536 series put identical lanes side by
         # side after the forecast sort) and the MEAN of three timed calls, like the headline's mean over passes
         dw = driver_workload.DriverWorkload(args.extra_points, args.hours, unique=None)

@@ -266,8 +266,7 @@ RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints, const RsConstants *c
   pl->stream = (hipStream_t)stream;
   if (const char *ev = getenv("ROADSURF_HIP_VARIANT")) { /* tuning: default flavour of new plans */
     const int v = atoi(ev);
-    if (v >= 0 && v % 10 <= 4 && v / 10 <= 4 && !(v % 10 >= RS_VARIANT_DUO && v / 10 != 0) &&
-        !(v % 10 == RS_VARIANT_REG && consts->NLayers != 15))
+    if (v >= 0 && v <= 4 && !(v == RS_VARIANT_REG && consts->NLayers != 15))
       pl->variant = v;
   }
   const size_t bytes = (size_t)RS_NSTATE * pl->np_pad * sizeof(double);
@@ -321,10 +320,6 @@ RsPlan *rs_hip_plan_create(int32_t device, int64_t npoints, const RsConstants *c
 }
 
 static inline int32_t underfilled(const RsPlan *pl) {
-  if (pl->f32) { /* (tuning, fp32 flavour) ROADSURF_HIP_F32_SURFACE_PRIO: 0 / 1 whatever the size */
-    static const int forced = [] { const char *e = getenv("ROADSURF_HIP_F32_SURFACE_PRIO"); return e ? atoi(e) : -1; }();
-    if (forced >= 0) return forced;
-  }
   return g_live_points[pl->device & 63].load() <= 131072 ? 1 : 0;
 }
 
@@ -409,22 +404,19 @@ int rs_hip_recluster_forecast(RsPlan *pl, const RsPreview *pv) {
   const int lowb = rs_forecast_key_low_bits(pv->mode);
   const int low = (a.compact || (bits >= 1 && bits + lowb <= RS_SORT_KEY_BITS)) ? lowb : 0;
   a.low_bits = low;
-  /* field 0 of the mode in classes of the longest expected loop (default), or - ROADSURF_HIP_EXTRA_CLASSES=0,
-   * round 4's form, A/B - the previews' extra passes summed and saturating at 7 */
-  static const int extra_log = getenv("ROADSURF_HIP_EXTRA_CLASSES") ? atoi(getenv("ROADSURF_HIP_EXTRA_CLASSES")) : -1;
-  /* ... which stays the form of an underfilled device: there a launch is as long as its slowest wavefront, and
-   * gathering the points of the slow band makes that wavefront slower (125 000 points: 1.40e10 against 1.37e10;
-   * 500 000: 2.39e10 against 2.44e10, profiles/r05_ab_extra_pass_classes_small_shards.txt) */
-  a.extra_log = extra_log >= 0 ? (extra_log ? 1 : 0) : underfilled(pl) ? 0 : 1;
+  /* field 0 of the mode in classes of the longest expected loop, or - round 4's form - the previews' extra passes
+   * summed and saturating at 7, which stays the form of an underfilled device: there a launch is as long as its
+   * slowest wavefront, and gathering the points of the slow band makes that wavefront slower (125 000 points:
+   * 1.40e10 against 1.37e10; 500 000: 2.39e10 against 2.44e10, profiles/r05_ab_extra_pass_classes_small_shards.txt) */
+  a.extra_log = underfilled(pl) ? 0 : 1;
   HIP_OK(rs_launch_forecast_keys(a, pl->stream));
   pl->wave_tab_valid = false;
   if (a.compact) {
     /* For the two-wavefront flavour: the classes of the key - its five most significant
      * bits: cover, unstable previews, table-path previews of the default field set - each start a wavefront
-     * of their own (rs_cluster_wave_table).  ROADSURF_HIP_WAVE_CLASS_BITS = 0 switches the table off,
-     * 1..6 sets the bits (tuning; classes hold at least 64 bins of the key). */
-    int cb = 5;
-    if (const char *e = getenv("ROADSURF_HIP_WAVE_CLASS_BITS")) cb = atoi(e);
+     * of their own (rs_cluster_wave_table; classes hold at least 64 bins of the key, so the default 10/11-bit keys
+     * take no table: profiles/r04_key_layouts.txt). */
+    const int cb = 5;
     const bool table = cb >= 1 && cb <= 6 && bits - wet_bit - cb >= 6 && !pl->f32;
     uint32_t *class_total = nullptr;
     int32_t maxw = 0;
@@ -544,13 +536,12 @@ int rs_hip_set_history_score(RsPlan *pl, int32_t on) {
 }
 
 int rs_hip_set_variant(RsPlan *pl, int32_t variant) {
-  if (!pl || variant < 0 || variant % 10 > 4 || variant / 10 > 4)
-    return set_err("rs_hip_set_variant: bad arguments");
-  if (variant % 10 == RS_VARIANT_REG && pl->c.NLayers != 15)
+  /* (until round 6 a tens digit bounded the waves per SIMD of flavours 1 and 2: the measured choices are the
+   * kernels' own launch bounds now) */
+  if (!pl || variant < 0 || variant > 4) return set_err("rs_hip_set_variant: the flavour is 0 (automatic) ... 4");
+  if (variant == RS_VARIANT_REG && pl->c.NLayers != 15)
     return set_err("register-profile kernel is built for NLayers == 15 only (got %d)",
                    pl->c.NLayers);
-  if (variant % 10 >= RS_VARIANT_DUO && variant / 10 != 0)
-    return set_err("flavours 3 and 4 take no waves-per-SIMD bound");
   pl->variant = variant;
   return 0;
 }

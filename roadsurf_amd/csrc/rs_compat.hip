@@ -225,8 +225,9 @@ RsCompat *rs_compat_begin(const RsConstants *consts, const LocalParameters *loca
     fail("rs_compat_begin: no HIP device visible - this library has no CPU path");
     return nullptr;
   }
-  const char *ed = getenv("ROADSURF_HIP_DEVICE");
-  const int device = ed ? atoi(ed) % ndev : 0;
+  /* the first entry of ROADSURF_HIP_DEVICES (the fan-out's list, rs_devices.hpp), or device 0 */
+  const char *ed = getenv("ROADSURF_HIP_DEVICES");
+  const int device = (ed && *ed >= '0' && *ed <= '9') ? atoi(ed) % ndev : 0;
   Ctx *c = nullptr;
   for (size_t k = 0; k < t_free.size(); ++k)
     if (t_free[k]->device == device && std::memcmp(&t_free[k]->consts, consts, sizeof(RsConstants)) == 0) {

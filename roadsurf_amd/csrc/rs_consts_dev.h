@@ -94,7 +94,6 @@ static inline void rs_consts_dev_fill(const RsConstants &c, RsConstantsDev &d) {
   }
   d.bareFastOk = (c.MaxWatmms >= 0.0 && c.MaxSnowmms >= 0.0 && c.MaxIcemms >= 0.0 && c.MaxDepmms >= 0.0) ? 1 : 0;
   d.precFastOk = (c.MinPrecmm >= 0.0) ? 1 : 0;
-  if (getenv("ROADSURF_HIP_NO_BARE_FAST")) d.bareFastOk = d.precFastOk = 0; /* A/B switch: same bits either way */
 }
 
 /* Operand domain the bare division/sqrt sequences of rs_math.hpp rely on, as far as it is set by

@@ -58,10 +58,7 @@ inline std::vector<int> device_list() {
   }
   int lo = 0, hi = ndev;
   if (!(e && *e)) {
-    if (const char *one = getenv("ROADSURF_HIP_DEVICE")) {
-      const int d = atoi(one);
-      if (d >= 0 && d < ndev) { lo = d; hi = d + 1; }
-    } else if (const char *lr = getenv("LOCAL_RANK")) {
+    if (const char *lr = getenv("LOCAL_RANK")) {
       /* one process per GPU (torch.distributed.run and friends): a rank that sees the whole node
        * keeps to its own device instead of spreading over - and oversubscribing - all of them.
        * Only where there ARE several local ranks: a lone process that a launcher happened to start
@@ -114,30 +111,15 @@ inline std::vector<Shard> make_shards(int64_t n, const std::vector<int> &devs, i
     s.push_back(Shard{d, 0, n});
     return s;
   }
-  /* ROADSURF_HIP_FIRST_BLOCK_PCT (tuning): the first block's share of an even share, in percent -
-   * its upload is the one no other block's kernels hide */
-  int64_t first = -1;
-  if (const char *e = getenv("ROADSURF_HIP_FIRST_BLOCK_PCT"))
-    if (k > 1 && atoi(e) >= 1 && atoi(e) < 100) first = std::max<int64_t>(min_shard, n / k * atoi(e) / 100);
   int64_t off = 0;
-  if (first > 0 && first < n) {
-    s.push_back(Shard{devs[0], 0, first});
-    off = first;
-    const int64_t base = (n - first) / (k - 1), rem = (n - first) % (k - 1);
-    for (int64_t i = 1; i < k; ++i) {
-      const int64_t cnt = base + (i - 1 < rem ? 1 : 0);
-      s.push_back(Shard{devs[(size_t)i], off, cnt});
-      off += cnt;
-    }
-    return s;
-  }
   /* Blocks that share ONE device take turns on the link, so they start staggered by an upload each and - of
-   * equal size - end staggered too, the last ones alone on the GPU.  ROADSURF_HIP_BLOCK_TAPER_PCT = t: the
-   * blocks shrink linearly, the last one to (100 - t) % of the first (default below; 0: equal blocks). */
+   * equal size - end staggered too, the last ones alone on the GPU.  With a taper of t % the blocks shrink
+   * linearly, the last one to (100 - t) % of the first (0: equal blocks; what the callers pass was measured level
+   * with equal blocks, profiles/r05_ab_block_taper.txt - the environment knobs for it and for an undersized first
+   * block are gone since round 6). */
   bool one_device = true;
   for (int64_t i = 1; i < k; ++i) one_device = one_device && devs[(size_t)i] == devs[0];
-  int taper = default_taper;
-  if (const char *e = getenv("ROADSURF_HIP_BLOCK_TAPER_PCT")) taper = atoi(e);
+  const int taper = default_taper;
   if (one_device && k > 1 && taper > 0 && taper < 90 && n / k >= 4 * min_shard) {
     double wsum = 0.0;
     std::vector<double> w((size_t)k);

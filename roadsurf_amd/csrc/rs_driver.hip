@@ -1362,11 +1362,12 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
   HOK(hipSetDevice(device));
   StreamGuard sg, sg_copy;
   HOK(hipStreamCreate(&sg.s));
-  /* ROADSURF_HIP_UPLOAD_STREAM=1: the uploads of a tile on a stream of their own, the transposes behind their
-   * pieces (TileLanding).  Off by default: a process has four hardware queues, and with two streams per worker
-   * two blocks' compute streams can land on one queue - their step kernels then take turns (measured: one queue
-   * with 102 of a call's 204 step launches, the call 0.64 s instead of 0.58 s) */
-  static const bool upload_stream = getenv("ROADSURF_HIP_UPLOAD_STREAM") != nullptr;
+  /* The uploads of a tile on a stream of their own, the transposes behind their pieces (TileLanding): measured
+   * and switched off - a process has four hardware queues, and with two streams per worker two blocks' compute
+   * streams can land on one queue, their step kernels then take turns (one queue with 102 of a call's 204 step
+   * launches, the call 0.64 s instead of 0.58 s; round 5 again: 0.35 -> 0.43 s, profiles/r05_ab_upload_stream.txt).
+   * A constant since round 6 (it was ROADSURF_HIP_UPLOAD_STREAM). */
+  constexpr bool upload_stream = false;
   if (upload_stream) HOK(hipStreamCreate(&sg_copy.s));
   hipStream_t stream = sg.s, copy_stream = upload_stream ? sg_copy.s : sg.s;
 
@@ -1428,7 +1429,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     explicit ArenaScope(rsu::Arena *a) : prev(rsu::tls_arena()) { rsu::tls_arena() = a; }
     ~ArenaScope() { rsu::tls_arena() = prev; }
   };
-  if (!getenv("ROADSURF_HIP_NO_ARENA")) {
+  {
     const size_t mpx = ((size_t)P + RS_BLOCK - 1) / RS_BLOCK * RS_BLOCK;
     size_t raw = 0;
     for (int k = 0; k < c.nsrc; ++k) {
@@ -1615,14 +1616,13 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
     }
     const int r_lo = cs_min, r_hi = std::min(ce_max + 1, L); /* replay block, 1-based inclusive */
     /* the replay rounds read the raw series too (rs_cpl_replay_raw) where the block ends before SimLen and
-     * there is no sky view; ROADSURF_HIP_CPL_REPLAY_WINDOWS=1: a window + the one-point-per-lane kernels (A/B) */
+     * there is no sky view */
     /* ... and is COMPACT - not much longer than one coupling window, rs_hip_cpl_replay's own rule: stations whose
      * observations end hours apart (the reference's operational example) make a block in which a lock-step
      * replay would step every listed point through all of it, round after round - those keep the forcing window
      * and the per-lane replay kernel */
     const bool replay_raw = use_raw && cpl_chunked && any_on && !skyview && std::min(ce_max + 1, L) < L &&
-                            (int64_t)(r_hi - r_lo + 1) * 4 <= ((int64_t)c.cplLen + 2) * 5 &&
-                            !getenv("ROADSURF_HIP_CPL_REPLAY_WINDOWS");
+                            (int64_t)(r_hi - r_lo + 1) * 4 <= ((int64_t)c.cplLen + 2) * 5;
     const bool need_win = !use_raw || (cpl_chunked && any_on && !replay_raw); /* raw-series stepping: windows for such replays only */
     const int WR = (cpl_chunked && any_on) ? (use_raw ? r_hi - r_lo + 1 : std::max(TC, r_hi - r_lo + 1)) : TC;
     if (cpl_chunked && WR > TC && (size_t)nwin * mp * WR * sizeof(double) > win_budget && m > 4096) {
@@ -1803,8 +1803,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
      * axes (their walks would have to be re-positioned for every preview), by the history of the
      * last launch. */
     Dev d_prev;
-    const char *ek = getenv("ROADSURF_HIP_SORT_KEY"); /* "history": round-1 key */
-    const bool forecast_key = !T.any_pp && !(ek && strcmp(ek, "history") == 0);
+    const bool forecast_key = !T.any_pp;
     /* nobody reads the step kernels' history score then: run the instances without it */
     if (rs_hip_set_history_score(pg.p, (cluster && forecast_key && !cpl_chunked) ? 0 : 1) != 0) return -14;
     auto resort_for = [&](int t_next, int len_next) -> int {
@@ -1825,7 +1824,7 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
         ra.status = ea.status;
         ra.order = ea.order;
         /* ... nine with the precipitation of the three indices (RsPreview::prec: the key's precipitation bit) */
-        static const bool wet_bit = !(getenv("ROADSURF_HIP_PRECIP_BIT") && atoi(getenv("ROADSURF_HIP_PRECIP_BIT")) == 0);
+        constexpr bool wet_bit = true; /* (+1.7 % / +4 %: profiles/r05_ab_precip_bit.txt; a constant since round 6) */
         ra.nrows = wet_bit ? 9 : 6;
         for (int q = 0; q < 3; ++q) {
           ra.fld[2 * q] = R_TAIR;
@@ -1861,10 +1860,9 @@ static int driver_run_range(const RsDriverInput *in, const InputSettings *st,
       }
       /* the boundary-layer regime at the window's first and last index; the middle one makes the key's count
        * fields finer and the order no better (relaxation 0.346 -> 0.343 s without it, as bench.py's FULL leg with
-       * its windows of whole hours: profiles/r05_ab_driver_previews.txt; ROADSURF_HIP_DRIVER_PREVIEWS=3: with it).
+       * its windows of whole hours: profiles/r05_ab_driver_previews.txt).
        * Its precipitation row stays: the key's precipitation bit reads every row it is given. */
-      static const int npv = getenv("ROADSURF_HIP_DRIVER_PREVIEWS") ? atoi(getenv("ROADSURF_HIP_DRIVER_PREVIEWS")) : 2;
-      if (npv == 2) {
+      {
         pv.n = 2;
         pv.tair[1] = pv.tair[2];
         pv.vz[1] = pv.vz[2];

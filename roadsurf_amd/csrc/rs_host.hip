@@ -251,7 +251,7 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
                     (size_t)Ppad * ((size_t)2 * RS_NSTATE * 8 + 64) + (size_t)2 * L * 8 + ((size_t)4 << 20);
   need_pin += need_pin / 8;
   need_dev += need_dev / 8;
-  const bool cached = !getenv("ROADSURF_HIP_NO_CALLER_CACHE") && need_dev <= kCacheDevMax && need_pin <= kCachePinMax &&
+  const bool cached = need_dev <= kCacheDevMax && need_pin <= kCachePinMax &&
                       n <= P && t_cache.reserve(device, need_dev, need_pin);
   struct ArenaScope { /* the thread's blocks serve Dev::alloc / Pinned::alloc / plan_malloc during this call */
     rsu::Arena *pd, *pp;
@@ -373,8 +373,8 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
 
   /* (a team of OpenMP threads only where the rows are worth it: a caller thread of the reference driver that
    * brings a few points would otherwise raise - and keep - a team of its own) */
-  const bool omp_rows = n >= 8;
-  const int row_threads = std::max(1, std::min(nthreads, (int)(n / 4)));
+  [[maybe_unused]] const bool omp_rows = n >= 8;
+  [[maybe_unused]] const int row_threads = std::max(1, std::min(nthreads, (int)(n / 4)));
   /* an item none of whose points has an output depth (depth(i) >= 0) needs no depth stream: the kernels read a
    * missing stream as -9999.9, and without one the launch can take the two-wavefront flavour (rs_hip_step) */
   int item_depth[2] = {1, 1};

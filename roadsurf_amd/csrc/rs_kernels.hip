@@ -30,12 +30,6 @@
 #ifndef RS_CPL_WAVES
 #define RS_CPL_WAVES 2 /* waves per SIMD the general (per-lane time index) kernel is compiled for */
 #endif
-#ifndef RS_CPL_PROFILE_DEFAULT
-#define RS_CPL_PROFILE_DEFAULT 3 /* profile of the lock-step coupling kernels: see rs_launch_step_cpl */
-#endif
-#ifndef RS_SKY_PROFILE_DEFAULT
-#define RS_SKY_PROFILE_DEFAULT 4 /* profile of the lock-step sky-view kernel: see rs_launch_step_sky */
-#endif
 #ifndef RS_REGIME_WINDOW
 #define RS_REGIME_WINDOW 30 /* indices at the end of a launch that define a point's regime
                                (rs_hip_recluster; 8 ... 90 measured equal) */
@@ -1133,8 +1127,10 @@ __device__ __forceinline__ double bl_score_key(int32_t score, const Scalars &s) 
   return (double)(lo | (covered << 19) | (((score >> 30) & 1) << 20));
 }
 
-template <int NL, bool FULL, int WPE, bool SCORE = true, bool A32 = false>
-__global__ void __launch_bounds__(kBlock, WPE) step_kernel_reg(const StepArgs a) {
+/* (waves per SIMD: LEAN four, FULL three - measured, rs_launch_step; the choice was a digit of the variant until
+ * round 6) */
+template <int NL, bool FULL, bool SCORE = true, bool A32 = false>
+__global__ void __launch_bounds__(kBlock, FULL ? 3 : 4) step_kernel_reg(const StepArgs a) {
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
   const MathTab mt = fill_math_tables(math_lds);
   __syncthreads();
@@ -1181,8 +1177,8 @@ __global__ void __launch_bounds__(kBlock, 4) step_kernel_hybrid(const StepArgs a
   if (SCORE) a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
 }
 
-template <bool FULL, int WPE>
-__global__ void __launch_bounds__(kBlock, WPE) step_kernel_lds(const StepArgs a) {
+template <bool FULL>
+__global__ void __launch_bounds__(kBlock, 4) step_kernel_lds(const StepArgs a) {
   extern __shared__ double lds[]; /* [NLayers][kBlock] */
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
   const MathTab mt = fill_math_tables(math_lds);
@@ -2476,8 +2472,10 @@ __global__ void __launch_bounds__(kBlock) synth_knots_kernel(const KnotArgs a) {
  * time indices is ONE basic block: the stores then take the scalar row base + 32-bit lane offset
  * form, LaneOff).  At r = 0 the interpolation adds +-0.0 to the knot value, which returns it
  * unchanged (no knot value is -0.0: rs_synth.h), so the first index needs no case of its own. */
-template <bool TDEW, bool OBS, bool DEPTH>
+/* (the optional streams - dew point, surface observation, output depth - are there or not for the whole launch:
+ * uniform tests of the window's pointers; they were three template parameters, eight instances, until round 6) */
 __global__ void __launch_bounds__(kBlock) expand_kernel(const ExpandArgs a) {
+  const bool TDEW = a.f.tdew != nullptr, OBS = a.f.tsurfobs != nullptr, DEPTH = a.f.depth != nullptr;
   __builtin_amdgcn_s_setprio(3); /* a link of the chain between two step launches of a block: all of it is waited for */
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= a.npoints) return;
@@ -2876,39 +2874,26 @@ hipError_t rs_launch_forecast_keys(const rs::ForecastArgs &a, hipStream_t stream
 
 hipError_t rs_launch_step_sky(const rs::StepArgs &a, int NL, bool score, hipStream_t stream) {
   const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
-  /* ROADSURF_HIP_SKY_PROFILE (tuning): 0 LDS profile at 3 waves/SIMD (any NLayers), 3 / 4 hybrid profile
-   * at that many waves (NLayers = 15).  Measured (rs_driver_run, sky view, 262 144 points in four blocks):
-   * 6.9e9 / 7.1e9 / 7.4e9 */
-  const char *e = getenv("ROADSURF_HIP_SKY_PROFILE");
-  const int m = (NL == 15) ? (e ? atoi(e) : RS_SKY_PROFILE_DEFAULT) : 0;
-  /* 5: two wavefronts per 64 points (no output depth, 32-bit window offsets: what rs_hip_step checked,
-   * StepArgs::duo_full_ok bit 2) - no spills (128 registers) where the one-point-per-lane sky kernels spill
-   * 62-106.  Taken by itself for launches of at most ROADSURF_HIP_DUO_MAX points, like the other
-   * two-wavefront instances: rs_driver_run with sky view, 65 536 points 3.5e9 -> 4.8e9, 200 000 points (four
-   * blocks) 7.6e9 -> 8.6e9; at 1 M points (blocks of 250 000) 1.06e10 -> 1.03e10 - four of its wavefronts
-   * leave a SIMD no register for the other blocks' window expansion, which then queues. */
-  const char *edm = getenv("ROADSURF_HIP_DUO_MAX");
-  const int64_t duo_max = edm ? atoll(edm) : RS_DUO_MAX_POINTS;
-  const bool duo_auto = !e && NL == 15 && a.npoints <= duo_max;
-  if ((m == 5 || duo_auto) && (a.duo_full_ok & 4)) {
+  /* NLayers = 15: the hybrid profile at four waves per SIMD (measured, rs_driver_run with sky view, 262 144 points
+   * in four blocks: LDS profile at three waves 6.9e9, hybrid at three 7.1e9, at four 7.4e9); other layer counts:
+   * the LDS profile.
+   * Two wavefronts per 64 points (no output depth, 32-bit window offsets: what rs_hip_step checked, StepArgs::
+   * duo_full_ok bit 2) - no spills (128 registers) where the one-point-per-lane sky kernels spill 62-106 - for
+   * launches of at most RS_DUO_MAX_POINTS points, like the other two-wavefront instances: rs_driver_run with sky
+   * view, 65 536 points 3.5e9 -> 4.8e9, 200 000 points (four blocks) 7.6e9 -> 8.6e9; at 1 M points (blocks of
+   * 250 000) 1.06e10 -> 1.03e10 - four of its wavefronts leave a SIMD no register for the other blocks' window
+   * expansion, which then queues. */
+  if (NL == 15 && a.npoints <= RS_DUO_MAX_POINTS && (a.duo_full_ok & 4)) {
     const dim3 gd(a.wave_start ? (unsigned)a.wave_n : (unsigned)((a.npoints + 63) / 64));
     if (score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, rs::SRC_WINDOW, true, true>), gd, dim3(128), 0, stream, a);
     else hipLaunchKernelGGL((rs::step_kernel_duo<15, false, rs::SRC_WINDOW, true, true>), gd, dim3(128), 0, stream, a);
     return hipGetLastError();
   }
-  if (m == 4 || m == 5) hipLaunchKernelGGL((rs::step_kernel_sky_h<4>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
-  else if (m == 3) hipLaunchKernelGGL((rs::step_kernel_sky_h<3>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
+  if (NL == 15) hipLaunchKernelGGL((rs::step_kernel_sky_h<4>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
   else hipLaunchKernelGGL(rs::step_kernel_sky, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
   return hipGetLastError();
 }
 
-/* ROADSURF_HIP_CPL_PROFILE (tuning): 0 LDS profile at 3 waves/SIMD (any NLayers), 3 / 4 hybrid
- * profile at that many waves (NLayers = 15) */
-static int cpl_profile_mode(int NL) {
-  const char *e = getenv("ROADSURF_HIP_CPL_PROFILE");
-  const int m = e ? atoi(e) : RS_CPL_PROFILE_DEFAULT;
-  return (NL == 15 && (m == 3 || m == 4)) ? m : 0;
-}
 
 hipError_t rs_launch_step_duo_knots(const rs::StepArgs &a, bool score, hipStream_t stream) {
   const dim3 gd(a.wave_start ? (unsigned)a.wave_n : (unsigned)((a.npoints + 63) / 64));
@@ -2943,28 +2928,25 @@ hipError_t rs_launch_step_duo_raw_replay(const rs::StepArgs &a, hipStream_t stre
 }
 
 hipError_t rs_launch_step_cpl(const rs::StepArgs &a, int NL, hipStream_t stream) {
-  /* measured (tools/r3_cpl.sh, rs_driver_run with coupling, 1 M points): hybrid profile at 3 waves/SIMD
-   * 7.75e9, LDS profile at 3 waves 7.0e9, hybrid at 4 waves (spills) 6.6e9; a profile wholly in
-   * registers was twice as slow (spills) */
-  const int m = cpl_profile_mode(NL);
+  /* NLayers = 15: the hybrid profile at three waves per SIMD (measured, tools/r3_cpl.sh, rs_driver_run with
+   * coupling, 1 M points: 7.75e9; LDS profile at 3 waves 7.0e9, hybrid at 4 waves - spills - 6.6e9; a profile wholly
+   * in registers was twice as slow); other layer counts: the LDS profile */
   const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
-  if (a.pp.sky_view && m != 0) hipLaunchKernelGGL((rs::step_kernel_cpl_h<3, true>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
-  else if (a.pp.sky_view) hipLaunchKernelGGL(rs::step_kernel_cpl<true>, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
-  else if (m == 4) hipLaunchKernelGGL((rs::step_kernel_cpl_h<4>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
-  else if (m == 3) hipLaunchKernelGGL((rs::step_kernel_cpl_h<3>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
-  else hipLaunchKernelGGL(rs::step_kernel_cpl<false>, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
+  const dim3 g = grid_for(a.npoints);
+  if (NL == 15 && a.pp.sky_view) hipLaunchKernelGGL((rs::step_kernel_cpl_h<3, true>), g, dim3(RS_BLOCK), 0, stream, a);
+  else if (NL == 15) hipLaunchKernelGGL((rs::step_kernel_cpl_h<3, false>), g, dim3(RS_BLOCK), 0, stream, a);
+  else if (a.pp.sky_view) hipLaunchKernelGGL(rs::step_kernel_cpl<true>, g, dim3(RS_BLOCK), lds, stream, a);
+  else hipLaunchKernelGGL(rs::step_kernel_cpl<false>, g, dim3(RS_BLOCK), lds, stream, a);
   return hipGetLastError();
 }
 
 hipError_t rs_launch_step_cpl_replay(const rs::StepArgs &a, int NL, hipStream_t stream) {
   if (!a.cpl_list || a.cpl_nlist < 1) return hipSuccess;
-  const int m = cpl_profile_mode(NL);
   const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
   const dim3 g = grid_for(a.cpl_nlist);
-  if (a.pp.sky_view && m != 0) hipLaunchKernelGGL((rs::step_kernel_cpl_replay_h<3, true>), g, dim3(RS_BLOCK), 0, stream, a);
+  if (NL == 15 && a.pp.sky_view) hipLaunchKernelGGL((rs::step_kernel_cpl_replay_h<3, true>), g, dim3(RS_BLOCK), 0, stream, a);
+  else if (NL == 15) hipLaunchKernelGGL((rs::step_kernel_cpl_replay_h<3, false>), g, dim3(RS_BLOCK), 0, stream, a);
   else if (a.pp.sky_view) hipLaunchKernelGGL(rs::step_kernel_cpl_replay<true>, g, dim3(RS_BLOCK), lds, stream, a);
-  else if (m == 4) hipLaunchKernelGGL((rs::step_kernel_cpl_replay_h<4>), g, dim3(RS_BLOCK), 0, stream, a);
-  else if (m == 3) hipLaunchKernelGGL((rs::step_kernel_cpl_replay_h<3>), g, dim3(RS_BLOCK), 0, stream, a);
   else hipLaunchKernelGGL(rs::step_kernel_cpl_replay<false>, g, dim3(RS_BLOCK), lds, stream, a);
   return hipGetLastError();
 }
@@ -2980,33 +2962,25 @@ hipError_t rs_launch_step_coupled(const rs::StepArgs &a, int NL, hipStream_t str
 hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant, bool score,
                           hipStream_t stream) {
   const dim3 g = grid_for(a.npoints), b(RS_BLOCK);
-  /* variant = flavour + 10 * waves-per-SIMD bound (0 = default for the flavour) */
-  int wpe = variant / 10;
-  variant %= 10;
   const bool auto_variant = variant == RS_VARIANT_AUTO;
   /* measured (tools/r3_full2.sh, 1 M points): FULL feature set - layers 8-15 in LDS at 4 waves/SIMD
    * 1.36e10, all in registers at 3 waves/SIMD (167 VGPRs) 1.34e10, at 4 waves (14 doubles spilled)
-   * 1.23e10, all in LDS 1.28e10.  LEAN: registers, 4 waves */
+   * 1.23e10, all in LDS 1.28e10.  LEAN: registers, 4 waves.  (tools/bench_driver_path.py relax, 1 M points, one
+   * plan: the FULL feature set in the register flavour at 3 waves/SIMD 0.745 s, at 2 waves 0.80 s, at 4 waves -
+   * 130 spilled VGPRs - 0.87 s; with the profile in LDS 0.86 s (3 waves) / 0.88 s (4 waves).)  The waves-per-SIMD
+   * bound was a digit of the variant until round 6; the measured choices are the kernels' launch bounds now. */
   if (auto_variant) variant = (NL != 15) ? RS_VARIANT_LDS : full ? RS_VARIANT_HYBRID : RS_VARIANT_REG;
-  /* measured (tools/bench_driver_path.py relax, 1 M points, one plan): the FULL feature set in the
-   * register flavour at 3 waves/SIMD (168 VGPRs) 0.745 s, at 2 waves 0.80 s, at 4 waves (130 spilled
-   * VGPRs) 0.87 s; with the profile in LDS 0.86 s (3 waves) / 0.88 s (4 waves).  LEAN: registers,
-   * 4 waves */
-  /* 32-bit window offsets (WinOff) where every stream of both windows spans < 4 GiB */
-  static const bool addr64 = getenv("ROADSURF_HIP_ADDR64") != nullptr; /* A/B switch */
+  /* 32-bit window offsets (WinOff) where every stream of both windows spans < 4 GiB (rs_a32_limit: the tests
+   * lower it to reach the 64-bit instances with windows of megabytes) */
   const int64_t out_rows = ((int64_t)a.t0 + a.nsteps - 2) / a.o.decimate - a.o.row0 + 1;
-  const bool a32 = (uint64_t)a.f.t_stride * (uint64_t)a.nsteps < (1ull << 29) &&
-                   (uint64_t)a.o.t_stride * (uint64_t)(out_rows > 0 ? out_rows : 1) < (1ull << 29) &&
-                   !addr64;
-  /* small shards: two wavefronts per 64 points (step_kernel_duo).  Measured on MI355X
-   * (tools/r3_eval.sh): faster than one point per lane below ROADSURF_HIP_DUO_MAX points per launch */
-  const char *edm = getenv("ROADSURF_HIP_DUO_MAX"); /* read per launch: the tests switch it */
-  const int64_t duo_max = edm ? atoll(edm) : RS_DUO_MAX_POINTS;
+  const bool a32 = (uint64_t)a.f.t_stride * (uint64_t)a.nsteps < rs_a32_limit() &&
+                   (uint64_t)a.o.t_stride * (uint64_t)(out_rows > 0 ? out_rows : 1) < rs_a32_limit();
+  /* small shards: two wavefronts per 64 points (step_kernel_duo).  Measured on MI355X (tools/r3_eval.sh): faster
+   * than one point per lane below RS_DUO_MAX_POINTS points per launch */
   const bool duo_ok = (!full || a.duo_full_ok) && NL == 15 && a32;
   if (variant == RS_VARIANT_DUO && !duo_ok) { /* not this launch: as AUTO */
     variant = (NL != 15) ? RS_VARIANT_LDS : full ? RS_VARIANT_HYBRID : RS_VARIANT_REG;
-    wpe = 0;
-  } else if (variant == RS_VARIANT_DUO || (auto_variant && wpe == 0 && duo_ok && a.npoints <= duo_max)) {
+  } else if (variant == RS_VARIANT_DUO || (auto_variant && duo_ok && a.npoints <= RS_DUO_MAX_POINTS)) {
     const dim3 gd(a.wave_start ? (unsigned)a.wave_n : (unsigned)((a.npoints + 63) / 64));
     if (full && score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, rs::SRC_WINDOW, true>), gd, dim3(128), 0, stream, a);
     else if (full) hipLaunchKernelGGL((rs::step_kernel_duo<15, false, rs::SRC_WINDOW, true>), gd, dim3(128), 0, stream, a);
@@ -3014,10 +2988,8 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
     else hipLaunchKernelGGL((rs::step_kernel_duo<15, false>), gd, dim3(128), 0, stream, a);
     return hipGetLastError();
   }
-  if (variant == RS_VARIANT_HYBRID && (NL != 15 || !full)) { /* not this launch: as AUTO */
+  if (variant == RS_VARIANT_HYBRID && (NL != 15 || !full)) /* not this launch: as AUTO */
     variant = (NL == 15) ? RS_VARIANT_REG : RS_VARIANT_LDS;
-    wpe = 0;
-  }
   if (variant == RS_VARIANT_HYBRID) {
 #define RS_HYB(S, A) \
   if (score == S && a32 == A) hipLaunchKernelGGL((rs::step_kernel_hybrid<S, A>), g, b, 0, stream, a);
@@ -3027,31 +2999,16 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
   }
   if (variant == RS_VARIANT_REG) {
     if (NL != 15) return hipErrorInvalidValue;
-    if (wpe == 0) wpe = full ? 3 : 4;
-    if (wpe < 2 || wpe > 4) return hipErrorInvalidValue;
-    /* instances without the history score: LEAN at 4 waves, FULL at 3 and 4 */
-    const bool sc = score || !(wpe == 4 || (full && wpe == 3));
-#define RS_REG(F, W, S, A)                                                              \
-  if (full == F && wpe == W && sc == S && a32 == A)                                      \
-    hipLaunchKernelGGL((rs::step_kernel_reg<15, F, W, S, A>), g, b, 0, stream, a);
-#define RS_REG_A(F, W, S) RS_REG(F, W, S, false) RS_REG(F, W, S, true)
-    RS_REG_A(false, 2, true) RS_REG_A(false, 3, true) RS_REG_A(false, 4, true) RS_REG_A(false, 4, false)
-    RS_REG_A(true, 2, true) RS_REG_A(true, 3, true) RS_REG_A(true, 4, true) RS_REG_A(true, 3, false)
-    RS_REG_A(true, 4, false)
+#define RS_REG(F, S, A) \
+  if (full == F && score == S && a32 == A) hipLaunchKernelGGL((rs::step_kernel_reg<15, F, S, A>), g, b, 0, stream, a);
+#define RS_REG_A(F, S) RS_REG(F, S, false) RS_REG(F, S, true)
+    RS_REG_A(false, true) RS_REG_A(false, false) RS_REG_A(true, true) RS_REG_A(true, false)
 #undef RS_REG_A
 #undef RS_REG
   } else {
     const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
-    if (wpe == 0) wpe = 4;
-    if (wpe < 3 || wpe > 4) return hipErrorInvalidValue; /* no instance: nothing would be launched */
-#define RS_LDS(W)                                                                        \
-  if (wpe == W) {                                                                        \
-    if (full)                                                                            \
-      hipLaunchKernelGGL((rs::step_kernel_lds<true, W>), g, b, lds, stream, a);          \
-    else                                                                                 \
-      hipLaunchKernelGGL((rs::step_kernel_lds<false, W>), g, b, lds, stream, a);         \
-  }
-    RS_LDS(3) RS_LDS(4)
+    if (full) hipLaunchKernelGGL((rs::step_kernel_lds<true>), g, b, lds, stream, a);
+    else hipLaunchKernelGGL((rs::step_kernel_lds<false>), g, b, lds, stream, a);
   }
   return hipGetLastError();
 }
@@ -3071,13 +3028,7 @@ hipError_t rs_launch_knots(const rs::KnotArgs &a, int32_t nknots, hipStream_t st
 hipError_t rs_launch_expand(const rs::ExpandArgs &a, int32_t nintervals, hipStream_t stream) {
   dim3 g = grid_for(a.npoints);
   g.y = (unsigned)nintervals;
-  const int m = (a.f.tdew ? 1 : 0) | (a.f.tsurfobs ? 2 : 0) | (a.f.depth ? 4 : 0);
-#define RS_EXPAND(M)                                                                          \
-  if (m == M)                                                                                 \
-    hipLaunchKernelGGL((rs::expand_kernel<(M & 1) != 0, (M & 2) != 0, (M & 4) != 0>), g,      \
-                       dim3(RS_BLOCK), 0, stream, a);
-  RS_EXPAND(0) RS_EXPAND(1) RS_EXPAND(2) RS_EXPAND(3) RS_EXPAND(4) RS_EXPAND(5) RS_EXPAND(6) RS_EXPAND(7)
-#undef RS_EXPAND
+  hipLaunchKernelGGL(rs::expand_kernel, g, dim3(RS_BLOCK), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -194,12 +194,6 @@ __device__ __forceinline__ void run(const rs::StepArgs &a, Prof &T) {
   }
 }
 
-__global__ void __launch_bounds__(kBlock, 4) step_kernel_f32_reg15(const rs::StepArgs a) {
-  if ((int64_t)blockIdx.x * kBlock + threadIdx.x >= a.npoints) return;
-  RegProfile<15> T;
-  run(a, T);
-}
-
 __global__ void __launch_bounds__(kBlock, 4) step_kernel_f32_lds(const rs::StepArgs a) {
   extern __shared__ float ldsf[];
   if ((int64_t)blockIdx.x * kBlock + threadIdx.x >= a.npoints) return;
@@ -242,8 +236,8 @@ __device__ __forceinline__ float rs32_lerp(float v0, float dv, float w) { return
 
 /* fp32 twin of expand_kernel (rs_kernels.hip: one basic block per time index, stores with a scalar
  * row base): same knots (fp64), interpolated in single precision (rs32_lerp). */
-template <bool TDEW, bool OBS>
 __global__ void __launch_bounds__(kBlock) expand_kernel_f32(const rs::ExpandArgs a) {
+  const bool OBS = a.f.tsurfobs != nullptr; /* (uniform; an fp32 window carries no dew point: rs_hip_expand_forcing) */
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= a.npoints) return;
   const int32_t k = a.kfirst + (int32_t)blockIdx.y;
@@ -279,7 +273,6 @@ __global__ void __launch_bounds__(kBlock) expand_kernel_f32(const rs::ExpandArgs
 #pragma unroll
     for (int q = 0; q < 7; ++q) v[q] = rs32_lerp((float)v0[q], (float)dv[q], w);
     st(a.f.tair, v[0]);
-    if (TDEW) st(a.f.tdew, v[1]);
     st(a.f.vz, v[2]);
     st(a.f.rhz, v[3]);
     st(a.f.prec, v[4]);
@@ -970,15 +963,12 @@ static inline dim3 grid_x2(int64_t n) { return dim3((unsigned)((n + 127) / 128))
 
 hipError_t rs32_launch_step(const rs::StepArgs &a, int NL, int variant, bool score, hipStream_t stream) {
   const dim3 g = grid_for32(a.npoints), b(RS_BLOCK);
-  const int v = variant % 10;
+  const int v = variant;
   if (NL == 15 && v != RS_VARIANT_REG && v != RS_VARIANT_LDS) {
     /* two points per lane, two wavefronts per 128 points (round 6); RS_VARIANT_REG / _LDS: round 2-5's one point
-     * per lane, for A/B */
+     * per lane with the profile in LDS, for A/B (and what other layer counts take) */
     if (score) hipLaunchKernelGGL((rs32::step_kernel_f32duo<rs32::X2_WINDOW, true>), grid_x2(a.npoints), dim3(128), 0, stream, a);
     else hipLaunchKernelGGL((rs32::step_kernel_f32duo<rs32::X2_WINDOW, false>), grid_x2(a.npoints), dim3(128), 0, stream, a);
-  } else if (v == RS_VARIANT_REG) {
-    if (NL != 15) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rs32::step_kernel_f32_reg15, g, b, 0, stream, a);
   } else {
     hipLaunchKernelGGL(rs32::step_kernel_f32_lds, g, b, (size_t)NL * RS_BLOCK * sizeof(float), stream, a);
   }
@@ -1000,13 +990,6 @@ hipError_t rs32_launch_init(const rs::InitArgs &a, hipStream_t stream) {
 hipError_t rs32_launch_expand(const rs::ExpandArgs &a, int32_t nintervals, hipStream_t stream) {
   dim3 g = grid_for32(a.npoints);
   g.y = (unsigned)nintervals;
-  if (a.f.tdew && a.f.tsurfobs)
-    hipLaunchKernelGGL((rs32::expand_kernel_f32<true, true>), g, dim3(RS_BLOCK), 0, stream, a);
-  else if (a.f.tdew)
-    hipLaunchKernelGGL((rs32::expand_kernel_f32<true, false>), g, dim3(RS_BLOCK), 0, stream, a);
-  else if (a.f.tsurfobs)
-    hipLaunchKernelGGL((rs32::expand_kernel_f32<false, true>), g, dim3(RS_BLOCK), 0, stream, a);
-  else
-    hipLaunchKernelGGL((rs32::expand_kernel_f32<false, false>), g, dim3(RS_BLOCK), 0, stream, a);
+  hipLaunchKernelGGL(rs32::expand_kernel_f32, g, dim3(RS_BLOCK), 0, stream, a);
   return hipGetLastError();
 }

@@ -361,7 +361,7 @@ class Plan:
 
 def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputParameters,
                local, chunk: int = 0, variant: int = 0, device: int = 0,
-               lean_if_possible: bool = True, year_month_day=None):
+               lean_if_possible: bool = True, year_month_day=None, history_score: bool | None = None):
     """Run host arrays ``forcing[name][n, SimLen]`` (numpy, reference layout) through the
     device-resident API and return outputs ``[n, SimLen]`` as numpy.  Test/bench helper:
     transposes with torch on the device, windows of ``chunk`` steps (0 = whole series)."""
@@ -374,6 +374,8 @@ def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputPara
     plan = Plan(n, settings, params, device)
     if variant:
         plan.set_variant(variant)
+    if history_score is not None:
+        plan.set_history_score(history_score)
     npad = plan.np_pad
     if isinstance(local, abi.LocalParameters):
         local = [local] * n

@@ -17,8 +17,6 @@ inside the timed region) before the slots are re-sorted for the next launch.
 """
 from __future__ import annotations
 
-import os
-
 import torch
 
 from . import device, lib
@@ -57,15 +55,16 @@ class SyntheticRun:
                           and plan.consts.NLayers == 15)
         # fp32 (round 6): the two-points-per-lane kernel reads the knots itself too, in either order (variants 1
         # and 2 keep round 2-5's one point per lane with a forcing window, for A/B)
-        if f32 and not full and plan.consts.NLayers == 15 and getattr(plan, "variant", 0) % 10 not in (1, 2):
+        if f32 and not full and plan.consts.NLayers == 15 and getattr(plan, "variant", 0) not in (1, 2):
             self.fused = True
         # sort key of the re-sort: forecast of the next window (rs_hip_recluster_forecast) or the
         # history of the last one (rs_hip_recluster)
         self.forecast, self.forecast_alpha, self.forecast_mode = forecast, forecast_alpha, forecast_mode
-        # round 5: one more key bit for "precipitation in the next window" (ROADSURF_HIP_PRECIP_BIT=0: A/B)
-        self.precip_bit = os.environ.get("ROADSURF_HIP_PRECIP_BIT", "1") != "0"
-        # ... and previews placed inside the window (ROADSURF_HIP_PREVIEWS_AT_KNOTS=1: round 4's, A/B)
-        self.previews_in_window = os.environ.get("ROADSURF_HIP_PREVIEWS_AT_KNOTS", "0") != "1"
+        # round 5: one more key bit for "precipitation in the next window" (profiles/r05_ab_precip_bit.txt) and
+        # previews placed inside the window (profiles/r05_ab_previews_in_window.txt); attributes, not environment
+        # knobs, since round 6
+        self.precip_bit = True
+        self.previews_in_window = True
         plan.set_history_score(not (plan_order and forecast))  # nobody reads it then
         dev, npad = plan.device, plan.np_pad
         wdtype = torch.float32 if f32 else torch.float64
@@ -162,9 +161,7 @@ class SyntheticRun:
             # half-hour window is not forecast from a knot half an hour old.  (Windows of whole hours keep their
             # knots: measured level or 0.5 % better, profiles/r05_ab_previews_in_window.txt)
             # (two: the middle index, and five or seven previews, sort no better, profiles/r05_sweep_previews.txt)
-            idx = [t_next - 1, t_next + ns - 2]
-            if os.environ.get("ROADSURF_HIP_PREVIEWS") == "3":  # (tuning) with the middle index: 0.4 % slower
-                idx = [idx[0], t_next - 1 + ns // 2, idx[1]]
+            idx = [t_next - 1, t_next + ns - 2]  # (with the middle index as a third preview: 0.4 % slower)
             ks = [min(i // SPK, kn.shape[0] - 2) for i in idx]
             plan.recluster_forecast([kn[k, 0] for k in ks], [kn[k, 2] for k in ks],
                                     [(self.spec.start_hour + i // SPK) % 24 for i in idx], None, self.forecast_alpha,

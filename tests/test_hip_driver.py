@@ -313,7 +313,7 @@ def test_shared_axis_chunked_coupling_in_plan_order(monkeypatch):
     ok = o["status"] == 0
     assert ok.sum() > n // 2
     monkeypatch.setenv("ROADSURF_HIP_CHUNK_STEPS", "60")
-    for env in (dict(), dict(ROADSURF_HIP_SORT_KEY="history"), dict(ROADSURF_HIP_CLUSTER="0")):
+    for env in (dict(), dict(ROADSURF_HIP_CLUSTER="0")):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         g = driver.run(src, s, p, t0, tf)

@@ -257,6 +257,21 @@ def test_full_size_properties_1M_points_48h():
 @pytest.mark.parametrize("full", [False, True], ids=["lean", "full"])
 @pytest.mark.parametrize("n,hours,chunk", [(5000, 6, 7), (5000, 6, 60), (4097, 5, 121), (64, 3, 240), (70000, 3, 90)])
 def test_knot_reading_flavour_matches_window_flavour(n, hours, chunk, full):
+    _knots_against_windows(n, hours, chunk, full)
+
+
+@pytest.mark.parametrize("full", [False, True], ids=["lean", "full"])
+@pytest.mark.parametrize("key", ["history", "wave_table"])
+def test_knot_reading_flavour_under_the_other_sort_keys(key, full):
+    """The same comparison with the plan re-sorted by the HISTORY of the last launch (rs_hip_recluster: the step
+    kernels then keep the history score - the SCORE instances of step_kernel_duo with the knots as source) and by
+    a forecast key of thirteen bits, for which every class of the key starts a wavefront of its own
+    (rs_cluster_wave_table, cs_wave_table_kernel: the default 10/11-bit keys take no table)."""
+    kw = dict(forecast=False) if key == "history" else dict(forecast_mode=378659)
+    _knots_against_windows(5000, 6, 60, full, **kw)
+
+
+def _knots_against_windows(n, hours, chunk, full, **run_kw):
     """rs_hip_step_knots (the two-wavefront flavour's ground wave interpolates the forcing from the resident
     knots) against the expansion kernel + forcing window + one point per lane, both in plan order: every
     output of every point at every index carries the same bits, whatever the launch length (windows that
@@ -274,7 +289,7 @@ def test_knot_reading_flavour_matches_window_flavour(n, hours, chunk, full):
         plan = device.Plan(n, s, p, 0)
         plan.set_variant(variant)
         run = workload.SyntheticRun(plan, 77, hours, chunk, point_offset=12345, plan_order=True, full=full,
-                                    initlen=200)
+                                    initlen=200, **run_kw)
         assert run.fused == (variant == 3)
         full_out = {k: torch.full((L, n), float("nan"), dtype=torch.float64, device=plan.device) for k in device.OUT_FIELDS}
 

@@ -294,3 +294,32 @@ def test_state_of_failed_points_is_the_same_in_every_flavour():
             assert np.array_equal(states[1][row], states[v][row]), (v, row)
         for row in range(abi.RS_MAX_LAYERS, abi.RS_MAX_LAYERS + 13):
             assert np.array_equal(states[1][row], states[v][row]), (v, row)
+
+
+@pytest.mark.parametrize("full", [False, True], ids=["lean", "full"])
+def test_every_instance_of_the_one_point_per_lane_kernels_has_the_same_bits(full, monkeypatch):
+    """step_kernel_reg / _hybrid / _lds are compiled with and without the history score of rs_hip_recluster and with
+    32- or 64-bit window offsets (64 where a stream of a window spans 4 GiB or more: rs_a32_limit).  The 64-bit
+    instances never ran in a test before round 6 (a window that large is tens of gigabytes); with the limit lowered
+    (ROADSURF_HIP_A32_LIMIT) a window of megabytes takes them: every combination against the reference, bit for
+    bit (profiles/r06_kernel_reachability.txt)."""
+    from roadsurf_amd import device
+    n, L = 300, 721
+    f = oh.synth_forcing(n, L, seed=31)
+    s = abi.default_settings(L); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
+    if full:
+        s.use_relaxation = 1
+        l.InitLenI = 240
+        l.tair_relax, l.VZ_relax, l.RH_relax = -2.0, 3.0, 85.0
+        f["tsurfobs"][:, :240] = f["tair"][:, :240] - 0.5
+    ora, _, _ = oh.run_oracle("ref" if oh.have_ref() else "port", f, s, p, l)
+    for variant in (1, 2, 4) if full else (1, 2):
+        for score in (True, False):
+            for limit in (None, "100000"):  # 512 padded columns x 721 rows = 369 152 elements per stream
+                if limit:
+                    monkeypatch.setenv("ROADSURF_HIP_A32_LIMIT", limit)
+                else:
+                    monkeypatch.delenv("ROADSURF_HIP_A32_LIMIT", raising=False)
+                res, nfail = device.run_points(f, s, p, l, variant=variant, history_score=score, chunk=0)
+                for k in oh.F64_OUT:
+                    assert np.array_equal(res[k], ora[k]), (variant, score, limit, k)

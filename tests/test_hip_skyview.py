@@ -78,23 +78,28 @@ def test_sky_view_with_coupling_and_c_abi():
         assert np.array_equal(out[k], ora[k]), k
 
 
-@pytest.mark.parametrize("chunk", [97, 400])
-def test_sky_view_with_coupling_time_chunked(chunk):
+@pytest.mark.parametrize("chunk,windows,nlayers", [(97, "spread", 15), (400, "spread", 15), (400, "compact", 15),
+                                                   (400, "compact", 12)])
+def test_sky_view_with_coupling_time_chunked(chunk, windows, nlayers):
     """Sky view and coupling together through the lock-step kernels (rs_hip_step_cpl + the replay rounds
     of rs_hip_cpl_replay, time_loop<SKY, CPL>): coupling windows that end at different indices, points
-    with and without a sky view, launch boundaries inside the windows - against the reference."""
+    with and without a sky view, launch boundaries inside the windows - against the reference.  compact: every
+    window ends within a few indices of the others, so the replay rounds run in LOCK STEP over the list
+    (step_kernel_cpl_replay_h<3, true>; with another layer count the LDS-profile twin step_kernel_cpl_replay<true>)
+    instead of the per-lane kernel - unreached by any test before round 6 (profiles/r06_kernel_reachability.txt)."""
     from roadsurf_amd import device
     n, SL = 200, 1441
     f, ls = _sky_case(n, SL, 11, summer=True)
     p = abi.default_parameters()
-    base, _, _ = oh.run_oracle("port", f, abi.default_settings(SL), p, ls)
+    s0 = abi.default_settings(SL); s0.NLayers = nlayers
+    base, _, _ = oh.run_oracle("port", f, s0, p, ls)
     rs = np.random.RandomState(3)
     for i, li in enumerate(ls):
-        ce = int(rs.choice([700, 900, 905]))
+        ce = int(rs.choice([700, 900, 905] if windows == "spread" else [900, 902, 905]))
         li.couplingIndexI = ce; li.InitLenI = ce
         li.couplingTsurf = float(base["tsurf"][i, ce - 1] + rs.choice([0.0, 1.0, -2.0, 5.0]))
     f["tsurfobs"][:, :] = base["tsurf"] + 0.2
-    s = abi.default_settings(SL); s.use_coupling = 1
+    s = abi.default_settings(SL); s.use_coupling = 1; s.NLayers = nlayers
     kind = "ref_cpl" if os.path.exists(oh.REF_CPL_SO) else "port"
     ora, _, _ = oh.run_oracle(kind, f, s, p, ls)
     whole, _ = device.run_points(f, s, p, ls)
@@ -102,7 +107,7 @@ def test_sky_view_with_coupling_time_chunked(chunk):
     for k in oh.F64_OUT:
         assert np.array_equal(whole[k], ora[k]), k
         assert np.array_equal(parts[k], ora[k]), k
-    off = abi.default_settings(SL)
+    off = abi.default_settings(SL); off.NLayers = nlayers
     plain, _, _ = oh.run_oracle("port", f, off, p, ls)
     assert np.abs(plain["tsurf"] - ora["tsurf"]).max() > 0.3  # coupling really acts on this case
 

@@ -7,15 +7,18 @@ import oracle_helpers as oh
 from roadsurf_amd import abi, device
 
 def run_f32(n, L, seed, offset=0, spk=120, chunk=480, cluster=False, fused=False, edit_knots=None, variant=0,
-            return_plan_info=False):
+            return_plan_info=False, history_score=None, nlayers=15):
     """fp32 run of the synthetic workload; with `cluster` the plan is re-sorted after every launch
     (rs_hip_recluster) and the outputs are mapped back through the order of each launch.  fused: the step kernel
     reads the knots itself (rs_hip_step_knots) instead of a forcing window; edit_knots(knots): change the resident
     knot block before the run (tests put values outside CheckValues' limits there)."""
     s = abi.default_settings(L); p = abi.default_parameters()
+    s.NLayers = nlayers
     plan = device.Plan(n, s, p, 0); plan.set_precision(32)
     if variant:
         plan.set_variant(variant)
+    if history_score is not None:
+        plan.set_history_score(history_score)
     dev, npad = plan.device, plan.np_pad
     spec, knots = plan.synth_knots(seed, (L - 1) // spk + 2, point_offset=offset, steps_per_knot=spk)
     if edit_knots is not None:
