@@ -531,12 +531,14 @@ int rs_hip_div_samples(RsPlan *plan, double *out);
  * storages), the other the layers below, meeting once per time step: the flavour for launches too
  * small to fill the chip with one point per lane (LEAN feature set, NLayers == 15, windows under
  * 4 GiB per stream; any other launch of such a plan runs as 0).  0 picks 3 for launches of at most
- * ROADSURF_HIP_DUO_MAX points (environment; the default is the measured break-even), else 1 for
- * NLayers == 15 with the LEAN feature set, 4 with the FULL one, else 2.
+ * 65 536 points (the measured break-even), else 1 for NLayers == 15 with the LEAN feature set, 4 with
+ * the FULL one, else 2.
  * 4: layers 1-7 in registers, 8-15 in LDS columns - the FULL feature set (NLayers == 15) at four
  * waves per SIMD without scratch spills; a LEAN launch of such a plan runs as 0.
- * + 10 * W: compile-time bound of W = 2..4 waves per SIMD for flavours 1 and 2 (tuning).
- * All flavours return the same bits. */
+ * (Until round 6 a tens digit bounded the waves per SIMD of flavours 1 and 2; the measured choices -
+ * LEAN four, FULL three - are the kernels' launch bounds now.)
+ * All flavours return the same bits.  An fp32 plan (rs_hip_set_precision): 0 = two points per lane, two
+ * wavefronts per 128 points (NLayers == 15); 1 or 2 = one point per lane with the profile in LDS. */
 int rs_hip_set_variant(RsPlan *plan, int32_t variant);
 
 /* ---- plan order: load balancing by regime ----------------------------------------------

@@ -73,11 +73,31 @@ struct Ctx {
   double ahead_out[6] = {};
 };
 
-thread_local std::vector<Ctx *> t_free; /* contexts this thread has finished with: plan, stream and buffers kept */
-/* contexts handed out and not yet given back: a derived-type COPY of the Fortran handle's owner makes two
- * finalizers release the same context - the second call finds it gone */
-std::mutex g_live_m;
-std::vector<Ctx *> g_live;
+/* Contexts (plan, stream, buffers) are kept for the next point: a free list of the PROCESS (round 6; it was
+ * thread-local and never released when its thread ended - a worker pool that starts and ends threads leaked a
+ * plan and a stream per thread).  A handle is not the context's address but a number that is never
+ * issued twice: a derived-type COPY of the Fortran handle's owner makes two finalizers release the same handle -
+ * the second finds it gone, even when the context behind it has been handed to another point since.  Leaked heap
+ * singletons: a FINAL procedure may run after static destruction. */
+struct Registry {
+  std::mutex m;
+  std::vector<Ctx *> free_list;                      /* at most kKeep contexts */
+  std::vector<std::pair<uint64_t, Ctx *>> live;      /* handles handed out and not yet given back */
+  uint64_t next = 1;
+};
+constexpr size_t kKeep = 16;
+Registry &reg() {
+  static Registry *r = new Registry();
+  return *r;
+}
+Ctx *ctx_of(RsCompat *h) {
+  const uint64_t id = (uint64_t)reinterpret_cast<uintptr_t>(h);
+  Registry &r = reg();
+  std::lock_guard<std::mutex> lk(r.m);
+  for (auto &e : r.live)
+    if (e.first == id) return e.second;
+  return nullptr;
+}
 
 /* the state slots module RoadSurf (RoadSurfCompat.f90) reads by number */
 static_assert(RS_ST_TNW1 == 32 && RS_ST_TNW2 == 33 && RS_ST_TSURF == 34 && RS_ST_WAT == 35 && RS_ST_SNOW == 36 &&
@@ -229,12 +249,16 @@ RsCompat *rs_compat_begin(const RsConstants *consts, const LocalParameters *loca
   const char *ed = getenv("ROADSURF_HIP_DEVICES");
   const int device = (ed && *ed >= '0' && *ed <= '9') ? atoi(ed) % ndev : 0;
   Ctx *c = nullptr;
-  for (size_t k = 0; k < t_free.size(); ++k)
-    if (t_free[k]->device == device && std::memcmp(&t_free[k]->consts, consts, sizeof(RsConstants)) == 0) {
-      c = t_free[k];
-      t_free.erase(t_free.begin() + (long)k);
-      break;
-    }
+  {
+    Registry &r = reg();
+    std::lock_guard<std::mutex> lk(r.m);
+    for (size_t k = 0; k < r.free_list.size(); ++k)
+      if (r.free_list[k]->device == device && std::memcmp(&r.free_list[k]->consts, consts, sizeof(RsConstants)) == 0) {
+        c = r.free_list[k];
+        r.free_list.erase(r.free_list.begin() + (long)k);
+        break;
+      }
+  }
   auto bail = [&](const char *msg) -> RsCompat * {
     if (msg) fail(msg);
     destroy(c);
@@ -322,11 +346,11 @@ RsCompat *rs_compat_begin(const RsConstants *consts, const LocalParameters *loca
     return bail("rs_compat_begin: upload failed");
   if (rs_hip_init_state(c->plan, &f, &pp) != 0) return bail(nullptr);
   if (pull_state(c, state_out) != 0) return bail(nullptr);
-  {
-    std::lock_guard<std::mutex> lk(g_live_m);
-    g_live.push_back(c);
-  }
-  return reinterpret_cast<RsCompat *>(c);
+  Registry &r = reg();
+  std::lock_guard<std::mutex> lk(r.m);
+  const uint64_t id = r.next++;
+  r.live.emplace_back(id, c);
+  return reinterpret_cast<RsCompat *>((uintptr_t)id);
 }
 
 /* One time index (BalanceModelOneStep and everything the fused kernel does with it: CheckValues,
@@ -335,7 +359,7 @@ RsCompat *rs_compat_begin(const RsConstants *consts, const LocalParameters *loca
  * caller's arrays in place, src/ModRadiation.f90:57-71) - written only where the point has a sky view and no
  * coupling.  Returns 0, or < 0 (rs_last_error). */
 int rs_compat_step(RsCompat *h, int32_t i, double *state_out, double *edits) {
-  Ctx *c = reinterpret_cast<Ctx *>(h);
+  Ctx *c = ctx_of(h);
   if (!c || !state_out || i < 1 || i > c->L) return fail("rs_compat_step: bad arguments");
   COK(hipSetDevice(c->device));
   if (c->coupled && (int32_t)c->last[RS_ST_CPL_RESUME] > i && c->failed_at == 0) {
@@ -394,7 +418,7 @@ int rs_compat_step(RsCompat *h, int32_t i, double *state_out, double *edits) {
  * on the device, the rewritten output rows straight into the caller's arrays.  rewritten[2]: first and last
  * index whose rows were rewritten, 0 0 if the point did not replay. */
 int rs_compat_replay(RsCompat *h, int32_t i, double *state_out, int32_t *rewritten) {
-  Ctx *c = reinterpret_cast<Ctx *>(h);
+  Ctx *c = ctx_of(h);
   if (!c || !state_out || !rewritten) return fail("rs_compat_replay: bad arguments");
   rewritten[0] = rewritten[1] = 0;
   if (!c->coupled || c->ce < 1 || i != c->ce) return pull_state(c, state_out);
@@ -436,7 +460,7 @@ int rs_compat_replay(RsCompat *h, int32_t i, double *state_out, int32_t *rewritt
 
 /* the state column as the last step / replay left it (no device traffic) */
 int rs_compat_last_state(const RsCompat *h, double *state_out) {
-  const Ctx *c = reinterpret_cast<const Ctx *>(h);
+  const Ctx *c = ctx_of(const_cast<RsCompat *>(h));
   if (!c || !state_out) return fail("rs_compat_last_state: bad arguments");
   std::memcpy(state_out, c->last, sizeof(c->last));
   return 0;
@@ -445,7 +469,7 @@ int rs_compat_last_state(const RsCompat *h, double *state_out) {
 /* the output row of index i as the step kernel wrote it: 0 and out[6] = Tsurf, Snow, Water, Ice, Deposit, Ice2,
  * or 1 if the last step was not index i (or wrote no row) */
 int rs_compat_outputs(const RsCompat *h, int32_t i, double *out) {
-  const Ctx *c = reinterpret_cast<const Ctx *>(h);
+  const Ctx *c = ctx_of(const_cast<RsCompat *>(h));
   if (!c || !out || c->last_out_i != i) return 1;
   std::memcpy(out, c->last_out, sizeof(c->last_out));
   return 0;
@@ -453,23 +477,27 @@ int rs_compat_outputs(const RsCompat *h, int32_t i, double *out) {
 
 /* 0, or the 1-based index at which the device failed the point (CheckValues inside the fused step) */
 int32_t rs_compat_failed_index(const RsCompat *h) {
-  const Ctx *c = reinterpret_cast<const Ctx *>(h);
+  const Ctx *c = ctx_of(const_cast<RsCompat *>(h));
   return c ? c->failed_at : 0;
 }
 
 /* the point is finished: its plan, stream and buffers wait for the thread's next point */
 void rs_compat_end(RsCompat *h) {
-  Ctx *c = reinterpret_cast<Ctx *>(h);
-  if (!c) return;
+  const uint64_t id = (uint64_t)reinterpret_cast<uintptr_t>(h);
+  Ctx *c = nullptr;
+  bool keep = false;
   {
-    std::lock_guard<std::mutex> lk(g_live_m);
+    Registry &r = reg();
+    std::lock_guard<std::mutex> lk(r.m);
     size_t k = 0;
-    while (k < g_live.size() && g_live[k] != c) ++k;
-    if (k == g_live.size()) return; /* released already */
-    g_live.erase(g_live.begin() + (long)k);
+    while (k < r.live.size() && r.live[k].first != id) ++k;
+    if (k == r.live.size()) return; /* released already (a copied handle's second finalizer), or never issued */
+    c = r.live[k].second;
+    r.live.erase(r.live.begin() + (long)k);
+    keep = r.free_list.size() < kKeep;
+    if (keep) r.free_list.push_back(c);
   }
-  if (t_free.size() < 4) t_free.push_back(c);
-  else destroy(c);
+  if (!keep) destroy(c);
 }
 
 } /* extern "C" */

@@ -95,21 +95,30 @@ struct CallerCacheData {
 };
 /* caches of threads that have ended: adopted by the next thread that needs one (a thread's end - or the
  * process's, when the runtime may be gone already - is no place for HIP calls) */
-std::mutex g_orphans_m;
-std::vector<CallerCacheData> g_orphans;
+/* (leaked heap singletons, like rs_coalesce.hip's runner: a thread that ends after static destruction - a detached
+ * or OpenMP worker at process exit - must still find them) */
+std::mutex &orphans_mutex() {
+  static std::mutex *m = new std::mutex();
+  return *m;
+}
+std::vector<CallerCacheData> &orphans() {
+  static std::vector<CallerCacheData> *v = new std::vector<CallerCacheData>();
+  return *v;
+}
 
 struct CallerCache : CallerCacheData {
   ~CallerCache() {
     if (device < 0) return;
-    std::lock_guard<std::mutex> lk(g_orphans_m);
-    g_orphans.push_back(static_cast<const CallerCacheData &>(*this));
+    std::lock_guard<std::mutex> lk(orphans_mutex());
+    orphans().push_back(static_cast<const CallerCacheData &>(*this));
   }
   void adopt(int d) {
-    std::lock_guard<std::mutex> lk(g_orphans_m);
-    for (size_t k = 0; k < g_orphans.size(); ++k)
-      if (g_orphans[k].device == d) {
-        static_cast<CallerCacheData &>(*this) = g_orphans[k];
-        g_orphans.erase(g_orphans.begin() + (long)k);
+    std::lock_guard<std::mutex> lk(orphans_mutex());
+    std::vector<CallerCacheData> &o = orphans();
+    for (size_t k = 0; k < o.size(); ++k)
+      if (o[k].device == d) {
+        static_cast<CallerCacheData &>(*this) = o[k];
+        o.erase(o.begin() + (long)k);
         return;
       }
   }

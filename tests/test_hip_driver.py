@@ -107,8 +107,16 @@ def test_read_input_edge_cases_match_checker():
             _compare_read_input(g, o, 3)
 
 
+@pytest.mark.parametrize("order", ["plan_order", "library_default", "natural"])
 @pytest.mark.parametrize("mode", ["plain", "relaxation", "coupling", "skyview", "skyview_coupling"])
-def test_run_matches_checker_bitwise(mode, monkeypatch):
+def test_run_matches_checker_bitwise(mode, order, monkeypatch):
+    """order: tests/conftest.py asks rs_driver_run for plan order whatever the block size (ROADSURF_HIP_CLUSTER=1);
+    the library's own default for blocks under 4 096 points - natural order, launches of eight hours, no re-sorts -
+    and natural order with the ordinary launch length are held to the same bits here."""
+    if order == "library_default":
+        monkeypatch.delenv("ROADSURF_HIP_CLUSTER", raising=False)
+    elif order == "natural":
+        monkeypatch.setenv("ROADSURF_HIP_CLUSTER", "0")
     n = 384
     src, L, t0, tf = dh.scenario(n, hours=12, seed=23)
     kw = {"plain": dict(), "relaxation": dict(use_relaxation=1),

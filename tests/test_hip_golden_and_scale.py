@@ -265,9 +265,9 @@ def test_knot_reading_flavour_matches_window_flavour(n, hours, chunk, full):
 def test_knot_reading_flavour_under_the_other_sort_keys(key, full):
     """The same comparison with the plan re-sorted by the HISTORY of the last launch (rs_hip_recluster: the step
     kernels then keep the history score - the SCORE instances of step_kernel_duo with the knots as source) and by
-    a forecast key of thirteen bits, for which every class of the key starts a wavefront of its own
+    a forecast key of twelve bits (fields 3, 1, 2, 5 + the precipitation bit), for which every class of the key starts a wavefront of its own
     (rs_cluster_wave_table, cs_wave_table_kernel: the default 10/11-bit keys take no table)."""
-    kw = dict(forecast=False) if key == "history" else dict(forecast_mode=378659)
+    kw = dict(forecast=False) if key == "history" else dict(forecast_mode=31259)
     _knots_against_windows(5000, 6, 60, full, **kw)
 
 
