@@ -55,8 +55,8 @@ ALGO_BYTES_PER_UNIT = 100.0    # 52 B read + 48 B written per poin
 # 120 indices (0.6 B) + the state block once per launch (134 slots x 8 B over >= 60 indices, read and written: <= 36 B
 # at 60 indices per launch, ~18 B at 120) - reported beside the contract's 100 B figure, never instead of it
 FUSED_BYTES_PER_UNIT = 48.0 + 9 * 8 / 120.0 + 2 * 49 * 8 / 60.0
-TRAFFIC_FILE = "profiles/r05_traffic.json"  # committed PMC summary the roofline's `traffic` is read from
-TRAFFIC_FILE_F32 = "profiles/r05_f32_traffic.json"
+TRAFFIC_FILE = "profiles/r06_traffic.json"  # committed PMC summary the roofline's `traffic` is read from
+TRAFFIC_FILE_F32 = "profiles/r06_f32_traffic.json"
 
 
 def effective_cpus() -> int:
@@ -182,6 +182,7 @@ def f32_config5_leg(make_plans, timed_leg, params, args) -> dict:
         pl.close()
     units = F32_POINTS * simlen
     achieved = 52.0 * units * steps / (busy / 1e3) / 1e9
+    traffic, valu, traffic_file, traffic_note = measured_traffic(F32_POINTS, chunk, F32_PLANS, True)
     return {
         "value": units * steps / el, "unit": "point-timesteps/s", "ms_per_step": el / steps * 1e3, "steps": steps,
         "warmup": 1, "dtype": "f32", "failed_points": int(nfail),
@@ -192,7 +193,10 @@ def f32_config5_leg(make_plans, timed_leg, params, args) -> dict:
                    "gate": "distribution of |fp32 - fp64 oracle| (tests/test_hip_f32.py): 99.999 % of the point-steps "
                            "within 0.05 K over 7 days, rms < 5e-4 K"},
         "roofline": {"bound": "hbm", "kernel": "rs32::step_kernel_f32duo", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": (traffic_file + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, mean per launch; "
+                                        "stamped with the hash of the kernel sources)") if traffic is not None else None,
+                     "traffic_note": traffic_note, "valu": valu,
                      "algorithmic_bytes_per_unit": 52.0, "avg_launch_ms": step_ms / max(nl, 1), "launches": nl,
                      "busy_ms": busy, "concurrent_launches": step_ms / busy,
                      "step_kernel_only_value": units * steps / (busy / 1e3),
