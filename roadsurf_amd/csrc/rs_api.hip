@@ -687,9 +687,9 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
    * without its stop event would poison rs_hip_timing_step_ms */
   if (pl->c.use_coupling && !pp->coupling_index)
     return set_err("rs_hip_step: use_coupling is set: pass coupling_index/coupling_tsurf");
-  if (pl->f32 && (full || coupled || skyview))
-    return set_err("rs_hip_step: the fp32 flavour supports the LEAN feature set only (no Tdew, "
-                   "observation forcing, depth, relaxation, coupling, sky view)");
+  if (pl->f32 && (coupled || skyview || f->depth || pl->c.tsurfOutputDepth >= 0.0 || (full && pl->c.NLayers != 15)))
+    return set_err("rs_hip_step: the fp32 flavour has no output depth, coupling or sky view, and the FULL feature "
+                   "set (dew point, observation forcing, relaxation) for NLayers = 15 only");
   rs::StepArgs a;
   a.consts = pl->f32 ? pl->consts32_dev : pl->consts_dev;
   a.f = *f;
@@ -744,7 +744,7 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
   }
   hipError_t le;
   if (pl->f32)
-    le = rs32_launch_step(a, pl->c.NLayers, pl->variant, pl->history_score, pl->stream);
+    le = rs32_launch_step(a, pl->c.NLayers, pl->variant, pl->history_score, full, pl->stream);
   else if (skyview && !coupled)
     le = rs_launch_step_sky(a, pl->c.NLayers, pl->history_score, pl->stream); /* lock-step FULL + sky view */
   else if (coupled) {
@@ -813,9 +813,6 @@ int rs_hip_step_knots(RsPlan *pl, const RsSynthSpec *spec, const double *knots, 
   const bool full = (pp->initlen != nullptr) || pl->c.force_tsurf || (pl->c.use_relaxation && pp->tair_relax != nullptr);
   if (pl->c.use_relaxation && pp->tair_relax && (!pp->vz_relax || !pp->rh_relax || !pp->initlen))
     return set_err("rs_hip_step_knots: relaxation needs tair_relax, vz_relax, rh_relax and initlen");
-  if (pl->f32 && full)
-    return set_err("rs_hip_step_knots: the fp32 flavour supports the LEAN feature set only (no initialization "
-                   "phase, observation forcing or relaxation)");
   const int32_t *order = rs_hip_plan_order(pl);
   if (!order) return -1;
   HIP_OK(hipSetDevice(pl->device));
@@ -859,7 +856,7 @@ int rs_hip_step_knots(RsPlan *pl, const RsSynthSpec *spec, const double *knots, 
     HIP_OK(hipEventRecord(e0, pl->stream));
   }
   /* fp32: two points per lane, each lane interpolating its own forcing (rs_kernels_f32.hip) */
-  const hipError_t le = pl->f32 ? rs32_launch_step_knots(a, pl->history_score, pl->stream)
+  const hipError_t le = pl->f32 ? rs32_launch_step_knots(a, pl->history_score, full, pl->stream)
                                 : rs_launch_step_duo_knots(a, pl->history_score, pl->stream);
   if (le != hipSuccess) return set_err("rs_hip_step_knots: kernel launch failed: %s", hipGetErrorString(le));
   if (pl->timing) {
@@ -1302,7 +1299,7 @@ static int expand_forcing(RsPlan *pl, const RsSynthSpec *spec, const double *kno
   a.r_spk = 1.0 / (double)spk;
   a.gather = gather;
   if (pl->f32) {
-    if (f->depth || f->tdew) return set_err("rs_hip_expand_forcing: fp32 windows carry no Tdew/depth");
+    if (f->depth) return set_err("rs_hip_expand_forcing: fp32 windows carry no depth stream");
     HIP_OK(rs32_launch_expand(a, (t0 + nsteps - 2) / spk - kfirst + 1, (hipStream_t)stream));
   } else {
     HIP_OK(rs_launch_expand(a, (t0 + nsteps - 2) / spk - kfirst + 1, (hipStream_t)stream));

@@ -4,8 +4,9 @@
  * arithmetic are fp32, exp/log/rcp/sqrt are the hardware approximations.  The reference's storage
  * logic branches on rounding residuals (rs_math.hpp), so an fp32 run cannot track an fp64 run point
  * by point; tests/test_hip_f32.py gates the DISTRIBUTION of the differences against the fp64 oracle,
- * with the tolerance written there.  LEAN feature set only (no observation forcing after index 1,
- * output depth, relaxation, coupling, sky view).
+ * with the tolerance written there.  Feature sets: LEAN, and (round 6, NLayers = 15) the FULL set of the
+ * two-wavefront kernels - dew-point test, observation forcing during an initialization phase, relaxation;
+ * no output depth, coupling or sky view.
  *
  * Round 6: step_kernel_f32duo, TWO POINTS PER LANE and two wavefronts per 128 points (NLayers = 15).
  * What decides the organisation is how a gfx950 SIMD issues fp32 (tools/f32_issue.hip,
@@ -225,6 +226,8 @@ __global__ void __launch_bounds__(kBlock) init_kernel_f32(const rs::InitArgs a) 
   st[(int64_t)RS_ST_T4MELT * np + p] = c.T4Melt0; st[(int64_t)RS_ST_ALBEDO * np + p] = c.Albedo0;
   st[(int64_t)RS_ST_VERYCOLD * np + p] = 0.f; st[(int64_t)RS_ST_FAILED * np + p] = 0.f;
   st[(int64_t)RS_ST_BLSCORE * np + p] = 0.f;
+  st[(int64_t)RS_ST_TAIR_END * np + p] = 0.f; st[(int64_t)RS_ST_VZ_END * np + p] = 0.f;
+  st[(int64_t)RS_ST_RH_END * np + p] = 0.f;
 }
 
 /* The forcing between two hourly knots in single precision: v0 + w (v1 - v0) with the knots' difference taken
@@ -237,7 +240,7 @@ __device__ __forceinline__ float rs32_lerp(float v0, float dv, float w) { return
 /* fp32 twin of expand_kernel (rs_kernels.hip: one basic block per time index, stores with a scalar
  * row base): same knots (fp64), interpolated in single precision (rs32_lerp). */
 __global__ void __launch_bounds__(kBlock) expand_kernel_f32(const rs::ExpandArgs a) {
-  const bool OBS = a.f.tsurfobs != nullptr; /* (uniform; an fp32 window carries no dew point: rs_hip_expand_forcing) */
+  const bool OBS = a.f.tsurfobs != nullptr, TDEW = a.f.tdew != nullptr; /* (uniform) */
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= a.npoints) return;
   const int32_t k = a.kfirst + (int32_t)blockIdx.y;
@@ -273,6 +276,7 @@ __global__ void __launch_bounds__(kBlock) expand_kernel_f32(const rs::ExpandArgs
 #pragma unroll
     for (int q = 0; q < 7; ++q) v[q] = rs32_lerp((float)v0[q], (float)dv[q], w);
     st(a.f.tair, v[0]);
+    if (TDEW) st(a.f.tdew, v[1]);
     st(a.f.vz, v[2]);
     st(a.f.rhz, v[3]);
     st(a.f.prec, v[4]);
@@ -444,21 +448,26 @@ __device__ __forceinline__ void x2_swait(f4s &r) { asm volatile("s_waitcnt lgkmc
  *                 1-2, melting, the storages, the outputs.  It never touches the forcing.
  * Half the registers per wavefront, twice the wavefronts for the same points, two different instruction
  * streams per SIMD. */
-#define RS_X2D_NPREP 11
-enum { XP_TAIR = 0, XP_C1, XP_K3, XP_RRA, XP_AVCAP, XP_PSYCH, XP_EAIR, XP_SW, XP_ELW, XP_RAIN, XP_SNOW };
+#define RS_X2D_NPREP 12
+enum { XP_TAIR = 0, XP_C1, XP_K3, XP_RRA, XP_AVCAP, XP_PSYCH, XP_EAIR, XP_SW, XP_ELW, XP_RAIN, XP_SNOW,
+       XP_OBS /* FULL: the observation SetCurrentValues forces on Tmp(1:2) at the index, or missing */ };
 struct X2Mail {
   float v[2][2][128];              /* [buffer][0: Tmp(2) from the surface wave, 1: Tmp(3) from the ground wave][point] */
   float prep[2][RS_X2D_NPREP][128]; /* [buffer = index parity][value][point] */
   uint32_t flags[2][128];          /* bit 0: CheckValues' verdict on the forcing; bit 1: night (SetDayDependendVariables) */
 };
 #ifndef RS_X2D_WAVES
-#define RS_X2D_WAVES 5 /* wavefronts per SIMD: 96 registers; the mailbox (14.3 KB per workgroup) allows ten workgroups per CU */
+#define RS_X2D_WAVES 5 /* wavefronts per SIMD: 96 registers; the mailbox (15.4 KB per workgroup) allows ten workgroups per CU */
 #endif
 __device__ __forceinline__ void x2_meet() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ f2 lds_ld2(const float *row, uint32_t lane) { return *reinterpret_cast<const f2 *>(row + 2 * lane); }
 __device__ __forceinline__ void lds_st2(float *row, uint32_t lane, f2 v) { *reinterpret_cast<f2 *>(row + 2 * lane) = v; }
 
-template <int SRC>
+/* FULL (round 6): the FULL feature set as the two-wavefront fp64 flavour has it (rs_kernels.hip duo_ground / duo_surface):
+ * CheckValues' dew-point test, the observation SetCurrentValues forces on Tmp(1:2) during the initialization phase
+ * (src/InputOutput.f90:116-148; force_tsurf: always), RelaxationOperations behind it (src/Relaxation.f90:10-47) - no
+ * output depth, coupling or sky view. */
+template <int SRC, bool FULL>
 __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) {
   KernArgs ka = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
   const uint32_t lane = threadIdx.x & 63u;
@@ -472,10 +481,32 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
   const f2 tbot = f2{(float)ka->pp.tbottom[p], (float)ka->pp.tbottom[p + 1]};
   const int32_t nsteps = ka->nsteps, t0 = ka->t0;
   rs::MathTab mt{nullptr, nullptr, nullptr};
-  f2 kv0[6], kdv[6];
+  constexpr int NK = FULL ? 7 : 6; /* tair, vz, rhz, prec, sw, lw [, tdew] */
+  f2 kv0[NK], kdv[NK];
   i2 kph0 = i2{0, 0}, kph1 = i2{0, 0};
   int32_t kcur = -1;
   bool knots_safe = false; /* uniform: no index of the current knot interval can fail CheckValues' forcing tests */
+  /* FULL: as the fp64 flavours set a point up (time_loop, duo_ground) */
+  i2 initlen = i2{0, 0};
+  b2 relax = b2{false, false};
+  f2 relax_dt = S2(0.f), relax_dv = S2(0.f), relax_dr = S2(0.f), tairR = S2(0.f), vzR = S2(0.f), rhR = S2(0.f);
+  f2 obs_next = S2(-9999.9f); /* the observation forced at the index the mailbox is being filled for */
+  if (FULL) {
+    if (ka->pp.initlen) initlen = i2{ka->pp.initlen[p], ka->pp.initlen[p + 1]};
+    if (consts_of(ka).use_relaxation && ka->pp.tair_relax) {
+      /* the targets through REAL(4), src/InputOutput.f90:19-26 */
+      tairR = f2{(float)ka->pp.tair_relax[p], (float)ka->pp.tair_relax[p + 1]};
+      vzR = f2{(float)ka->pp.vz_relax[p], (float)ka->pp.vz_relax[p + 1]};
+      rhR = f2{(float)ka->pp.rh_relax[p], (float)ka->pp.rh_relax[p + 1]};
+      auto valid = [](float t, float v, float r) {
+        return !(t < -100.0f || t > 100.0f || v < 0.0f || v > 100.0f || r < 0.0f || r > 110.f);
+      };
+      relax = b2{valid(tairR.x, vzR.x, rhR.x), valid(tairR.y, vzR.y, rhR.y)};
+      relax_dt = tairR - *reinterpret_cast<const f2 *>(st + (int64_t)RS_ST_TAIR_END * np + p);
+      relax_dv = vzR - *reinterpret_cast<const f2 *>(st + (int64_t)RS_ST_VZ_END * np + p);
+      relax_dr = rhR - *reinterpret_cast<const f2 *>(st + (int64_t)RS_ST_RH_END * np + p);
+    }
+  }
   int64_t kcolx = p, kcoly = p + 1;
   if (SRC == X2_KNOTS && ka->knot_gather) {
     kcolx = ka->knot_gather[p];
@@ -485,11 +516,12 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
   /* the forcing's share of index `in` -> mailbox buffer `buf` */
   auto prep = [&](int buf, int32_t in) {
     const ConstsAS &c = consts_of(ka);
-    f2 tair, vz, rhz, prec, sw, lw;
+    f2 tair, vz, rhz, prec, sw, lw, tdew = S2(0.f), tsobs = S2(-9999.9f);
     i2 phase;
     int32_t hour_u = 0;
     i2 hour_p = i2{0, 0};
     bool hour_per_point = false;
+    bool has_tdew = false;
     if (SRC == X2_KNOTS) {
       const int32_t spk = ka->spk;
       const int32_t t = in - 1;
@@ -497,12 +529,12 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
       const int32_t rr = t - kk * spk;
       if (kk != kcur) { /* uniform: a new knot interval - expand_kernel_f32's loads and differences */
         kcur = kk;
-        const int fld[6] = {0, 2, 3, 4, 5, 6};
+        const int fld[7] = {0, 2, 3, 4, 5, 6, 1};
         const double *ka_ = ka->knots + ((int64_t)(kk - ka->knot_k0) * RS_KNOT_FIELDS) * np;
         const bool has_b = (kk + 1 - ka->knot_k0) < ka->knot_n;
         const double *kb_ = ka_ + (int64_t)RS_KNOT_FIELDS * np;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
+        for (int q = 0; q < NK; ++q) {
           const double ax = ka_[(int64_t)fld[q] * np + kcolx], ay = ka_[(int64_t)fld[q] * np + kcoly];
           const double bx = has_b ? kb_[(int64_t)fld[q] * np + kcolx] : ax, by = has_b ? kb_[(int64_t)fld[q] * np + kcoly] : ay;
           kv0[q] = f2{(float)ax, (float)ay};
@@ -525,6 +557,7 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
             ok = ok && v0(3) > -0.1f + m && v1(3) > -0.1f + m && v0(3) < 500.f - m && v1(3) < 500.f - m;   /* prec */
             ok = ok && v0(4) > -0.1f + m && v1(4) > -0.1f + m && v0(4) < 4000.f - m && v1(4) < 4000.f - m; /* sw */
             ok = ok && v0(5) > -0.1f + m && v1(5) > -0.1f + m && v0(5) < 1000.f - m && v1(5) < 1000.f - m; /* lw */
+            if (FULL) ok = ok && v0(NK - 1) > -90.f + m && v1(NK - 1) > -90.f + m && v0(NK - 1) < 100.f - m && v1(NK - 1) < 100.f - m; /* tdew */
             return ok;
           };
           knots_safe = wave_all2(b2{inside(0), inside(1)});
@@ -535,6 +568,14 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
       prec = fma2(w, kdv[3], kv0[3]); sw = fma2(w, kdv[4], kv0[4]); lw = fma2(w, kdv[5], kv0[5]);
       phase = (rr == 0) ? kph0 : kph1;
       hour_u = rs_sy_hour(in, spk, ka->start_hour);
+      if (FULL) { /* expand_kernel_f32: the dew point like the others, the observation at index 1 only */
+        tdew = fma2(w, kdv[NK - 1], kv0[NK - 1]);
+        has_tdew = (ka->duo_full_ok & 2) != 0;
+        if (t == 0) {
+          const double *k7 = ka->knots + ((int64_t)(kk - ka->knot_k0) * RS_KNOT_FIELDS + 7) * np;
+          tsobs = f2{(float)k7[kcolx], (float)k7[kcoly]};
+        }
+      }
     } else {
       const int64_t row = (int64_t)(in - t0) * ka->f.t_stride + p;
       auto in2 = [&](const void *base) -> f2 {
@@ -548,6 +589,12 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
       hour_per_point = ka->f.hour_pstride != 0;
       if (hour_per_point) hour_p = i2{liveX ? (ka->f.hour + row)[0] : 0, liveY ? (ka->f.hour + row)[1] : 0};
       else hour_u = ka->f.hour[in - t0];
+      if (FULL) {
+        has_tdew = ka->f.tdew != nullptr;
+        if (has_tdew) tdew = in2(ka->f.tdew);
+        if (ka->f.tsurfobs) tsobs = in2(ka->f.tsurfobs);
+        if (ka->f.tsurfobs && !liveY) tsobs.y = -9999.9f;
+      }
     }
     if (in == 1) vz = max2(vz, S2(0.4f)); /* src/Initialization.f90:121-123 */
     uint32_t flx = 0u, fly = 0u;
@@ -559,7 +606,39 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
       fa.phase = phase.x; fb.phase = phase.y; fa.hour = fb.hour = 0;
       flx = check_values_forcing(c, fa) ? 1u : 0u;
       fly = check_values_forcing(c, fb) ? 1u : 0u;
+      if (FULL && has_tdew) { /* :59-62 */
+        flx |= (tdew.x < -90.f || tdew.x > 100.0f) ? 1u : 0u;
+        fly |= (tdew.y < -90.f || tdew.y > 100.0f) ? 1u : 0u;
+      }
     }
+    f2 obs = S2(-9999.9f);
+    if (FULL && in < c.SimLen) {
+      /* SetCurrentValues' observation forcing (src/InputOutput.f90:116-124): decided here, applied by both waves */
+      const b2 forced = b2{(in <= initlen.x || c.force_tsurf) && tsobs.x > -100.0f, (in <= initlen.y || c.force_tsurf) && tsobs.y > -100.0f};
+      obs = sel2(forced, tsobs, obs);
+      if (wave_any2(relax)) { /* RelaxationOperations, src/Relaxation.f90:10-47 */
+        const b2 at = and2(relax, b2{in == initlen.x, in == initlen.y});
+        if (wave_any2(at)) { /* the anchors: once per point (atm%TairInitEnd ...), the forcing as the index has it */
+          relax_dt = sel2(at, tairR - tair, relax_dt);
+          relax_dv = sel2(at, vzR - vz, relax_dv);
+          relax_dr = sel2(at, rhR - rhz, relax_dr);
+          float *sw_ = reinterpret_cast<float *>(ka->state);
+          if (at.x && liveX) { sw_[(int64_t)RS_ST_TAIR_END * np + p] = tair.x; sw_[(int64_t)RS_ST_VZ_END * np + p] = vz.x; sw_[(int64_t)RS_ST_RH_END * np + p] = rhz.x; }
+          if (at.y && liveY) { sw_[(int64_t)RS_ST_TAIR_END * np + p + 1] = tair.y; sw_[(int64_t)RS_ST_VZ_END * np + p + 1] = vz.y; sw_[(int64_t)RS_ST_RH_END * np + p + 1] = rhz.y; }
+        }
+        const b2 behind = and2(relax, b2{in > initlen.x, in > initlen.y});
+        if (wave_any2(behind)) {
+          /* exp(-(DTSecs in - DTSecs InitLenI) / (4 x 3600)) */
+          const f2 d = f2{(float)(in - initlen.x), (float)(in - initlen.y)};
+          const f2 e = exp2v(S2(-c.DTSecs * (1.0f / 14400.0f)) * d);
+          tair = sel2(behind, tair - relax_dt * e, tair);
+          vz = sel2(behind, vz - relax_dv * e, vz);
+          const f2 rh = min2(rhz - relax_dr * e, S2(100.0f));
+          rhz = sel2(behind, rh, rhz);
+        }
+      }
+    }
+    if (FULL) obs_next = obs;
     /* PrecipitationToStorage without the storages (src/Storage.f90:9-29, src/Cond.f90:143-249): the amounts */
     const f2 prec_ts = (prec * S2(__builtin_amdgcn_rcpf(3600.0f))) * S2(c.DTSecs);
     f2 rain = S2(0.f), snowfall = S2(0.f);
@@ -616,6 +695,7 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
     lds_st2(w[XP_RRA], lane, rRA); lds_st2(w[XP_AVCAP], lane, AirVCap); lds_st2(w[XP_PSYCH], lane, PsychC);
     lds_st2(w[XP_EAIR], lane, hum * ESat); lds_st2(w[XP_SW], lane, sw); lds_st2(w[XP_ELW], lane, S2(c.Emiss) * lw);
     lds_st2(w[XP_RAIN], lane, rain); lds_st2(w[XP_SNOW], lane, snowfall);
+    if (FULL) lds_st2(w[XP_OBS], lane, obs);
     *reinterpret_cast<uint2 *>(&mail.flags[buf][2 * lane]) = uint2{flx, fly};
   };
   lds_st2(mail.v[0][1], lane, T[0]);
@@ -625,7 +705,11 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
     asm volatile("" : "+s"(ka));
     const ConstsAS &c = consts_of(ka);
     const int32_t k = __builtin_amdgcn_readfirstlane(kv);
-    const f2 t2 = lds_ld2(mail.v[k & 1][0], lane); /* Tmp(2) as the last step left it (melting included) */
+    f2 t2 = lds_ld2(mail.v[k & 1][0], lane); /* Tmp(2) as the last step left it (melting included) */
+    if (FULL) { /* SetCurrentValues has forced Tmp(1:2) at this index: the flux into layer 3 sees the forced Tmp(2) */
+      const f2 obs_cur = obs_next;
+      t2 = sel2(gt2(obs_cur, S2(-100.0f)), obs_cur, t2);
+    }
     /* (a point that has failed keeps stepping here: its layers are never read again) */
     f2 Gprev = S2(c.lk4[2][2]) * (T[0] - t2); /* G(2), the expression layer 2 itself evaluates */
     const f2 dts = S2(c.DTSecs);
@@ -668,7 +752,7 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
   }
 }
 
-template <bool SCORE>
+template <bool SCORE, bool FULL>
 __device__ __forceinline__ void x2d_surface(X2Mail &mail, const rs::StepArgs &a) {
   KernArgs ka = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
   const uint32_t lane = threadIdx.x & 63u;
@@ -731,6 +815,21 @@ __device__ __forceinline__ void x2d_surface(X2Mail &mail, const rs::StepArgs &a)
         const bool bady = !was_failed.y && ((fl.y & 1u) || check_values_tsurf(c, s.tsurf.y));
         if (badx) { s.failed.x = true; st[(int64_t)RS_ST_FAILED * np + p] = (float)i; }
         if (bady) { s.failed.y = true; st[(int64_t)RS_ST_FAILED * np + p + 1] = (float)i; }
+      }
+      /* TmpNw(1:2) as CalcHCapHCond sees them (src/BalanceModel.f90:215): SetCurrentValues forces Tmp, not TmpNw */
+      const f2 stale1 = T1, stale2 = T2;
+      if (FULL) {
+        if (i < c.SimLen) {
+          const f2 obs = lds_ld2(w[XP_OBS], lane);
+          const b2 forced = gt2(obs, S2(-100.0f));
+          if (wave_any2(forced)) {
+            T1 = sel2(forced, obs, T1);
+            T2 = sel2(forced, obs, T2);
+            s.tsurf = sel2(forced, (T1 + T2) * S2(0.5f), s.tsurf);
+          }
+        } else { /* lastValues (src/InputOutput.f90:169-198): no output depth in this flavour */
+          s.tsurf = (T1 + T2) * S2(0.5f);
+        }
       }
       s.wat = s.wat + lds_ld2(w[XP_RAIN], lane);
       s.snow = s.snow + lds_ld2(w[XP_SNOW], lane);
@@ -851,10 +950,10 @@ __device__ __forceinline__ void x2d_surface(X2Mail &mail, const rs::StepArgs &a)
         f2 Gprev = ((rnet - le) + trffric) + blcond * (tair - t1old);
         X2Lit lit;
         lit.make();
-        const f2 rcap1 = x2_layer_rcap(c, lit, 1, t1old, &hs1);
+        const f2 rcap1 = x2_layer_rcap(c, lit, 1, FULL ? stale1 : t1old, &hs1);
         const f2 G1 = S2(c.lk4[1][2]) * (t2old - t1old);
         T1 = fma2(dts, rcap1 * (Gprev - G1), t1old);
-        const f2 rcap2 = x2_layer_rcap(c, lit, 2, t2old, nullptr);
+        const f2 rcap2 = x2_layer_rcap(c, lit, 2, FULL ? stale2 : t2old, nullptr);
         const f2 G2 = S2(c.lk4[2][2]) * (t3 - t2old);
         T2 = fma2(dts, rcap2 * (G1 - G2), t2old);
       }
@@ -929,15 +1028,15 @@ __device__ __forceinline__ void x2d_surface(X2Mail &mail, const rs::StepArgs &a)
   }
 }
 
-template <int SRC, bool SCORE>
+template <int SRC, bool SCORE, bool FULL = false>
 __global__ void __launch_bounds__(128, RS_X2D_WAVES) step_kernel_f32duo(const rs::StepArgs a) {
   __shared__ X2Mail mail;
   /* no early return: both wavefronts walk to every barrier; points beyond npoints are dead weight */
   if (threadIdx.x < 64) {
     if (a.surface_prio) __builtin_amdgcn_s_setprio(1); /* the longer chain of the two issues first (StepArgs::surface_prio) */
-    x2d_surface<SCORE>(mail, a);
+    x2d_surface<SCORE, FULL>(mail, a);
   } else {
-    x2d_ground<SRC>(mail, a);
+    x2d_ground<SRC, FULL>(mail, a);
   }
 }
 
@@ -961,26 +1060,37 @@ hipError_t rs32_upload_constants(void *dst, const RsConstants *c, hipStream_t st
 
 static inline dim3 grid_x2(int64_t n) { return dim3((unsigned)((n + 127) / 128)); } /* a workgroup steps 128 points */
 
-hipError_t rs32_launch_step(const rs::StepArgs &a, int NL, int variant, bool score, hipStream_t stream) {
+#define RS32_DUO(SRC)                                                                                                  \
+  do {                                                                                                                 \
+    const dim3 g2 = grid_x2(a.npoints);                                                                                \
+    if (full && score) hipLaunchKernelGGL((rs32::step_kernel_f32duo<SRC, true, true>), g2, dim3(128), 0, stream, a);   \
+    else if (full) hipLaunchKernelGGL((rs32::step_kernel_f32duo<SRC, false, true>), g2, dim3(128), 0, stream, a);      \
+    else if (score) hipLaunchKernelGGL((rs32::step_kernel_f32duo<SRC, true, false>), g2, dim3(128), 0, stream, a);     \
+    else hipLaunchKernelGGL((rs32::step_kernel_f32duo<SRC, false, false>), g2, dim3(128), 0, stream, a);               \
+  } while (0)
+
+/* full: the launch carries the FULL feature set (dew point, observation forcing, relaxation): the two-points-per-lane
+ * kernel only (NLayers = 15) */
+hipError_t rs32_launch_step(const rs::StepArgs &a, int NL, int variant, bool score, bool full, hipStream_t stream) {
   const dim3 g = grid_for32(a.npoints), b(RS_BLOCK);
   const int v = variant;
-  if (NL == 15 && v != RS_VARIANT_REG && v != RS_VARIANT_LDS) {
+  if (NL == 15 && (full || (v != RS_VARIANT_REG && v != RS_VARIANT_LDS))) {
     /* two points per lane, two wavefronts per 128 points (round 6); RS_VARIANT_REG / _LDS: round 2-5's one point
      * per lane with the profile in LDS, for A/B (and what other layer counts take) */
-    if (score) hipLaunchKernelGGL((rs32::step_kernel_f32duo<rs32::X2_WINDOW, true>), grid_x2(a.npoints), dim3(128), 0, stream, a);
-    else hipLaunchKernelGGL((rs32::step_kernel_f32duo<rs32::X2_WINDOW, false>), grid_x2(a.npoints), dim3(128), 0, stream, a);
+    RS32_DUO(rs32::X2_WINDOW);
   } else {
+    if (full) return hipErrorInvalidValue;
     hipLaunchKernelGGL(rs32::step_kernel_f32_lds, g, b, (size_t)NL * RS_BLOCK * sizeof(float), stream, a);
   }
   return hipGetLastError();
 }
 
 /* the two-points-per-lane kernel reading the hourly knots itself (StepArgs::knots): no forcing window */
-hipError_t rs32_launch_step_knots(const rs::StepArgs &a, bool score, hipStream_t stream) {
-  if (score) hipLaunchKernelGGL((rs32::step_kernel_f32duo<rs32::X2_KNOTS, true>), grid_x2(a.npoints), dim3(128), 0, stream, a);
-  else hipLaunchKernelGGL((rs32::step_kernel_f32duo<rs32::X2_KNOTS, false>), grid_x2(a.npoints), dim3(128), 0, stream, a);
+hipError_t rs32_launch_step_knots(const rs::StepArgs &a, bool score, bool full, hipStream_t stream) {
+  RS32_DUO(rs32::X2_KNOTS);
   return hipGetLastError();
 }
+#undef RS32_DUO
 
 hipError_t rs32_launch_init(const rs::InitArgs &a, hipStream_t stream) {
   hipLaunchKernelGGL(rs32::init_kernel_f32, grid_for32(a.npoints), dim3(RS_BLOCK), 0, stream, a);

@@ -361,7 +361,8 @@ class Plan:
 
 def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputParameters,
                local, chunk: int = 0, variant: int = 0, device: int = 0,
-               lean_if_possible: bool = True, year_month_day=None, history_score: bool | None = None):
+               lean_if_possible: bool = True, year_month_day=None, history_score: bool | None = None,
+               precision: int = 64):
     """Run host arrays ``forcing[name][n, SimLen]`` (numpy, reference layout) through the
     device-resident API and return outputs ``[n, SimLen]`` as numpy.  Test/bench helper:
     transposes with torch on the device, windows of ``chunk`` steps (0 = whole series)."""
@@ -376,6 +377,9 @@ def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputPara
         plan.set_variant(variant)
     if history_score is not None:
         plan.set_history_score(history_score)
+    if precision == 32:  # the fp32 flavour: windows and outputs hold floats (rs_hip_set_precision)
+        plan.set_precision(32)
+    wdt = torch.float32 if precision == 32 else torch.float64
     npad = plan.np_pad
     if isinstance(local, abi.LocalParameters):
         local = [local] * n
@@ -393,13 +397,13 @@ def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputPara
         t[:, :n] = torch.from_numpy(np.ascontiguousarray(a)).to(dev).T
         return t
 
-    tens = {k: pad_t(forcing[k], torch.float64) for k in ("tair", "vz", "rhz", "prec", "sw", "lw")}
-    tens["tsurfobs"] = pad_t(forcing["tsurfobs"], torch.float64)
-    tens["tdew"] = pad_t(forcing["tdew"], torch.float64) if need_full else None
+    tens = {k: pad_t(forcing[k], wdt) for k in ("tair", "vz", "rhz", "prec", "sw", "lw")}
+    tens["tsurfobs"] = pad_t(forcing["tsurfobs"], wdt)
+    tens["tdew"] = pad_t(forcing["tdew"], wdt) if need_full else None
     # no depth stream where no value of it can act (depth(i) >= 0 takes the surface temperature from the
     # profile at that depth): the kernels read a missing stream as -9999.9, and the two-wavefront flavour
     # has the FULL feature set only without one
-    tens["depth"] = pad_t(forcing["depth"], torch.float64) if need_full and bool((forcing["depth"] >= 0).any()) else None
+    tens["depth"] = pad_t(forcing["depth"], wdt) if need_full and bool((forcing["depth"] >= 0).any()) else None
     tens["precphase"] = pad_t(forcing["precphase"], torch.int32)
     tens["hour"] = torch.from_numpy(np.ascontiguousarray(forcing["hour"])).to(dev)
     sky = None
@@ -446,7 +450,7 @@ def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputPara
             sky)
     else:
         pp = plan.point_params(tb)
-    out = OutputWindow.empty(L, npad, dev)
+    out = OutputWindow.empty(L, npad, dev, dtype=wdt)
     plan.init_state(win, pp)
     if coupled and chunk:
         # time-chunked coupling: lock-step chunks up to the last coupling-window end, the replay
@@ -479,7 +483,7 @@ def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputPara
             plan.step(win, out, pp, t0, ns, window_row=t0 - 1, out_row0=0)
             t0 += ns
     plan.sync()
-    res = {k: out.tensors[k][:, :n].T.contiguous().cpu().numpy() for k in OUT_FIELDS}
+    res = {k: out.tensors[k][:, :n].T.contiguous().double().cpu().numpy() for k in OUT_FIELDS}
     nfail = plan.failed_count()
     plan.close()
     return res, nfail

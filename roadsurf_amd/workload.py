@@ -55,7 +55,7 @@ class SyntheticRun:
                           and plan.consts.NLayers == 15)
         # fp32 (round 6): the two-points-per-lane kernel reads the knots itself too, in either order (variants 1
         # and 2 keep round 2-5's one point per lane with a forcing window, for A/B)
-        if f32 and not full and plan.consts.NLayers == 15 and getattr(plan, "variant", 0) not in (1, 2):
+        if f32 and not (full and depth_stream) and plan.consts.NLayers == 15 and getattr(plan, "variant", 0) not in (1, 2):
             self.fused = True
         # sort key of the re-sort: forecast of the next window (rs_hip_recluster_forecast) or the
         # history of the last one (rs_hip_recluster)
