@@ -166,35 +166,39 @@ def host_batch_leg(n: int, simlen: int, seed: int) -> dict:
 F32_POINTS, F32_HOURS, F32_PLANS, F32_CHUNK = 1_250_000, 168, 2, 360
 
 
-def f32_config5_leg(make_plans, timed_leg, params, args) -> dict:
+def f32_config5_leg(make_plans, timed_leg, params, args, full: bool = False) -> dict:
     """BASELINE config 5's per-GPU share through the fp32 flavour (rs_kernels_f32.hip step_kernel_f32duo: two
-    points per lane, two wavefronts per 128 points, forcing interpolated from the resident knots)."""
+    points per lane, two wavefronts per 128 points, forcing interpolated from the resident knots).  `full`: the
+    FULL feature set on the same points (dew-point and observation streams, 6 h initialization phase, relaxation)."""
     from roadsurf_amd import abi, workload
 
     simlen = F32_HOURS * workload.SPK + 1
     s32 = abi.default_settings(simlen)
+    if full:
+        s32.use_relaxation = 1
     plans, offs = make_plans(F32_PLANS, s32, 0, npoints=F32_POINTS, f32=True)
     steps = 3
-    el, step_ms, nl, chunk, busy = timed_leg(True, plans, offs, F32_CHUNK, False, steps=steps, warmup=1,
+    el, step_ms, nl, chunk, busy = timed_leg(True, plans, offs, F32_CHUNK, full, steps=steps, warmup=1,
                                              hours=F32_HOURS, f32=True)
     nfail = sum(pl.failed_count() for pl in plans)
     for pl in plans:
         pl.close()
     units = F32_POINTS * simlen
     achieved = 52.0 * units * steps / (busy / 1e3) / 1e9
-    traffic, valu, traffic_file, traffic_note = measured_traffic(F32_POINTS, chunk, F32_PLANS, True)
+    traffic, valu, traffic_file, traffic_note = ((None, None, None, "not collected for the FULL instance") if full else
+                                                 measured_traffic(F32_POINTS, chunk, F32_PLANS, True))
     return {
         "value": units * steps / el, "unit": "point-timesteps/s", "ms_per_step": el / steps * 1e3, "steps": steps,
         "warmup": 1, "dtype": "f32", "failed_points": int(nfail),
         "config": {"workload": f"{F32_POINTS} synthetic points x {F32_HOURS} h (SimLen {simlen}, DTSecs 30, NLayers 15), "
-                               "fp32 state / forcing / outputs / arithmetic, LEAN feature set, outputs every time "
+                               f"fp32 state / forcing / outputs / arithmetic, {'FULL (dew point and observation streams, 6 h initialization phase, relaxation)' if full else 'LEAN'} feature set, outputs every time "
                                "index, attributable to points; hourly knots of every point resident in HBM",
                    "plans_per_gpu": F32_PLANS, "chunk_steps": chunk, "plan_order": True,
                    "gate": "distribution of |fp32 - fp64 oracle| (tests/test_hip_f32.py): 99.999 % of the point-steps "
                            "within 0.05 K over 7 days, rms < 5e-4 K"},
-        "roofline": {"bound": "hbm", "kernel": "rs32::step_kernel_f32duo", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "rs32::step_kernel_f32duo" + ("<FULL>" if full else ""), "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": (traffic_file + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, mean per launch; "
+                     "traffic_source": (str(traffic_file) + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, mean per launch; "
                                         "stamped with the hash of the kernel sources)") if traffic is not None else None,
                      "traffic_note": traffic_note, "valu": valu,
                      "algorithmic_bytes_per_unit": 52.0, "avg_launch_ms": step_ms / max(nl, 1), "launches": nl,
@@ -622,6 +626,8 @@ def main() -> None:
         # tolerance-gated against the fp64 oracle (tests/test_hip_f32.py), its own roofline block (52 algorithmic
         # bytes per point-timestep: 6 x 4 + 4 read, 6 x 4 written)
         extra["f32_config5"] = f32_config5_leg(make_plans, timed_leg, params, args)
+        # ... and with the FULL feature set (a hindcast has observations to start from)
+        extra["f32_config5_full"] = f32_config5_leg(make_plans, timed_leg, params, args, full=True)
         extra["seconds"] = time.perf_counter() - t_x
     # dominant kernel: step kernel, HIP events on its own stream around every launch (this rank).
     # achieved = algorithmic bytes of the launches / time the device spent in them.  With one plan

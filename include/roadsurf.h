@@ -500,7 +500,9 @@ int rs_hip_expand_forcing_on(RsPlan *plan, const RsSynthSpec *spec,
 int rs_hip_test_math(RsPlan *plan, int32_t fn, int64_t n, const double *x, double *y);
 
 /* Arithmetic flavour of a plan: 64 (default; the parity path) or 32 (BASELINE config 5:
- * fp32 state/forcing/outputs/arithmetic, LEAN feature set, tolerance-gated against fp64).
+ * fp32 state/forcing/outputs/arithmetic, tolerance-gated against fp64; LEAN feature set for any
+ * NLayers, the FULL one - dew-point test, observation forcing, relaxation - for NLayers == 15;
+ * output depth, coupling and sky view are refused).
  * With 32 the `double *` members of RsForcing/RsOutputs point to FLOAT arrays of the same
  * [t][p] layout (precphase/hour stay int32, tbottom stays double), and the state block
  * holds floats.  Set before rs_hip_init_state. */
