@@ -33,7 +33,7 @@ The default run (N = 1) adds short extra legs under the same clock, reported as 
 one JSON line: `full_feature_value` (the FULL feature set on the same points) and
 `driver_path_{relax,coupling,sky}_value` (rs_driver_run from raw series in host arrays, PCIe
 inclusive), `driver_path_relax_holes_value` (the same on observation series with missing sensors,
-gaps and early ends), `host_batch_value` (runsimulation_batch from step-resolution host arrays);
+gaps and early ends), `driver_path_relax_bench_weather_value` (the same on the headline's weather), `host_batch_value` (runsimulation_batch from step-resolution host arrays);
 `--no-extra-legs` skips them.
 
 Prints ONE JSON line on rank 0.
@@ -596,6 +596,23 @@ def main() -> None:
                                    "series with holes: 10 % of the stations without an air-temperature / humidity / "
                                    "wind sensor each, 10 % of the road-temperature observations missing, 20 % of the "
                                    "series ending 1-3 h early",
+                       "series": "distinct for every point", "value_is": "mean of the timed calls", "pcie_inclusive": True},
+        }
+        del r, dw
+        # ... and on the weather the device-resident legs above run on, put into raw series (round 6: what of the
+        # distance between driver_path_relax and full_feature_value is the workload - here precipitation is one event
+        # on 30 % of the points, there it is independent from hour to hour on all of them - and what the code path;
+        # profiles/r06_driver_weather.txt)
+        dw = driver_workload.DriverWorkload(args.extra_points, args.hours, unique=None, weather="bench", seed=args.seed)
+        best, times, r = dw.time_calls("relax", reps=3, warm=1, device=-1)
+        mean = sum(times) / len(times)
+        extra["driver_path_relax_bench_weather"] = {
+            "value": dw.n * dw.simlen / mean, "unit": "point-timesteps/s", "seconds_per_call": mean,
+            "seconds_per_call_all": times, "best_call_value": dw.n * dw.simlen / best,
+            "calls_timed": len(times), "calls_warm": 1, "points_ok": int((r["status"] == 0).sum()),
+            "config": {"workload": f"rs_driver_run as driver_path_relax, {dw.n} points x {args.hours} h, the raw series "
+                                   "holding the synthetic weather of the headline and full_feature legs (csrc/rs_synth.h: "
+                                   "hourly knots as the forecast source, the observations on the same lines)",
                        "series": "distinct for every point", "value_is": "mean of the timed calls", "pcie_inclusive": True},
         }
         del r, dw

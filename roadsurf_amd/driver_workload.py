@@ -35,13 +35,36 @@ def _pin(a: np.ndarray) -> np.ndarray:
 _PINNED_KEEP: list = []
 
 
+def _bench_weather(u: int, nt_fc: int, nt_ob: int, seed: int):
+    """bench.py's synthetic weather (the device generator's hourly knots, rs_hip_synth_knots) as the two raw sources."""
+    import torch
+
+    from . import device
+
+    plan = device.Plan(u, abi.default_settings(121), abi.default_parameters(), torch.cuda.current_device())
+    _, kn = plan.synth_knots(seed, nt_fc)
+    k = kn[:, :, :u].permute(1, 2, 0).contiguous().cpu().numpy()  # [field][point][knot]: tair tdew vz rhz prec sw lw tsurf0
+    plan.close()
+    del kn
+    fc = dict(tair=k[0], tdew=k[1], vz=k[2], prec=k[4], sw=k[5], lw=k[6])
+    pos = 1.0 + np.arange(nt_ob) / 6.0  # the forecast's axis starts an hour before the observations'
+    i0 = np.minimum(pos.astype(np.int64), nt_fc - 2)
+    w = pos - i0
+
+    def at_obs(a):
+        return np.ascontiguousarray(a[:, i0] + w[None, :] * (a[:, i0 + 1] - a[:, i0]))
+
+    ob = dict(tair=at_obs(k[0]), rhz=at_obs(k[3]), vz=at_obs(k[2]), tsurfobs=at_obs(k[7]))
+    return fc, ob
+
+
 class DriverWorkload:
     """Inputs of one batch.  ``unique``: the series are generated for that many points and tiled up
     to ``n`` (bounds the host time spent making inputs; the regimes inside a tile are what a batch
     of that size has)."""
 
     def __init__(self, n: int, hours: int = 48, seed: int = 1, unique: int | None = None, pinned: bool = False,
-                 missing: float = 0.0, ragged: float = 0.0):
+                 missing: float = 0.0, ragged: float = 0.0, weather: str = "driver"):
         self.n, self.hours, self.pinned = n, hours, pinned
         self.simlen = hours * 120 + 1
         u = n if unique is None else min(unique, n)
@@ -70,6 +93,14 @@ class DriverWorkload:
         self.ob_t = START + np.arange(nt_ob, dtype=np.int64) * 600
         ob = dict(tair=series(nt_ob, 600, -12, 6, 1.0), rhz=np.clip(series(nt_ob, 600, 70, 95, 5.0), 5, 100),
                   vz=np.abs(series(nt_ob, 600, 1, 8, 1.0)) + 0.2, tsurfobs=series(nt_ob, 600, -10, 4, 1.0))
+        if weather == "bench":
+            # A/B (tools/experiments/r6_driver_weather.sh): the weather bench.py's device-resident legs run on
+            # (csrc/rs_synth.h: a daily cycle and a synoptic wave per point, one precipitation event on 30 % of the
+            # points) as hourly forecast series, the observations on the same lines - what of the distance between
+            # the driver legs and the FULL leg is the workload, and what the code path
+            fc, ob = _bench_weather(u, nt_fc, nt_ob, seed)
+        elif weather != "driver":
+            raise ValueError("weather: 'driver' or 'bench'")
         if missing > 0.0:
             # stations as real networks have them: some without an air-temperature / humidity / wind sensor (no
             # value of that variable in the observation source at all), and gaps in the road-temperature series -

@@ -13,7 +13,8 @@ depth = float(sys.argv[4]) if len(sys.argv) > 4 else None
 unique = int(os.environ["BENCH_UNIQUE"]) if "BENCH_UNIQUE" in os.environ else None
 w = driver_workload.DriverWorkload(n, hours, unique=unique, pinned=bool(int(os.environ.get("BENCH_PINNED", "0"))),
                                    missing=float(os.environ.get("BENCH_MISSING", "0")),  # BENCH_MISSING=0.1: stations without sensors, gaps
-                                   ragged=float(os.environ.get("BENCH_RAGGED", "0")))    # BENCH_RAGGED=0.2: observations that end hours apart
+                                   ragged=float(os.environ.get("BENCH_RAGGED", "0")),    # BENCH_RAGGED=0.2: observations that end hours apart
+                                   weather=os.environ.get("BENCH_WEATHER", "driver"))   # BENCH_WEATHER=bench: bench.py's weather as raw series (A/B)
 best, times, r = w.time_calls(mode, reps=int(os.environ.get("BENCH_REPS", "3")), warm=1,
                               device=int(os.environ.get("BENCH_DEVICE", "-1")), tsurf_output_depth=depth,
                               verbose=True, pause=float(os.environ.get("BENCH_PAUSE_S", "0")))

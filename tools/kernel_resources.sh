@@ -19,7 +19,7 @@ for b in blocks[1:]:
     g = lambda k: (re.search(r"\." + k + r":\s+(\S+)", b) or [None, "?"])[1]
     name = g("name")
     try:
-        dem = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip()
+        dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
     except Exception:
         dem = name
     if pat not in dem:
