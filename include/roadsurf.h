@@ -429,6 +429,20 @@ int rs_hip_clock_probe(int32_t device, void *out, uint32_t spin_us, void *stream
  * still taken and saved, later outputs read -9999.0 (examples/example1/src/Simulation.f90:58,
  * src/InputOutput.f90:55-82).  The reference only prints this ("BAD input value!"). */
 int rs_hip_first_failed_index(RsPlan *plan, int32_t *first_failed);
+/* The reference's other run-time messages (it prints them and carries on): from CalcBLCondAndLE
+ * " ERROR : UStar negative,vz" + the values line inside the boundary-layer loop and " Max number of BLCond
+ * iterations (MaxIter,BLCond_Old,BLCond) :" behind it (src/BoundaryLayer.f90:69-74,98-101), from Coupling_control
+ * "coupling coefficient too small / too big, coupling failed" (src/Coupling.f90:400-401,451-452).
+ * rs_hip_set_diagnostics(plan, 1) - fp64 plans in natural order; launches of such a plan take the one-point-per-
+ * lane kernels with the profile in LDS, which re-run the loop of every step out of line for the two tests: a
+ * debugging switch, not a production setting - zeroes the plan's record; rs_hip_diagnostics copies it out,
+ * out[npoints][RS_DIAG_COLS]: 0 time indices that printed "Max number ...", 1 the first of them, 2-4 its j,
+ * BLCond_Old, BLCond; 5 passes that printed "UStar negative", 6 the time index of the first, 7-11 its Tair, VZ,
+ * Rhz, BLCond, TSurfAve; 12 the coupling messages (8 = too small, 16 = too big; these are kept by every kernel
+ * flavour, with or without the switch). */
+#define RS_DIAG_COLS 13
+int rs_hip_set_diagnostics(RsPlan *plan, int32_t on);
+int rs_hip_diagnostics(RsPlan *plan, double *out);
 int rs_hip_sync(RsPlan *plan);
 
 /* Synthetic forcing: hourly knots from a counter-based hash,
@@ -672,6 +686,9 @@ typedef struct RsHostExtras {
    * (src/InputOutput.f90:75-77: SW_dir(i) = min(SW_dir(i), SW(i)) at every checked index;
    * src/ModRadiation.f90:57-71: SW, SW_dir, LW as the sky-view correction leaves them) */
   int32_t writeback;
+  /* out, [n][RS_DIAG_COLS] or NULL: rs_hip_diagnostics' record of every point (the plans of the call then run
+   * with rs_hip_set_diagnostics) */
+  double *diagnostics;
 } RsHostExtras;
 
 /* `device` >= 0: that device.  `device` < 0 (what runsimulation_batch / runsimulation pass): the
@@ -811,7 +828,7 @@ void rs_compat_end(RsCompat *ctx);
 /* Hash of the sources this library was built from (16 hex digits; roadsurf_amd/provenance.py build_sha16()):
  * tests/conftest.py rebuilds a prebuilt library whose stamp is not the hash of the sources beside it. */
 const char *rs_build_sha16(void);
-#define RS_ABI_VERSION 10 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles; 4: RsPointParams::horizon_index, rs_hip_step_knots; 5: RS_SUN_COLS 6, RsPointParams::horizons_by_point; 6: rs_driver_last_raw_launches (rs_driver_run without forcing windows); 7: rs_compat_* (module RoadSurf's per-step procedures); 8: RsPreview::prec; 9: RsPreview::tair_b / vz_b / w; 10: rs_hip_outputs_by_point */
+#define RS_ABI_VERSION 11 /* 2: round 2 additions (forecast re-sort, coupling rounds, fan-out, writeback, failure index); 3: RsPreview::index, rs_hip_expand_forcing_ordered, rs_hip_clock_probe, rs_driver_last_tiles; 4: RsPointParams::horizon_index, rs_hip_step_knots; 5: RS_SUN_COLS 6, RsPointParams::horizons_by_point; 6: rs_driver_last_raw_launches (rs_driver_run without forcing windows); 7: rs_compat_* (module RoadSurf's per-step procedures); 8: RsPreview::prec; 9: RsPreview::tair_b / vz_b / w; 10: rs_hip_outputs_by_point; 11: rs_hip_set_diagnostics / rs_hip_diagnostics, RsHostExtras::diagnostics */
 int rs_abi_version(void);
 /* sizeof of the boundary structs as the C side / the Fortran side see them
  * (0 InputPointers, 1 OutputPointers, 2 InputSettings, 3 InputParameters,

@@ -76,6 +76,9 @@ struct RsPlan {
   bool cpl_windows_closed = false; /* rs_hip_coupling_windows_closed: re-sorts leave the saved state */
   bool history_score = true; /* the step kernels leave the sort key of rs_hip_recluster */
   bool f32 = false; /* single-precision flavour: windows and state hold floats */
+  double *diag = nullptr; /* rs_hip_set_diagnostics: [RS_DIAG_ROWS][np_pad], by slot; NULL = off */
+  bool diag_on = false;
+  bool resorted = false; /* the order row has been something else than the identity since the last reset */
   /* wave table of the two-wavefront flavour (rs_cluster_wave_table): [2][wave_n] start, count; valid
    * for the slot order the last forecast re-sort left */
   int32_t *wave_tab = nullptr;
@@ -363,6 +366,7 @@ static int recluster_buffers(RsPlan *pl) {
 }
 
 static int recluster_apply(RsPlan *pl) {
+  pl->resorted = true;
   HIP_OK(rs_cluster_apply(pl->state, pl->state_alt, pl->f32, pl->order, pl->order_alt,
                           pl->sort_keys + 3 * pl->np_pad, pl->np_pad, pl->npoints, pl->c.NLayers,
                           pl->c.use_coupling == 0 ? 0 : pl->cpl_windows_closed ? 1 : 2, pl->stream));
@@ -381,6 +385,8 @@ int rs_hip_recluster_forecast(RsPlan *pl, const RsPreview *pv) {
     if ((pv->tair_b[q] != nullptr) != (pv->vz_b[q] != nullptr) || (pv->tair_b[q] && !(pv->w[q] >= 0.0 && pv->w[q] <= 1.0)))
       return set_err("rs_hip_recluster_forecast: preview %d: tair_b and vz_b come together, with 0 <= w <= 1", q);
   }
+  if (pl->diag_on)
+    return set_err("rs_hip_recluster_forecast: a plan with diagnostics keeps its order (rs_hip_set_diagnostics)");
   if (!rs_hip_plan_order(pl)) return -1;
   HIP_OK(hipSetDevice(pl->device));
   if (recluster_buffers(pl)) return -1;
@@ -445,6 +451,7 @@ int rs_hip_recluster(RsPlan *pl) {
   if (!pl) return set_err("rs_hip_recluster: null plan");
   if (!pl->history_score)
     return set_err("rs_hip_recluster: the plan's history score is switched off (rs_hip_set_history_score)");
+  if (pl->diag_on) return set_err("rs_hip_recluster: a plan with diagnostics keeps its order (rs_hip_set_diagnostics)");
   if (!rs_hip_plan_order(pl)) return -1;
   pl->wave_tab_valid = false;
   HIP_OK(hipSetDevice(pl->device));
@@ -489,6 +496,7 @@ int rs_hip_plan_reset_order(RsPlan *pl) {
   if (!pl->order) return rs_hip_plan_order(pl) ? 0 : -1; /* allocated as the identity */
   HIP_OK(hipSetDevice(pl->device));
   HIP_OK(rs_cluster_identity(pl->order, pl->np_pad, pl->stream));
+  pl->resorted = false;
   return 0;
 }
 
@@ -514,6 +522,39 @@ int rs_hip_set_writeback(RsPlan *pl, double *sw, double *sw_dir, double *lw, int
   if ((sw || sw_dir || lw) && (!sw || !sw_dir || !lw || t_stride < pl->npoints))
     return set_err("rs_hip_set_writeback: all three streams and t_stride >= npoints, or all NULL");
   pl->wb = rs::Writeback{sw, sw_dir, lw, t_stride};
+  return 0;
+}
+
+int rs_hip_set_diagnostics(RsPlan *pl, int32_t on) {
+  if (!pl) return set_err("rs_hip_set_diagnostics: null plan");
+  if (on && pl->f32) return set_err("rs_hip_set_diagnostics: the fp64 flavour only");
+  if (on && pl->resorted)
+    return set_err("rs_hip_set_diagnostics: the block is kept by slot - not for a plan that has been re-sorted");
+  HIP_OK(hipSetDevice(pl->device));
+  if (on) {
+    const size_t bytes = (size_t)RS_DIAG_ROWS * pl->np_pad * sizeof(double);
+    if (!pl->diag) HIP_OK(plan_malloc(pl, &pl->diag, bytes));
+    HIP_OK(hipMemsetAsync(pl->diag, 0, bytes, pl->stream)); /* (every call: a cached plan starts a new batch) */
+  }
+  pl->diag_on = on != 0;
+  return 0;
+}
+
+int rs_hip_diagnostics(RsPlan *pl, double *out) {
+  if (!pl || !out) return set_err("rs_hip_diagnostics: bad arguments");
+  if (!pl->diag_on || !pl->diag) return set_err("rs_hip_diagnostics: rs_hip_set_diagnostics(plan, 1) first");
+  HIP_OK(hipSetDevice(pl->device));
+  std::vector<double> rows((size_t)(RS_DIAG_ROWS + 1) * pl->np_pad);
+  HIP_OK(hipMemcpyAsync(rows.data(), pl->diag, (size_t)RS_DIAG_ROWS * pl->np_pad * sizeof(double), hipMemcpyDeviceToHost,
+                        pl->stream));
+  HIP_OK(hipMemcpyAsync(rows.data() + (size_t)RS_DIAG_ROWS * pl->np_pad, pl->state + (size_t)RS_ST_CPL_FLAGS * pl->np_pad,
+                        (size_t)pl->np_pad * sizeof(double), hipMemcpyDeviceToHost, pl->stream));
+  HIP_OK(hipStreamSynchronize(pl->stream));
+  for (int64_t p = 0; p < pl->npoints; ++p) {
+    for (int r = 0; r < RS_DIAG_ROWS; ++r) out[(size_t)p * RS_DIAG_COLS + r] = rows[(size_t)r * pl->np_pad + p];
+    const int32_t fl = (int32_t)rows[(size_t)RS_DIAG_ROWS * pl->np_pad + p];
+    out[(size_t)p * RS_DIAG_COLS + RS_DIAG_ROWS] = (double)(fl & (RS_CPL_MSG_SMALL | RS_CPL_MSG_BIG));
+  }
   return 0;
 }
 
@@ -687,6 +728,7 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
    * without its stop event would poison rs_hip_timing_step_ms */
   if (pl->c.use_coupling && !pp->coupling_index)
     return set_err("rs_hip_step: use_coupling is set: pass coupling_index/coupling_tsurf");
+  if (pl->f32 && pl->diag_on) return set_err("rs_hip_step: diagnostics: the fp64 flavour only");
   if (pl->f32 && (coupled || skyview || f->depth || pl->c.tsurfOutputDepth >= 0.0 || (full && pl->c.NLayers != 15)))
     return set_err("rs_hip_step: the fp32 flavour has no output depth, coupling or sky view, and the FULL feature "
                    "set (dew point, observation forcing, relaxation) for NLayers = 15 only");
@@ -726,6 +768,7 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
   a.knot_k0 = a.knot_n = a.spk = a.start_hour = 0;
   a.r_spk = 0.0;
   std::memset(&a.raw, 0, sizeof(a.raw));
+  a.diag = pl->diag_on ? pl->diag : nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (pl->timing) {
     if (pl->ev_used + 2 > pl->ev.size()) {
@@ -839,6 +882,7 @@ int rs_hip_step_knots(RsPlan *pl, const RsSynthSpec *spec, const double *knots, 
   a.spk = spk;
   a.start_hour = spec->start_hour;
   a.r_spk = 1.0 / (double)spk;
+  a.diag = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (pl->timing) {
     if (pl->ev_used + 2 > pl->ev.size()) {
@@ -920,6 +964,7 @@ int rs_step_raw(RsPlan *pl, const rs::RawForcing *raw, const double *sun, const 
   a.duo_full_ok = 3; /* the driver's series always carry a dew point (completed from the humidity where absent) */
   a.surface_prio = underfilled(pl);
   a.raw = *raw;
+  a.diag = nullptr;
   /* out_by_point: the rows of slot s go to column order[s] of `o` (scattered stores: meant for decimated rows) */
   a.out_index = (out_by_point && pl->order) ? pl->order : nullptr;
   const hipError_t le = rs_launch_step_duo_raw(a, pl->history_score, sky, coupled, pl->stream);
@@ -960,6 +1005,7 @@ int rs_cpl_replay_raw(RsPlan *pl, const rs::RawForcing *raw, const RsOutputs *o,
   a.nsteps = nsteps;
   a.duo_full_ok = 3;
   a.raw = *raw;
+  a.diag = nullptr;
   a.out_index = (out_by_point && pl->order) ? pl->order : nullptr;
   { /* the block must cover the coupling windows of the points that replay (as rs_hip_cpl_replay checks) */
     if (!pl->cpl_list) {
@@ -1032,6 +1078,7 @@ static int cpl_args(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const Rs
   a.wave_n = 0;
   a.duo_full_ok = 0;
   a.surface_prio = 0;
+  a.diag = pl->diag_on ? pl->diag : nullptr;
   a.knots = nullptr;
   a.knot_gather = nullptr;
   a.knot_k0 = a.knot_n = a.spk = a.start_hour = 0;

@@ -205,6 +205,7 @@ int rs_host_run_batch(int32_t n, OutputPointers *outPointers, const InputPointer
       if (ex.cos_lat) ex.cos_lat += sh.off;
       if (ex.lon_rad) ex.lon_rad += sh.off;
       if (ex.first_failed) ex.first_failed += sh.off;
+      if (ex.diagnostics) ex.diagnostics += (size_t)sh.off * RS_DIAG_COLS;
       exp = &ex;
     }
     return run_batch_on_device((int32_t)sh.cnt, outPointers + sh.off, inPointers + sh.off, consts,
@@ -317,6 +318,7 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
   std::vector<int32_t> pp32((size_t)Ppad * 2);
   const bool writeback = extras && extras->writeback;
   int32_t *first_failed = extras ? extras->first_failed : nullptr;
+  double *diagnostics = extras ? extras->diagnostics : nullptr; /* [n][RS_DIAG_COLS]: the plans run with rs_hip_set_diagnostics */
   /* sky view + writeback: SW, SW_dir, LW as the reference leaves them come back from the device
    * (rs_hip_set_writeback); [3][Ppad*TC] windows, their [3][P*TC] transposes, two pinned sets */
   const bool wb_dev = writeback && skyview;
@@ -430,6 +432,7 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
    * reference makes to its inputs, on the host: CheckValues ran for every index up to the one
    * that failed the point (or SimLen-1) and clamped SW_dir there (src/InputOutput.f90:75-77) */
   auto finish_tile = [&](RsPlan *pl, int64_t p0, int m) -> int {
+    if (diagnostics && rs_hip_diagnostics(pl, diagnostics + (size_t)p0 * RS_DIAG_COLS) != 0) return -15;
     if (!first_failed && !(writeback && !wb_dev)) return 0;
     if (rs_hip_first_failed_index(pl, ff_tile.data()) != 0) return -15;
     if (first_failed) std::memcpy(first_failed + p0, ff_tile.data(), (size_t)m * sizeof(int32_t));
@@ -560,6 +563,8 @@ static int run_batch_on_device(int32_t n, OutputPointers *outPointers, const Inp
       HOK(hipMemcpyAsync(w + 2 * fs, fo.lw, fs * sizeof(double), hipMemcpyDeviceToDevice, stream));
       if (rs_hip_set_writeback(plan, w, w + fs, w + 2 * fs, mp) != 0) return -16;
     }
+    /* (a cached plan: the switch is set for every tile, and switching it on zeroes the record) */
+    if (t0 == 1 && rs_hip_set_diagnostics(plan, diagnostics ? 1 : 0) != 0) return -12;
     if (t0 == 1 && rs_hip_init_state(plan, &fo, &pp) != 0) return -12;
     if (rs_hip_step(plan, &fo, &oo, &pp, t0, len) != 0) return -13;
     for (int f = 0; f < 6; ++f)

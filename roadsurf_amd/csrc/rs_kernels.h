@@ -72,6 +72,8 @@ struct StepArgs {
    * makes the forcing of the next index from the RAW series (JsonSource::interpolate + the GetWeather
    * overlay, rs_raw.hpp); raw.nsrc = 0: not this launch */
   RawForcing raw;
+  /* the plan's diagnostics block (rs_hip_set_diagnostics; rs_state.h RsDiagRow), or NULL */
+  double *diag;
 };
 
 struct InitArgs {

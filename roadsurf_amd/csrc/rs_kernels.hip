@@ -329,6 +329,7 @@ struct Coupling {
   double tabove, tbelow, radcoeff, rcabove, rcbelow, rcprev, swcof, lwcof, swcorr, lwcorr,
       tend1, lastobs;
   int32_t iter, cs, ce; /* Coupling_iterations, couplingStartI, couplingEndI */
+  int32_t msg;          /* bits 3-4 of RS_ST_CPL_FLAGS: what Coupling_control has printed for the point (rs_state.h) */
   bool again, failed, on;
 };
 
@@ -374,7 +375,8 @@ __device__ __forceinline__ void coupling_control(Coupling &q, double &tsurf) {
       q.tabove = -9999;
       q.tbelow = -9999;
     }
-    if (q.radcoeff < R4(0.01)) {
+    if (q.radcoeff < R4(0.01)) { /* "coupling coefficient too small, coupling failed" (:400-401) */
+      q.msg |= RS_CPL_MSG_SMALL;
       q.radcoeff = R4(1.0);
       q.failed = true;
       q.swcof = R4(1.0); q.lwcof = R4(1.0); q.swcorr = R4(0.0); q.lwcorr = R4(0.0);
@@ -401,7 +403,8 @@ __device__ __forceinline__ void coupling_control(Coupling &q, double &tsurf) {
     }
     q.rcprev = q.radcoeff;
   } else {
-    if (q.radcoeff > R4(3.0)) {
+    if (q.radcoeff > R4(3.0)) { /* "coupling coefficient too big, coupling failed" (:451-452) */
+      q.msg |= RS_CPL_MSG_BIG;
       q.failed = true;
       q.radcoeff = R4(1.0);
       q.swcof = R4(1.0); q.lwcof = R4(1.0); q.swcorr = R4(0.0); q.lwcorr = R4(0.0);
@@ -422,7 +425,7 @@ __device__ __forceinline__ void coupling_control(Coupling &q, double &tsurf) {
 __device__ __forceinline__ void load_coupling(const double *st, int64_t np, int64_t p, Coupling &q) {
   q.iter = (int32_t)st[(int64_t)RS_ST_CPL_ITER * np + p];
   const int32_t fl = (int32_t)st[(int64_t)RS_ST_CPL_FLAGS * np + p];
-  q.again = fl & 1; q.failed = (fl >> 1) & 1;
+  q.again = fl & 1; q.failed = (fl >> 1) & 1; q.msg = fl & (RS_CPL_MSG_SMALL | RS_CPL_MSG_BIG);
   q.tabove = st[(int64_t)RS_ST_CPL_TABOVE * np + p]; q.tbelow = st[(int64_t)RS_ST_CPL_TBELOW * np + p];
   q.radcoeff = st[(int64_t)RS_ST_CPL_RADCOEFF * np + p];
   q.rcabove = st[(int64_t)RS_ST_CPL_RCABOVE * np + p]; q.rcbelow = st[(int64_t)RS_ST_CPL_RCBELOW * np + p];
@@ -436,7 +439,7 @@ __device__ __forceinline__ void load_coupling(const double *st, int64_t np, int6
 __device__ __forceinline__ void store_coupling(double *st, int64_t np, int64_t p, const Coupling &q) {
   st[(int64_t)RS_ST_CPL_ITER * np + p] = (double)q.iter;
   const int32_t keep = ((int32_t)st[(int64_t)RS_ST_CPL_FLAGS * np + p]) & 4;
-  st[(int64_t)RS_ST_CPL_FLAGS * np + p] = (double)(keep | (q.again ? 1 : 0) | (q.failed ? 2 : 0));
+  st[(int64_t)RS_ST_CPL_FLAGS * np + p] = (double)(keep | (q.again ? 1 : 0) | (q.failed ? 2 : 0) | q.msg);
   st[(int64_t)RS_ST_CPL_TABOVE * np + p] = q.tabove; st[(int64_t)RS_ST_CPL_TBELOW * np + p] = q.tbelow;
   st[(int64_t)RS_ST_CPL_RADCOEFF * np + p] = q.radcoeff;
   st[(int64_t)RS_ST_CPL_RCABOVE * np + p] = q.rcabove; st[(int64_t)RS_ST_CPL_RCBELOW * np + p] = q.rcbelow;
@@ -462,6 +465,64 @@ __device__ __forceinline__ double cpl_decay(const ConstsAS &c, const MathTab &mt
   const uint32_t d = (uint32_t)(i - ce);
   if (c.cpl_tab && d <= (uint32_t)c.SimLen) return ((const double *)c.cpl_tab)[d];
   return rs_exp(mt, rs_div(-((c.DTSecs * i) - (c.DTSecs * ce)), c.cplReduction));
+}
+
+/* Diagnostics (rs_hip_set_diagnostics; ROADSURF_HIP_DIAGNOSTICS=1 on the host paths): what CalcBLCondAndLE prints
+ * besides computing - "ERROR : UStar negative" inside the loop and "Max number of BLCond iterations" behind it
+ * (src/BoundaryLayer.f90:69-74,98-101).  The loop of the step about to be taken is run once more, out of line, with
+ * IEEE division and square root (the bits the bare sequences return, rs_math.hpp), and the first occurrence and the
+ * count of either message go to the plan's diagnostics block (rs_state.h RsDiagRow; one lane owns a point: plain
+ * read-modify-write).  Only the one-point-per-lane kernels with the profile in LDS call it - the launchers send a
+ * plan with diagnostics there - so the flavours that are tuned to their register budget do not carry the call. */
+__device__ __attribute__((noinline)) void bl_diagnose(const ConstsAS *cp, const uint64_t *expT, const double *logT,
+                                                      const double *K, double tsurf, double tair, double vz,
+                                                      double rhz, int32_t hour, int32_t i, double *dg, int64_t np,
+                                                      int64_t p) {
+  const ConstsAS &c = *cp;
+  MathTab mt;
+  mt.expT = expT;
+  mt.logT = logT;
+  mt.K = K;
+  mt.S = (rs::MathCoef)rs::c_gl_scoef;
+  asm volatile("" : "+s"(mt.S));
+  /* SetDayDependendVariables' calm limit (fluxes_pre) */
+  const double calmN = c.CalmLimNgt, calmD = c.CalmLimDay;
+  const bool night = ((double)hour >= c.NightOn) || ((double)hour <= c.NightOff);
+  const double calm = night ? calmN : calmD;
+  if (vz < calm) vz = calm;
+  BlInv v;
+  BlVar x;
+  BlAux a;
+  bl_setup<true>(c, tsurf, tair, vz, v, x, a);
+  const double stab_num = bl_stab_num(c);
+  double old = 0.0;
+  int j = 1;
+  for (; j <= RS_BL_MAXIT; ++j) {
+    old = x.BLCond;
+    if (rs_dvb<true>(v.vkvz, c.logUstar + x.PSIM) < 0.0) { /* :69-73, with BLCond as the pass before left it */
+      const double n = dg[(int64_t)RS_DG_USTAR_N * np + p];
+      if (n == 0.0) {
+        dg[(int64_t)RS_DG_USTAR_I * np + p] = (double)i;
+        dg[(int64_t)RS_DG_USTAR_TAIR * np + p] = tair;
+        dg[(int64_t)RS_DG_USTAR_VZ * np + p] = vz;
+        dg[(int64_t)RS_DG_USTAR_RHZ * np + p] = rhz;
+        dg[(int64_t)RS_DG_USTAR_BL * np + p] = old;
+        dg[(int64_t)RS_DG_USTAR_TSURF * np + p] = tsurf;
+      }
+      dg[(int64_t)RS_DG_USTAR_N * np + p] = n + 1.0;
+    }
+    if (bl_iteration<true>(c, mt, v, x, j, stab_num)) break;
+  }
+  if ((fabs(x.BLCond - old) > 10 * R4(0.001)) && (j >= 5)) { /* :98-101; j = MaxIter + 1 behind a DO loop that ran out */
+    const double n = dg[(int64_t)RS_DG_MAXIT_N * np + p];
+    if (n == 0.0) {
+      dg[(int64_t)RS_DG_MAXIT_I * np + p] = (double)i;
+      dg[(int64_t)RS_DG_MAXIT_J * np + p] = (double)j;
+      dg[(int64_t)RS_DG_MAXIT_OLD * np + p] = old;
+      dg[(int64_t)RS_DG_MAXIT_BL * np + p] = x.BLCond;
+    }
+    dg[(int64_t)RS_DG_MAXIT_N * np + p] = n + 1.0;
+  }
 }
 
 /* The time loop of runsimulation (examples/example1/src/Simulation.f90:57-115)
@@ -701,7 +762,7 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
           st[(int64_t)RS_ST_CPL_SAVE_DEP * np + p] = s.dep;
           st[(int64_t)RS_ST_CPL_SAVE_SNOW * np + p] = s.snow;
           st[(int64_t)RS_ST_CPL_SAVE_ALBEDO * np + p] = s.albedo;
-          const int32_t fl = ((int32_t)st[(int64_t)RS_ST_CPL_FLAGS * np + p]) & 3;
+          const int32_t fl = ((int32_t)st[(int64_t)RS_ST_CPL_FLAGS * np + p]) & (3 | RS_CPL_MSG_SMALL | RS_CPL_MSG_BIG);
           st[(int64_t)RS_ST_CPL_FLAGS * np + p] = (double)(fl | (s.verycold ? 4 : 0));
           const int N = T.nlayers();
           for (int j = 1; j <= N; ++j) st[(int64_t)(RS_ST_CPL_SAVE_TMP0 + j - 1) * np + p] = T.get(j);
@@ -807,6 +868,8 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
         (ka->wb.lw + wrow)[lane] = lw_in;
       }
     }
+    if (!Prof::kUnrolled && ka->diag) /* (the LDS-profile kernels: see bl_diagnose) */
+      bl_diagnose(&c, mt.expT, mt.logT, mt.K, s.tsurf, tair, vz, rhz, f.hour, i, ka->diag, ka->np_pad, row0 + lane);
     const Fluxes fx =
         model_step_fluxes<SCORE>(c, mt, s, tair, vz, rhz, prec_ts, sw_in, lw_in, f.phase, f.hour, cp);
     /* scheduling hint (bl_score_key): extra passes of this launch; bit 30 of the counter = the
@@ -975,7 +1038,7 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Sc
           st[(int64_t)RS_ST_CPL_SAVE_DEP * np + p] = s.dep;
           st[(int64_t)RS_ST_CPL_SAVE_SNOW * np + p] = s.snow;
           st[(int64_t)RS_ST_CPL_SAVE_ALBEDO * np + p] = s.albedo;
-          const int32_t fl = ((int32_t)st[(int64_t)RS_ST_CPL_FLAGS * np + p]) & 3;
+          const int32_t fl = ((int32_t)st[(int64_t)RS_ST_CPL_FLAGS * np + p]) & (3 | RS_CPL_MSG_SMALL | RS_CPL_MSG_BIG);
           st[(int64_t)RS_ST_CPL_FLAGS * np + p] = (double)(fl | (s.verycold ? 4 : 0));
           for (int j = 1; j <= N; ++j) st[(int64_t)(RS_ST_CPL_SAVE_TMP0 + j - 1) * np + p] = T.get(j);
           q.swcof = R4(1.0); q.lwcof = R4(1.0); q.swcorr = R4(0.0); q.lwcorr = R4(0.0);
@@ -1079,6 +1142,7 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Sc
         ka->wb.lw[woff] = lw_in;
       }
     }
+    if (ka->diag) bl_diagnose(&c, mt.expT, mt.logT, mt.K, s.tsurf, tair, vz, rhz, f.hour, i, ka->diag, np, p);
     const Fluxes fx = model_step_fluxes(c, mt, s, tair, vz, rhz, prec_ts, sw_in, lw_in, f.phase,
                                         f.hour, cp);
     if (i + 1 < tend) { /* next index's forcing, half a step ahead of its use */
@@ -1463,7 +1527,7 @@ __device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, co
             st[(int64_t)RS_ST_CPL_SAVE_DEP * np + pp_] = s.dep;
             st[(int64_t)RS_ST_CPL_SAVE_SNOW * np + pp_] = s.snow;
             st[(int64_t)RS_ST_CPL_SAVE_ALBEDO * np + pp_] = s.albedo;
-            const int32_t fl = ((int32_t)st[(int64_t)RS_ST_CPL_FLAGS * np + pp_]) & 3;
+            const int32_t fl = ((int32_t)st[(int64_t)RS_ST_CPL_FLAGS * np + pp_]) & (3 | RS_CPL_MSG_SMALL | RS_CPL_MSG_BIG);
             st[(int64_t)RS_ST_CPL_FLAGS * np + pp_] = (double)(fl | (s.verycold ? 4 : 0));
             st[(int64_t)(RS_ST_CPL_SAVE_TMP0 + 0) * np + pp_] = T.get(1);
             st[(int64_t)(RS_ST_CPL_SAVE_TMP0 + 1) * np + pp_] = T.get(2);
@@ -2883,13 +2947,14 @@ hipError_t rs_launch_step_sky(const rs::StepArgs &a, int NL, bool score, hipStre
    * view, 65 536 points 3.5e9 -> 4.8e9, 200 000 points (four blocks) 7.6e9 -> 8.6e9; at 1 M points (blocks of
    * 250 000) 1.06e10 -> 1.03e10 - four of its wavefronts leave a SIMD no register for the other blocks' window
    * expansion, which then queues. */
-  if (NL == 15 && a.npoints <= RS_DUO_MAX_POINTS && (a.duo_full_ok & 4)) {
+  if (NL == 15 && a.npoints <= RS_DUO_MAX_POINTS && (a.duo_full_ok & 4) && !a.diag) {
     const dim3 gd(a.wave_start ? (unsigned)a.wave_n : (unsigned)((a.npoints + 63) / 64));
     if (score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, rs::SRC_WINDOW, true, true>), gd, dim3(128), 0, stream, a);
     else hipLaunchKernelGGL((rs::step_kernel_duo<15, false, rs::SRC_WINDOW, true, true>), gd, dim3(128), 0, stream, a);
     return hipGetLastError();
   }
-  if (NL == 15) hipLaunchKernelGGL((rs::step_kernel_sky_h<4>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
+  /* (a plan with diagnostics: the LDS profile, the flavour that carries bl_diagnose - here and below) */
+  if (NL == 15 && !a.diag) hipLaunchKernelGGL((rs::step_kernel_sky_h<4>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
   else hipLaunchKernelGGL(rs::step_kernel_sky, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
   return hipGetLastError();
 }
@@ -2933,8 +2998,9 @@ hipError_t rs_launch_step_cpl(const rs::StepArgs &a, int NL, hipStream_t stream)
    * in registers was twice as slow); other layer counts: the LDS profile */
   const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
   const dim3 g = grid_for(a.npoints);
-  if (NL == 15 && a.pp.sky_view) hipLaunchKernelGGL((rs::step_kernel_cpl_h<3, true>), g, dim3(RS_BLOCK), 0, stream, a);
-  else if (NL == 15) hipLaunchKernelGGL((rs::step_kernel_cpl_h<3, false>), g, dim3(RS_BLOCK), 0, stream, a);
+  const bool hyb = NL == 15 && !a.diag;
+  if (hyb && a.pp.sky_view) hipLaunchKernelGGL((rs::step_kernel_cpl_h<3, true>), g, dim3(RS_BLOCK), 0, stream, a);
+  else if (hyb) hipLaunchKernelGGL((rs::step_kernel_cpl_h<3, false>), g, dim3(RS_BLOCK), 0, stream, a);
   else if (a.pp.sky_view) hipLaunchKernelGGL(rs::step_kernel_cpl<true>, g, dim3(RS_BLOCK), lds, stream, a);
   else hipLaunchKernelGGL(rs::step_kernel_cpl<false>, g, dim3(RS_BLOCK), lds, stream, a);
   return hipGetLastError();
@@ -2944,8 +3010,9 @@ hipError_t rs_launch_step_cpl_replay(const rs::StepArgs &a, int NL, hipStream_t 
   if (!a.cpl_list || a.cpl_nlist < 1) return hipSuccess;
   const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
   const dim3 g = grid_for(a.cpl_nlist);
-  if (NL == 15 && a.pp.sky_view) hipLaunchKernelGGL((rs::step_kernel_cpl_replay_h<3, true>), g, dim3(RS_BLOCK), 0, stream, a);
-  else if (NL == 15) hipLaunchKernelGGL((rs::step_kernel_cpl_replay_h<3, false>), g, dim3(RS_BLOCK), 0, stream, a);
+  const bool hyb = NL == 15 && !a.diag;
+  if (hyb && a.pp.sky_view) hipLaunchKernelGGL((rs::step_kernel_cpl_replay_h<3, true>), g, dim3(RS_BLOCK), 0, stream, a);
+  else if (hyb) hipLaunchKernelGGL((rs::step_kernel_cpl_replay_h<3, false>), g, dim3(RS_BLOCK), 0, stream, a);
   else if (a.pp.sky_view) hipLaunchKernelGGL(rs::step_kernel_cpl_replay<true>, g, dim3(RS_BLOCK), lds, stream, a);
   else hipLaunchKernelGGL(rs::step_kernel_cpl_replay<false>, g, dim3(RS_BLOCK), lds, stream, a);
   return hipGetLastError();
@@ -2969,7 +3036,8 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
    * plan: the FULL feature set in the register flavour at 3 waves/SIMD 0.745 s, at 2 waves 0.80 s, at 4 waves -
    * 130 spilled VGPRs - 0.87 s; with the profile in LDS 0.86 s (3 waves) / 0.88 s (4 waves).)  The waves-per-SIMD
    * bound was a digit of the variant until round 6; the measured choices are the kernels' launch bounds now. */
-  if (auto_variant) variant = (NL != 15) ? RS_VARIANT_LDS : full ? RS_VARIANT_HYBRID : RS_VARIANT_REG;
+  if (a.diag) variant = RS_VARIANT_LDS;
+  else if (auto_variant) variant = (NL != 15) ? RS_VARIANT_LDS : full ? RS_VARIANT_HYBRID : RS_VARIANT_REG;
   /* 32-bit window offsets (WinOff) where every stream of both windows spans < 4 GiB (rs_a32_limit: the tests
    * lower it to reach the 64-bit instances with windows of megabytes) */
   const int64_t out_rows = ((int64_t)a.t0 + a.nsteps - 2) / a.o.decimate - a.o.row0 + 1;
@@ -2980,7 +3048,7 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
   const bool duo_ok = (!full || a.duo_full_ok) && NL == 15 && a32;
   if (variant == RS_VARIANT_DUO && !duo_ok) { /* not this launch: as AUTO */
     variant = (NL != 15) ? RS_VARIANT_LDS : full ? RS_VARIANT_HYBRID : RS_VARIANT_REG;
-  } else if (variant == RS_VARIANT_DUO || (auto_variant && duo_ok && a.npoints <= RS_DUO_MAX_POINTS)) {
+  } else if (variant == RS_VARIANT_DUO || (auto_variant && !a.diag && duo_ok && a.npoints <= RS_DUO_MAX_POINTS)) {
     const dim3 gd(a.wave_start ? (unsigned)a.wave_n : (unsigned)((a.npoints + 63) / 64));
     if (full && score) hipLaunchKernelGGL((rs::step_kernel_duo<15, true, rs::SRC_WINDOW, true>), gd, dim3(128), 0, stream, a);
     else if (full) hipLaunchKernelGGL((rs::step_kernel_duo<15, false, rs::SRC_WINDOW, true>), gd, dim3(128), 0, stream, a);

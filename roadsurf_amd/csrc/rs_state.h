@@ -40,7 +40,8 @@ enum RsStateSlot {
                                     the end of the launch; rs_cluster.hip sorts these 21 bits */
   /* ---- coupling (src/CouplingVariables.f90.inc); touched only by the coupled kernel ---- */
   RS_ST_CPL_ITER,                /* Coupling_iterations */
-  RS_ST_CPL_FLAGS,               /* bit0 start_coupling_again, bit1 Coupling_failed, bit2 VeryColdSave */
+  RS_ST_CPL_FLAGS,               /* bit0 start_coupling_again, bit1 Coupling_failed, bit2 VeryColdSave, bits 3-4 what
+                                    Coupling_control has printed for the point (RS_CPL_MSG_*) */
   RS_ST_CPL_TABOVE,              /* TsurfNearestAbove */
   RS_ST_CPL_TBELOW,              /* TsurfNearestBelow */
   RS_ST_CPL_RADCOEFF,            /* RadCoeff */
@@ -69,5 +70,32 @@ enum RsStateSlot {
                                     read by the first step of a replay only; RS_MAX_LAYERS slots */
   RS_NSTATE = RS_ST_CPL_STALE_TMP0 + RS_MAX_LAYERS
 };
+
+/* the reference's messages from Coupling_control (src/Coupling.f90:400-401,451-452), kept as bits of
+ * RS_ST_CPL_FLAGS for rs_hip_diagnostics */
+#define RS_CPL_MSG_SMALL 8  /* "coupling coefficient too small, coupling failed" */
+#define RS_CPL_MSG_BIG 16   /* "coupling coefficient too big, coupling failed" */
+
+/* Rows of a plan's diagnostics block (rs_hip_set_diagnostics: [RS_DIAG_ROWS][np_pad] doubles, by slot): what the
+ * reference prints from CalcBLCondAndLE (src/BoundaryLayer.f90:69-74,98-101), first occurrence and count per point. */
+enum RsDiagRow {
+  RS_DG_MAXIT_N = 0, /* "Max number of BLCond iterations": how many time indices printed it */
+  RS_DG_MAXIT_I,     /* ... the first of them (1-based), */
+  RS_DG_MAXIT_J,     /* its j (MaxIter + 1: the DO loop ran out), */
+  RS_DG_MAXIT_OLD,   /* BLCond_Old */
+  RS_DG_MAXIT_BL,    /* and BLCond */
+  RS_DG_USTAR_N,     /* "ERROR : UStar negative": how many passes printed it */
+  RS_DG_USTAR_I,     /* the time index of the first, */
+  RS_DG_USTAR_TAIR,  /* and the values of its two lines: vz, then Tair, VZ, Rhz, BLCond, TSurfAve */
+  RS_DG_USTAR_VZ,
+  RS_DG_USTAR_RHZ,
+  RS_DG_USTAR_BL,
+  RS_DG_USTAR_TSURF,
+  RS_DIAG_ROWS
+};
+/* rs_hip_diagnostics: the rows above per point, then the coupling messages (RS_CPL_MSG_* bits) */
+#ifdef __cplusplus
+static_assert(RS_DIAG_COLS == RS_DIAG_ROWS + 1, "include/roadsurf.h: RS_DIAG_COLS");
+#endif
 
 #endif

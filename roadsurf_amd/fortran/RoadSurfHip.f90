@@ -28,6 +28,7 @@ module RoadSurfHip
    private
 
    integer, parameter, public :: RS_MAX_LAYERS = 32
+   integer, parameter, public :: RS_DIAG_COLS = 13   ! include/roadsurf.h
 
    type, bind(C), public :: InputPointers
       integer(c_int) :: inputLen
@@ -106,6 +107,7 @@ module RoadSurfHip
       real(c_double) :: albedo_surroundings
       type(c_ptr) :: first_failed
       integer(c_int) :: writeback
+      type(c_ptr) :: diagnostics
    end type RsHostExtras
 
    interface
@@ -556,6 +558,8 @@ contains
       integer(c_int), value :: wb_default
       type(c_ptr) :: first_failed
       integer(c_int), allocatable, target :: ffdiag(:)
+      real(c_double), allocatable, target :: dgdiag(:, :), gdg(:, :)
+      real(c_double), pointer :: dg_all(:, :)
       logical :: diag
       character(len=8) :: envv
       integer :: envl, envs
@@ -620,6 +624,13 @@ contains
       extras%sun = c_null_ptr; extras%sin_lat = c_null_ptr; extras%cos_lat = c_null_ptr
       extras%lon_rad = c_null_ptr; extras%albedo_surroundings = inputParam%Albedo_surroundings
       extras%first_failed = first_failed
+      extras%diagnostics = c_null_ptr
+      if (diag) then
+         ! ... and its other messages (boundary-layer loop, Coupling_control): rs_hip_diagnostics' record per point
+         allocate (dgdiag(RS_DIAG_COLS, n))
+         dgdiag = 0.0_c_double
+         extras%diagnostics = c_loc(dgdiag)
+      end if
       extras%writeback = wb_default
       call get_environment_variable('ROADSURF_HIP_WRITEBACK', envv, envl, envs)
       if (envs == 0 .and. envl >= 1) then
@@ -676,12 +687,24 @@ contains
                extras%lon_rad = c_loc(glrad)
                extras%first_failed = c_null_ptr
                if (c_associated(first_failed)) extras%first_failed = c_loc(gff)
+               extras%diagnostics = c_null_ptr
+               if (diag) then
+                  allocate (gdg(RS_DIAG_COLS, m))
+                  gdg = 0.0_c_double
+                  extras%diagnostics = c_loc(gdg)
+               end if
                rc = rs_host_run_batch(int(m, c_int), go, gi, consts, gl, gtb, extras, rs_host_default_device())
                if (rc /= 0 .and. status == 0) status = rc
                if (c_associated(first_failed)) then
                   do k = 1, m
                      ff_all(gidx(k)) = gff(k)
                   end do
+               end if
+               if (diag) then
+                  do k = 1, m
+                     dgdiag(:, gidx(k)) = gdg(:, k)
+                  end do
+                  deallocate (gdg)
                end if
                deallocate (gi, go, gl, gtb, gslat, gclat, glrad, gff, gidx)
             end do
@@ -693,8 +716,45 @@ contains
          if (rc /= 0) status = rc
       end if
       deallocate (tbottom)
-      if (diag .and. status == 0) call print_diagnostics(n, outPointers, inPointers, localParam, first_failed)
+      if (diag .and. status == 0) then
+         call print_diagnostics(n, outPointers, inPointers, localParam, first_failed)
+         call print_loop_diagnostics(n, dgdiag)
+      end if
    end subroutine rs_batch_core
+
+   !> The reference's messages from CalcBLCondAndLE and Coupling_control (src/BoundaryLayer.f90:69-74,98-101,
+   !! src/Coupling.f90:400-401,451-452) from rs_hip_diagnostics' record: the text and format of the reference for
+   !! the FIRST occurrence at a point; the reference repeats them at every pass / time index they occur at, here
+   !! a line with the point, the time index and the count follows instead.
+   subroutine print_loop_diagnostics(n, dg)
+      integer(c_int), intent(in) :: n
+      real(c_double), intent(in) :: dg(RS_DIAG_COLS, n)
+      integer :: p, msg
+      do p = 1, n
+         if (dg(6, p) > 0.0) then
+            Write (*, *) ' ERROR : UStar negative,vz ', dg(9, p)
+            write (*, *) dg(8, p), dg(9, p), dg(10, p), dg(11, p), dg(12, p)
+            write (*, '(a,i0,a,i0,a,i0,a)') ' (roadsurf_hip: point ', p, ', first at time index ', &
+               int(dg(7, p)), '; passes with this message: ', int(dg(6, p)), ')'
+         end if
+         if (dg(1, p) > 0.0) then
+            Write (*, "(' Max number of BLCond iterations (MaxIter,BLCond_Old,BLCond) :',I5,2F10.5)") &
+               int(dg(3, p)), dg(4, p), dg(5, p)
+            write (*, '(a,i0,a,i0,a,i0,a)') ' (roadsurf_hip: point ', p, ', first at time index ', &
+               int(dg(2, p)), '; time indices with this message: ', int(dg(1, p)), ')'
+         end if
+         msg = int(dg(13, p))
+         if (iand(msg, 8) /= 0) then
+            write (*, *) "coupling coefficient too small, coupling failed"
+            write (*, '(a,i0,a)') ' (roadsurf_hip: point ', p, ')'
+         end if
+         if (iand(msg, 16) /= 0) then
+            write (*, *) "coupling coefficient too big, coupling failed"
+            write (*, '(a,i0,a)') ' (roadsurf_hip: point ', p, ')'
+         end if
+      end do
+      flush (6)
+   end subroutine print_loop_diagnostics
 
    !> The reference's diagnostics for the points CheckValues failed (src/InputOutput.f90:55-82): the
    !! same three messages on standard output, from the caller's arrays at the failing index.  The

@@ -71,7 +71,8 @@ class RsPointParams(C.Structure):
 
 class RsHostExtras(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("sun", "sin_lat", "cos_lat", "lon_rad")] + \
-               [("albedo_surroundings", C.c_double), ("first_failed", C.c_void_p), ("writeback", C.c_int32)]
+               [("albedo_surroundings", C.c_double), ("first_failed", C.c_void_p), ("writeback", C.c_int32),
+                ("diagnostics", C.c_void_p)]
 
 
 RS_PREVIEW_MAX = 8
@@ -98,7 +99,7 @@ EXPORTS = (
     "rs_last_error", "rs_hip_device_count", "rs_hip_plan_create", "rs_hip_plan_destroy",
     "rs_hip_plan_npoints", "rs_hip_plan_npoints_padded", "rs_hip_plan_state_bytes",
     "rs_hip_init_state", "rs_hip_step", "rs_hip_step_cpl", "rs_hip_cpl_replay", "rs_hip_set_output_by_point", "rs_hip_state_download", "rs_hip_state_upload",
-    "rs_hip_failed_count", "rs_hip_clock_probe", "rs_hip_first_failed_index", "rs_hip_sync", "rs_hip_synth_knots", "rs_hip_expand_forcing", "rs_hip_expand_forcing_ordered", "rs_hip_step_knots", "rs_hip_expand_forcing_on",
+    "rs_hip_failed_count", "rs_hip_clock_probe", "rs_hip_first_failed_index", "rs_hip_set_diagnostics", "rs_hip_diagnostics", "rs_hip_sync", "rs_hip_synth_knots", "rs_hip_expand_forcing", "rs_hip_expand_forcing_ordered", "rs_hip_step_knots", "rs_hip_expand_forcing_on",
     "rs_hip_plan_order", "rs_hip_recluster", "rs_hip_recluster_forecast", "rs_hip_set_history_score", "rs_hip_coupling_windows_closed", "rs_hip_set_writeback", "rs_hip_plan_order_copy", "rs_hip_outputs_by_point", "rs_hip_plan_reset_order", "rs_hip_set_variant", "rs_hip_set_precision", "rs_hip_test_math", "rs_hip_division_mode", "rs_hip_div_mismatch_count", "rs_hip_div_special_count", "rs_hip_div_samples", "rs_hip_timing_reset", "rs_hip_timing_step_ms", "rs_hip_timing_intervals",
     "rs_host_run_batch", "rs_last_fanout", "rs_driver_run", "rs_driver_last_tiles", "rs_driver_last_raw_launches", "rs_hip_bl_stats", "rs_compat_begin", "rs_compat_step", "rs_compat_replay", "rs_compat_failed_index", "rs_compat_last_state", "rs_compat_outputs", "rs_compat_end", "rs_driver_expand", "rs_driver_release_cache", "rs_abi_version", "rs_abi_sizeof", "rs_fortran_sizeof",
 )
@@ -173,6 +174,8 @@ def load() -> C.CDLL:
     L.rs_hip_state_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.rs_hip_sync.argtypes = [C.c_void_p]
     L.rs_hip_first_failed_index.argtypes = [C.c_void_p, C.c_void_p]
+    L.rs_hip_set_diagnostics.argtypes = [C.c_void_p, C.c_int32]
+    L.rs_hip_diagnostics.argtypes = [C.c_void_p, C.c_void_p]
     L.rs_hip_synth_knots.argtypes = [C.c_void_p, P(RsSynthSpec), C.c_void_p, C.c_int32, C.c_int32]
     L.rs_hip_expand_forcing.argtypes = [C.c_void_p, P(RsSynthSpec), C.c_void_p, C.c_int32,
                                         C.c_int32, P(RsForcing), C.c_int32, C.c_int32]

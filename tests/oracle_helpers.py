@@ -144,10 +144,12 @@ class quiet_stdout:
     (src/BoundaryLayer.f90:71-74,98-101, src/InputOutput.f90:63-65), millions of lines on
     adversarial inputs."""
 
+    target = os.devnull
+
     def __enter__(self):
         sys.stdout.flush()
         self._saved = os.dup(1)
-        self._null = os.open(os.devnull, os.O_WRONLY)
+        self._null = os.open(self.target, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
         os.dup2(self._null, 1)
         return self
 
@@ -163,3 +165,15 @@ class quiet_stdout:
         os.close(self._null)
         os.close(self._saved)
         return False
+
+
+class capture_stdout(quiet_stdout):
+    """What the code inside the block writes to file descriptor 1 (the reference's and the product's Fortran
+    diagnostics included), kept in ``path``; ``text()`` afterwards."""
+
+    def __init__(self, path: str):
+        self.target = path
+
+    def text(self) -> str:
+        with open(self.target) as fh:
+            return fh.read()

@@ -44,7 +44,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
     for sym in declared:
         assert hasattr(hip_lib, sym), sym
-    assert hip_lib.rs_abi_version() == 10
+    assert hip_lib.rs_abi_version() == 11
 
 
 def test_c_fortran_ctypes_sizes_agree(hip_lib):
