@@ -1029,7 +1029,12 @@ __device__ __forceinline__ void x2d_surface(X2Mail &mail, const rs::StepArgs &a)
 }
 
 template <int SRC, bool SCORE, bool FULL = false>
-__global__ void __launch_bounds__(128, RS_X2D_WAVES) step_kernel_f32duo(const rs::StepArgs a) {
+#ifndef RS_X2D_FULL_WAVES /* measured (tools/experiments/r6_f32_full_waves.sh, config 5's shape): the FULL knot-reading
+                             instance at five wavefronts per SIMD - 96 registers, 119 spilled - 5.86e10; at four - 128
+                             registers, 42 spilled - 5.59e10 */
+#define RS_X2D_FULL_WAVES RS_X2D_WAVES
+#endif
+__global__ void __launch_bounds__(128, FULL ? RS_X2D_FULL_WAVES : RS_X2D_WAVES) step_kernel_f32duo(const rs::StepArgs a) {
   __shared__ X2Mail mail;
   /* no early return: both wavefronts walk to every barrier; points beyond npoints are dead weight */
   if (threadIdx.x < 64) {

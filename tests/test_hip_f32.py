@@ -282,8 +282,10 @@ def test_fp32_full_feature_set_against_the_fp64_reference(chunk):
     assert np.abs(ora["tsurf"][ok] - base["tsurf"][ok]).max() > 0.5
 
 
-def test_fp32_full_feature_set_reads_the_knots_like_a_window():
-    """... and through the object bench.py times: the knot-reading launch of the FULL fp32 flavour (rs_hip_step_knots:
+@pytest.mark.parametrize("forecast", [True, False], ids=["forecast-key", "history-key"])
+def test_fp32_full_feature_set_reads_the_knots_like_a_window(forecast):
+    """(history-key: the re-sort by the last window's passes - the instances that keep the score.)
+    ... and through the object bench.py times: the knot-reading launch of the FULL fp32 flavour (rs_hip_step_knots:
     dew point interpolated like the other variables, the observation of index 1, initialization phase, relaxation
     towards per-plan targets) equals its window launch bit for bit, in plan order."""
     import torch
@@ -296,7 +298,8 @@ def test_fp32_full_feature_set_reads_the_knots_like_a_window():
     for variant in (2, 0):  # 2: windows + one point per lane is LEAN only -> windows through the duo kernel: variant 0 unfused
         plan = device.Plan(n, s, p, 0)
         plan.set_precision(32)
-        run = workload.SyntheticRun(plan, 9, hours, chunk, point_offset=777, plan_order=True, f32=True, full=True, initlen=300)
+        run = workload.SyntheticRun(plan, 9, hours, chunk, point_offset=777, plan_order=True, f32=True, full=True, initlen=300,
+                                    forecast=forecast)
         if variant == 2:
             run.fused = False  # the same kernel from a forcing window (expand_kernel_f32 + rs_hip_step)
             run.win = device.ForcingWindow.empty(run.chunk, plan.np_pad, plan.device, optional=("tdew", "tsurfobs"),
