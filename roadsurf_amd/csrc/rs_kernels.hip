@@ -2164,6 +2164,30 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
       }
     }
     if (FULL) anchor_due = false;
+#ifdef RS_EXP_SURFACE_MOVED /* (experiment build with -DRS_EXP_SURFACE_LIGHT, tools/experiments/r6_surface_moved.sh: the work
+                               the light surface wave no longer does, done HERE on stand-in values - storages occupied in
+                               three wave-steps of eight, as on the bench workload - so that the SIMDs issue what they
+                               issued before: what MOVING the block to this wavefront could buy, not removing it) */
+    if (!FULL && !mail.failed[ml]) {
+      Scalars d = Scalars();
+      const bool occ = (k & 7) < 3;
+      d.tsurf = t2;
+      d.wat = occ ? fabs(Tg[1]) * 1e-2 : 0.0;
+      d.snow = occ ? fabs(Tg[2]) * 1e-2 : 0.0;
+      d.ice = occ ? fabs(Tg[3]) * 1e-3 : 0.0;
+      d.ice2 = d.ice;
+      d.dep = occ ? fabs(Tg[4]) * 1e-3 : 0.0;
+      d.q2melt = occ ? fabs(Tg[5]) : 0.0;
+      d.t4melt = 0.0;
+      d.albedo = 0.1;
+      road_condition(c, d, occ ? Tg[6] * 1e-5 : 0.0, true);
+      const double as = (t2 < 0) ? R4(21.875) : R4(17.269);
+      const double bs = (t2 < 0) ? R4(265.5) : R4(237.3);
+      const double es = R4(0.61078) * rs_exp(mt, rs_div(as * t2, t2 + bs));
+      mail.prep[k & 1][RS_DUO_NPREP - 1][ml] = d.wat + d.snow + d.ice + d.ice2 + d.dep + d.albedo + d.q2melt + d.t4melt + es +
+                                                (d.verycold ? 1.0 : 0.0); /* (the FULL set's slot: unused here) */
+    }
+#endif
     mail.v[(k & 1) ^ 1][1][ml] = Tg[0];
     if (k + 1 < nsteps) {
       const int32_t in = t0 + k + 1;
