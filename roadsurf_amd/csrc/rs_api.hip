@@ -1078,7 +1078,7 @@ static int cpl_args(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const Rs
   a.wave_n = 0;
   a.duo_full_ok = 0;
   a.surface_prio = 0;
-  a.diag = pl->diag_on ? pl->diag : nullptr;
+  a.diag = nullptr; /* (the lock-step coupling launches have no instance with diagnostics) */
   a.knots = nullptr;
   a.knot_gather = nullptr;
   a.knot_k0 = a.knot_n = a.spk = a.start_hour = 0;

@@ -472,8 +472,9 @@ __device__ __forceinline__ double cpl_decay(const ConstsAS &c, const MathTab &mt
  * (src/BoundaryLayer.f90:69-74,98-101).  The loop of the step about to be taken is run once more, out of line, with
  * IEEE division and square root (the bits the bare sequences return, rs_math.hpp), and the first occurrence and the
  * count of either message go to the plan's diagnostics block (rs_state.h RsDiagRow; one lane owns a point: plain
- * read-modify-write).  Only the one-point-per-lane kernels with the profile in LDS call it - the launchers send a
- * plan with diagnostics there - so the flavours that are tuned to their register budget do not carry the call. */
+ * read-modify-write).  Only the DIAG instances of the one-point-per-lane kernels with the profile in LDS call it
+ * (step_kernel_lds<., true>, step_kernel_sky<true>, step_kernel_coupled<true>) - the launchers send a plan with
+ * diagnostics there - so no other kernel carries the call. */
 __device__ __attribute__((noinline)) void bl_diagnose(const ConstsAS *cp, const uint64_t *expT, const double *logT,
                                                       const double *K, double tsurf, double tair, double vz,
                                                       double rhz, int32_t hour, int32_t i, double *dg, int64_t np,
@@ -546,7 +547,7 @@ __device__ __attribute__((noinline)) void bl_diagnose(const ConstsAS *cp, const 
  * Coupling_control decide again at the end.  `point` is the lane's slot: the list breaks the tie
  * between thread and point, so accesses are base[point] with the row base on the scalar unit. */
 template <bool FULL, class Prof, bool SKY = false, bool SCORE = true, bool CPL = false,
-          bool REPLAY = false, bool A32 = false>
+          bool REPLAY = false, bool A32 = false, bool DIAG = false>
 __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s, int32_t &score,
                                           uint32_t point = 0u) {
   static_assert(!A32 || (!SKY && !CPL), "32-bit window offsets: the plain lock-step kernels only");
@@ -868,7 +869,7 @@ __device__ __forceinline__ void time_loop(const MathTab &mt, Prof &T, Scalars &s
         (ka->wb.lw + wrow)[lane] = lw_in;
       }
     }
-    if (!Prof::kUnrolled && ka->diag) /* (the LDS-profile kernels: see bl_diagnose) */
+    if (DIAG) /* (instances of their own, step_kernel_lds<., true> and step_kernel_sky<true>: see bl_diagnose) */
       bl_diagnose(&c, mt.expT, mt.logT, mt.K, s.tsurf, tair, vz, rhz, f.hour, i, ka->diag, ka->np_pad, row0 + lane);
     const Fluxes fx =
         model_step_fluxes<SCORE>(c, mt, s, tair, vz, rhz, prec_ts, sw_in, lw_in, f.phase, f.hour, cp);
@@ -939,7 +940,7 @@ __device__ __forceinline__ Forcing gather_forcing(KernArgs ka, int64_t p, int32_
 /* runsimulation's loop with coupling (examples/example1/src/Simulation.f90:57-115):
  * CheckValues -> CouplingOperations1 (may rewind i) -> SetCurrentValues -> relaxation ->
  * roadModelOneStep -> SaveOutput -> CheckEndCoupling. */
-template <class Prof>
+template <class Prof, bool DIAG = false>
 __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Scalars &s,
                                                   Coupling &q, double *st, int64_t np, int64_t p) {
   KernArgs ka = kernargs();
@@ -1142,7 +1143,7 @@ __device__ __forceinline__ void time_loop_coupled(const MathTab &mt, Prof &T, Sc
         ka->wb.lw[woff] = lw_in;
       }
     }
-    if (ka->diag) bl_diagnose(&c, mt.expT, mt.logT, mt.K, s.tsurf, tair, vz, rhz, f.hour, i, ka->diag, np, p);
+    if (DIAG) bl_diagnose(&c, mt.expT, mt.logT, mt.K, s.tsurf, tair, vz, rhz, f.hour, i, ka->diag, np, p);
     const Fluxes fx = model_step_fluxes(c, mt, s, tair, vz, rhz, prec_ts, sw_in, lw_in, f.phase,
                                         f.hour, cp);
     if (i + 1 < tend) { /* next index's forcing, half a step ahead of its use */
@@ -1241,7 +1242,10 @@ __global__ void __launch_bounds__(kBlock, 4) step_kernel_hybrid(const StepArgs a
   if (SCORE) a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
 }
 
-template <bool FULL>
+/* DIAG (here, step_kernel_sky and step_kernel_coupled): the instance a plan with diagnostics runs (bl_diagnose): a
+ * call in the middle of the step costs the kernel around it 11 % even when it is not taken (measured, FULL: 1.70e10
+ * -> 1.52e10, tools/experiments/r6_diag_hook_cost.sh), so the regular instances do not contain it */
+template <bool FULL, bool DIAG = false>
 __global__ void __launch_bounds__(kBlock, 4) step_kernel_lds(const StepArgs a) {
   extern __shared__ double lds[]; /* [NLayers][kBlock] */
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
@@ -1253,7 +1257,7 @@ __global__ void __launch_bounds__(kBlock, 4) step_kernel_lds(const StepArgs a) {
   Scalars s;
   int32_t score = 0;
   load_state<FULL>(a.state, a.np_pad, p, T, s);
-  time_loop<FULL>(mt, T, s, score);
+  time_loop<FULL, LdsProfile, false, true, false, false, false, DIAG>(mt, T, s, score);
   store_state<FULL>(a.state, a.np_pad, p, T, s);
   a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
 }
@@ -2301,6 +2305,7 @@ __global__ void __launch_bounds__((SKY && SRC == SRC_RAW) ? 192 : 128, REPLAY ? 
 }
 
 /* FULL feature set + sky view in lock step, LDS profile (any NLayers). */
+template <bool DIAG = false>
 __global__ void __launch_bounds__(kBlock, 3) step_kernel_sky(const StepArgs a) {
   extern __shared__ double lds[]; /* [NLayers][kBlock] */
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
@@ -2312,7 +2317,7 @@ __global__ void __launch_bounds__(kBlock, 3) step_kernel_sky(const StepArgs a) {
   Scalars s;
   int32_t score = 0;
   load_state<true>(a.state, a.np_pad, p, T, s);
-  time_loop<true, LdsProfile, true>(mt, T, s, score);
+  time_loop<true, LdsProfile, true, true, false, false, false, DIAG>(mt, T, s, score);
   store_state<true>(a.state, a.np_pad, p, T, s);
   a.state[(int64_t)RS_ST_BLSCORE * a.np_pad + p] = bl_score_key(score, s);
 }
@@ -2429,6 +2434,7 @@ __global__ void __launch_bounds__(kBlock, 3) step_kernel_cpl_replay(const StepAr
 }
 
 /* Coupled variant: LDS profile (any NLayers), FULL feature set + coupling. */
+template <bool DIAG = false>
 __global__ void __launch_bounds__(kBlock, RS_CPL_WAVES) step_kernel_coupled(const StepArgs a) {
   extern __shared__ double lds[]; /* [NLayers][kBlock] */
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
@@ -2444,7 +2450,7 @@ __global__ void __launch_bounds__(kBlock, RS_CPL_WAVES) step_kernel_coupled(cons
   Coupling q;
   load_state<true>(a.state, a.np_pad, p, T, s);
   load_coupling(a.state, a.np_pad, p, q);
-  time_loop_coupled(mt, T, s, q, a.state, a.np_pad, p);
+  time_loop_coupled<LdsProfile, DIAG>(mt, T, s, q, a.state, a.np_pad, p);
   store_state<true, LdsProfile, true>(a.state, a.np_pad, p, T, s);
   store_coupling(a.state, a.np_pad, p, q);
 }
@@ -2977,9 +2983,10 @@ hipError_t rs_launch_step_sky(const rs::StepArgs &a, int NL, bool score, hipStre
     else hipLaunchKernelGGL((rs::step_kernel_duo<15, false, rs::SRC_WINDOW, true, true>), gd, dim3(128), 0, stream, a);
     return hipGetLastError();
   }
-  /* (a plan with diagnostics: the LDS profile, the flavour that carries bl_diagnose - here and below) */
-  if (NL == 15 && !a.diag) hipLaunchKernelGGL((rs::step_kernel_sky_h<4>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
-  else hipLaunchKernelGGL(rs::step_kernel_sky, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
+  /* (a plan with diagnostics: the instance that carries bl_diagnose - here and below) */
+  if (a.diag) hipLaunchKernelGGL(rs::step_kernel_sky<true>, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
+  else if (NL == 15) hipLaunchKernelGGL((rs::step_kernel_sky_h<4>), grid_for(a.npoints), dim3(RS_BLOCK), 0, stream, a);
+  else hipLaunchKernelGGL(rs::step_kernel_sky<false>, grid_for(a.npoints), dim3(RS_BLOCK), lds, stream, a);
   return hipGetLastError();
 }
 
@@ -3022,9 +3029,8 @@ hipError_t rs_launch_step_cpl(const rs::StepArgs &a, int NL, hipStream_t stream)
    * in registers was twice as slow); other layer counts: the LDS profile */
   const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
   const dim3 g = grid_for(a.npoints);
-  const bool hyb = NL == 15 && !a.diag;
-  if (hyb && a.pp.sky_view) hipLaunchKernelGGL((rs::step_kernel_cpl_h<3, true>), g, dim3(RS_BLOCK), 0, stream, a);
-  else if (hyb) hipLaunchKernelGGL((rs::step_kernel_cpl_h<3, false>), g, dim3(RS_BLOCK), 0, stream, a);
+  if (NL == 15 && a.pp.sky_view) hipLaunchKernelGGL((rs::step_kernel_cpl_h<3, true>), g, dim3(RS_BLOCK), 0, stream, a);
+  else if (NL == 15) hipLaunchKernelGGL((rs::step_kernel_cpl_h<3, false>), g, dim3(RS_BLOCK), 0, stream, a);
   else if (a.pp.sky_view) hipLaunchKernelGGL(rs::step_kernel_cpl<true>, g, dim3(RS_BLOCK), lds, stream, a);
   else hipLaunchKernelGGL(rs::step_kernel_cpl<false>, g, dim3(RS_BLOCK), lds, stream, a);
   return hipGetLastError();
@@ -3034,9 +3040,8 @@ hipError_t rs_launch_step_cpl_replay(const rs::StepArgs &a, int NL, hipStream_t 
   if (!a.cpl_list || a.cpl_nlist < 1) return hipSuccess;
   const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
   const dim3 g = grid_for(a.cpl_nlist);
-  const bool hyb = NL == 15 && !a.diag;
-  if (hyb && a.pp.sky_view) hipLaunchKernelGGL((rs::step_kernel_cpl_replay_h<3, true>), g, dim3(RS_BLOCK), 0, stream, a);
-  else if (hyb) hipLaunchKernelGGL((rs::step_kernel_cpl_replay_h<3, false>), g, dim3(RS_BLOCK), 0, stream, a);
+  if (NL == 15 && a.pp.sky_view) hipLaunchKernelGGL((rs::step_kernel_cpl_replay_h<3, true>), g, dim3(RS_BLOCK), 0, stream, a);
+  else if (NL == 15) hipLaunchKernelGGL((rs::step_kernel_cpl_replay_h<3, false>), g, dim3(RS_BLOCK), 0, stream, a);
   else if (a.pp.sky_view) hipLaunchKernelGGL(rs::step_kernel_cpl_replay<true>, g, dim3(RS_BLOCK), lds, stream, a);
   else hipLaunchKernelGGL(rs::step_kernel_cpl_replay<false>, g, dim3(RS_BLOCK), lds, stream, a);
   return hipGetLastError();
@@ -3046,7 +3051,8 @@ hipError_t rs_launch_step_coupled(const rs::StepArgs &a, int NL, hipStream_t str
   const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
   const int64_t n = a.cpl_list ? (int64_t)a.cpl_nlist : a.npoints;
   if (n < 1) return hipSuccess;
-  hipLaunchKernelGGL(rs::step_kernel_coupled, grid_for(n), dim3(RS_BLOCK), lds, stream, a);
+  if (a.diag) hipLaunchKernelGGL(rs::step_kernel_coupled<true>, grid_for(n), dim3(RS_BLOCK), lds, stream, a);
+  else hipLaunchKernelGGL(rs::step_kernel_coupled<false>, grid_for(n), dim3(RS_BLOCK), lds, stream, a);
   return hipGetLastError();
 }
 
@@ -3099,7 +3105,10 @@ hipError_t rs_launch_step(const rs::StepArgs &a, int NL, bool full, int variant,
 #undef RS_REG
   } else {
     const size_t lds = (size_t)NL * RS_BLOCK * sizeof(double);
-    if (full) hipLaunchKernelGGL((rs::step_kernel_lds<true>), g, b, lds, stream, a);
+    /* (diagnostics: the FULL instance whatever the launch's feature set - it reads a missing optional stream as
+     * "no value" and is exact for a LEAN launch too) */
+    if (a.diag) hipLaunchKernelGGL((rs::step_kernel_lds<true, true>), g, b, lds, stream, a);
+    else if (full) hipLaunchKernelGGL((rs::step_kernel_lds<true>), g, b, lds, stream, a);
     else hipLaunchKernelGGL((rs::step_kernel_lds<false>), g, b, lds, stream, a);
   }
   return hipGetLastError();

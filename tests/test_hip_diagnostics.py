@@ -66,7 +66,9 @@ def _by_point(lines):
 
 
 @pytest.mark.skipif(not oh.have_ref(), reason="needs the compiled reference (oracle/_ref)")
-def test_boundary_layer_messages_as_the_reference_prints_them(tmp_path, monkeypatch):
+@pytest.mark.parametrize("mode", ["plain", "skyview"])
+def test_boundary_layer_messages_as_the_reference_prints_them(mode, tmp_path, monkeypatch):
+    """plain: step_kernel_lds<true, true>; skyview: step_kernel_sky<true> (per-point sky view on half the points)."""
     n, SL = 6, 61
     f = oh.synth_forcing(n, SL, seed=5)
     f["prec"][:] = 0.0
@@ -79,6 +81,17 @@ def test_boundary_layer_messages_as_the_reference_prints_them(tmp_path, monkeypa
     s = abi.default_settings(SL); p = abi.default_parameters(); l = abi.default_local(); l.InitLenI = 1
     p.CalmLimDay = 0.01; p.CalmLimNgt = 0.01
     ls = [l] * n
+    if mode == "skyview":
+        ls = []
+        for q in range(n):
+            lq = abi.default_local(); lq.InitLenI = 1
+            lq.lat, lq.lon = 60.0 + q, 25.0
+            if q % 2 == 0:
+                lq.sky_view = 0.6
+            ls.append(lq)
+        f["sw_dir"] = np.ascontiguousarray(0.5 * f["sw"])
+        f["lw_net"] = np.full_like(f["lw"], -40.0)
+        f["local_horizons"] = np.zeros((n, 360))
     ref_out, ref_lines = _reference("ref", f, s, p, ls, tmp_path, monkeypatch)
     out, lines = _product(f, s, p, ls, tmp_path, monkeypatch, "hip_bl.txt")
     for k in oh.F64_OUT:  # the kernels that carry the diagnostics return the reference's bits too
