@@ -1276,47 +1276,52 @@ __global__ void __launch_bounds__(kBlock, 4) step_kernel_lds(const StepArgs a) {
  * step shrinks from ~1 460 to ~1 020 vector instructions and the shard occupies twice as many
  * wave slots.  Same arithmetic in the same order per point: same bits (layer_step is the one
  * function both flavours call).  LEAN feature set, NLayers = 15, 32-bit window offsets. */
-#define RS_DUO_NPREP 12
-struct DuoMail {
+/* what a step needs of its forcing alone (ForcingPrep), [value][lane]: nine values, ten with the FULL feature set */
+enum { PR_TAIR = 0, PR_VZ, PR_RHZ, PR_RAIN, PR_SNOW, PR_AVC, PR_EAIR, PR_SW, PR_LW, PR_OBS, PR_LEAN = PR_OBS, PR_FULL = PR_OBS + 1 };
+template <int NPREP>
+struct DuoMailT {
   double v[2][2][64]; /* [buffer][0: Tmp(2) from the surface wave, 1: Tmp(3) from the ground wave][lane] */
   uint32_t failed[64]; /* sticky, set by the surface wave: the point's loop has exited (the ground wave
                           then leaves Tmp(3..N) alone, as the one-point-per-lane flavours do) */
   /* round 4: what a step needs of its forcing alone (ForcingPrep, rs_physics_body.inc), worked out by
-   * the ground wave one index ahead: [buffer = index parity][value][lane].  Eleven values per lane (+ the
-   * forced surface observation of the FULL feature set) - the traffic friction is the same for every
-   * point of an index (one word per buffer), VK x VZ and the two products with the air's volumetric heat
-   * capacity are four multiplications for the surface wave: with 15 values the workgroup took 22 336 B
-   * of LDS, seven workgroups to a CU (3.5 wavefronts per SIMD where the registers allow 4); now 19 280 B:
-   * eight. */
-  double prep[2][RS_DUO_NPREP][64];
+   * the ground wave one index ahead: [buffer = index parity][value][lane].  The traffic friction is the same for
+   * every point of an index (one bit per buffer), VK x VZ and the products with the air's volumetric heat capacity
+   * are multiplications for the surface wave.  Round 6: the air's density and specific heat travel as their product
+   * (all the surface wave ever forms of them; a product is the same bits in either order) and the psychrometric
+   * constant is three operations on the air temperature the surface wave has anyway: nine values instead of eleven
+   * (+ 1.2 % at 1 M points; 16 192 B per workgroup of the LEAN instances, see RS_DUO_LEAN_WAVES). */
+  double prep[2][NPREP][64];
   /* bit 0: CheckValues' verdict on the forcing; bit 1: the index falls in the night of
    * SetDayDependendVariables (src/BalanceModel.f90:354-387) - per LANE: with RsForcing::hour_pstride = 1
    * (runsimulation_batch: every point brings its own calendar) the hour is the point's, not the index's */
   uint32_t prep_bad[2][64];
 };
 
-template <bool FULL, bool SKYG = false>
-__device__ __forceinline__ void duo_put_prep(DuoMail &mail, int buf, uint32_t lane, const ForcingPrep &q) {
+template <bool FULL, bool SKYG = false, class Mail>
+__device__ __forceinline__ void duo_put_prep(Mail &mail, int buf, uint32_t lane, const ForcingPrep &q) {
   double (*w)[64] = mail.prep[buf];
-  w[0][lane] = q.tair; w[1][lane] = q.vz; w[2][lane] = q.rhz; w[3][lane] = q.rain; w[4][lane] = q.snow;
-  w[5][lane] = q.AirDens; w[6][lane] = q.AirHCap; w[7][lane] = q.PsychC;
-  w[8][lane] = q.EAir;
+  w[PR_TAIR][lane] = q.tair; w[PR_VZ][lane] = q.vz; w[PR_RHZ][lane] = q.rhz; w[PR_RAIN][lane] = q.rain;
+  w[PR_SNOW][lane] = q.snow;
+  w[PR_AVC][lane] = q.AirHCap * q.AirDens; /* AirVCap, forcing_prep_tail's expression */
+  w[PR_EAIR][lane] = q.EAir;
   if (!SKYG) { /* (SKYG: the radiation is the sky wave's to hand over, duo_sky) */
-    w[9][lane] = q.sw;
-    w[10][lane] = q.lw;
+    w[PR_SW][lane] = q.sw;
+    w[PR_LW][lane] = q.lw;
   }
-  if (FULL) w[11][lane] = q.tsurfobs;
+  if (FULL) w[PR_OBS][lane] = q.tsurfobs;
   mail.prep_bad[buf][lane] = (q.bad ? 1u : 0u) | (q.night ? 2u : 0u) | (q.bad_rw ? 8u : 0u);
 }
-template <bool FULL, bool SKYG = false, class C>
-__device__ __forceinline__ ForcingPrep duo_get_prep(const C &c, const DuoMail &mail, int buf, uint32_t lane,
+template <bool FULL, bool SKYG = false, class C, class Mail>
+__device__ __forceinline__ ForcingPrep duo_get_prep(const C &c, const Mail &mail, int buf, uint32_t lane,
                                                     const uint32_t *skyfl = nullptr) {
   const double (*w)[64] = mail.prep[buf];
   ForcingPrep q;
-  q.tair = w[0][lane]; q.vz = w[1][lane]; q.rhz = w[2][lane]; q.rain = w[3][lane]; q.snow = w[4][lane];
-  q.AirDens = w[5][lane]; q.AirHCap = w[6][lane]; q.PsychC = w[7][lane];
-  q.EAir = w[8][lane]; q.sw = w[9][lane]; q.lw = w[10][lane];
-  if (FULL) q.tsurfobs = w[11][lane];
+  q.tair = w[PR_TAIR][lane]; q.vz = w[PR_VZ][lane]; q.rhz = w[PR_RHZ][lane]; q.rain = w[PR_RAIN][lane];
+  q.snow = w[PR_SNOW][lane];
+  const double AirVCap = w[PR_AVC][lane];
+  q.AirVCap = AirVCap;
+  q.EAir = w[PR_EAIR][lane]; q.sw = w[PR_SW][lane]; q.lw = w[PR_LW][lane];
+  if (FULL) q.tsurfobs = w[PR_OBS][lane];
   uint32_t flags = mail.prep_bad[buf][lane];
   if (SKYG) flags |= skyfl[buf * 64 + lane]; /* the sky wave's share of CheckValues (bit 0) and its `stop` (bit 2) */
   { /* both constants first (scalar loads), then the lane picks a VALUE: see fluxes_pre */
@@ -1325,7 +1330,7 @@ __device__ __forceinline__ ForcingPrep duo_get_prep(const C &c, const DuoMail &m
     q.trffric = q.night ? fricN : fricD;
   }
   /* forcing_prep_tail's expressions on forcing_prep_tail's values */
-  const double AirVCap = q.AirHCap * q.AirDens;
+  q.PsychC = R4(0.1) * (R4(0.00063) * (q.tair + R4(273.15)) + R4(0.47496));
   q.den0 = AirVCap * (q.tair + R4(273.15));
   q.vkvz = c.VK_Const * q.vz;
   q.avk = AirVCap * c.VK_Const;
@@ -1362,7 +1367,7 @@ __device__ __forceinline__ void duo_meet() { asm volatile("s_waitcnt lgkmcnt(0)\
  * between lane and point: `lane` below is the POINT (row0 = 0), `ml` the lane of the mailbox. */
 template <int NL, bool SCORE, bool FULL = false, bool SKY = false, bool SKYG = false, bool OUTIDX = false,
           bool CPL = false, bool REPLAY = false>
-__device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMail &mail, const StepArgs &a,
+__device__ __forceinline__ void duo_surface(const MathTab &mt, DuoMailT<FULL ? PR_FULL : PR_LEAN> &mail, const StepArgs &a,
                                             const uint32_t *skyfl = nullptr) {
   static_assert(FULL || !SKY, "sky view belongs to the FULL feature set");
   static_assert(!(SKY && SKYG), "the sky view is this wave's or the ground wave's");
@@ -1980,7 +1985,7 @@ enum { SRC_WINDOW = 0, SRC_KNOTS = 1, SRC_RAW = 2 }; /* where the ground wave's 
  * flux and heat capacities of that step from the restored profile and the end-of-window one (the stale TmpNw),
  * and hands over CheckValues' verdict on the forcing of the index behind the window (ForcingPrep::bad_rw). */
 template <int NL, int SRC = SRC_WINDOW, bool FULL = false, bool SKYG = false, bool CPL = false, bool REPLAY = false>
-__device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, const StepArgs &a) {
+__device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMailT<FULL ? PR_FULL : PR_LEAN> &mail, const StepArgs &a) {
   constexpr bool KNOTS = SRC == SRC_KNOTS, RAW = SRC == SRC_RAW;
   static_assert(FULL || !CPL, "coupling belongs to the FULL feature set");
   static_assert(!RAW || FULL, "the driver's series carry the FULL feature set");
@@ -2168,30 +2173,6 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
       }
     }
     if (FULL) anchor_due = false;
-#ifdef RS_EXP_SURFACE_MOVED /* (experiment build with -DRS_EXP_SURFACE_LIGHT, tools/experiments/r6_surface_moved.sh: the work
-                               the light surface wave no longer does, done HERE on stand-in values - storages occupied in
-                               three wave-steps of eight, as on the bench workload - so that the SIMDs issue what they
-                               issued before: what MOVING the block to this wavefront could buy, not removing it) */
-    if (!FULL && !mail.failed[ml]) {
-      Scalars d = Scalars();
-      const bool occ = (k & 7) < 3;
-      d.tsurf = t2;
-      d.wat = occ ? fabs(Tg[1]) * 1e-2 : 0.0;
-      d.snow = occ ? fabs(Tg[2]) * 1e-2 : 0.0;
-      d.ice = occ ? fabs(Tg[3]) * 1e-3 : 0.0;
-      d.ice2 = d.ice;
-      d.dep = occ ? fabs(Tg[4]) * 1e-3 : 0.0;
-      d.q2melt = occ ? fabs(Tg[5]) : 0.0;
-      d.t4melt = 0.0;
-      d.albedo = 0.1;
-      road_condition(c, d, occ ? Tg[6] * 1e-5 : 0.0, true);
-      const double as = (t2 < 0) ? R4(21.875) : R4(17.269);
-      const double bs = (t2 < 0) ? R4(265.5) : R4(237.3);
-      const double es = R4(0.61078) * rs_exp(mt, rs_div(as * t2, t2 + bs));
-      mail.prep[k & 1][RS_DUO_NPREP - 1][ml] = d.wat + d.snow + d.ice + d.ice2 + d.dep + d.albedo + d.q2melt + d.t4melt + es +
-                                                (d.verycold ? 1.0 : 0.0); /* (the FULL set's slot: unused here) */
-    }
-#endif
     mail.v[(k & 1) ^ 1][1][ml] = Tg[0];
     if (k + 1 < nsteps) {
       const int32_t in = t0 + k + 1;
@@ -2216,7 +2197,7 @@ __device__ __forceinline__ void duo_ground(const MathTab &mt, DuoMail &mail, con
  * receives the radiation as the sky view leaves it (mailbox values 9 and 10) plus this wave's flags.  Done on
  * the ground wave, beside thirteen layers and the other six variables, the sky view spilled 86-106 registers;
  * on the surface wave it lengthens the step's serial chain. */
-__device__ __forceinline__ void duo_sky(DuoMail &mail, uint32_t *skyfl, const StepArgs &a) {
+__device__ __forceinline__ void duo_sky(DuoMailT<PR_FULL> &mail, uint32_t *skyfl, const StepArgs &a) {
   KernArgs ka = kernargs();
   const uint32_t lane = threadIdx.x & 63u;
   const int64_t row0 = a.wave_start ? (int64_t)a.wave_start[blockIdx.x] : (int64_t)blockIdx.x * 64;
@@ -2262,8 +2243,8 @@ __device__ __forceinline__ void duo_sky(DuoMail &mail, uint32_t *skyfl, const St
                               ka->pp.horizons_by_point ? (int64_t)1 : ka->np_pad, sw, sw_dir, lw, lw_net))
         stop = true; /* the reference would `stop` the process here: the point is failed at this index, checked or not */
     }
-    mail.prep[buf][9][lane] = sw;
-    mail.prep[buf][10][lane] = lw;
+    mail.prep[buf][PR_SW][lane] = sw;
+    mail.prep[buf][PR_LW][lane] = lw;
     skyfl[buf * 64 + lane] = (bad ? 1u : 0u) | (stop ? 4u : 0u);
   };
   put(0, t0);
@@ -2280,12 +2261,19 @@ __device__ __forceinline__ void duo_sky(DuoMail &mail, uint32_t *skyfl, const St
  * or, with SRC_RAW, on a third wavefront (duo_sky). */
 template <int NL, bool SCORE, int SRC = SRC_WINDOW, bool FULL = false, bool SKY = false, bool CPL = false,
           bool REPLAY = false>
-__global__ void __launch_bounds__((SKY && SRC == SRC_RAW) ? 192 : 128, REPLAY ? 3 : 4) step_kernel_duo(const StepArgs a) {
+#ifndef RS_DUO_LEAN_WAVES
+/* The LEAN instances' 16 192 B of LDS would let ten workgroups onto a CU, and at five wavefronts per SIMD they fit 96
+ * registers with 9-14 spilled - measured (tools/experiments/r6_ab3.sh, profiles/r06_lean_waves_per_simd.txt): 1 M
+ * points 2.513e10 at five against 2.560e10 at four (2.529e10 with round 5's mailbox of eleven values), level at
+ * 250 000 and 125 000 points.  The pass is bound by what the wavefronts issue, not by how many of them wait. */
+#define RS_DUO_LEAN_WAVES 4
+#endif
+__global__ void __launch_bounds__((SKY && SRC == SRC_RAW) ? 192 : 128, REPLAY ? 3 : FULL ? 4 : RS_DUO_LEAN_WAVES) step_kernel_duo(const StepArgs a) {
   /* (REPLAY at three waves per SIMD: with the rewind's code the instance spilled 50 registers at four) */
   static_assert(!CPL || SRC == SRC_RAW, "coupling in the two-wavefront flavour: the driver path's lock-step chunks");
   constexpr bool SKYG = SKY && SRC == SRC_RAW;
   __shared__ double math_lds[RS_MATH_LDS_DOUBLES];
-  __shared__ DuoMail mail;
+  __shared__ DuoMailT<FULL ? PR_FULL : PR_LEAN> mail;
   __shared__ uint32_t skyfl[SKYG ? 2 * 64 : 1]; /* duo_sky's flags, [buffer][lane] */
   const MathTab mt = fill_math_tables(math_lds);
   __syncthreads();
@@ -2300,7 +2288,7 @@ __global__ void __launch_bounds__((SKY && SRC == SRC_RAW) ? 192 : 128, REPLAY ? 
   } else if (!SKYG || threadIdx.x < 128) {
     duo_ground<NL, SRC, FULL, SKYG, CPL, REPLAY>(mt, mail, a);
   } else {
-    duo_sky(mail, skyfl, a);
+    if constexpr (SKYG) duo_sky(mail, skyfl, a);
   }
 }
 
