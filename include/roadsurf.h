@@ -515,11 +515,13 @@ int rs_hip_test_math(RsPlan *plan, int32_t fn, int64_t n, const double *x, doubl
 
 /* Arithmetic flavour of a plan: 64 (default; the parity path) or 32 (BASELINE config 5:
  * fp32 state/forcing/outputs/arithmetic, tolerance-gated against fp64; LEAN feature set for any
- * NLayers, the FULL one - dew-point test, observation forcing, relaxation - for NLayers == 15;
- * output depth, coupling and sky view are refused).
+ * NLayers, the FULL one - dew-point test, observation forcing, relaxation, and through rs_hip_step
+ * sky view with local horizons - for NLayers == 15; output depth and coupling are refused).
  * With 32 the `double *` members of RsForcing/RsOutputs point to FLOAT arrays of the same
- * [t][p] layout (precphase/hour stay int32, tbottom stays double), and the state block
- * holds floats.  Set before rs_hip_init_state. */
+ * [t][p] layout, sw_dir and lw_net included (precphase/hour stay int32; tbottom, the sun table and
+ * the per-point members of RsPointParams - sky view, latitude / longitude terms, horizons - stay
+ * double: the sun's position is worked out in fp64 in either flavour), and the state block holds
+ * floats.  Set before rs_hip_init_state. */
 int rs_hip_set_precision(RsPlan *plan, int32_t bits);
 
 /* How this build divides: 0 = compiler's IEEE expansion everywhere (-DRS_IEEE_DIV),

@@ -729,9 +729,11 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
   if (pl->c.use_coupling && !pp->coupling_index)
     return set_err("rs_hip_step: use_coupling is set: pass coupling_index/coupling_tsurf");
   if (pl->f32 && pl->diag_on) return set_err("rs_hip_step: diagnostics: the fp64 flavour only");
-  if (pl->f32 && (coupled || skyview || f->depth || pl->c.tsurfOutputDepth >= 0.0 || (full && pl->c.NLayers != 15)))
-    return set_err("rs_hip_step: the fp32 flavour has no output depth, coupling or sky view, and the FULL feature "
-                   "set (dew point, observation forcing, relaxation) for NLayers = 15 only");
+  if (pl->f32 && (coupled || f->depth || pl->c.tsurfOutputDepth >= 0.0 || ((full || skyview) && pl->c.NLayers != 15)))
+    return set_err("rs_hip_step: the fp32 flavour has no output depth and no coupling, and the FULL feature "
+                   "set (dew point, observation forcing, relaxation, sky view) for NLayers = 15 only");
+  if (pl->f32 && skyview && pl->wb.sw_dir)
+    return set_err("rs_hip_step: the fp32 flavour does not write the in-place input edits back (fp64 arrays)");
   rs::StepArgs a;
   a.consts = pl->f32 ? pl->consts32_dev : pl->consts_dev;
   a.f = *f;
@@ -787,7 +789,7 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
   }
   hipError_t le;
   if (pl->f32)
-    le = rs32_launch_step(a, pl->c.NLayers, pl->variant, pl->history_score, full, pl->stream);
+    le = rs32_launch_step(a, pl->c.NLayers, pl->variant, pl->history_score, full || skyview, skyview, pl->stream);
   else if (skyview && !coupled)
     le = rs_launch_step_sky(a, pl->c.NLayers, pl->history_score, pl->stream); /* lock-step FULL + sky view */
   else if (coupled) {

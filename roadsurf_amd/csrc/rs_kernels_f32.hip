@@ -5,8 +5,9 @@
  * logic branches on rounding residuals (rs_math.hpp), so an fp32 run cannot track an fp64 run point
  * by point; tests/test_hip_f32.py gates the DISTRIBUTION of the differences against the fp64 oracle,
  * with the tolerance written there.  Feature sets: LEAN, and (round 6, NLayers = 15) the FULL set of the
- * two-wavefront kernels - dew-point test, observation forcing during an initialization phase, relaxation;
- * no output depth, coupling or sky view.
+ * two-wavefront kernels - dew-point test, observation forcing during an initialization phase, relaxation - and,
+ * from a forcing window, sky view with local horizons (step_kernel_f32duo<., ., true, true>); no output depth, no
+ * coupling.
  *
  * Round 6: step_kernel_f32duo, TWO POINTS PER LANE and two wavefronts per 128 points (NLayers = 15).
  * What decides the organisation is how a gfx950 SIMD issues fp32 (tools/f32_issue.hip,
@@ -44,6 +45,7 @@
  */
 #include <hip/hip_runtime.h>
 #include "rs_math.hpp"
+#include "rs_skyview.hpp"
 #include "rs_const_f32.h"
 #include "rs_state.h"
 #include "rs_synth.h"
@@ -454,7 +456,8 @@ enum { XP_TAIR = 0, XP_C1, XP_K3, XP_RRA, XP_AVCAP, XP_PSYCH, XP_EAIR, XP_SW, XP
 struct X2Mail {
   float v[2][2][128];              /* [buffer][0: Tmp(2) from the surface wave, 1: Tmp(3) from the ground wave][point] */
   float prep[2][RS_X2D_NPREP][128]; /* [buffer = index parity][value][point] */
-  uint32_t flags[2][128];          /* bit 0: CheckValues' verdict on the forcing; bit 1: night (SetDayDependendVariables) */
+  uint32_t flags[2][128];          /* bit 0: CheckValues' verdict on the forcing; bit 1: night (SetDayDependendVariables);
+                                      bit 2 (SKY): SunPosition would `stop` (rs_skyview.hpp) */
 };
 #ifndef RS_X2D_WAVES
 #define RS_X2D_WAVES 5 /* wavefronts per SIMD: 96 registers; the mailbox (15.4 KB per workgroup) allows ten workgroups per CU */
@@ -466,9 +469,17 @@ __device__ __forceinline__ void lds_st2(float *row, uint32_t lane, f2 v) { *rein
 /* FULL (round 6): the FULL feature set as the two-wavefront fp64 flavour has it (rs_kernels.hip duo_ground / duo_surface):
  * CheckValues' dew-point test, the observation SetCurrentValues forces on Tmp(1:2) during the initialization phase
  * (src/InputOutput.f90:116-148; force_tsurf: always), RelaxationOperations behind it (src/Relaxation.f90:10-47) - no
- * output depth, coupling or sky view. */
-template <int SRC, bool FULL>
+ * output depth, no coupling.
+ * SKY (with FULL, from a forcing window that carries SW_dir and LW_net): sky view and local horizons
+ * (examples/example1/src/Simulation.f90:154-156, src/ModRadiation.f90:7-73, src/SunPosition.f90:123-193) on the ground
+ * wave, which owns the forcing: CheckValues' sky-view tests and the SW_dir clamp (src/InputOutput.f90:68-77), then
+ * ModRadiationBySurroundings on the short and long wave the surface wave receives.  The sun's position and what is
+ * decided from it - elevation > 0, which degree of azimuth, horizon above the sun or not - stay in fp64, the fp64
+ * flavours' own function on the same table of the host (rs_sun_table): an fp32 azimuth would pick the neighbouring
+ * degree of the horizon now and then, a difference of another kind than rounding. */
+template <int SRC, bool FULL, bool SKY = false>
 __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) {
+  static_assert(!SKY || (FULL && SRC == X2_WINDOW), "sky view: the FULL feature set, from a forcing window");
   KernArgs ka = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
   const uint32_t lane = threadIdx.x & 63u;
   const int64_t p = 2 * ((int64_t)blockIdx.x * 64 + lane); /* < np_pad: every array below has np_pad columns */
@@ -505,6 +516,27 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
       relax_dt = tairR - *reinterpret_cast<const f2 *>(st + (int64_t)RS_ST_TAIR_END * np + p);
       relax_dv = vzR - *reinterpret_cast<const f2 *>(st + (int64_t)RS_ST_VZ_END * np + p);
       relax_dr = rhR - *reinterpret_cast<const f2 *>(st + (int64_t)RS_ST_RH_END * np + p);
+    }
+  }
+  /* SKY: as the fp64 flavours set a point up (rs_kernels.hip time_loop<SKY>) */
+  double skyv[2] = {1.0, 1.0}, sinlat[2] = {0, 0}, coslat[2] = {0, 0}, lonrad[2] = {0, 0}, coslon[2] = {1.0, 1.0}, sinlon[2] = {0, 0};
+  bool sky_on[2] = {false, false};
+  int64_t hcol[2] = {p, p + 1};
+  if (SKY) {
+#pragma unroll
+    for (int comp = 0; comp < 2; ++comp) {
+      if (!(comp ? liveY : liveX)) continue;
+      const int64_t q = p + comp;
+      skyv[comp] = ka->pp.sky_view[q];
+      sky_on[comp] = skyv[comp] < (double)1.0f && skyv[comp] > (double)-0.01f;
+      if (sky_on[comp]) {
+        sinlat[comp] = ka->pp.sin_lat[q];
+        coslat[comp] = ka->pp.cos_lat[q];
+        lonrad[comp] = ka->pp.lon_rad[q];
+        coslon[comp] = ::cos(lonrad[comp]);
+        sinlon[comp] = ::sin(lonrad[comp]);
+      }
+      if (ka->pp.horizon_index) hcol[comp] = ka->pp.horizon_index[q];
     }
   }
   int64_t kcolx = p, kcoly = p + 1;
@@ -609,6 +641,35 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
       if (FULL && has_tdew) { /* :59-62 */
         flx |= (tdew.x < -90.f || tdew.x > 100.0f) ? 1u : 0u;
         fly |= (tdew.y < -90.f || tdew.y > 100.0f) ? 1u : 0u;
+      }
+    }
+    if (SKY) {
+      const int64_t row = (int64_t)(in - t0) * ka->f.t_stride + p;
+      auto in2s = [&](const void *base) -> f2 {
+        const float *q = reinterpret_cast<const float *>(base) + row;
+        return f2{liveX ? q[0] : 0.f, liveY ? q[1] : 0.f};
+      };
+      f2 sw_dir = in2s(ka->f.sw_dir);
+      const f2 lw_net = in2s(ka->f.lw_net);
+      if (in < c.SimLen) {
+        /* CheckValues' sky-view tests and the clamp of the direct short wave, src/InputOutput.f90:68-77 */
+        auto outside = [](float d, float l) { return d < -0.1f || d > 4000.0f || l < -1000.0f || l > 1000.0f; };
+        flx |= (sky_on[0] && outside(sw_dir.x, lw_net.x)) ? 1u : 0u;
+        fly |= (sky_on[1] && outside(sw_dir.y, lw_net.y)) ? 1u : 0u;
+        sw_dir = f2{sw_dir.x > sw.x ? sw.x : sw_dir.x, sw_dir.y > sw.y ? sw.y : sw_dir.y};
+      }
+      const double *sunrow = ka->f.sun + (int64_t)(in - t0) * RS_SUN_COLS;
+#pragma unroll
+      for (int comp = 0; comp < 2; ++comp) {
+        if (!sky_on[comp]) continue;
+        double dsw = comp ? sw.y : sw.x, dsd = comp ? sw_dir.y : sw_dir.x, dlw = comp ? lw.y : lw.x;
+        const double dln = comp ? lw_net.y : lw_net.x;
+        const double *hz = ka->pp.horizons ? ka->pp.horizons + (ka->pp.horizons_by_point ? hcol[comp] * 360 : hcol[comp]) : nullptr;
+        const bool ok = rs::sky_view_radiation(sunrow, sinlat[comp], coslat[comp], lonrad[comp], coslon[comp], sinlon[comp], skyv[comp],
+                                               ka->pp.albedo_surroundings, hz, ka->pp.horizons_by_point ? (int64_t)1 : np, dsw, dsd,
+                                               dlw, dln);
+        if (comp) { sw.y = (float)dsw; lw.y = (float)dlw; fly |= ok ? 0u : 4u; }
+        else { sw.x = (float)dsw; lw.x = (float)dlw; flx |= ok ? 0u : 4u; }
       }
     }
     f2 obs = S2(-9999.9f);
@@ -752,7 +813,7 @@ __device__ __forceinline__ void x2d_ground(X2Mail &mail, const rs::StepArgs &a) 
   }
 }
 
-template <bool SCORE, bool FULL>
+template <bool SCORE, bool FULL, bool SKY = false>
 __device__ __forceinline__ void x2d_surface(X2Mail &mail, const rs::StepArgs &a) {
   KernArgs ka = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
   const uint32_t lane = threadIdx.x & 63u;
@@ -815,6 +876,10 @@ __device__ __forceinline__ void x2d_surface(X2Mail &mail, const rs::StepArgs &a)
         const bool bady = !was_failed.y && ((fl.y & 1u) || check_values_tsurf(c, s.tsurf.y));
         if (badx) { s.failed.x = true; st[(int64_t)RS_ST_FAILED * np + p] = (float)i; }
         if (bady) { s.failed.y = true; st[(int64_t)RS_ST_FAILED * np + p + 1] = (float)i; }
+      }
+      if (SKY && ((fl.x | fl.y) & 4u)) { /* where the reference would `stop` in SunPosition: flagged failed, at any index */
+        if (!was_failed.x && (fl.x & 4u)) { s.failed.x = true; st[(int64_t)RS_ST_FAILED * np + p] = (float)i; }
+        if (!was_failed.y && (fl.y & 4u)) { s.failed.y = true; st[(int64_t)RS_ST_FAILED * np + p + 1] = (float)i; }
       }
       /* TmpNw(1:2) as CalcHCapHCond sees them (src/BalanceModel.f90:215): SetCurrentValues forces Tmp, not TmpNw */
       const f2 stale1 = T1, stale2 = T2;
@@ -1028,20 +1093,21 @@ __device__ __forceinline__ void x2d_surface(X2Mail &mail, const rs::StepArgs &a)
   }
 }
 
-template <int SRC, bool SCORE, bool FULL = false>
+template <int SRC, bool SCORE, bool FULL = false, bool SKY = false>
 #ifndef RS_X2D_FULL_WAVES /* measured (tools/experiments/r6_f32_full_waves.sh, config 5's shape): the FULL knot-reading
                              instance at five wavefronts per SIMD - 96 registers, 119 spilled - 5.86e10; at four - 128
                              registers, 42 spilled - 5.59e10 */
 #define RS_X2D_FULL_WAVES RS_X2D_WAVES
 #endif
-__global__ void __launch_bounds__(128, FULL ? RS_X2D_FULL_WAVES : RS_X2D_WAVES) step_kernel_f32duo(const rs::StepArgs a) {
+/* (SKY: four wavefronts per SIMD - the ground wave keeps a point pair's geometry in fp64 beside its thirteen layers) */
+__global__ void __launch_bounds__(128, SKY ? 4 : FULL ? RS_X2D_FULL_WAVES : RS_X2D_WAVES) step_kernel_f32duo(const rs::StepArgs a) {
   __shared__ X2Mail mail;
   /* no early return: both wavefronts walk to every barrier; points beyond npoints are dead weight */
   if (threadIdx.x < 64) {
     if (a.surface_prio) __builtin_amdgcn_s_setprio(1); /* the longer chain of the two issues first (StepArgs::surface_prio) */
-    x2d_surface<SCORE, FULL>(mail, a);
+    x2d_surface<SCORE, FULL, SKY>(mail, a);
   } else {
-    x2d_ground<SRC, FULL>(mail, a);
+    x2d_ground<SRC, FULL, SKY>(mail, a);
   }
 }
 
@@ -1075,10 +1141,17 @@ static inline dim3 grid_x2(int64_t n) { return dim3((unsigned)((n + 127) / 128))
   } while (0)
 
 /* full: the launch carries the FULL feature set (dew point, observation forcing, relaxation): the two-points-per-lane
- * kernel only (NLayers = 15) */
-hipError_t rs32_launch_step(const rs::StepArgs &a, int NL, int variant, bool score, bool full, hipStream_t stream) {
+ * kernel only (NLayers = 15); sky: and per-point sky view (a window with SW_dir and LW_net, the sun table) */
+hipError_t rs32_launch_step(const rs::StepArgs &a, int NL, int variant, bool score, bool full, bool sky, hipStream_t stream) {
   const dim3 g = grid_for32(a.npoints), b(RS_BLOCK);
   const int v = variant;
+  if (sky) {
+    if (NL != 15) return hipErrorInvalidValue;
+    const dim3 g2 = grid_x2(a.npoints);
+    if (score) hipLaunchKernelGGL((rs32::step_kernel_f32duo<rs32::X2_WINDOW, true, true, true>), g2, dim3(128), 0, stream, a);
+    else hipLaunchKernelGGL((rs32::step_kernel_f32duo<rs32::X2_WINDOW, false, true, true>), g2, dim3(128), 0, stream, a);
+    return hipGetLastError();
+  }
   if (NL == 15 && (full || (v != RS_VARIANT_REG && v != RS_VARIANT_LDS))) {
     /* two points per lane, two wavefronts per 128 points (round 6); RS_VARIANT_REG / _LDS: round 2-5's one point
      * per lane with the profile in LDS, for A/B (and what other layer counts take) */

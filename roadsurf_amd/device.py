@@ -409,8 +409,8 @@ def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputPara
     sky = None
     if sky_on:
         Lh = lib.load()
-        tens["sw_dir"] = pad_t(forcing["sw_dir"], torch.float64)
-        tens["lw_net"] = pad_t(forcing["lw_net"], torch.float64)
+        tens["sw_dir"] = pad_t(forcing["sw_dir"], wdt)  # (window streams: the plan's precision; the geometry stays fp64)
+        tens["lw_net"] = pad_t(forcing["lw_net"], wdt)
         sun = np.zeros((L, 6))  # RS_SUN_COLS
         ax = [np.ascontiguousarray(forcing[k], np.int32) for k in ("year", "month", "day", "hour", "minute", "second")]
         Lh.rs_sun_table(L, *[C.c_void_p(a.ctypes.data) for a in ax], C.c_void_p(sun.ctypes.data))
