@@ -729,10 +729,10 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
   if (pl->c.use_coupling && !pp->coupling_index)
     return set_err("rs_hip_step: use_coupling is set: pass coupling_index/coupling_tsurf");
   if (pl->f32 && pl->diag_on) return set_err("rs_hip_step: diagnostics: the fp64 flavour only");
-  if (pl->f32 && (coupled || f->depth || pl->c.tsurfOutputDepth >= 0.0 || ((full || skyview) && pl->c.NLayers != 15)))
-    return set_err("rs_hip_step: the fp32 flavour has no output depth and no coupling, and the FULL feature "
+  if (pl->f32 && (f->depth || pl->c.tsurfOutputDepth >= 0.0 || (!coupled && (full || skyview) && pl->c.NLayers != 15)))
+    return set_err("rs_hip_step: the fp32 flavour has no output depth, and without coupling the FULL feature "
                    "set (dew point, observation forcing, relaxation, sky view) for NLayers = 15 only");
-  if (pl->f32 && skyview && pl->wb.sw_dir)
+  if (pl->f32 && (skyview || coupled) && pl->wb.sw_dir)
     return set_err("rs_hip_step: the fp32 flavour does not write the in-place input edits back (fp64 arrays)");
   rs::StepArgs a;
   a.consts = pl->f32 ? pl->consts32_dev : pl->consts_dev;
@@ -788,7 +788,9 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
     HIP_OK(hipEventRecord(e0, pl->stream));
   }
   hipError_t le;
-  if (pl->f32)
+  if (pl->f32 && coupled) /* every point replays its coupling window inside the one launch (rs_kernels_f32.hip) */
+    le = rs32_launch_step_coupled(a, pl->c.NLayers, pl->stream);
+  else if (pl->f32)
     le = rs32_launch_step(a, pl->c.NLayers, pl->variant, pl->history_score, full || skyview, skyview, pl->stream);
   else if (skyview && !coupled)
     le = rs_launch_step_sky(a, pl->c.NLayers, pl->history_score, pl->stream); /* lock-step FULL + sky view */
@@ -1045,7 +1047,7 @@ static int cpl_args(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const Rs
   if (!pp || !pp->tbottom || !pp->coupling_index || !pp->coupling_tsurf)
     return set_err("%s: tbottom, coupling_index and coupling_tsurf are required", who);
   if (!pl->c.use_coupling) return set_err("%s: the plan's settings have use_coupling = 0", who);
-  if (pl->f32) return set_err("%s: coupling needs the fp64 flavour", who);
+  if (pl->f32) return set_err("%s: time-chunked coupling needs the fp64 flavour (an fp32 plan runs a coupled series whole: rs_hip_step)", who);
   if (pp->sky_view) {
     if (!pp->sin_lat || !pp->cos_lat || !pp->lon_rad || !f->sw_dir || !f->lw_net || !f->sun)
       return set_err("%s: sky view needs sin_lat, cos_lat, lon_rad, sw_dir, lw_net and sun", who);

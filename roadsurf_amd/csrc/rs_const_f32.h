@@ -28,6 +28,10 @@ struct RsConstantsF {
   /* ... and per layer, side by side (one scalar load per layer): A = DyC WCont, B = DyC dryCap - capDZ =
    * -1 / (A chwt + B) -, condDZ, capDZ of the frozen layer */
   float lk4[RS_MAX_LAYERS + 2][4];
+  /* coupling (step_kernel_f32_coupled): settings%use_coupling, the window length as an integer and as a real
+   * (src/Coupling.f90:512-517), couplingEffectReduction */
+  int32_t use_coupling, cplLenI;
+  float cplLenR, cplReduction;
 };
 
 static inline void rs_constants_to_f32(const RsConstants &c, RsConstantsF &f) {
@@ -45,4 +49,6 @@ static inline void rs_constants_to_f32(const RsConstants &c, RsConstantsF &f) {
   f.r_twoDT = 0.f;
   for (int i = 0; i < RS_MAX_LAYERS + 2; ++i)
     for (int q = 0; q < 4; ++q) f.lk4[i][q] = 0.f;
+  f.use_coupling = c.use_coupling; f.cplLenI = c.cplLenI;
+  f.cplLenR = (float)c.cplLenR; f.cplReduction = (float)c.cplReduction;
 }

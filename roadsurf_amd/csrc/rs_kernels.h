@@ -206,6 +206,7 @@ hipError_t rs_cluster_apply(const double *state_src, double *state_dst, bool f32
 size_t rs32_constants_bytes(void);
 hipError_t rs32_upload_constants(void *dst, const RsConstants *c, hipStream_t stream);
 hipError_t rs32_launch_step(const rs::StepArgs &a, int NL, int variant, bool score, bool full, bool sky, hipStream_t stream);
+hipError_t rs32_launch_step_coupled(const rs::StepArgs &a, int NL, hipStream_t stream);
 hipError_t rs32_launch_step_knots(const rs::StepArgs &a, bool score, bool full, hipStream_t stream);
 hipError_t rs32_launch_init(const rs::InitArgs &a, hipStream_t stream);
 hipError_t rs32_launch_expand(const rs::ExpandArgs &a, int32_t nintervals, hipStream_t stream);

@@ -230,6 +230,18 @@ __global__ void __launch_bounds__(kBlock) init_kernel_f32(const rs::InitArgs a) 
   st[(int64_t)RS_ST_BLSCORE * np + p] = 0.f;
   st[(int64_t)RS_ST_TAIR_END * np + p] = 0.f; st[(int64_t)RS_ST_VZ_END * np + p] = 0.f;
   st[(int64_t)RS_ST_RH_END * np + p] = 0.f;
+  if (c.use_coupling) { /* initCoupling, src/Coupling.f90:144-169 */
+    st[(int64_t)RS_ST_CPL_ITER * np + p] = 0.f; st[(int64_t)RS_ST_CPL_FLAGS * np + p] = 0.f;
+    st[(int64_t)RS_ST_CPL_TABOVE * np + p] = -9999.0f; st[(int64_t)RS_ST_CPL_TBELOW * np + p] = -9999.0f;
+    st[(int64_t)RS_ST_CPL_RADCOEFF * np + p] = 1.0f;
+    st[(int64_t)RS_ST_CPL_RCABOVE * np + p] = -9999.0f; st[(int64_t)RS_ST_CPL_RCBELOW * np + p] = -9999.0f;
+    st[(int64_t)RS_ST_CPL_RCPREV * np + p] = 1.0f;
+    st[(int64_t)RS_ST_CPL_SWCOF * np + p] = 1.0f; st[(int64_t)RS_ST_CPL_LWCOF * np + p] = 1.0f;
+    st[(int64_t)RS_ST_CPL_SWCORR * np + p] = 0.0f; st[(int64_t)RS_ST_CPL_LWCORR * np + p] = 0.0f;
+    st[(int64_t)RS_ST_CPL_TEND1 * np + p] = 0.f;
+    st[(int64_t)RS_ST_CPL_LASTOBS * np + p] = a.pp.coupling_tsurf ? (float)a.pp.coupling_tsurf[p] : -9999.0f;
+    st[(int64_t)RS_ST_CPL_RESUME * np + p] = 1.0f;
+  }
 }
 
 /* The forcing between two hourly knots in single precision: v0 + w (v1 - v0) with the knots' difference taken
@@ -1111,6 +1123,342 @@ __global__ void __launch_bounds__(128, SKY ? 4 : FULL ? RS_X2D_FULL_WAVES : RS_X
   }
 }
 
+/* ==== coupling in single precision (src/Coupling.f90) =================================================
+ * fp32 twin of rs_kernels.hip's general coupling kernel (Coupling, coupling_control, time_loop_coupled,
+ * step_kernel_coupled): one point per lane, the profile in LDS (any NLayers), every lane with its OWN time index -
+ * a point that Coupling_control sends back rewinds to its window start inside the loop (src/Coupling.f90:61-78), up
+ * to 25 times, so the launch is the whole series (rs_hip_step demands t0 = 1, nsteps = SimLen of a coupled plan) and
+ * forcing reads and output writes are per-lane.  The FULL feature set rides along as in the fp64 kernel: dew-point
+ * test, observation forcing (never inside or behind a coupling window: src/InputOutput.f90:116-124), relaxation, sky
+ * view (the sun's position in fp64: rs_skyview.hpp).  No output depth, no diagnostics, no write-back of the in-place
+ * input edits; the time-chunked pair rs_hip_step_cpl / rs_hip_cpl_replay stays with the fp64 flavour.
+ * Tolerance, not bits: Coupling_control stops on |Tsurf - observation| <= 0.1 K, so a replay more or less than the
+ * fp64 run is possible where the two straddle that limit - tests/test_hip_f32.py says what is gated. */
+struct Coupling32 {
+  float tabove, tbelow, radcoeff, rcabove, rcbelow, rcprev, swcof, lwcof, swcorr, lwcorr, tend1, lastobs;
+  int32_t iter, cs, ce, msg;
+  bool again, failed, on;
+};
+
+/* Coupling_control, src/Coupling.f90:292-481 (the Kelvin round trip of TsurfAve and LastTsurfObs included) */
+__device__ __forceinline__ void coupling_control32(Coupling32 &q, float &tsurf) {
+  auto reset_cof = [&]() { q.swcof = 1.0f; q.lwcof = 1.0f; q.swcorr = 0.0f; q.lwcorr = 0.0f; };
+  auto secant = [&]() {
+    const float da = q.tabove - q.lastobs, db = q.lastobs - q.tbelow;
+    return q.rcabove - rs_div(da, da + db) * (q.rcabove - q.rcbelow);
+  };
+  q.again = false;
+  tsurf = tsurf + 273.16f;
+  q.lastobs = q.lastobs + 273.16f;
+  if (q.iter == 0) q.tend1 = tsurf;
+  if (q.iter == 25) {
+    if (__builtin_fabsf(q.tend1 - q.lastobs) < __builtin_fabsf(tsurf - q.lastobs)) q.again = true;
+    reset_cof();
+    q.radcoeff = 1.0f;
+    q.failed = true;
+  } else if (q.lastobs < -100.f) {
+    reset_cof();
+    q.radcoeff = 1.0f;
+    q.failed = true;
+    q.again = true;
+  } else if (tsurf < 170.0f || tsurf > 400.0f) {
+    reset_cof();
+    q.failed = true;
+    q.again = true;
+    q.radcoeff = 1.0f;
+  } else if (tsurf - q.lastobs > 0.1f) {
+    if (q.tabove < -100.f || q.tabove - q.lastobs > tsurf - q.lastobs) {
+      q.tabove = tsurf;
+      q.rcabove = q.radcoeff;
+    }
+    q.again = true;
+    q.radcoeff = (q.tabove > -100.f && q.tbelow > -100.f) ? secant() : 0.5f * q.radcoeff;
+    if (__builtin_fabsf(q.radcoeff - q.rcprev) < 0.00005f) {
+      q.tabove = -9999.f;
+      q.tbelow = -9999.f;
+    }
+    if (q.radcoeff < 0.01f) { /* "coupling coefficient too small, coupling failed" (:400-401) */
+      q.msg |= RS_CPL_MSG_SMALL;
+      q.radcoeff = 1.0f;
+      q.failed = true;
+      reset_cof();
+    }
+    q.rcprev = q.radcoeff;
+  } else if (q.lastobs - tsurf > 0.1f) {
+    if (q.tbelow < -100.f || q.tbelow - q.lastobs < tsurf - q.lastobs) {
+      q.tbelow = tsurf;
+      q.rcbelow = q.radcoeff;
+    }
+    q.again = true;
+    q.radcoeff = (q.tabove > -100.f && q.tbelow > -100.f) ? secant() : 2.0f * q.radcoeff;
+    if (__builtin_fabsf(q.radcoeff - q.rcprev) < 0.00005f) {
+      q.tabove = -9999.f;
+      q.tbelow = -9999.f;
+    }
+    q.rcprev = q.radcoeff;
+  } else {
+    if (q.radcoeff > 3.0f) { /* "coupling coefficient too big, coupling failed" (:451-452) */
+      q.msg |= RS_CPL_MSG_BIG;
+      q.failed = true;
+      q.radcoeff = 1.0f;
+      reset_cof();
+    }
+    q.swcorr = q.swcof - 1.0f;
+    q.lwcorr = q.lwcof - 1.0f;
+    q.failed = false;
+    q.iter = -1;
+    q.tabove = -9999.0f; q.tbelow = -9999.0f;
+    q.radcoeff = 1.0f;
+    q.rcabove = -9999.0f; q.rcbelow = -9999.0f;
+    q.rcprev = 1.0f;
+  }
+  tsurf = tsurf - 273.16f;
+  q.lastobs = q.lastobs - 273.16f;
+}
+
+struct GlobalProfile32 { /* the stale TmpNw of a replay's first step, parked in the state block */
+  const float *col;
+  int64_t stride;
+  __device__ __forceinline__ float get(int j) const { return col[(int64_t)(j - 1) * stride]; }
+};
+
+__device__ __forceinline__ Forcing gather_forcing32(KernArgs ka, int64_t p, int32_t i, int32_t t0) {
+  Forcing o;
+  const int64_t off = (int64_t)(i - t0) * ka->f.t_stride + p;
+  auto F = [&](const double *base) { return reinterpret_cast<const float *>(base)[off]; };
+  o.tair = F(ka->f.tair); o.vz = F(ka->f.vz); o.rhz = F(ka->f.rhz);
+  o.prec = F(ka->f.prec); o.sw = F(ka->f.sw); o.lw = F(ka->f.lw);
+  o.phase = ka->f.precphase[off];
+  o.hour = ka->f.hour_pstride ? ka->f.hour[off] : ka->f.hour[i - t0];
+  o.tdew = ka->f.tdew ? F(ka->f.tdew) : 0.f;
+  o.tsurfobs = ka->f.tsurfobs ? F(ka->f.tsurfobs) : -9999.9f;
+  o.depth = -9999.9f;
+  return o;
+}
+
+__global__ void __launch_bounds__(kBlock, 2) step_kernel_f32_coupled(const rs::StepArgs a) {
+  extern __shared__ float ldsf[]; /* [NLayers][kBlock] */
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= a.npoints) return; /* no barriers below: each lane owns its column */
+  KernArgs ka = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  const ConstsAS &c = consts_of(ka);
+  const int64_t np = a.np_pad;
+  float *st = reinterpret_cast<float *>(a.state);
+  auto S = [&](int slot) -> float & { return st[(int64_t)slot * np + p]; };
+  LdsProfile T{ldsf + threadIdx.x, c.NLayers};
+  const int N = T.nlayers();
+  rs::MathTab mt{nullptr, nullptr, nullptr};
+  Scalars s;
+  for (int j = 1; j <= N; ++j) T.set(j, S(RS_ST_TMP0 + j - 1));
+  s.tnw1 = T.get(1); s.tnw2 = T.get(2);
+  s.tsurf = S(RS_ST_TSURF); s.wat = S(RS_ST_WAT); s.snow = S(RS_ST_SNOW); s.ice = S(RS_ST_ICE); s.ice2 = S(RS_ST_ICE2);
+  s.dep = S(RS_ST_DEP); s.q2melt = S(RS_ST_Q2MELT); s.t4melt = S(RS_ST_T4MELT); s.albedo = S(RS_ST_ALBEDO);
+  s.verycold = S(RS_ST_VERYCOLD) != 0.f; s.failed = S(RS_ST_FAILED) != 0.f;
+  s.tair_end = S(RS_ST_TAIR_END); s.vz_end = S(RS_ST_VZ_END); s.rh_end = S(RS_ST_RH_END);
+  Coupling32 q;
+  {
+    q.iter = (int32_t)S(RS_ST_CPL_ITER);
+    const int32_t fl = (int32_t)S(RS_ST_CPL_FLAGS);
+    q.again = fl & 1; q.failed = (fl >> 1) & 1; q.msg = fl & (RS_CPL_MSG_SMALL | RS_CPL_MSG_BIG);
+    q.tabove = S(RS_ST_CPL_TABOVE); q.tbelow = S(RS_ST_CPL_TBELOW); q.radcoeff = S(RS_ST_CPL_RADCOEFF);
+    q.rcabove = S(RS_ST_CPL_RCABOVE); q.rcbelow = S(RS_ST_CPL_RCBELOW); q.rcprev = S(RS_ST_CPL_RCPREV);
+    q.swcof = S(RS_ST_CPL_SWCOF); q.lwcof = S(RS_ST_CPL_LWCOF); q.swcorr = S(RS_ST_CPL_SWCORR); q.lwcorr = S(RS_ST_CPL_LWCORR);
+    q.tend1 = S(RS_ST_CPL_TEND1); q.lastobs = S(RS_ST_CPL_LASTOBS);
+  }
+  const int32_t t0 = ka->t0, tend = ka->t0 + ka->nsteps;
+  const float tbot = (float)ka->pp.tbottom[p];
+  const int32_t initlen = ka->pp.initlen ? ka->pp.initlen[p] : 0;
+  bool relax = false;
+  float tairR = 0.f, vzR = 0.f, rhR = 0.f;
+  if (c.use_relaxation && ka->pp.tair_relax) {
+    tairR = (float)ka->pp.tair_relax[p]; vzR = (float)ka->pp.vz_relax[p]; rhR = (float)ka->pp.rh_relax[p];
+    relax = !(tairR < -100.0f || tairR > 100.0f || vzR < 0.0f || vzR > 100.0f || rhR < 0.0f || rhR > 110.f);
+  }
+  /* setInputParam + initCouplingTimes, src/InputOutput.f90:30-36, src/Coupling.f90:486-534 */
+  const int32_t cidx = ka->pp.coupling_index ? ka->pp.coupling_index[p] : 0;
+  q.on = c.use_coupling && ka->pp.coupling_index && !(ka->pp.coupling_tsurf[p] < -100 || cidx < 1);
+  q.cs = -99; q.ce = -99;
+  if (q.on) {
+    q.ce = cidx;
+    q.cs = ((float)cidx <= c.cplLenR) ? 1 : cidx - c.cplLenI;
+  }
+  double skyv = 1.0, sinlat = 0, coslat = 0, lonrad = 0, coslon = 1.0, sinlon = 0;
+  bool sky_on = false;
+  if (ka->pp.sky_view) {
+    skyv = ka->pp.sky_view[p];
+    sky_on = skyv < (double)1.0f && skyv > (double)-0.01f;
+    if (sky_on) {
+      sinlat = ka->pp.sin_lat[p]; coslat = ka->pp.cos_lat[p]; lonrad = ka->pp.lon_rad[p];
+      coslon = ::cos(lonrad); sinlon = ::sin(lonrad);
+    }
+  }
+  auto fail_at = [&](int32_t idx) {
+    s.failed = true;
+    S(RS_ST_FAILED) = (float)idx;
+  };
+  auto out_row = [&](int32_t i, int64_t &row) -> bool { /* SaveOutput's decimation (rs_kernels.hip output_row) */
+    int32_t r = i - 1;
+    const int32_t dec = ka->o.decimate;
+    if (dec > 1) {
+      if (r % dec != 0) return false;
+      r /= dec;
+    }
+    row = ((int64_t)r - ka->o.row0) * ka->o.t_stride + p;
+    return true;
+  };
+  auto store = [&](int64_t row, bool valid) {
+    auto O = [&](double *base, float v) { reinterpret_cast<float *>(base)[row] = valid ? v : -9999.0f; };
+    O(ka->o.tsurf, s.tsurf); O(ka->o.snow, s.snow); O(ka->o.water, s.wat);
+    O(ka->o.ice, s.ice); O(ka->o.deposit, s.dep); O(ka->o.ice2, s.ice2);
+  };
+  auto sky_streams = [&](int32_t i, float &sw_dir, float &lw_net) {
+    const int64_t off = (int64_t)(i - t0) * ka->f.t_stride + p;
+    sw_dir = reinterpret_cast<const float *>(ka->f.sw_dir)[off];
+    lw_net = reinterpret_cast<const float *>(ka->f.lw_net)[off];
+  };
+  const int32_t resume = (int32_t)S(RS_ST_CPL_RESUME);
+  int32_t i = resume > t0 ? resume : t0;
+  int32_t written_hi = i - 1; /* highest index the point has saved an output for */
+  bool stale_all = false;     /* first step after a restore: TmpNw is the pre-restore profile */
+  while (i < tend) {
+    if (s.failed) {
+      /* the reference's loop has exited: rows it never saved stay -9999.0; a point that fails in the middle of a replay
+       * keeps, beyond the failure, what the EARLIER passes saved there (src/InputOutput.f90:151-165 only overwrites) */
+      int64_t orow;
+      if (i > written_hi && out_row(i, orow)) store(orow, false);
+      ++i;
+      continue;
+    }
+    Forcing f = gather_forcing32(ka, p, i, t0);
+    if (i == 1 && f.vz < 0.4f) f.vz = 0.4f;
+    CouplingInputs cp;
+    float sw_dir = 0.f, lw_net = 0.f;
+    if (ka->f.sw_dir) sky_streams(i, sw_dir, lw_net);
+    if (i < c.SimLen) {
+      if (check_values(c, f, s.tsurf, ka->f.tdew != nullptr)) fail_at(i);
+      if (sky_on && (sw_dir < -0.1f || sw_dir > 4000.0f || lw_net < -1000.0f || lw_net > 1000.0f)) fail_at(i); /* src/InputOutput.f90:68-74 */
+      if (sw_dir > f.sw) sw_dir = f.sw;                                                                          /* :75-77 */
+      if (q.on) { /* CouplingOperations1, src/Coupling.f90:10-96 */
+        const bool in_phase = (i >= q.cs && i <= q.ce);
+        if (i == q.cs && q.iter == 0) { /* saveDataForCoupling :172-210 */
+          S(RS_ST_CPL_SAVE_TSURF) = s.tsurf; S(RS_ST_CPL_SAVE_WAT) = s.wat; S(RS_ST_CPL_SAVE_ICE2) = s.ice2;
+          S(RS_ST_CPL_SAVE_DEP) = s.dep; S(RS_ST_CPL_SAVE_SNOW) = s.snow; S(RS_ST_CPL_SAVE_ALBEDO) = s.albedo;
+          const int32_t fl = ((int32_t)S(RS_ST_CPL_FLAGS)) & (3 | RS_CPL_MSG_SMALL | RS_CPL_MSG_BIG);
+          S(RS_ST_CPL_FLAGS) = (float)(fl | (s.verycold ? 4 : 0));
+          for (int j = 1; j <= N; ++j) S(RS_ST_CPL_SAVE_TMP0 + j - 1) = T.get(j);
+          q.swcof = 1.0f; q.lwcof = 1.0f; q.swcorr = 0.0f; q.lwcorr = 0.0f;
+        }
+        if (q.again) { /* uploadDataForCoupling :213-255: back to the window start; SrfIcemms, Q2Melt, T4Melt and TmpNw are NOT restored */
+          i = q.cs;
+          s.tsurf = S(RS_ST_CPL_SAVE_TSURF); s.wat = S(RS_ST_CPL_SAVE_WAT); s.ice2 = S(RS_ST_CPL_SAVE_ICE2);
+          s.dep = S(RS_ST_CPL_SAVE_DEP); s.snow = S(RS_ST_CPL_SAVE_SNOW); s.albedo = S(RS_ST_CPL_SAVE_ALBEDO);
+          s.verycold = (((int32_t)S(RS_ST_CPL_FLAGS)) & 4) != 0;
+          for (int j = 1; j <= N; ++j) {
+            S(RS_ST_CPL_STALE_TMP0 + j - 1) = T.get(j); /* TmpNw keeps the end-of-window profile */
+            T.set(j, S(RS_ST_CPL_SAVE_TMP0 + j - 1));
+          }
+          stale_all = true;
+          q.again = false;
+          f = gather_forcing32(ka, p, i, t0);
+          if (i == 1 && f.vz < 0.4f) f.vz = 0.4f;
+          if (ka->f.sw_dir) { /* the restored window holds SW_dir as CheckValues left it in the first pass: clamped (:204-208,249-253) */
+            sky_streams(i, sw_dir, lw_net);
+            if (sw_dir > f.sw) sw_dir = f.sw;
+          }
+          if (f.sw > f.lw && !sky_on) { /* short-wave scaling by day, long-wave by night - and always with sky view (:68-76) */
+            q.swcof = q.radcoeff;
+            q.lwcof = 1.0f;
+          } else {
+            q.swcof = 1.0f;
+            q.lwcof = q.radcoeff;
+          }
+        }
+        if (i > q.ce) { /* the correction decays behind the window (:80-88) */
+          const float e = __expf(rs_div(-((c.DTSecs * (float)i) - (c.DTSecs * (float)q.ce)), c.cplReduction));
+          q.swcof = 1.0f + q.swcorr * e;
+          q.lwcof = 1.0f + q.lwcorr * e;
+        }
+        if (in_phase) { /* snowIceCheck :259-289 */
+          if (q.lastobs > c.TLimMeltSnow && s.snow > 0.f) { s.wat = s.wat + s.snow; s.snow = 0.f; }
+          if (q.lastobs > c.TLimMeltIce && s.ice > 0.f) { s.wat = s.wat + s.ice; s.ice = 0.f; }
+          if (q.lastobs > c.TLimMeltIce && s.ice2 > 0.f) s.ice2 = 0.f;
+          if (q.lastobs > c.TLimMeltDep && s.dep > 0.f) { s.wat = s.wat + s.dep; s.dep = 0.f; }
+        }
+        cp.in_phase = in_phase;
+      }
+      /* SetCurrentValues' observation forcing, src/InputOutput.f90:116-148 */
+      if ((i <= initlen || c.force_tsurf) && f.tsurfobs > -100.0f && (!q.on || i < q.cs)) {
+        T.set(1, f.tsurfobs);
+        T.set(2, f.tsurfobs);
+        s.tsurf = (T.get(1) + T.get(2)) / 2.0f;
+      }
+    } else { /* lastValues, src/InputOutput.f90:169-198; coupling%inCouplingPhase keeps the value of index SimLen - 1 */
+      s.tsurf = (T.get(1) + T.get(2)) / 2.0f;
+      cp.in_phase = q.on && (c.SimLen - 1 >= q.cs && c.SimLen - 1 <= q.ce);
+    }
+    float tair = f.tair, vz = f.vz, rhz = f.rhz;
+    const float prec_ts = rs_div(f.prec, 3600.0f) * c.DTSecs;
+    if (i < c.SimLen && relax) { /* RelaxationOperations, src/Relaxation.f90:10-47 */
+      if (i == initlen) { s.tair_end = tair; s.vz_end = vz; s.rh_end = rhz; }
+      if (i > initlen) {
+        const float e = __expf(rs_div(-((c.DTSecs * (float)i) - (c.DTSecs * (float)initlen)), 4.f * 3600.f));
+        tair = tair - (tairR - s.tair_end) * e;
+        vz = vz - (vzR - s.vz_end) * e;
+        rhz = rhz - (rhR - s.rh_end) * e;
+        if (rhz > 100.f) rhz = 100.0f;
+      }
+    }
+    cp.sw_cof = q.swcof; cp.lw_cof = q.lwcof; cp.last_tsurf_obs = q.lastobs;
+    float sw_in = f.sw, lw_in = f.lw;
+    if (sky_on) { /* ModRadiationBySurroundings (examples/example1/src/Simulation.f90:151-162) */
+      double dsw = sw_in, dsd = sw_dir, dlw = lw_in;
+      const int64_t hcol = ka->pp.horizon_index ? (int64_t)ka->pp.horizon_index[p] : p;
+      if (!rs::sky_view_radiation(ka->f.sun + (int64_t)(i - t0) * RS_SUN_COLS, sinlat, coslat, lonrad, coslon, sinlon, skyv,
+                                  ka->pp.albedo_surroundings,
+                                  ka->pp.horizons ? ka->pp.horizons + hcol * (ka->pp.horizons_by_point ? 360 : 1) : nullptr,
+                                  ka->pp.horizons_by_point ? (int64_t)1 : np, dsw, dsd, dlw, (double)lw_net))
+        fail_at(i); /* the reference would `stop` the process here */
+      sw_in = (float)dsw;
+      lw_in = (float)dlw;
+    }
+    const Fluxes fx = model_step_fluxes(c, mt, s, tair, vz, rhz, prec_ts, sw_in, lw_in, f.phase, f.hour, cp);
+    if (stale_all) { /* observation forcing cannot follow a restore (i >= couplingStartI): TmpNw(1:2) are the stale values too */
+      const GlobalProfile32 Tstale{st + (int64_t)RS_ST_CPL_STALE_TMP0 * np + p, np};
+      model_step_ground<LdsProfile, GlobalProfile32, false>(c, s, T, tbot, tair, fx, -9999.9f, cp, &Tstale);
+      stale_all = false;
+    } else {
+      model_step_ground<LdsProfile, LdsProfile, false>(c, s, T, tbot, tair, fx, -9999.9f, cp);
+    }
+    int64_t orow;
+    if (out_row(i, orow)) store(orow, true);
+    if (i > written_hi) written_hi = i;
+    /* CheckEndCoupling + CouplingOperations2, src/Coupling.f90:98-141 */
+    if (i < c.SimLen && q.on && i == q.ce && !q.failed) {
+      if (q.iter == 0) q.tend1 = s.tsurf;
+      coupling_control32(q, s.tsurf);
+      q.iter = q.iter + 1;
+      if (s.failed) q.again = false; /* failed at this index: the loop exits, no rewind */
+    }
+    ++i;
+  }
+  S(RS_ST_CPL_RESUME) = (float)i;
+  for (int j = 1; j <= N; ++j) S(RS_ST_TMP0 + j - 1) = T.get(j);
+  S(RS_ST_TNW1) = s.tnw1; S(RS_ST_TNW2) = s.tnw2;
+  S(RS_ST_TSURF) = s.tsurf; S(RS_ST_WAT) = s.wat; S(RS_ST_SNOW) = s.snow; S(RS_ST_ICE) = s.ice; S(RS_ST_ICE2) = s.ice2;
+  S(RS_ST_DEP) = s.dep; S(RS_ST_Q2MELT) = s.q2melt; S(RS_ST_T4MELT) = s.t4melt; S(RS_ST_ALBEDO) = s.albedo;
+  S(RS_ST_VERYCOLD) = s.verycold ? 1.f : 0.f;
+  S(RS_ST_TAIR_END) = s.tair_end; S(RS_ST_VZ_END) = s.vz_end; S(RS_ST_RH_END) = s.rh_end;
+  {
+    S(RS_ST_CPL_ITER) = (float)q.iter;
+    const int32_t keep = ((int32_t)S(RS_ST_CPL_FLAGS)) & 4;
+    S(RS_ST_CPL_FLAGS) = (float)(keep | (q.again ? 1 : 0) | (q.failed ? 2 : 0) | q.msg);
+    S(RS_ST_CPL_TABOVE) = q.tabove; S(RS_ST_CPL_TBELOW) = q.tbelow; S(RS_ST_CPL_RADCOEFF) = q.radcoeff;
+    S(RS_ST_CPL_RCABOVE) = q.rcabove; S(RS_ST_CPL_RCBELOW) = q.rcbelow; S(RS_ST_CPL_RCPREV) = q.rcprev;
+    S(RS_ST_CPL_SWCOF) = q.swcof; S(RS_ST_CPL_LWCOF) = q.lwcof; S(RS_ST_CPL_SWCORR) = q.swcorr; S(RS_ST_CPL_LWCORR) = q.lwcorr;
+    S(RS_ST_CPL_TEND1) = q.tend1; S(RS_ST_CPL_LASTOBS) = q.lastobs;
+  }
+}
+
 }  // namespace rs32
 
 static inline dim3 grid_for32(int64_t n) { return dim3((unsigned)((n + RS_BLOCK - 1) / RS_BLOCK)); }
@@ -1169,6 +1517,12 @@ hipError_t rs32_launch_step_knots(const rs::StepArgs &a, bool score, bool full, 
   return hipGetLastError();
 }
 #undef RS32_DUO
+
+/* a coupled plan's whole series (rs_hip_step): every point replays its coupling window inside the launch */
+hipError_t rs32_launch_step_coupled(const rs::StepArgs &a, int NL, hipStream_t stream) {
+  hipLaunchKernelGGL(rs32::step_kernel_f32_coupled, grid_for32(a.npoints), dim3(RS_BLOCK), (size_t)NL * RS_BLOCK * sizeof(float), stream, a);
+  return hipGetLastError();
+}
 
 hipError_t rs32_launch_init(const rs::InitArgs &a, hipStream_t stream) {
   hipLaunchKernelGGL(rs32::init_kernel_f32, grid_for32(a.npoints), dim3(RS_BLOCK), 0, stream, a);
