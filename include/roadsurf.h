@@ -514,14 +514,20 @@ int rs_hip_expand_forcing_on(RsPlan *plan, const RsSynthSpec *spec,
 int rs_hip_test_math(RsPlan *plan, int32_t fn, int64_t n, const double *x, double *y);
 
 /* Arithmetic flavour of a plan: 64 (default; the parity path) or 32 (BASELINE config 5:
- * fp32 state/forcing/outputs/arithmetic, tolerance-gated against fp64; LEAN feature set for any
- * NLayers, the FULL one - dew-point test, observation forcing, relaxation, and through rs_hip_step
- * sky view with local horizons - for NLayers == 15; output depth and coupling are refused).
+ * fp32 state/forcing/outputs/arithmetic, tolerance-gated against fp64).  Every feature of the
+ * model runs in either flavour.  Which fp32 kernel a launch takes: NLayers == 15 without an output
+ * depth or coupling - two points per lane, two wavefronts per 128 points (LEAN, the FULL set, and
+ * through rs_hip_step sky view with local horizons); anything else - coupling (rs_hip_step over
+ * the whole series: every point replays its coupling window inside the launch), tsurfOutputDepth
+ * or a depth stream, the FULL set or sky view at another layer count - the general kernel with one
+ * point per lane and the profile in LDS; LEAN launches at another layer count likewise one point
+ * per lane.  Refused on an fp32 plan: rs_hip_step_cpl / rs_hip_cpl_replay (time-chunked coupling),
+ * rs_hip_set_diagnostics, the write-back of the in-place input edits (rs_hip_set_writeback).
  * With 32 the `double *` members of RsForcing/RsOutputs point to FLOAT arrays of the same
- * [t][p] layout, sw_dir and lw_net included (precphase/hour stay int32; tbottom, the sun table and
- * the per-point members of RsPointParams - sky view, latitude / longitude terms, horizons - stay
- * double: the sun's position is worked out in fp64 in either flavour), and the state block holds
- * floats.  Set before rs_hip_init_state. */
+ * [t][p] layout, depth, sw_dir and lw_net included (precphase/hour stay int32; tbottom, the sun
+ * table and the per-point members of RsPointParams - relaxation targets, coupling observation,
+ * sky view, latitude / longitude terms, horizons - stay double: the sun's position is worked out
+ * in fp64 in either flavour), and the state block holds floats.  Set before rs_hip_init_state. */
 int rs_hip_set_precision(RsPlan *plan, int32_t bits);
 
 /* How this build divides: 0 = compiler's IEEE expansion everywhere (-DRS_IEEE_DIV),

@@ -611,7 +611,6 @@ int rs_hip_init_state(RsPlan *pl, const RsForcing *f, const RsPointParams *pp) {
   a.np_pad = pl->np_pad;
   pl->cpl_windows_closed = false; /* a new run: its coupling windows lie ahead */
   if (pl->f32) {
-    if (f->depth) return set_err("rs_hip_init_state: the fp32 flavour has no output-depth support");
     HIP_OK(rs32_launch_init(a, pl->stream));
   } else {
     HIP_OK(rs_launch_init(a, pl->stream));
@@ -729,9 +728,6 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
   if (pl->c.use_coupling && !pp->coupling_index)
     return set_err("rs_hip_step: use_coupling is set: pass coupling_index/coupling_tsurf");
   if (pl->f32 && pl->diag_on) return set_err("rs_hip_step: diagnostics: the fp64 flavour only");
-  if (pl->f32 && (f->depth || pl->c.tsurfOutputDepth >= 0.0 || (!coupled && (full || skyview) && pl->c.NLayers != 15)))
-    return set_err("rs_hip_step: the fp32 flavour has no output depth, and without coupling the FULL feature "
-                   "set (dew point, observation forcing, relaxation, sky view) for NLayers = 15 only");
   if (pl->f32 && (skyview || coupled) && pl->wb.sw_dir)
     return set_err("rs_hip_step: the fp32 flavour does not write the in-place input edits back (fp64 arrays)");
   rs::StepArgs a;
@@ -788,7 +784,9 @@ int rs_hip_step(RsPlan *pl, const RsForcing *f, const RsOutputs *o, const RsPoin
     HIP_OK(hipEventRecord(e0, pl->stream));
   }
   hipError_t le;
-  if (pl->f32 && coupled) /* every point replays its coupling window inside the one launch (rs_kernels_f32.hip) */
+  if (pl->f32 && (coupled || f->depth || pl->c.tsurfOutputDepth >= 0.0 || ((full || skyview) && pl->c.NLayers != 15)))
+    /* the general fp32 kernel (rs_kernels_f32.hip): every point replays its coupling window inside the one launch; or
+     * an output depth, or the FULL feature set / sky view at a layer count the two-wavefront kernels are not built for */
     le = rs32_launch_step_coupled(a, pl->c.NLayers, pl->stream);
   else if (pl->f32)
     le = rs32_launch_step(a, pl->c.NLayers, pl->variant, pl->history_score, full || skyview, skyview, pl->stream);

@@ -221,7 +221,25 @@ __global__ void __launch_bounds__(kBlock) init_kernel_f32(const rs::InitArgs a) 
     st[(int64_t)(RS_ST_TMP0 + i - 1) * np + p] =
         t4 + (tbot - t4) / (c.ZDpth[N + 1] - c.ZDpth[4]) * (c.ZDpth[i] - c.ZDpth[4]);
   st[(int64_t)RS_ST_TNW1 * np + p] = t4; st[(int64_t)RS_ST_TNW2 * np + p] = t4;
-  st[(int64_t)RS_ST_TSURF * np + p] = (t4 + t4) / 2.0f;
+  float tsurf0 = (t4 + t4) / 2.0f;
+  if (a.f.depth) { /* getTempAtDepth on the fresh profile, src/Initialization.f90:129-136 */
+    const float depth = reinterpret_cast<const float *>(a.f.depth)[p];
+    if (depth >= 0.f) {
+      if (__builtin_fabsf(depth) < 0.00001f) tsurf0 = t4;
+      else if (depth > c.ZDpth[N + 1]) tsurf0 = tbot;
+      else {
+        tsurf0 = 0.f;
+        for (int k = 1; k <= N; ++k)
+          if (depth > c.ZDpth[k] && depth <= c.ZDpth[k + 1]) {
+            const float tk = st[(int64_t)(RS_ST_TMP0 + k - 1) * np + p];
+            const float tk1 = (k == N) ? tbot : st[(int64_t)(RS_ST_TMP0 + k) * np + p];
+            tsurf0 = tk + (depth - c.ZDpth[k]) * (tk1 - tk) / (c.ZDpth[k + 1] - c.ZDpth[k]);
+            break;
+          }
+      }
+    }
+  }
+  st[(int64_t)RS_ST_TSURF * np + p] = tsurf0;
   st[(int64_t)RS_ST_WAT * np + p] = 0.f; st[(int64_t)RS_ST_SNOW * np + p] = 0.f;
   st[(int64_t)RS_ST_ICE * np + p] = 0.f; st[(int64_t)RS_ST_ICE2 * np + p] = 0.f;
   st[(int64_t)RS_ST_DEP * np + p] = 0.f; st[(int64_t)RS_ST_Q2MELT * np + p] = 0.f;
@@ -1123,15 +1141,18 @@ __global__ void __launch_bounds__(128, SKY ? 4 : FULL ? RS_X2D_FULL_WAVES : RS_X
   }
 }
 
-/* ==== coupling in single precision (src/Coupling.f90) =================================================
- * fp32 twin of rs_kernels.hip's general coupling kernel (Coupling, coupling_control, time_loop_coupled,
- * step_kernel_coupled): one point per lane, the profile in LDS (any NLayers), every lane with its OWN time index -
- * a point that Coupling_control sends back rewinds to its window start inside the loop (src/Coupling.f90:61-78), up
- * to 25 times, so the launch is the whole series (rs_hip_step demands t0 = 1, nsteps = SimLen of a coupled plan) and
+/* ==== the general kernel in single precision: every feature, coupling included (src/Coupling.f90) ===========
+ * fp32 twin of rs_kernels.hip's general kernel (Coupling, coupling_control, time_loop_coupled, step_kernel_coupled):
+ * one point per lane, the profile in LDS (any NLayers), every lane with its OWN time index - a point that
+ * Coupling_control sends back rewinds to its window start inside the loop (src/Coupling.f90:61-78), up to 25 times,
+ * so a coupled launch is the whole series (rs_hip_step demands t0 = 1, nsteps = SimLen of a coupled plan) and
  * forcing reads and output writes are per-lane.  The FULL feature set rides along as in the fp64 kernel: dew-point
  * test, observation forcing (never inside or behind a coupling window: src/InputOutput.f90:116-124), relaxation, sky
- * view (the sun's position in fp64: rs_skyview.hpp).  No output depth, no diagnostics, no write-back of the in-place
- * input edits; the time-chunked pair rs_hip_step_cpl / rs_hip_cpl_replay stays with the fp64 flavour.
+ * view (the sun's position in fp64: rs_skyview.hpp), an output depth (tsurfOutputDepth or a depth stream:
+ * getTempAtDepth, src/BalanceModel.f90:390-417).  It is also what an fp32 plan WITHOUT coupling launches for what the
+ * two-wavefront kernels do not have - an output depth, the FULL set or sky view at NLayers != 15 - in chunks like
+ * any other launch.  No diagnostics, no write-back of the in-place input edits; the time-chunked coupling pair
+ * rs_hip_step_cpl / rs_hip_cpl_replay stays with the fp64 flavour.
  * Tolerance, not bits: Coupling_control stops on |Tsurf - observation| <= 0.1 K, so a replay more or less than the
  * fp64 run is possible where the two straddle that limit - tests/test_hip_f32.py says what is gated. */
 struct Coupling32 {
@@ -1232,7 +1253,7 @@ __device__ __forceinline__ Forcing gather_forcing32(KernArgs ka, int64_t p, int3
   o.hour = ka->f.hour_pstride ? ka->f.hour[off] : ka->f.hour[i - t0];
   o.tdew = ka->f.tdew ? F(ka->f.tdew) : 0.f;
   o.tsurfobs = ka->f.tsurfobs ? F(ka->f.tsurfobs) : -9999.9f;
-  o.depth = -9999.9f;
+  o.depth = ka->f.depth ? F(ka->f.depth) : -9999.9f;
   return o;
 }
 
@@ -1255,8 +1276,9 @@ __global__ void __launch_bounds__(kBlock, 2) step_kernel_f32_coupled(const rs::S
   s.dep = S(RS_ST_DEP); s.q2melt = S(RS_ST_Q2MELT); s.t4melt = S(RS_ST_T4MELT); s.albedo = S(RS_ST_ALBEDO);
   s.verycold = S(RS_ST_VERYCOLD) != 0.f; s.failed = S(RS_ST_FAILED) != 0.f;
   s.tair_end = S(RS_ST_TAIR_END); s.vz_end = S(RS_ST_VZ_END); s.rh_end = S(RS_ST_RH_END);
-  Coupling32 q;
-  {
+  Coupling32 q{};
+  q.swcof = q.lwcof = q.radcoeff = q.rcprev = 1.0f; /* (a plan without coupling: CouplingInputs' defaults) */
+  if (c.use_coupling) {
     q.iter = (int32_t)S(RS_ST_CPL_ITER);
     const int32_t fl = (int32_t)S(RS_ST_CPL_FLAGS);
     q.again = fl & 1; q.failed = (fl >> 1) & 1; q.msg = fl & (RS_CPL_MSG_SMALL | RS_CPL_MSG_BIG);
@@ -1316,7 +1338,7 @@ __global__ void __launch_bounds__(kBlock, 2) step_kernel_f32_coupled(const rs::S
     sw_dir = reinterpret_cast<const float *>(ka->f.sw_dir)[off];
     lw_net = reinterpret_cast<const float *>(ka->f.lw_net)[off];
   };
-  const int32_t resume = (int32_t)S(RS_ST_CPL_RESUME);
+  const int32_t resume = c.use_coupling ? (int32_t)S(RS_ST_CPL_RESUME) : t0;
   int32_t i = resume > t0 ? resume : t0;
   int32_t written_hi = i - 1; /* highest index the point has saved an output for */
   bool stale_all = false;     /* first step after a restore: TmpNw is the pre-restore profile */
@@ -1390,10 +1412,10 @@ __global__ void __launch_bounds__(kBlock, 2) step_kernel_f32_coupled(const rs::S
       if ((i <= initlen || c.force_tsurf) && f.tsurfobs > -100.0f && (!q.on || i < q.cs)) {
         T.set(1, f.tsurfobs);
         T.set(2, f.tsurfobs);
-        s.tsurf = (T.get(1) + T.get(2)) / 2.0f;
+        s.tsurf = surface_temperature(c, T, tbot, (c.tsurfOutputDepth >= 0.0f) ? c.tsurfOutputDepth : f.depth);
       }
     } else { /* lastValues, src/InputOutput.f90:169-198; coupling%inCouplingPhase keeps the value of index SimLen - 1 */
-      s.tsurf = (T.get(1) + T.get(2)) / 2.0f;
+      s.tsurf = surface_temperature(c, T, tbot, f.depth);
       cp.in_phase = q.on && (c.SimLen - 1 >= q.cs && c.SimLen - 1 <= q.ce);
     }
     float tair = f.tair, vz = f.vz, rhz = f.rhz;
@@ -1424,10 +1446,10 @@ __global__ void __launch_bounds__(kBlock, 2) step_kernel_f32_coupled(const rs::S
     const Fluxes fx = model_step_fluxes(c, mt, s, tair, vz, rhz, prec_ts, sw_in, lw_in, f.phase, f.hour, cp);
     if (stale_all) { /* observation forcing cannot follow a restore (i >= couplingStartI): TmpNw(1:2) are the stale values too */
       const GlobalProfile32 Tstale{st + (int64_t)RS_ST_CPL_STALE_TMP0 * np + p, np};
-      model_step_ground<LdsProfile, GlobalProfile32, false>(c, s, T, tbot, tair, fx, -9999.9f, cp, &Tstale);
+      model_step_ground<LdsProfile, GlobalProfile32, true>(c, s, T, tbot, tair, fx, f.depth, cp, &Tstale);
       stale_all = false;
     } else {
-      model_step_ground<LdsProfile, LdsProfile, false>(c, s, T, tbot, tair, fx, -9999.9f, cp);
+      model_step_ground<LdsProfile, LdsProfile, true>(c, s, T, tbot, tair, fx, f.depth, cp);
     }
     int64_t orow;
     if (out_row(i, orow)) store(orow, true);
@@ -1441,14 +1463,14 @@ __global__ void __launch_bounds__(kBlock, 2) step_kernel_f32_coupled(const rs::S
     }
     ++i;
   }
-  S(RS_ST_CPL_RESUME) = (float)i;
+  if (c.use_coupling) S(RS_ST_CPL_RESUME) = (float)i;
   for (int j = 1; j <= N; ++j) S(RS_ST_TMP0 + j - 1) = T.get(j);
   S(RS_ST_TNW1) = s.tnw1; S(RS_ST_TNW2) = s.tnw2;
   S(RS_ST_TSURF) = s.tsurf; S(RS_ST_WAT) = s.wat; S(RS_ST_SNOW) = s.snow; S(RS_ST_ICE) = s.ice; S(RS_ST_ICE2) = s.ice2;
   S(RS_ST_DEP) = s.dep; S(RS_ST_Q2MELT) = s.q2melt; S(RS_ST_T4MELT) = s.t4melt; S(RS_ST_ALBEDO) = s.albedo;
   S(RS_ST_VERYCOLD) = s.verycold ? 1.f : 0.f;
   S(RS_ST_TAIR_END) = s.tair_end; S(RS_ST_VZ_END) = s.vz_end; S(RS_ST_RH_END) = s.rh_end;
-  {
+  if (c.use_coupling) {
     S(RS_ST_CPL_ITER) = (float)q.iter;
     const int32_t keep = ((int32_t)S(RS_ST_CPL_FLAGS)) & 4;
     S(RS_ST_CPL_FLAGS) = (float)(keep | (q.again ? 1 : 0) | (q.failed ? 2 : 0) | q.msg);
@@ -1518,7 +1540,8 @@ hipError_t rs32_launch_step_knots(const rs::StepArgs &a, bool score, bool full, 
 }
 #undef RS32_DUO
 
-/* a coupled plan's whole series (rs_hip_step): every point replays its coupling window inside the launch */
+/* the general kernel: a coupled plan's whole series (every point replays its coupling window inside the launch), or a
+ * chunk of a plan without coupling whose features the two-wavefront kernels do not have */
 hipError_t rs32_launch_step_coupled(const rs::StepArgs &a, int NL, hipStream_t stream) {
   hipLaunchKernelGGL(rs32::step_kernel_f32_coupled, grid_for32(a.npoints), dim3(RS_BLOCK), (size_t)NL * RS_BLOCK * sizeof(float), stream, a);
   return hipGetLastError();

@@ -39,22 +39,11 @@ def test_fp32_distribution_gate_against_fp64_oracle():
 
 
 def test_fp32_rejects_what_it_does_not_have():
-    """Output depth and coupling are not in the fp32 flavour, and the FULL feature set (dew point, observation
-    forcing, relaxation, sky view) only for NLayers = 15: refused with a message, not computed wrongly."""
+    """What the fp32 flavour still refuses, with a message: time-chunked coupling (rs_hip_step_cpl / rs_hip_cpl_replay; a
+    coupled fp32 plan runs its series whole), diagnostics, the write-back of the in-place input edits."""
     import torch
     from roadsurf_amd import device
     p = abi.default_parameters()
-    for nl, opt, msg in ((15, ("tdew", "depth"), "no output depth"), (12, ("tdew",), "NLayers = 15 only")):
-        s = abi.default_settings(100); s.NLayers = nl
-        plan = device.Plan(64, s, p, 0)
-        plan.set_precision(32)
-        dev = plan.device
-        win = device.ForcingWindow.empty(10, plan.np_pad, dev, optional=opt, dtype=torch.float32)
-        out = device.OutputWindow.empty(10, plan.np_pad, dev, dtype=torch.float32)
-        pp = plan.point_params(5.0)
-        with pytest.raises(RuntimeError, match=msg):
-            plan.step(win, out, pp, 1, 10)
-        plan.close()
     # coupling: the whole series in one launch (rs_hip_step); the time-chunked pair stays with the fp64 flavour
     s = abi.default_settings(100); s.use_coupling = 1
     plan = device.Plan(64, s, p, 0)
@@ -67,6 +56,8 @@ def test_fp32_rejects_what_it_does_not_have():
         plan.step_cpl(win, out, pp, 1, 50)
     with pytest.raises(RuntimeError, match="whole series"):
         plan.step(win, out, pp, 1, 50)
+    from roadsurf_amd import lib
+    assert plan.L.rs_hip_set_diagnostics(plan._h, 1) != 0 and "fp64 flavour only" in lib.last_error()
     plan.close()
 
 
@@ -343,6 +334,51 @@ def test_fp32_sky_view_against_the_fp64_reference(summer, world, chunk, history)
         assert np.percentile(e, 99.9) < max(5e-4, 1.5 * np.percentile(e0, 99.9)) and e.max() < max(0.1, 1.5 * e0.max()), k
     # the sky view really acts: without it the same forcing ends somewhere else
     assert np.abs(plain["tsurf"][ok] - ora["tsurf"][ok]).max() > 0.5
+
+
+@pytest.mark.parametrize("nl,chunk", [(15, 0), (12, 97)])
+def test_fp32_output_depth_and_the_full_feature_set_at_any_layer_count(nl, chunk):
+    """The general fp32 kernel (step_kernel_f32_coupled, here without coupling) takes what the two-wavefront kernels do not
+    have: an output depth - tsurfOutputDepth, or a depth stream with values inside the grid, below it and exactly 0
+    (getTempAtDepth, src/BalanceModel.f90:390-417; src/Initialization.f90:129-136 for the first index) - and the FULL
+    feature set (initialization phase with observations, relaxation) at NLayers != 15, whole series and launches of 97
+    indices.  Against the fp64 reference, the FULL flavour's gate."""
+    from roadsurf_amd import device
+    n, L, seed = 512, 2881, 23
+    f = oh.synth_forcing(n, L, seed=seed)
+    p = abi.default_parameters()
+    s0 = abi.default_settings(L); s0.NLayers = nl
+    l0 = abi.default_local(); l0.InitLenI = 1
+    base, _, _ = oh.run_oracle("port", f, s0, p, l0)
+    rs = np.random.RandomState(3)
+    ls = []
+    for i in range(n):
+        li = abi.default_local(); li.InitLenI = int(rs.choice([1, 240, 600]))
+        li.tair_relax = float(f["tair"][i, min(li.InitLenI, L - 1)] + rs.uniform(-2, 2))
+        li.VZ_relax = float(rs.uniform(0.5, 6.0)); li.RH_relax = float(rs.uniform(60, 99))
+        ls.append(li)
+    f["tsurfobs"][:, :] = base["tsurf"] + rs.uniform(-1.0, 1.0, (n, 1))
+    for what in ("depth-setting", "depth-array"):
+        g = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in f.items()}
+        s = abi.default_settings(L); s.NLayers = nl; s.use_relaxation = 1
+        if what == "depth-setting":
+            s.tsurfOutputDepth = 0.05
+        else:
+            g["depth"][:] = 0.0; g["depth"][::2] = 0.12; g["depth"][1::4] = 7.0
+        ora, _, _ = oh.run_oracle("ref" if oh.have_ref() else "port", g, s, p, ls)
+        res, nfail = device.run_points(g, s, p, ls, chunk=chunk, precision=32)
+        assert nfail == 0
+        d = np.abs(res["tsurf"] - ora["tsurf"])
+        print("fp32 %s NLayers %d: tsurf rms %.2e p99.9 %.2e max %.3f frac>0.05K %.1e" %
+              (what, nl, np.sqrt((d ** 2).mean()), np.percentile(d, 99.9), d.max(), (d > 0.05).mean()))
+        assert np.percentile(d, 99.9) < 1e-3 and (d > 0.05).mean() < 1e-4 and d.max() < 5.0
+        for k in ("snow", "water", "ice", "deposit", "ice2"):
+            e = np.abs(res[k] - ora[k])
+            assert np.percentile(e, 99.9) < 5e-4 and (e > 0.05).mean() < 1e-5 and e.max() < 0.2, k
+        # the depth really acts: the surface temperature at 5 cm / at the stream's depths is not the two-layer mean
+        s1 = abi.default_settings(L); s1.NLayers = nl; s1.use_relaxation = 1
+        plain, _, _ = oh.run_oracle("port", f, s1, p, ls)
+        assert np.abs(plain["tsurf"] - ora["tsurf"]).max() > 0.1
 
 
 def _coupling_gate(res, ora, ls, what):
