@@ -414,6 +414,187 @@ __device__ __forceinline__ Scalars x2_scalars(const X2State &s, int comp, float 
   return q;
 }
 
+/* ---- the storages for a point PAIR ---------------------------------------------------------------------
+ * melting (src/Storage.f90:319-402) and RoadCond with the four storages, NewMeltFreezeHeat and CalcAlbedo
+ * (src/Cond.f90:9-139, src/Storage.f90:33-314,409-432) for the lane's two points at once: the statements of the
+ * one-point source (rs_physics_body.inc melting / road_condition) in their order, operation for operation - a
+ * point's bits are what the one-point functions give it (A/B: -DRS_X2_ROAD_SCALAR) - with every `if (cond) x = e`
+ * as a select.  Compares and selects do not pack, but the two points' streams are independent of each other, and
+ * in ONE basic block the SIMD issues an instruction of the one behind an instruction of the other (2.35 cycles
+ * each instead of 4.5, profiles/r06_f32_issue_rates.txt); run one point after the other through the one-point
+ * source, each behind its own wavefront-uniform branches, they never met.  The wavefront-uniform shortcuts of the
+ * one-point source stay, over both points of every lane. */
+__device__ __forceinline__ b2 is_pz2(f2 a) { return b2{rs_is_pos_zero(a.x), rs_is_pos_zero(a.y)}; }
+__device__ __forceinline__ f2 div2(f2 a, f2 b) { return a * rcp2(b); } /* rs_div(float, float), rs_math.hpp */
+
+__device__ __forceinline__ void x2_melting(X2State &s, f2 &T1, f2 &T2, f2 hstor, f2 hs1) {
+  const b2 cover = or2(or2(gt2(s.snow, S2(0.f)), gt2(s.ice, S2(0.f))), gt2(s.ice2, S2(0.f)));
+  const b2 A = or2(or2(le2(hstor, S2(0.00001f)), le2(s.tsurf, s.t4melt)), le2(s.q2melt, S2(0.f)));
+  const f2 QAvail = hs1 * (T1 - s.t4melt);
+  const b2 cold = lt2(s.tsurf, S2(0.5f));
+  const b2 r1 = and2(and2(cover, A), cold);                                      /* Q2Melt = 0, the profile stays */
+  const b2 r2 = and2(and2(and2(cover, A), not2(cold)), gt2(s.tsurf, S2(2.0f)));  /* Q2Melt = min(Q2Melt, QAvail) */
+  const b2 mainb = and2(cover, not2(or2(r1, r2)));
+  const b2 all_in = and2(mainb, ge2(s.q2melt, QAvail));                          /* everything available goes into melting */
+  const b2 part = and2(mainb, not2(ge2(s.q2melt, QAvail)));
+  const f2 t4p = s.t4melt + S2(0.01f);
+  const f2 t1part = s.t4melt + div2(QAvail - s.q2melt, hs1);
+  f2 q = s.q2melt;
+  q = sel2(and2(r2, lt2(QAvail, s.q2melt)), QAvail, q);
+  q = sel2(all_in, QAvail, q);
+  q = sel2(or2(r1, not2(cover)), S2(0.f), q);
+  s.q2melt = q;
+  T1 = sel2(all_in, t4p, sel2(part, t1part, T1));
+  T2 = sel2(mainb, t4p, T2);
+}
+
+__device__ __forceinline__ void x2_road_condition(const ConstsAS &c, X2State &s, f2 evap) {
+  const f2 Z = S2(0.f);
+  auto pos = [&](f2 a) { return gt2(a, Z); };
+  auto nonpos = [&](f2 a) { return le2(a, Z); };
+  {
+    const b2 bare = and2(and2(and2(is_pz2(s.wat), is_pz2(s.snow)), and2(is_pz2(s.ice), is_pz2(s.ice2))),
+                         and2(is_pz2(s.dep), b2{evap.x == 0.f, evap.y == 0.f}));
+    if (RS_BARE_FAST(c) && wave_all2(bare)) {
+      s.verycold = and2(s.verycold, not2(gt2(s.tsurf, S2(c.TLimColdH))));
+      s.verycold = or2(s.verycold, lt2(s.tsurf, S2(c.TLimColdL)));
+      s.q2melt = Z;
+      s.albedo = S2(c.AlbDry);
+      return;
+    }
+  }
+  const bool snow_here = !(RS_BARE_FAST(c) && wave_all2(is_pz2(s.snow)));
+  /* WearFactors */
+  auto floor_at = [&](f2 v, float lo) { return sel2(gt2(v, S2(lo)), v, S2(lo)); };
+  f2 SnowTran = Z;
+  if (snow_here) {
+    SnowTran = floor_at(S2(c.wSnowTran) * s.snow, 0.01f);
+    SnowTran = sel2(lt2(s.snow, S2(0.2f)), SnowTran * S2(3.f), SnowTran);
+    SnowTran = SnowTran * S2(c.Tph);
+  }
+  const f2 IceWear = floor_at(S2(c.wIce) * s.ice, 0.01f) * S2(c.Tph);
+  const f2 IceWear2 = floor_at(S2(c.wIce2) * s.ice2, 0.01f) * S2(c.Tph);
+  const f2 DepWear = floor_at(S2(c.wDep) * s.dep, 0.01f) * S2(c.Tph);
+  f2 WatWear = (S2(10.f) * floor_at(S2(c.wWat) * s.wat, 0.06f)) * S2(c.Tph);
+  /* RoadCond head: the VeryCold hysteresis (src/Cond.f90:34-39) */
+  s.verycold = and2(s.verycold, not2(gt2(s.tsurf, S2(c.TLimColdH))));
+  s.verycold = or2(s.verycold, lt2(s.tsurf, S2(c.TLimColdL)));
+  /* WaterStorage, src/Storage.f90:33-84 */
+  {
+    const b2 evaporates = and2(and2(nonpos(s.snow), nonpos(s.ice)), and2(nonpos(s.dep), gt2(s.tsurf, S2(c.TLimDew))));
+    const f2 w1 = sel2(gt2(s.wat, S2(c.MaxPormms)), s.wat - evap, s.wat - S2(c.PorEvaF) * evap);
+    s.wat = sel2(evaporates, w1, s.wat);
+    const b2 wp = pos(s.wat);
+    WatWear = sel2(and2(wp, lt2(s.wat, S2(c.WWearLim))), Z, WatWear);
+    const f2 w2 = sel2(gt2(s.wat, S2(c.WWetLim)), s.wat - WatWear, s.wat - S2(c.DampWearF) * WatWear);
+    s.wat = sel2(wp, w2, s.wat);
+    s.wat = sel2(lt2(s.wat, S2(c.MinWatmms)), Z, s.wat);
+    s.wat = sel2(gt2(s.wat, S2(c.MaxWatmms)), S2(c.MaxWatmms), s.wat);
+  }
+  f2 ext = s.wat - S2(c.MaxPormms);
+  ext = sel2(pos(ext), ext, Z);
+  /* SnowStorage, src/Storage.f90:88-196 */
+  if (snow_here) {
+    const f2 RDummy = ext + s.snow;
+    const f2 WatSnowRat = sel2(gt2(RDummy, S2(0.001f)), div2(ext, RDummy), Z);
+    const b2 sn0 = pos(s.snow);
+    const b2 wet = and2(sn0, gt2(WatSnowRat, S2(c.WetSnowFormR)));
+    {
+      const b2 m = and2(sn0, pos(s.dep));
+      s.ice = sel2(m, s.ice + s.dep, s.ice);
+      s.dep = sel2(m, Z, s.dep);
+      const b2 melts = and2(sn0, and2(pos(s.q2melt), ge2(s.tsurf, S2(c.TLimMeltSnow))));
+      const f2 M1000 = S2(1000.f) * div2(s.q2melt * S2(c.DTSecs), S2(RS_MELTDEN));
+      s.snow = sel2(melts, s.snow - M1000, s.snow);
+      s.wat = sel2(melts, s.wat + M1000, s.wat);
+    }
+    {
+      const b2 m = pos(s.snow);
+      const f2 toice = S2(c.wSnow2Ice) * SnowTran;
+      s.snow = sel2(m, s.snow - SnowTran, s.snow);
+      s.ice = sel2(m, s.ice + toice, s.ice);
+      s.ice2 = sel2(m, s.ice2 + toice, s.ice2);
+    }
+    {
+      const b2 sw = and2(pos(s.snow), wet);
+      const b2 m1 = and2(sw, gt2(WatSnowRat, S2(c.WetSnowMeltR)));
+      s.wat = sel2(m1, s.wat + s.snow, s.wat);
+      s.snow = sel2(m1, Z, s.snow);
+      const b2 m2 = and2(sw, lt2(s.tsurf, S2(c.TLimFreeze)));
+      s.ice = sel2(m2, (s.ice + s.snow) + s.wat, s.ice);
+      s.ice2 = sel2(m2, (s.ice2 + s.snow) + s.wat, s.ice2);
+      s.snow = sel2(m2, Z, s.snow);
+      s.wat = sel2(m2, Z, s.wat);
+    }
+    s.snow = sel2(lt2(s.snow, S2(c.MinSnowmms)), Z, s.snow);
+    s.snow = sel2(gt2(s.snow, S2(c.MaxSnowmms)), s.snow - S2(c.MaxSnowmms * 0.5f), s.snow);
+  }
+  /* IceStorage, src/Storage.f90:199-267 */
+  const b2 freezes = and2(lt2(s.tsurf, S2(c.TLimFreeze)), pos(s.wat));
+  const bool ice_here = !(RS_BARE_FAST(c) && wave_all2(and2(and2(is_pz2(s.ice), is_pz2(s.ice2)), not2(freezes))));
+  if (ice_here) {
+    s.ice = sel2(freezes, s.ice + s.wat, s.ice);
+    s.ice2 = sel2(freezes, s.ice2 + s.wat, s.ice2);
+    s.wat = sel2(freezes, Z, s.wat);
+    const b2 melts = and2(and2(nonpos(s.snow), pos(s.ice)), and2(pos(s.q2melt), ge2(s.tsurf, S2(c.TLimMeltIce))));
+    const f2 M1000 = S2(1000.f) * div2(s.q2melt * S2(c.DTSecs), S2(RS_MELTDEN));
+    s.ice = sel2(melts, s.ice - M1000, s.ice);
+    s.ice2 = sel2(melts, s.ice2 - M1000, s.ice2);
+    s.wat = sel2(melts, s.wat + M1000, s.wat);
+    s.ice = sel2(pos(s.ice), s.ice - IceWear, s.ice);
+    s.ice2 = sel2(pos(s.ice2), s.ice2 - IceWear2, s.ice2);
+    s.ice = sel2(lt2(s.ice, S2(c.MinIcemms)), Z, s.ice);
+    s.ice = sel2(gt2(s.ice, S2(c.MaxIcemms)), S2(c.MaxIcemms), s.ice);
+    s.ice2 = sel2(lt2(s.ice2, S2(c.MinIcemms)), Z, s.ice2);
+    s.ice2 = sel2(gt2(s.ice2, S2(c.MaxIcemms)), S2(c.MaxIcemms), s.ice2);
+  }
+  /* DepositStorage, src/Storage.f90:271-314 */
+  s.dep = sel2(lt2(evap, Z), s.dep - evap, s.dep);
+  {
+    const b2 m = gt2(s.tsurf, S2(c.TLimMeltDep));
+    s.wat = sel2(m, s.wat + s.dep, s.wat);
+    s.dep = sel2(m, Z, s.dep);
+  }
+  s.dep = sel2(and2(nonpos(s.snow), pos(s.dep)), s.dep - DepWear, s.dep);
+  s.dep = sel2(lt2(s.dep, S2(c.MinDepmms)), Z, s.dep);
+  {
+    const b2 m = gt2(s.dep, S2(c.MaxDepmms));
+    s.wat = sel2(m, s.wat + (s.dep - S2(c.MaxDepmms)), s.wat);
+    s.dep = sel2(m, S2(c.MaxDepmms), s.dep);
+  }
+  /* RoadCond tail, src/Cond.f90:61-62 */
+  s.wat = sel2(lt2(s.wat, S2(c.MinWatmms)), Z, s.wat);
+  s.wat = sel2(gt2(s.wat, S2(c.MaxWatmms)), S2(c.MaxWatmms), s.wat);
+  const float IceMax = 1.5f;
+  const f2 span = S2(c.AlbSnow - c.AlbDry);
+  if (!snow_here && !ice_here) { /* no melt heat, the deposit alone in the albedo (rs_physics_body.inc) */
+    s.q2melt = Z;
+    const f2 mid = S2(c.AlbDry) + div2(s.dep, S2(IceMax)) * span;
+    s.albedo = sel2(gt2(s.dep, S2(0.01f)), sel2(lt2(s.dep, S2(IceMax)), mid, S2(c.AlbSnow)), S2(c.AlbDry));
+    return;
+  }
+  /* NewMeltFreezeHeat, src/Storage.f90:409-432 */
+  {
+    const b2 sn = pos(s.snow), ic = and2(nonpos(s.snow), pos(s.ice));
+    auto heat = [&](f2 mm) { return div2(S2(RS_MELTDEN) * div2(mm, S2(1000.f)), S2(c.DTSecs)); };
+    f2 q = sel2(sn, heat(s.snow), Z);
+    s.t4melt = sel2(sn, S2(c.TLimMeltSnow), s.t4melt);
+    q = sel2(ic, heat(s.ice), q);
+    s.t4melt = sel2(ic, S2(c.TLimMeltIce), s.t4melt);
+    s.q2melt = sel2(lt2(q, Z), Z, q);
+  }
+  /* CalcAlbedo, src/Cond.f90:105-139 */
+  {
+    f2 IceSum = S2(0.5f) * (s.ice + s.ice2) + s.dep;
+    IceSum = sel2(lt2(IceSum, Z), Z, IceSum);
+    const b2 snowy = and2(gt2(s.snow, S2(0.01f)), gt2(s.snow, s.ice));
+    const b2 icy = or2(gt2(s.ice, S2(0.01f)), gt2(s.dep, S2(0.01f)));
+    const f2 mid = S2(c.AlbDry) + div2(IceSum, S2(IceMax)) * span;
+    const f2 a_icy = sel2(lt2(IceSum, S2(IceMax)), mid, S2(c.AlbSnow));
+    s.albedo = sel2(snowy, S2(c.AlbSnow), sel2(icy, a_icy, S2(c.AlbDry)));
+  }
+}
+
 /* The three literals of a layer update that cannot ride on an instruction as its one scalar operand, kept in vector
  * registers for a whole time step (left to itself the compiler re-materialises them in every layer) */
 struct X2Lit {
@@ -1062,20 +1243,26 @@ __device__ __forceinline__ void x2d_surface(X2Mail &mail, const rs::StepArgs &a)
         const b2 frozen_cover = b2{(s.snow.x > 0.f) || (s.ice.x > 0.f) || (s.ice2.x > 0.f),
                                    (s.snow.y > 0.f) || (s.ice.y > 0.f) || (s.ice2.y > 0.f)};
         const bool melt_here = wave_any2(frozen_cover);
+#ifndef RS_X2_ROAD_SCALAR
+#ifndef RS_ABL_NOROAD /* (ablation builds, tools/experiments/r6_ablate.sh: what a part costs) */
+        if (melt_here) x2_melting(s, T1, T2, hstor, hs1);
+        else s.q2melt = S2(0.f);
+#endif
+        s.tsurf = (T1 + T2) * S2(0.5f);
+#ifndef RS_ABL_NOROAD
+        x2_road_condition(c, s, evap);
+#endif
+#else /* the one-point source, one point after the other (A/B) */
 #pragma unroll
         for (int comp = 0; comp < 2; ++comp) {
           RegProfile<2> TT;
           TT.set(1, comp ? T1.y : T1.x);
           TT.set(2, comp ? T2.y : T2.x);
           Scalars q = x2_scalars(s, comp, TT.get(1), TT.get(2));
-#ifndef RS_ABL_NOROAD /* (ablation builds, tools/experiments/r6_ablate.sh: what a part costs) */
           if (melt_here) melting(q, TT, comp ? hstor.y : hstor.x, comp ? hs1.y : hs1.x, false, 0.f);
           else q.q2melt = 0.f;
-#endif
           q.tsurf = (TT.get(1) + TT.get(2)) / 2.0f;
-#ifndef RS_ABL_NOROAD
           road_condition(c, q, comp ? evap.y : evap.x);
-#endif
           if (comp) {
             T1.y = TT.get(1); T2.y = TT.get(2);
             s.tsurf.y = q.tsurf; s.wat.y = q.wat; s.snow.y = q.snow; s.ice.y = q.ice; s.ice2.y = q.ice2; s.dep.y = q.dep;
@@ -1086,6 +1273,7 @@ __device__ __forceinline__ void x2d_surface(X2Mail &mail, const rs::StepArgs &a)
             s.q2melt.x = q.q2melt; s.t4melt.x = q.t4melt; s.albedo.x = q.albedo; s.verycold.x = q.verycold;
           }
         }
+#endif
       }
     }
     /* SaveOutput (src/InputOutput.f90:151-165); -9999.0 for a point that failed before this index */
