@@ -4,10 +4,11 @@
  * arithmetic are fp32, exp/log/rcp/sqrt are the hardware approximations.  The reference's storage
  * logic branches on rounding residuals (rs_math.hpp), so an fp32 run cannot track an fp64 run point
  * by point; tests/test_hip_f32.py gates the DISTRIBUTION of the differences against the fp64 oracle,
- * with the tolerance written there.  Feature sets: LEAN, and (round 6, NLayers = 15) the FULL set of the
- * two-wavefront kernels - dew-point test, observation forcing during an initialization phase, relaxation - and,
- * from a forcing window, sky view with local horizons (step_kernel_f32duo<., ., true, true>); no output depth, no
- * coupling.
+ * with the tolerance written there.  Every feature of the model (round 6): LEAN and, for NLayers = 15, the FULL set
+ * of the two-wavefront kernels - dew-point test, observation forcing during an initialization phase, relaxation, and
+ * from a forcing window sky view with local horizons (step_kernel_f32duo<., ., true, true>); coupling, an output
+ * depth and the FULL set / sky view at other layer counts through the general kernel at the end of the file
+ * (step_kernel_f32_coupled: one point per lane, a time index per lane).
  *
  * Round 6: step_kernel_f32duo, TWO POINTS PER LANE and two wavefronts per 128 points (NLayers = 15).
  * What decides the organisation is how a gfx950 SIMD issues fp32 (tools/f32_issue.hip,
@@ -39,8 +40,9 @@
  *     bit from v_rcp_f32's, and a point's bits would depend on its wavefront); the water polynomials in Horner
  *     form; a layer's four constants by one scalar load issued a layer ahead;
  *   - CheckValues' forcing tests an hour at a time where both knots keep a margin to the limits;
- *   - the storages' state machine (src/Storage.f90, src/Cond.f90: compares and selects, nothing to pack)
- *     per point through the one-point physics source, behind its wavefront-uniform shortcuts.
+ *   - the storages' state machine (src/Storage.f90, src/Cond.f90: compares and selects, nothing to pack) for the
+ *     lane's two points in ONE basic block (x2_road_condition, x2_melting: the one-point source's operations, as
+ *     selects), so that the two independent streams issue behind one another; the wavefront-uniform shortcuts stay.
  * Other layer counts keep one point per lane with the profile in LDS (step_kernel_f32_lds).
  */
 #include <hip/hip_runtime.h>
@@ -679,8 +681,8 @@ __device__ __forceinline__ void lds_st2(float *row, uint32_t lane, f2 v) { *rein
 
 /* FULL (round 6): the FULL feature set as the two-wavefront fp64 flavour has it (rs_kernels.hip duo_ground / duo_surface):
  * CheckValues' dew-point test, the observation SetCurrentValues forces on Tmp(1:2) during the initialization phase
- * (src/InputOutput.f90:116-148; force_tsurf: always), RelaxationOperations behind it (src/Relaxation.f90:10-47) - no
- * output depth, no coupling.
+ * (src/InputOutput.f90:116-148; force_tsurf: always), RelaxationOperations behind it (src/Relaxation.f90:10-47).  A
+ * launch with an output depth or coupling goes to the general kernel (step_kernel_f32_coupled).
  * SKY (with FULL, from a forcing window that carries SW_dir and LW_net): sky view and local horizons
  * (examples/example1/src/Simulation.f90:154-156, src/ModRadiation.f90:7-73, src/SunPosition.f90:123-193) on the ground
  * wave, which owns the forcing: CheckValues' sky-view tests and the SW_dir clamp (src/InputOutput.f90:68-77), then
@@ -1103,7 +1105,7 @@ __device__ __forceinline__ void x2d_surface(X2Mail &mail, const rs::StepArgs &a)
             T2 = sel2(forced, obs, T2);
             s.tsurf = sel2(forced, (T1 + T2) * S2(0.5f), s.tsurf);
           }
-        } else { /* lastValues (src/InputOutput.f90:169-198): no output depth in this flavour */
+        } else { /* lastValues (src/InputOutput.f90:169-198): no output depth in this kernel's launches */
           s.tsurf = (T1 + T2) * S2(0.5f);
         }
       }
