@@ -3,7 +3,7 @@
 # sources) and the rocprofv3 summaries from gpurun_out/prof_r06* into profiles/
 set -e
 python tools/make_traffic_json.py gpurun_out/prof_r06 profiles/r06_traffic.json
-TRAFFIC_POINTS=1250000 TRAFFIC_SIMLEN=20161 TRAFFIC_BYTES_PER_UNIT=52 python tools/make_traffic_json.py gpurun_out/prof_r06_f32 profiles/r06_f32_traffic.json "step_kernel_f32duo<1, false, false>" 360 2
+TRAFFIC_POINTS=1250000 TRAFFIC_SIMLEN=20161 TRAFFIC_BYTES_PER_UNIT=52 python tools/make_traffic_json.py gpurun_out/prof_r06_f32 profiles/r06_f32_traffic.json "step_kernel_f32duo<1, false, false, false>" 360 2
 G=gpurun_out
 cp $G/prof_r06/bench.json profiles/r06_bench.json
 cp $G/prof_r06_f32/bench.json profiles/r06_f32_bench.json
