@@ -362,7 +362,7 @@ class Plan:
 def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputParameters,
                local, chunk: int = 0, variant: int = 0, device: int = 0,
                lean_if_possible: bool = True, year_month_day=None, history_score: bool | None = None,
-               precision: int = 64):
+               precision: int = 64, horizon_index=None):
     """Run host arrays ``forcing[name][n, SimLen]`` (numpy, reference layout) through the
     device-resident API and return outputs ``[n, SimLen]`` as numpy.  Test/bench helper:
     transposes with torch on the device, windows of ``chunk`` steps (0 = whole series)."""
@@ -429,6 +429,10 @@ def run_points(forcing: dict, settings: abi.InputSettings, params: abi.InputPara
             h = torch.zeros((360, npad), dtype=torch.float64, device=dev)
             h[:, :n] = torch.from_numpy(np.ascontiguousarray(hz)).to(dev).T
             sky["horizons"] = h
+            if horizon_index is not None:  # point i of this call reads column horizon_index[i] of local_horizons
+                hi = torch.zeros((npad,), dtype=torch.int32, device=dev)
+                hi[:n] = torch.from_numpy(np.ascontiguousarray(horizon_index, np.int32))
+                sky["horizon_index"] = hi
     win = ForcingWindow(L, npad, tens)
     if year_month_day is None:
         year_month_day = (int(forcing["year"][0]), int(forcing["month"][0]), int(forcing["day"][0]))

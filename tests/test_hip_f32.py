@@ -386,6 +386,29 @@ def test_fp32_output_depth_and_the_full_feature_set_at_any_layer_count(nl, chunk
         assert np.abs(plain["tsurf"] - ora["tsurf"]).max() > 0.1
 
 
+@pytest.mark.parametrize("precision", [32, 64])
+def test_sky_view_reads_the_horizons_through_the_index_row(precision):
+    """RsPointParams::horizon_index (a plan in another order than the caller's horizon table): the points handed over in a
+    permuted order with the horizon table left as it was and the permutation as index row give every point the values of
+    the plain run, bit for bit - two-wavefront kernels of either precision."""
+    from roadsurf_amd import device
+    from test_hip_skyview import _sky_case
+    n, L = 200, 2881  # (a whole day: the sun has to stand above some horizons and below others)
+    f, ls = _sky_case(n, L, 5, summer=True)
+    for li in ls:
+        li.InitLenI = 1
+    s = abi.default_settings(L); p = abi.default_parameters()
+    plain, _ = device.run_points(f, s, p, ls, precision=precision)
+    perm = np.random.RandomState(2).permutation(n)
+    g = {k: (v[perm].copy() if isinstance(v, np.ndarray) and v.ndim == 2 and v.shape[0] == n and k != "local_horizons" else v)
+         for k, v in f.items()}
+    moved, _ = device.run_points(g, s, p, [ls[i] for i in perm], precision=precision, horizon_index=perm)
+    for k in plain:
+        assert np.array_equal(moved[k], plain[k][perm]), k
+    wrong, _ = device.run_points(g, s, p, [ls[i] for i in perm], precision=precision)  # without the index row: other horizons
+    assert not np.array_equal(wrong["tsurf"], plain["tsurf"][perm])
+
+
 def _coupling_gate(res, ora, ls, what):
     """fp32 against fp64 with coupling: the bulk within microkelvins as without coupling; Coupling_control stops a point's
     replays on |Tsurf - observation| <= 0.1 K, so where the two runs straddle that limit one of them replays once more
